@@ -1,0 +1,466 @@
+"""CPU ORACLE -- test infrastructure, NOT the product.
+
+Python face of ``oracle/tpg_oracle.c`` plus restatements of the R-level drivers
+that sit around the reference's native kernels.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the checker / timed CPU baseline.
+
+Parity pinning: ``tests/test_oracle_golden.py`` checks these functions against
+the golden vectors of the reference's own tests (PLINK .mibs, KING .kin0,
+scikit-allel Fst files, literal matrices).  The reference itself cannot be
+built or run here (R + Rcpp + bigstatsr are absent), so there is no
+``oracle/_ref``.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference checkout).  Third-party arithmetic that is not under the reference
+tree (bigstatsr / bigsnpr / bigparallelr) is marked "(recalled)".
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtpg_oracle.so")
+
+NA = float("nan")
+
+# bigsnpr code tables (recalled; R/gt_has_imputed.R:101-106 switches between them)
+CODE_012 = np.full(256, np.nan)
+CODE_012[:3] = [0.0, 1.0, 2.0]
+CODE_IMPUTE_PRED = np.full(256, np.nan)
+CODE_IMPUTE_PRED[:3] = [0.0, 1.0, 2.0]
+CODE_IMPUTE_PRED[4:7] = [0.0, 1.0, 2.0]
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle (gcc) if needed and return the .so path."""
+    src = os.path.join(_HERE, "tpg_oracle.c")
+    hdr = os.path.join(_HERE, "..", "tidypopgen_amd", "csrc", "synth_common.h")
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_square_frobenius.restype = C.c_double
+        _lib.orc_pca_center_scale_gram.restype = C.c_int
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _fbm(fbm):
+    fbm = np.asarray(fbm)
+    assert fbm.dtype == np.uint8 and fbm.ndim == 2
+    if not fbm.flags.f_contiguous:
+        fbm = np.asfortranarray(fbm)
+    return fbm
+
+
+def _ind(x, default_len):
+    if x is None:
+        return np.arange(1, default_len + 1, dtype=np.int32)
+    return np.ascontiguousarray(x, dtype=np.int32)
+
+
+def _view(fbm, rowInd, colInd):
+    fbm = _fbm(fbm)
+    r = _ind(rowInd, fbm.shape[0])
+    c = _ind(colInd, fbm.shape[1])
+    return fbm, r, c
+
+
+def _args(fbm, r, c):
+    return (_p(fbm, C.c_uint8), C.c_int64(fbm.shape[0]), _p(r, C.c_int32), C.c_int(len(r)),
+            _p(c, C.c_int32), C.c_int(len(c)))
+
+
+def _d(a):
+    return _p(a, C.c_double)
+
+
+# --------------------------------------------------------------------------
+# helpers that exist on the R side
+
+def fbm_from_genotypes(g) -> np.ndarray:
+    """Dosage matrix (NaN / negative = missing) -> FBM bytes, NA = 3
+    (R/gen_tibble_fbm.R:185-194: missing is written as max_ploidy + 1)."""
+    g = np.asarray(g, dtype=float)
+    out = np.where(np.isnan(g), 3, g).astype(np.uint8)
+    return np.asfortranarray(out)
+
+
+def read_bed(path: str, n: int, m: int) -> np.ndarray:
+    """PLINK .bed (SNP-major) -> FBM bytes via bigsnpr's getCode() table
+    (third-party, recalled): 2-bit 00,01,10,11 -> byte 2,3,1,0."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    assert raw[0] == 0x6C and raw[1] == 0x1B and raw[2] == 0x01, "not a SNP-major .bed"
+    bpl = (n + 3) // 4
+    body = raw[3:3 + bpl * m].reshape(m, bpl)
+    codes = np.stack([(body >> s) & 3 for s in (0, 2, 4, 6)], axis=2).reshape(m, bpl * 4)[:, :n]
+    table = np.array([2, 3, 1, 0], dtype=np.uint8)
+    return np.asfortranarray(table[codes].T)
+
+
+def split_len(total_len: int, nb: int):
+    """bigparallelr::split_len (recalled) -> (lower, upper), 1-based inclusive."""
+    lo = np.zeros(nb, dtype=np.int32)
+    up = np.zeros(nb, dtype=np.int32)
+    lib().orc_split_len(C.c_int(total_len), C.c_int(nb), _p(lo, C.c_int32), _p(up, C.c_int32))
+    return lo, up
+
+
+def cut_by_size(m: int, block_size: int):
+    """CutBySize, R/local_reimplementations.R:13-15."""
+    nb = int(math.ceil(m / block_size))
+    return split_len(m, nb)
+
+
+def block_size_default(n: int, ncores: int = 1) -> int:
+    """bigstatsr::block_size (recalled): floor(block.sizeGB * 1024^3 / (8 n ncores)),
+    block.sizeGB = 1, at least 1."""
+    return max(1, int(math.floor(1024.0 ** 3 / (8.0 * n * ncores))))
+
+
+# --------------------------------------------------------------------------
+# native per-block kernels
+
+def increment_ibs_counts(K, K2, fbm, rowInd, colInd):
+    """src/snp_ibs.cpp:22-74"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    lib().orc_increment_ibs_counts(*_args(fbm, r, c), _d(K), _d(K2))
+
+
+def increment_king_numerator(K, N_Aa_i, fbm, rowInd, colInd):
+    """src/snp_king.cpp:21-74"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    lib().orc_increment_king_numerator(*_args(fbm, r, c), _d(K), _d(N_Aa_i))
+
+
+def increment_as_counts(K, K2, fbm, rowInd, colInd, pad_quirk=False):
+    """src/snp_as.cpp:22-67 (pad_quirk: reference quirk Q1, see tpg_oracle.c)"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    lib().orc_increment_as_counts(*_args(fbm, r, c), C.c_int(int(pad_quirk)), _d(K), _d(K2))
+
+
+def alt_freq_dip_pseudo_cpp(fbm, rowInd, colInd, ploidy, as_counts=False, code256=CODE_012):
+    """src/alt_freq_dip_pseudo_cpp.cpp:8-58 -> (m, 2) matrix"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    ploidy = np.ascontiguousarray(ploidy, dtype=float)
+    out = np.zeros((len(c), 2), order="F")
+    lib().orc_alt_freq_dip_pseudo(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)), _d(ploidy),
+                                  C.c_int(int(as_counts)), _d(out))
+    return out
+
+
+def grouped_alt_freq_dip_pseudo_cpp(fbm, rowInd, colInd, groupIds, ngroups, ploidy, as_counts=False,
+                                    code256=CODE_012):
+    """src/grouped_alt_freq_dip_pseudo_cpp.cpp:8-58 -> (m, 2G) matrix"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    ploidy = np.ascontiguousarray(ploidy, dtype=float)
+    gid = np.ascontiguousarray(groupIds, dtype=np.int32)
+    out = np.zeros((len(c), 2 * ngroups), order="F")
+    lib().orc_grouped_alt_freq_dip_pseudo(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)),
+                                          _p(gid, C.c_int32), C.c_int(ngroups), _d(ploidy),
+                                          C.c_int(int(as_counts)), _d(out))
+    return out
+
+
+def grouped_missingness_cpp(fbm, rowInd, colInd, groupIds, ngroups, code256=CODE_012):
+    """src/grouped_missingness_cpp.cpp:8-33 -> (m, G) matrix"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    gid = np.ascontiguousarray(groupIds, dtype=np.int32)
+    out = np.zeros((len(c), ngroups), order="F")
+    lib().orc_grouped_missingness(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)),
+                                  _p(gid, C.c_int32), C.c_int(ngroups), _d(out))
+    return out
+
+
+def grouped_summaries_dip_pseudo_cpp(fbm, rowInd, colInd, groupIds, ngroups, ploidy, code256=CODE_012):
+    """src/grouped_summaries_dip_pseudo_cpp.cpp:11-63 -> dict of four (m, G) matrices"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    ploidy = np.ascontiguousarray(ploidy, dtype=float)
+    gid = np.ascontiguousarray(groupIds, dtype=np.int32)
+    outs = [np.zeros((len(c), ngroups), order="F") for _ in range(4)]
+    lib().orc_grouped_summaries_dip_pseudo(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)),
+                                           _p(gid, C.c_int32), C.c_int(ngroups), _d(ploidy),
+                                           *[_d(o) for o in outs])
+    return dict(freq_alt=outs[0], freq_ref=outs[1], n=outs[2], het_obs=outs[3])
+
+
+def _fst_loop(fn, pairs1, m, mats, by_locus, return_num_dem):
+    pairs1 = np.ascontiguousarray(np.asarray(pairs1, dtype=np.int32).T)  # (P, 2) rows = (pop1, pop2)
+    P = pairs1.shape[0]
+    tot = np.zeros(P)
+    a = np.zeros((m, P), order="F") if by_locus else np.zeros((0, 0))
+    b = np.zeros((m, P), order="F") if return_num_dem else np.zeros((0, 0))
+    fn(_p(pairs1, C.c_int32), C.c_int(P), C.c_int(m), *[_d(np.asfortranarray(x)) for x in mats],
+       C.c_int(int(by_locus)), C.c_int(int(return_num_dem)), _d(tot), _d(a), _d(b))
+    if not return_num_dem:
+        return dict(fst_locus=a, fst_tot=tot)
+    return dict(Fst_by_locus_num=a, Fst_by_locus_den=b)
+
+
+def pairwise_fst_hudson_loop(pairwise_combn, n, freq_alt, freq_ref, by_locus=False, return_num_dem=False):
+    """src/pairwise_fst_hudson_loop.cpp:5-63; pairwise_combn is 2 x P, 1-based"""
+    return _fst_loop(lib().orc_pairwise_fst_hudson_loop, pairwise_combn, n.shape[0],
+                     [n, freq_alt, freq_ref], by_locus, return_num_dem)
+
+
+def pairwise_fst_wc84_loop(pairwise_combn, n, freq_alt, het_obs, by_locus=False, return_num_dem=False):
+    """src/pairwise_fst_wc84_loop.cpp:5-121"""
+    return _fst_loop(lib().orc_pairwise_fst_wc84_loop, pairwise_combn, n.shape[0],
+                     [n, freq_alt, het_obs], by_locus, return_num_dem)
+
+
+def pairwise_fst_nei87_loop(pairwise_combn, n, het_obs, freq_alt, freq_ref, by_locus=False,
+                            return_num_dem=False):
+    """src/pairwise_fst_nei87_loop.cpp:5-115"""
+    return _fst_loop(lib().orc_pairwise_fst_nei87_loop, pairwise_combn, n.shape[0],
+                     [n, het_obs, freq_alt, freq_ref], by_locus, return_num_dem)
+
+
+def fbm256_prod_and_rowSumsSq(fbm, ind_row, ind_col, center, scale, V, code256=CODE_012):
+    """src/fbm_prod_and_rowSumSq.cpp:10-47 -> (XV (n,K), rowSumsSq (n,))"""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    V = np.asfortranarray(V, dtype=float)
+    assert V.shape[0] == len(c)
+    XV = np.zeros((len(r), V.shape[1]), order="F")
+    rss = np.zeros(len(r))
+    lib().orc_fbm256_prod_and_rowSumsSq(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)),
+                                        _d(np.ascontiguousarray(center, dtype=float)),
+                                        _d(np.ascontiguousarray(scale, dtype=float)), _d(V),
+                                        C.c_int(V.shape[1]), _d(XV), _d(rss))
+    return XV, rss
+
+
+# --------------------------------------------------------------------------
+# R-level drivers (block loop + epilogue)
+
+def _blocks(m, block_size):
+    lo, up = cut_by_size(m, block_size)
+    return [(int(a) - 1, int(b)) for a, b in zip(lo, up)]  # python slices
+
+
+def snp_ibs(fbm, ind_row=None, ind_col=None, type="proportion", block_size=None):
+    """R/snp_ibs.R:42-104"""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    n, m = len(r), len(c)
+    block_size = block_size or block_size_default(fbm.shape[0])
+    IBS = np.zeros((n, n), order="F")
+    valid = np.zeros((n, n), order="F")
+    for a, b in _blocks(m, block_size):
+        increment_ibs_counts(IBS, valid, fbm, r, c[a:b])
+    if type == "raw_counts":
+        return dict(ibs=IBS, valid_n=valid)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        prop = IBS / valid
+    return prop if type == "proportion" else prop * m
+
+
+def snp_king(fbm, ind_row=None, ind_col=None, block_size=None):
+    """R/snp_king.R:32-103"""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    n, m = len(r), len(c)
+    block_size = block_size or block_size_default(fbm.shape[0]) * 4
+    K = np.zeros((n, n), order="F")
+    Ni = np.zeros((n, n), order="F")
+    for a, b in _blocks(m, block_size):
+        increment_king_numerator(K, Ni, fbm, r, c[a:b])
+    return king_epilogue(K, Ni)
+
+
+def king_epilogue(K, Ni):
+    """R/snp_king.R:79-101"""
+    Nj = Ni.T
+    mn = np.minimum(Ni, Nj)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn
+
+
+def snp_allele_sharing(fbm, ind_row=None, ind_col=None, block_size=None, emulate_as_pad_quirk=False):
+    """R/snp_allele_sharing.R:33-82.  emulate_as_pad_quirk=True reproduces what the
+    reference BINARY does at unequal block sizes (quirk Q1); the default is the
+    mathematically intended value that the reference's own test asserts."""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    n, m = len(r), len(c)
+    block_size = block_size or block_size_default(fbm.shape[0])
+    num = np.zeros((n, n), order="F")
+    den = np.zeros((n, n), order="F")
+    blocks = _blocks(m, block_size)
+    widest = max(b - a for a, b in blocks)
+    for a, b in blocks:
+        increment_as_counts(num, den, fbm, r, c[a:b],
+                            pad_quirk=emulate_as_pad_quirk and (b - a) < widest)
+    return as_epilogue(num, den)
+
+
+def as_epilogue(num, den):
+    """R/snp_allele_sharing.R:77-81"""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        res = 0.5 * (1 + num / den)
+    res[den == 0] = np.nan
+    return res
+
+
+def pairwise_grm(allele_sharing_mat):
+    """R/pairwise_grm.R:42-50"""
+    M = np.array(allele_sharing_mat, dtype=float, copy=True)
+    off = M.copy()
+    np.fill_diagonal(off, np.nan)
+    mb = np.nanmean(off)
+    return (M - mb) / (1 - mb) * 2
+
+
+def loci_alt_freq(fbm, ind_row=None, ind_col=None, ploidy=None, as_counts=False, block_size=None,
+                  code256=CODE_012):
+    """R/loci_alt_freq.R:328-379 (diploid / pseudohaploid path, >1 individual)"""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    ploidy = np.full(len(r), 2.0) if ploidy is None else np.asarray(ploidy, dtype=float)
+    block_size = block_size or len(c)
+    parts = [alt_freq_dip_pseudo_cpp(fbm, r, c[a:b], ploidy, as_counts, code256)
+             for a, b in _chunks(len(c), block_size)]
+    freq = np.vstack(parts)
+    return freq if as_counts else freq[:, 0]
+
+
+def _chunks(m, block_size):
+    """bigstatsr::big_apply splits `ind` with CutBySize semantics (recalled)."""
+    return _blocks(m, block_size)
+
+
+def loci_missingness(fbm, ind_row=None, ind_col=None, as_counts=False, code256=CODE_012):
+    """R/loci_missingness.R:97-134; the count itself is bigstatsr::big_counts
+    (third-party, recalled: per column, number of entries decoding to NA)."""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    gid = np.zeros(len(r), dtype=np.int32)
+    n_na = grouped_missingness_cpp(fbm, r, c, gid, 1, code256)[:, 0]
+    return n_na if as_counts else n_na / len(r)
+
+
+def combn2(G: int) -> np.ndarray:
+    """utils::combn(G, 2): 2 x P, 1-based, column order (1,2),(1,3),...,(G-1,G)
+    (R/pairwise_pop_fst.R:119)."""
+    cols = [(a, b) for a in range(1, G + 1) for b in range(a + 1, G + 1)]
+    return np.array(cols, dtype=np.int32).T.reshape(2, -1)
+
+
+def pairwise_pop_fst(fbm, ind_row, ind_col, groupIds, ngroups, ploidy=None, method="Hudson",
+                     by_locus=False, return_num_dem=False, code256=CODE_012):
+    """R/pairwise_pop_fst.R:116-161"""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    ploidy = np.full(len(r), 2.0) if ploidy is None else np.asarray(ploidy, dtype=float)
+    if return_num_dem:
+        by_locus = True
+    pf = grouped_summaries_dip_pseudo_cpp(fbm, r, c, groupIds, ngroups, ploidy, code256)
+    pairs = combn2(ngroups)
+    if method == "Hudson":
+        return pairwise_fst_hudson_loop(pairs, pf["n"], pf["freq_alt"], pf["freq_ref"], by_locus, return_num_dem)
+    if method == "Nei87":
+        return pairwise_fst_nei87_loop(pairs, pf["n"], pf["het_obs"], pf["freq_alt"], pf["freq_ref"], by_locus,
+                                       return_num_dem)
+    if method == "WC84":
+        return pairwise_fst_wc84_loop(pairs, pf["n"], pf["freq_alt"], pf["het_obs"], by_locus, return_num_dem)
+    raise ValueError(method)
+
+
+def pca_gram(fbm, ind_row=None, ind_col=None, code256=CODE_IMPUTE_PRED):
+    """center / scale (bigsnpr::snp_scaleBinom, recalled) and K = Z Z'
+    (bigstatsr::big_SVD, recalled); call site R/gt_pca_partialSVD.R:82-89."""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    n, m = len(r), len(c)
+    center = np.zeros(m)
+    scale = np.zeros(m)
+    K = np.zeros((n, n), order="F")
+    rc = lib().orc_pca_center_scale_gram(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)),
+                                         _d(center), _d(scale), _d(K))
+    if rc != 0:
+        raise ValueError("missing values or zero scale: big_SVD would stop")
+    return center, scale, K
+
+
+def square_frobenius(fbm, ind_row, ind_col, center, scale, code256=CODE_IMPUTE_PRED):
+    """R/square_frobenius.R:19-35"""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    return float(lib().orc_square_frobenius(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)),
+                                            _d(np.ascontiguousarray(center, dtype=float)),
+                                            _d(np.ascontiguousarray(scale, dtype=float))))
+
+
+def gt_pca_partialSVD(fbm, ind_row=None, ind_col=None, k=10, total_var=True, code256=CODE_IMPUTE_PRED):
+    """R/gt_pca_partialSVD.R:67-108 around bigstatsr::big_SVD (recalled):
+    eigen(K) -> d = sqrt(lambda_1..k), u = eigenvectors, v = Z'u/d."""
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    center, scale, K = pca_gram(fbm, r, c, code256)
+    w, U = np.linalg.eigh(K)
+    order = np.argsort(w)[::-1][:k]
+    d = np.sqrt(w[order])
+    u = np.asfortranarray(U[:, order])
+    v = np.zeros((len(c), k), order="F")
+    lib().orc_pca_loadings(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)), _d(center), _d(scale),
+                           _d(u), _d(d), C.c_int(k), _d(v))
+    out = dict(d=d, u=u, v=v, center=center, scale=scale)
+    if total_var:
+        out["square_frobenius"] = square_frobenius(fbm, r, c, center, scale, code256)
+    return out
+
+
+# --------------------------------------------------------------------------
+# "as the reference does it" CPU baseline: dense FP64 one-hot blocks and the
+# same 6 / 4 / 2 products per block through the threaded BLAS numpy links
+# (src/snp_ibs.cpp:67-72, src/snp_king.cpp:70-72, src/snp_as.cpp:64-65).
+
+def _onehots(fbm, r, c):
+    sub = fbm[np.ix_(r - 1, c - 1)]
+    return [(sub == v).astype(np.float64) for v in (0, 1, 2)]
+
+
+def blas_increment_ibs(K, K2, fbm, r, c):
+    g0, g1, g2 = _onehots(fbm, r, c)
+    K += 2 * (g2 @ g2.T + g1 @ g1.T + g0 @ g0.T) + g1 @ (g0 + g2).T + (g0 + g2) @ g1.T
+    v = g0 + g1 + g2
+    K2 += 2 * v @ v.T
+
+
+def blas_increment_king(K, Ni, fbm, r, c):
+    g0, g1, g2 = _onehots(fbm, r, c)
+    v = g0 + g1 + g2
+    K += g1 @ g1.T - 2 * (g0 @ g2.T + g2 @ g0.T)
+    Ni += g1 @ v.T
+
+
+def blas_increment_as(K, K2, fbm, r, c):
+    sub = fbm[np.ix_(r - 1, c - 1)]
+    na = (sub < 3).astype(np.float64)
+    dos = (sub.astype(np.float64) - 1.0) * na
+    K += dos @ dos.T
+    K2 += na @ na.T
+
+
+# --------------------------------------------------------------------------
+# synthetic panel (bit-identical to the HIP generator)
+
+def synth_fbm(seed: int, n: int, m: int, j0: int = 0, npop: int = 51, miss: float = 0.02,
+              imputed_bytes: bool = False) -> np.ndarray:
+    out = np.zeros((n, m), dtype=np.uint8, order="F")
+    thr = int(round(miss * 2 ** 32))
+    thr = min(thr, 2 ** 32 - 1)
+    lib().orc_synth_fbm(C.c_uint64(seed), C.c_int64(n), C.c_int64(m), C.c_int64(j0), C.c_int(npop),
+                        C.c_uint32(thr), C.c_int(int(imputed_bytes)), _p(out, C.c_uint8))
+    return out
