@@ -1,0 +1,187 @@
+/*
+ * tpg.h -- C ABI of the MI355X-native tidypopgen hot path (libtpg_hip.so).
+ *
+ * This is the drop-in boundary.  The reference crosses from R into native code
+ * through `.Call` on Rcpp-generated shims (R/RcppExports.R:4-91, registration
+ * table src/RcppExports.cpp:348-377); every entry point below states which of
+ * those native functions (and which R driver loop around it) it replaces.  An R
+ * shim that binds them is shown in INTEGRATION.md.
+ *
+ * Conventions (identical to the reference's):
+ *   - the genotype store is a bigstatsr FBM.code256: uint8, column-major,
+ *     element (i,j) at bytes[i + j*nrow];
+ *   - rowInd / colInd are 1-based int32 (as R passes them; src/snp_ibs.cpp:35);
+ *   - groupIds are 0-based int32 (R/loci_alt_freq.R:179);
+ *   - code256 is double[256], NA = any NaN.  The device path packs genotypes to
+ *     2 bits, so every non-NA entry of code256 that occurs must be 0, 1 or 2
+ *     (CODE_012 / CODE_IMPUTE_PRED both are); anything else -> TPG_EUNSUPPORTED.
+ *     code256 == NULL means "raw bytes": 0/1/2 valid, everything else missing,
+ *     which is what increment_{ibs,king,as}_counts do regardless of code256
+ *     (src/snp_ibs.cpp:47-54);
+ *   - all matrices are column-major doubles, as R stores them;
+ *   - output pointers may be host or device memory (hipMemcpyDefault).
+ *
+ * Every function returns 0 on success, a TPG_E* code otherwise; the message is
+ * available from tpg_last_error() (thread-local).  Nothing throws across the
+ * boundary.  One host thread per context at a time (R's main thread).
+ * There is NO CPU fallback: without a usable HIP device every call fails.
+ */
+#ifndef TPG_H
+#define TPG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPG_OK 0
+#define TPG_EINVAL 1       /* bad argument */
+#define TPG_EHIP 2         /* HIP runtime error (no device, OOM, launch failure) */
+#define TPG_EUNSUPPORTED 3 /* e.g. code256 value outside {0,1,2,NA} */
+#define TPG_ENUMERIC 4     /* e.g. missing value / zero scale in PCA (big_SVD stops too) */
+
+typedef struct tpg_ctx tpg_ctx;   /* one GPU, one stream */
+typedef struct tpg_fbm tpg_fbm;   /* FBM bytes resident in HBM */
+typedef struct tpg_view tpg_view; /* (FBM, rowInd, colInd, code256) packed to 2 bits in HBM */
+typedef struct tpg_pairwise tpg_pairwise; /* int32 N x N cross-product accumulators in HBM */
+
+const char* tpg_last_error(void);
+const char* tpg_version(void);
+
+/* ---- context ---------------------------------------------------------- */
+int tpg_ctx_create(int device, tpg_ctx** out);
+void tpg_ctx_destroy(tpg_ctx* ctx);
+/* use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream */
+int tpg_ctx_set_stream(tpg_ctx* ctx, void* hip_stream);
+int tpg_ctx_sync(tpg_ctx* ctx);
+/* per-kernel HIP-event timing (on the context's stream) */
+int tpg_prof_enable(tpg_ctx* ctx, int on);
+int tpg_prof_reset(tpg_ctx* ctx);
+/* total milliseconds and launch count of kernels whose name starts with `prefix` */
+int tpg_prof_get(tpg_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches);
+/* writes "name\tlaunches\ttotal_ms\n" lines into buf (truncated to cap) */
+int tpg_prof_dump(tpg_ctx* ctx, char* buf, size_t cap);
+
+/* ---- genotype store (replaces the mmapped FBM) -------- */
+int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, tpg_fbm** out);
+/* mmap bigstatsr's <backingfile>.bk and upload it */
+int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int64_t ncol, tpg_fbm** out);
+/* deterministic synthetic panel generated on the device (csrc/synth_common.h) */
+int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0, int npop,
+                  uint32_t miss_thresh, int imputed_bytes, tpg_fbm** out);
+int tpg_fbm_to_host(tpg_ctx* ctx, const tpg_fbm* fbm, uint8_t* bytes);
+void tpg_fbm_free(tpg_fbm* fbm);
+
+/* The (rowInd, colInd) view every reference kernel receives, packed once:
+ * rowInd NULL = all rows, colInd NULL = all columns. */
+int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n,
+                    const int32_t* colInd1, int64_t m, const double* code256, tpg_view** out);
+void tpg_view_free(tpg_view* v);
+int64_t tpg_view_n(const tpg_view* v);
+int64_t tpg_view_m(const tpg_view* v);
+/* unpack to one byte per genotype (0,1,2,3=NA), column-major n x m (tests) */
+int tpg_view_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* codes);
+
+/* ---- per-locus sweeps --------------------------------------------------- */
+/* genotype counts per locus: out is m x 4 int32 row-major {n0,n1,n2,nNA}
+ * (the counts behind a4/a6/a11; also bigstatsr::big_counts, R/loci_missingness.R:109-122) */
+int tpg_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out);
+/* replaces alt_freq_dip_pseudo_cpp (src/alt_freq_dip_pseudo_cpp.cpp:8-58) for the whole
+ * colInd at once (the big_apply block loop R/loci_alt_freq.R:351-359 collapses):
+ * out m x 2 = {n_alt | freq, n_valid} */
+int tpg_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const double* ploidy, int as_counts,
+                            double* out);
+/* replaces grouped_alt_freq_dip_pseudo_cpp (src/grouped_alt_freq_dip_pseudo_cpp.cpp:8-58):
+ * out m x 2G */
+int tpg_grouped_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0,
+                                    int ngroups, const double* ploidy, int as_counts, double* out);
+/* replaces grouped_missingness_cpp (src/grouped_missingness_cpp.cpp:8-33): out m x G */
+int tpg_grouped_missingness(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                            double* out);
+/* replaces grouped_summaries_dip_pseudo_cpp (src/grouped_summaries_dip_pseudo_cpp.cpp:11-63):
+ * four m x G outputs (any may be NULL) */
+int tpg_grouped_summaries_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0,
+                                     int ngroups, const double* ploidy, double* freq_alt,
+                                     double* freq_ref, double* n, double* het_obs);
+
+/* ---- pairwise population Fst --------------------------------------------- */
+#define TPG_FST_HUDSON 0
+#define TPG_FST_NEI87 1
+#define TPG_FST_WC84 2
+/* Fused path: grouped summaries + pair loop without materialising the m x G matrices
+ * (replaces R/pairwise_pop_fst.R:123-161).  pairs1 is 2 x P column-major, 1-based.
+ * fst_tot[P]; out_a / out_b are m x P (by_locus ratio or numerator / denominator), may be
+ * NULL when by_locus == 0. */
+int tpg_pairwise_pop_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                         const double* ploidy, int method, const int32_t* pairs1, int P, int by_locus,
+                         int return_num_dem, double* fst_tot, double* out_a, double* out_b);
+/* Literal mirrors of the three loop functions (src/pairwise_fst_hudson_loop.cpp:5-63,
+ * src/pairwise_fst_wc84_loop.cpp:5-121, src/pairwise_fst_nei87_loop.cpp:5-115): inputs are
+ * the m x G double matrices the reference passes; unused ones may be NULL. */
+int tpg_pairwise_fst_loop(tpg_ctx* ctx, int method, const int32_t* pairs1, int P, int64_t m, int G,
+                          const double* n, const double* freq_alt, const double* freq_ref,
+                          const double* het_obs, int by_locus, int return_num_dem, double* fst_tot,
+                          double* out_a, double* out_b);
+
+/* ---- pairwise individual matrices (IBS / KING / allele sharing / GRM) ---- */
+/* Accumulators for the four integer cross-products V=vv', D=dd', H=hh', A=hv'
+ * (v valid, d = dosage-1, h heterozygous), from which every count matrix of
+ * increment_ibs_counts / increment_king_numerator / increment_as_counts follows.
+ * If ext_buffer != NULL it must be device memory of tpg_pairwise_buffer_bytes(n)
+ * bytes (e.g. a torch tensor, so that the caller can all-reduce it over RCCL). */
+size_t tpg_pairwise_buffer_bytes(int64_t n);
+int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tpg_pairwise** out);
+void tpg_pairwise_free(tpg_pairwise* pw);
+int tpg_pairwise_zero(tpg_ctx* ctx, tpg_pairwise* pw);
+/* add loci [col_begin, col_end) of the view (0-based, end exclusive; -1 = m) */
+int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
+                            int64_t col_end);
+/* raw count matrices, n x n column-major doubles, any may be NULL:
+ * ibs / ibs_valid (snp_ibs raw_counts), king_num / n_Aa_i (snp_king), as_num / as_den */
+int tpg_pairwise_counts(tpg_ctx* ctx, const tpg_pairwise* pw, double* ibs, double* ibs_valid,
+                        double* king_num, double* n_Aa_i, double* as_num, double* as_den);
+/* epilogues of the R drivers */
+#define TPG_IBS_PROPORTION 0
+#define TPG_IBS_ADJUSTED_COUNTS 1
+int tpg_pairwise_ibs(tpg_ctx* ctx, const tpg_pairwise* pw, int type, int64_t m, double* out); /* R/snp_ibs.R:84-103 */
+int tpg_pairwise_king(tpg_ctx* ctx, const tpg_pairwise* pw, double* out);           /* R/snp_king.R:79-101 */
+int tpg_pairwise_allele_sharing(tpg_ctx* ctx, const tpg_pairwise* pw, double* out); /* R/snp_allele_sharing.R:77-81 */
+int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* out);            /* R/pairwise_grm.R:42-50 */
+
+/* Literal per-block mirrors of the three increment_* entry points
+ * (src/snp_ibs.cpp:22-74, src/snp_king.cpp:21-74, src/snp_as.cpp:22-67): the caller-owned
+ * n x n doubles are incremented in place; the scratch matrices of the reference are not needed.
+ * fbm_bytes is the host (mmapped) FBM. */
+int tpg_increment_ibs_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes,
+                             int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
+                             const int32_t* colInd1, int64_t m);
+int tpg_increment_king_numerator(tpg_ctx* ctx, double* K, double* N_Aa_i, const uint8_t* fbm_bytes,
+                                 int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
+                                 const int32_t* colInd1, int64_t m);
+int tpg_increment_as_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes,
+                            int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
+                            const int32_t* colInd1, int64_t m);
+
+/* ---- PCA (gt_pca_partialSVD) ---------------------------------------------- */
+/* center / scale of bigsnpr::snp_scaleBinom; TPG_ENUMERIC on a missing value or zero scale */
+int tpg_pca_center_scale(tpg_ctx* ctx, const tpg_view* v, double* center, double* scale);
+/* Gram matrix K = Z Z' (n x n) accumulated behind bigstatsr::big_SVD
+ * (call site R/gt_pca_partialSVD.R:82-89) */
+int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale, double* K);
+/* full partial SVD: d[k], u n x k, v m x k, center[m], scale[m]; square_frobenius may be NULL
+ * (R/square_frobenius.R:19-35) */
+int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,
+                        double* center, double* scale, double* square_frobenius);
+/* replaces fbm256_prod_and_rowSumsSq (src/fbm_prod_and_rowSumSq.cpp:10-47): V m x K,
+ * XV n x K, rss[n] */
+int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx* ctx, const tpg_view* v, const double* center,
+                                  const double* scale, const double* V, int K, double* XV, double* rss);
+int tpg_square_frobenius(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale,
+                         double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPG_H */

@@ -1,0 +1,293 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs,
+against the committed golden fixtures, and edge cases the reference tests cover."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tpg():
+    import tidypopgen_amd as t
+
+    t.default_context()
+    return t
+
+
+def _X(tpg, g):
+    return tpg.FBM.from_numpy(orc.fbm_from_genotypes(g))
+
+
+# ---------------------------------------------------------------- pack / synth
+def test_synth_matches_host_generator(tpg):
+    for (seed, n, m, G, imp) in ((3, 50, 200, 7, False), (9, 333, 1000, 51, True)):
+        X = tpg.FBM.synth(seed, n, m, npop=G, imputed_bytes=imp)
+        assert np.array_equal(X.to_numpy(), orc.synth_fbm(seed, n, m, npop=G, imputed_bytes=imp))
+    X = tpg.FBM.synth(3, 50, 80, j0=120, npop=7)
+    assert np.array_equal(X.to_numpy(), orc.synth_fbm(3, 50, 200, npop=7)[:, 120:])
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (12, 961), (129, 257), (300, 1000)])
+def test_pack_roundtrip_and_views(tpg, n, m):
+    fbm = orc.synth_fbm(5, n, m, npop=3, miss=0.1)
+    X = tpg.FBM.from_numpy(fbm)
+    assert np.array_equal(tpg.View(X).unpack(), fbm)  # also cross-checks T against L on the device
+    rng = np.random.default_rng(0)
+    rows = rng.permutation(n)[: max(1, n // 2)] + 1
+    cols = rng.permutation(m)[: max(1, m // 3)] + 1
+    assert np.array_equal(tpg.View(X, rows, cols).unpack(), fbm[np.ix_(rows - 1, cols - 1)])
+    # imputed code table: bytes 4..6 decode to 0..2, raw view keeps them missing
+    fbi = orc.synth_fbm(5, n, m, npop=3, miss=0.1, imputed_bytes=True)
+    Xi = tpg.FBM.from_numpy(fbi, code256=tpg.CODE_IMPUTE_PRED)
+    assert np.array_equal(tpg.View(Xi).unpack(), np.where(fbi > 3, fbi - 4, fbi))
+    assert np.array_equal(tpg.View(Xi, code256=None).unpack(), np.where(fbi > 2, 3, fbi))
+
+
+def test_view_errors(tpg):
+    X = tpg.FBM.from_numpy(orc.synth_fbm(1, 10, 20, npop=2))
+    with pytest.raises(tpg._lib.TpgError):
+        tpg.View(X, [0, 1], None)  # 1-based: 0 is out of range
+    with pytest.raises(tpg._lib.TpgError):
+        tpg.View(X, None, [21])
+    bad = tpg.CODE_012.copy()
+    bad[1] = 0.5  # dosage the 2-bit path cannot represent
+    with pytest.raises(tpg._lib.TpgError) as e:
+        tpg.View(X, None, None, code256=bad)
+    assert e.value.code == 3
+
+
+# ---------------------------------------------------------------- per-locus
+def test_alt_freq_reference_cases(tpg):
+    # tests/testthat/test_loci_freq.R:1-96
+    g = fx.FREQ_3x6
+    X = _X(tpg, g)
+    freq = np.nansum(g, axis=0) / (np.array([3, 3, 3, 2, 3, 1]) * 2)
+    assert np.array_equal(tpg.loci_alt_freq(X), freq)
+    counts = tpg.loci_alt_freq(X, as_counts=True)
+    assert np.array_equal(counts[:, 0] / counts[:, 1], freq)
+    f1 = tpg.loci_alt_freq(X, ind_row=[1, 3], ind_col=[1, 2, 4, 6])
+    assert np.array_equal(f1, np.nansum(g[[0, 2]][:, [0, 1, 3, 5]], axis=0) / (np.array([2, 2, 2, 1]) * 2))
+    f2 = tpg.loci_alt_freq(X, ind_row=[2, 3], ind_col=[1, 2, 5, 6])
+    assert np.isnan(f2[3]) and np.array_equal(f2[:3], np.nansum(g[1:][:, [0, 1, 4]], axis=0) / 4)
+    f3 = tpg.loci_alt_freq(_X(tpg, fx.FREQ2_3x6), ind_row=[2, 3])
+    assert np.isnan(f3[3]) and np.isnan(f3[5])
+
+
+def test_missingness_reference_cases(tpg):
+    # tests/testthat/test_loci_missingness.R:27-75
+    g = fx.FREQ_3x6
+    X = _X(tpg, g)
+    n_na = np.isnan(g).sum(axis=0)
+    assert np.array_equal(tpg.loci_missingness(X, as_counts=True), n_na)
+    assert np.array_equal(tpg.loci_missingness(X), n_na / 3)
+    assert np.array_equal(tpg.loci_missingness(X, ind_row=[2, 3], as_counts=True), np.isnan(g[1:]).sum(axis=0))
+
+
+@pytest.mark.parametrize("n,m,G,hap", [(7, 6, 3, False), (200, 1500, 5, False), (333, 2100, 51, False),
+                                       (150, 700, 40, True), (1000, 4000, 70, False)])
+def test_per_locus_and_grouped_bit_exact(tpg, n, m, G, hap):
+    fbm = orc.synth_fbm(21, n, m, npop=G, miss=0.05)
+    X = tpg.FBM.from_numpy(fbm)
+    rng = np.random.default_rng(1)
+    gid = rng.integers(0, G, n).astype(np.int32)
+    ploidy = np.full(n, 2.0)
+    if hap:
+        hapmask = rng.random(n) < 0.3
+        ploidy[hapmask] = 1.0
+        fbm = fbm.copy()
+        sub = fbm[hapmask]
+        sub[sub == 1] = 2  # pseudohaploid genotypes are 0 / 2
+        fbm[hapmask] = sub
+        X = tpg.FBM.from_numpy(fbm)
+    v = tpg.View(X)
+    for as_counts in (True, False):
+        a = tpg.alt_freq_dip_pseudo_cpp(v, ploidy, as_counts)
+        b = orc.alt_freq_dip_pseudo_cpp(fbm, None, None, ploidy, as_counts)
+        assert np.array_equal(a, b, equal_nan=True)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ga = tpg.grouped_alt_freq_dip_pseudo_cpp(v, gid, G, ploidy, as_counts)
+            gb = orc.grouped_alt_freq_dip_pseudo_cpp(fbm, None, None, gid, G, ploidy, as_counts)
+        assert np.array_equal(ga, gb, equal_nan=True)
+    assert np.array_equal(tpg.grouped_missingness_cpp(v, gid, G), orc.grouped_missingness_cpp(fbm, None, None, gid, G))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sa = tpg.grouped_summaries_dip_pseudo_cpp(v, gid, G, ploidy)
+        sb = orc.grouped_summaries_dip_pseudo_cpp(fbm, None, None, gid, G, ploidy)
+    for k in sb:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+    cnt = tpg.loci_counts(v)
+    for c in range(3):
+        assert np.array_equal(cnt[:, c], (fbm == c).sum(axis=0))
+    assert np.array_equal(cnt[:, 3], (fbm > 2).sum(axis=0))
+
+
+# ---------------------------------------------------------------- pairwise individual matrices
+def test_ibs_reference_cases_and_plink_golden(tpg):
+    # tests/testthat/test_snp_ibs.R:28-105
+    X = _X(tpg, fx.IBS_3x6)
+    raw = tpg.snp_ibs(X, type="raw_counts")
+    assert raw["ibs"][0, 1] == sum([1, 2, 2, 1, 1, 2])
+    sub = tpg.snp_ibs(X, ind_row=[1, 3], ind_col=[2, 3, 5, 6], type="raw_counts")
+    assert sub["ibs"][0, 1] == sum(np.array([1, 1, 2, 1, 2, 1])[[1, 2, 4, 5]])
+    fam = tpg.FBM.from_numpy(fx.families_fbm())
+    assert np.array_equal(np.round(tpg.snp_ibs(fam), 6), fx.plink_mibs())
+    assert np.array_equal(tpg.snp_ibs(fam, type="adjusted_counts"), orc.snp_ibs(fx.families_fbm(), type="adjusted_counts"))
+
+
+def test_king_reference_cases_and_golden(tpg):
+    # tests/testthat/test_snp_king.R:155-236
+    X = _X(tpg, fx.IBS_3x6)
+    assert np.array_equal(tpg.snp_king(X), fx.king_r(fx.IBS_3x6), equal_nan=True)
+    fam_h = fx.families_fbm()
+    Xf = fam_h.astype(float)
+    Xf[Xf == 3] = np.nan
+    k = tpg.snp_king(tpg.FBM.from_numpy(fam_h))
+    assert np.array_equal(k, fx.king_r(Xf), equal_nan=True)
+    assert np.nanmax(np.abs(k - fx.king_kin0_matrix())) < 1e-4
+
+
+def test_allele_sharing_and_grm_reference_cases(tpg):
+    # tests/testthat/test_pairwise_allele_sharing.R:29-47, test_pairwise_grm.R:33-41
+    X = _X(tpg, fx.AS_3x6)
+    assert np.allclose(tpg.snp_allele_sharing(X), fx.matching(fx.AS_3x6), rtol=0, atol=1e-15, equal_nan=True)
+    X7 = _X(tpg, fx.FST_7x6)
+    M = fx.matching(fx.FST_7x6)
+    off = M[~np.eye(7, dtype=bool)]
+    assert np.allclose(tpg.pairwise_grm(X7), 2 * (M - off.mean()) / (1 - off.mean()), rtol=0, atol=1e-14)
+    # a pair with no locus typed in common -> NA
+    g = np.array([[0, np.nan, 1, np.nan], [np.nan, 2, np.nan, 1], [1, 1, 1, 1]], dtype=float)
+    a = tpg.snp_allele_sharing(_X(tpg, g))
+    assert np.isnan(a[0, 1]) and np.isnan(a[1, 0]) and np.isnan(tpg.snp_ibs(_X(tpg, g))[0, 1])
+    assert np.array_equal(a, orc.snp_allele_sharing(orc.fbm_from_genotypes(g)), equal_nan=True)
+
+
+@pytest.mark.parametrize("n,m,miss", [(64, 128, 0.0), (65, 129, 0.05), (200, 3000, 0.02), (333, 5001, 0.3),
+                                      (700, 20000, 0.02)])
+def test_pairwise_counts_bit_exact_and_epilogues(tpg, n, m, miss):
+    fbm = orc.synth_fbm(31, n, m, npop=9, miss=miss, imputed_bytes=(n == 333))
+    X = tpg.FBM.from_numpy(fbm)
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, n)
+    pw.accumulate(v)
+    c = pw.counts()
+    K = np.zeros((n, n), order="F"); K2 = np.zeros((n, n), order="F")
+    orc.increment_ibs_counts(K, K2, fbm, None, None)
+    assert np.array_equal(c["ibs"], K) and np.array_equal(c["ibs_valid"], K2)
+    K[:] = 0; K2[:] = 0
+    orc.increment_king_numerator(K, K2, fbm, None, None)
+    assert np.array_equal(c["king_num"], K) and np.array_equal(c["n_Aa_i"], K2)
+    K[:] = 0; K2[:] = 0
+    orc.increment_as_counts(K, K2, fbm, None, None)
+    assert np.array_equal(c["as_num"], K) and np.array_equal(c["as_den"], K2)
+    # epilogues: same formulas, same operation order -> identical doubles
+    assert np.array_equal(pw.ibs("proportion"), orc.snp_ibs(fbm), equal_nan=True)
+    assert np.array_equal(pw.king(), orc.snp_king(fbm), equal_nan=True)
+    assert np.array_equal(pw.allele_sharing(), orc.snp_allele_sharing(fbm), equal_nan=True)
+    assert np.allclose(pw.grm(), orc.pairwise_grm(orc.snp_allele_sharing(fbm)), rtol=1e-12, atol=1e-13, equal_nan=True)
+
+
+def test_pairwise_block_invariance_and_subsets(tpg):
+    # block invariance (test_snp_ibs.R:35-36, test_snp_king.R:160-161): accumulate in aligned pieces
+    n, m = 150, 1000
+    fbm = orc.synth_fbm(41, n, m, npop=4)
+    X = tpg.FBM.from_numpy(fbm)
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, n)
+    pw.accumulate(v)
+    whole = pw.counts()
+    pw.zero()
+    for a, b in ((0, 256), (256, 640), (640, m)):
+        pw.accumulate(v, a, b)
+    parts = pw.counts()
+    for k in whole:
+        assert np.array_equal(whole[k], parts[k]), k
+    with pytest.raises(tpg._lib.TpgError):
+        pw.accumulate(v, 100, 300)  # unaligned start
+    # arbitrary row / locus subsets and orders (SURVEY.md §8a "other semantics")
+    rows = np.array([5, 3, 149, 77, 10, 11, 12], dtype=np.int32)
+    cols = np.random.default_rng(3).permutation(m)[:333].astype(np.int32) + 1
+    assert np.array_equal(tpg.snp_king(X, rows, cols), orc.snp_king(fbm, rows, cols), equal_nan=True)
+    assert np.array_equal(tpg.snp_ibs(X, rows, cols, type="raw_counts")["ibs"], orc.snp_ibs(fbm, rows, cols, type="raw_counts")["ibs"])
+
+
+def test_increment_mirrors(tpg):
+    fbm = fx.families_fbm()
+    n = 12
+    lo, up = orc.cut_by_size(961, 300)
+    cols = np.arange(1, 962, dtype=np.int32)
+    rows = np.arange(1, 13, dtype=np.int32)
+    for inc_t, inc_o in ((tpg.increment_ibs_counts, orc.increment_ibs_counts),
+                         (tpg.increment_king_numerator, orc.increment_king_numerator),
+                         (tpg.increment_as_counts, orc.increment_as_counts)):
+        A = np.zeros((n, n), order="F"); B = np.zeros((n, n), order="F")
+        Ao = np.zeros((n, n), order="F"); Bo = np.zeros((n, n), order="F")
+        for a, b in zip(lo, up):  # unequal blocks 240,240,241,240 as R/snp_ibs.R:59-82 would cut them
+            inc_t(A, B, fbm, rows, cols[a - 1:b])
+            inc_o(Ao, Bo, fbm, rows, cols[a - 1:b])
+        assert np.array_equal(A, Ao) and np.array_equal(B, Bo)
+
+
+# ---------------------------------------------------------------- Fst
+def test_fst_scikit_allel_golden(tpg):
+    # tests/testthat/test_pairwise_pop_fst.R:55-343
+    gid = fx.FST_GROUPS_2
+    for method, tag in (("Hudson", "fst_hudson"), ("WC84", "fst_wc")):
+        r = tpg.pairwise_pop_fst(_X(tpg, fx.FST_7x6), None, None, gid, 2, method=method, by_locus=True)
+        assert r["fst_tot"][0] == pytest.approx(float(fx.scikit(tag)), rel=0, abs=3e-16)
+        assert np.allclose(r["fst_locus"][:, 0], fx.scikit(tag + "_per_loc"), rtol=0, atol=3e-16)
+        mono = tpg.pairwise_pop_fst(_X(tpg, fx.FST_MONO_7x6), None, None, gid, 2, method=method)["fst_tot"]
+        assert mono[0] == pytest.approx(float(fx.scikit(tag + "_monomorphic")), rel=0, abs=3e-16)
+        a = tpg.pairwise_pop_fst(_X(tpg, fx.FST_MISSPOP_7x6), None, None, gid, 2, method=method)["fst_tot"]
+        b = tpg.pairwise_pop_fst(_X(tpg, fx.FST_MISSPOP_7x5), None, None, gid, 2, method=method)["fst_tot"]
+        assert a[0] == b[0]
+
+
+@pytest.mark.parametrize("n,m,G", [(7, 6, 3), (300, 2500, 6), (500, 3000, 51)])
+@pytest.mark.parametrize("method", ["Hudson", "WC84", "Nei87"])
+def test_fst_vs_oracle(tpg, n, m, G, method):
+    if n == 7:
+        fbm, gid = orc.fbm_from_genotypes(fx.FST_7x6), fx.FST_GROUPS_3
+    else:
+        fbm = orc.synth_fbm(51, n, m, npop=G, miss=0.05)
+        gid = (np.arange(n) % G).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        o_tot = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method)["fst_tot"]
+        o_loc = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method, by_locus=True)["fst_locus"]
+        o_nd = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method, return_num_dem=True)
+    t = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method, by_locus=True)
+    assert np.allclose(t["fst_tot"], o_tot, rtol=1e-12, atol=0, equal_nan=True)
+    assert np.array_equal(t["fst_locus"], o_loc, equal_nan=True)  # same statements, contraction off -> same bits
+    nd = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method, return_num_dem=True)
+    assert np.array_equal(nd["Fst_by_locus_num"], o_nd["Fst_by_locus_num"], equal_nan=True)
+    assert np.array_equal(nd["Fst_by_locus_den"], o_nd["Fst_by_locus_den"], equal_nan=True)
+    # literal loop mirrors fed with the oracle's summary matrices
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pf = orc.grouped_summaries_dip_pseudo_cpp(fbm, None, None, gid, G, np.full(n, 2.0))
+    pairs = tpg.combn2(G)
+    if method == "Hudson":
+        lm = tpg.pairwise_fst_hudson_loop(pairs, pf["n"], pf["freq_alt"], pf["freq_ref"])
+    elif method == "WC84":
+        lm = tpg.pairwise_fst_wc84_loop(pairs, pf["n"], pf["freq_alt"], pf["het_obs"])
+    else:
+        lm = tpg.pairwise_fst_nei87_loop(pairs, pf["n"], pf["het_obs"], pf["freq_alt"], pf["freq_ref"])
+    assert np.allclose(lm["fst_tot"], o_tot, rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_fst_pseudohaploid_hudson_only(tpg):
+    n, m, G = 120, 900, 4
+    fbm = orc.synth_fbm(61, n, m, npop=G, miss=0.05)
+    ploidy = np.full(n, 2.0)
+    ploidy[::3] = 1.0
+    sub = fbm[::3]
+    sub[sub == 1] = 0
+    fbm[::3] = sub
+    gid = (np.arange(n) % G).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        o = orc.pairwise_pop_fst(fbm, None, None, gid, G, ploidy=ploidy, method="Hudson")["fst_tot"]
+    assert np.allclose(tpg.pairwise_pop_fst(X, None, None, gid, G, ploidy=ploidy, method="Hudson")["fst_tot"], o, rtol=1e-12)
+    with pytest.raises(tpg._lib.TpgError):  # R/pairwise_pop_fst.R:113-115
+        tpg.pairwise_pop_fst(X, None, None, gid, G, ploidy=ploidy, method="WC84")

@@ -1,0 +1,76 @@
+"""ctypes binding of libtpg_hip.so (the C ABI declared in include/tpg.h).
+
+There is no CPU fallback: if the shared library has not been built, importing
+this module raises; if no HIP device is usable, creating a context raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtpg_hip.so")
+
+
+class TpgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[tpg error {code}] {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    import subprocess
+
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j8", "-s"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP extension first "
+        "(python -c 'import __graft_entry__ as g; g.build()' or make -C tidypopgen_amd/csrc). "
+        "tidypopgen_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+c_i32p = C.POINTER(C.c_int32)
+c_u8p = C.POINTER(C.c_uint8)
+c_f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+lib.tpg_last_error.restype = C.c_char_p
+lib.tpg_version.restype = C.c_char_p
+lib.tpg_pairwise_buffer_bytes.restype = C.c_size_t
+lib.tpg_pairwise_buffer_bytes.argtypes = [C.c_int64]
+lib.tpg_view_n.restype = C.c_int64
+lib.tpg_view_m.restype = C.c_int64
+lib.tpg_view_n.argtypes = [vp]
+lib.tpg_view_m.argtypes = [vp]
+for _name in ("tpg_ctx_destroy", "tpg_fbm_free", "tpg_view_free", "tpg_pairwise_free"):
+    getattr(lib, _name).restype = None
+    getattr(lib, _name).argtypes = [vp]
+
+# every symbol include/tpg.h declares (checked by tests/test_abi.py against the header)
+SYMBOLS = [
+    "tpg_last_error", "tpg_version", "tpg_ctx_create", "tpg_ctx_destroy", "tpg_ctx_set_stream", "tpg_ctx_sync",
+    "tpg_prof_enable", "tpg_prof_reset", "tpg_prof_get", "tpg_prof_dump", "tpg_fbm_from_host", "tpg_fbm_open_bk",
+    "tpg_fbm_synth", "tpg_fbm_to_host", "tpg_fbm_free", "tpg_view_create", "tpg_view_free", "tpg_view_n",
+    "tpg_view_m", "tpg_view_unpack", "tpg_loci_counts", "tpg_alt_freq_dip_pseudo",
+    "tpg_grouped_alt_freq_dip_pseudo", "tpg_grouped_missingness", "tpg_grouped_summaries_dip_pseudo",
+    "tpg_pairwise_pop_fst", "tpg_pairwise_fst_loop", "tpg_pairwise_buffer_bytes", "tpg_pairwise_create",
+    "tpg_pairwise_free", "tpg_pairwise_zero", "tpg_pairwise_accumulate", "tpg_pairwise_counts", "tpg_pairwise_ibs",
+    "tpg_pairwise_king", "tpg_pairwise_allele_sharing", "tpg_pairwise_grm", "tpg_increment_ibs_counts",
+    "tpg_increment_king_numerator", "tpg_increment_as_counts", "tpg_pca_center_scale", "tpg_pca_gram",
+    "tpg_pca_partial_svd", "tpg_fbm256_prod_and_rowSumsSq", "tpg_square_frobenius",
+]
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise TpgError(rc, lib.tpg_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,514 @@
+"""Host-side mirror of tidypopgen's interface for the genotype-matrix hot path.
+
+The reference's host language is R; R is not available in this image, so the
+host side above the C ABI is Python, with the reference's function names,
+argument meaning and error behaviour (an error is raised where the reference
+raises an R error):
+
+    snp_ibs / snp_king / snp_allele_sharing   R/snp_ibs.R:42, R/snp_king.R:32, R/snp_allele_sharing.R:33
+    pairwise_grm                              R/pairwise_grm.R:30
+    loci_alt_freq / loci_missingness          R/loci_alt_freq.R:328, R/loci_missingness.R:97
+    grouped_* kernels                         R/RcppExports.R:16-26
+    pairwise_pop_fst                          R/pairwise_pop_fst.R:71
+    gt_pca_partialSVD, fbm256_prod_and_rowSumsSq   R/gt_pca_partialSVD.R:67, R/predict_gt_pca.R:248
+
+Index vectors are 1-based (as in R) and matrices come back as Fortran-ordered
+numpy arrays (as R stores them).  All arithmetic runs on the GPU through
+libtpg_hip.so; nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+CODE_012 = np.full(256, np.nan)
+CODE_012[:3] = [0.0, 1.0, 2.0]
+CODE_IMPUTE_PRED = np.full(256, np.nan)
+CODE_IMPUTE_PRED[:3] = [0.0, 1.0, 2.0]
+CODE_IMPUTE_PRED[4:7] = [0.0, 1.0, 2.0]
+
+FST_METHODS = {"Hudson": 0, "Nei87": 1, "WC84": 2}
+
+
+def _ptr(x):
+    """numpy array -> its data pointer; int -> raw (device) pointer; None -> NULL."""
+    if x is None:
+        return C.c_void_p(None)
+    if isinstance(x, (int, np.integer)):
+        return C.c_void_p(int(x))
+    return C.c_void_p(x.ctypes.data)
+
+
+def _i32(x):
+    return None if x is None else np.ascontiguousarray(x, dtype=np.int32)
+
+
+def _f64(x):
+    return None if x is None else np.ascontiguousarray(x, dtype=np.float64)
+
+
+class Context:
+    """One GPU + one stream (tpg_ctx)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        check(lib.tpg_ctx_create(C.c_int(device), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def set_stream(self, hip_stream: Optional[int]):
+        check(lib.tpg_ctx_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def sync(self):
+        check(lib.tpg_ctx_sync(self.h))
+
+    def prof_enable(self, on: bool = True):
+        check(lib.tpg_prof_enable(self.h, C.c_int(int(on))))
+
+    def prof_reset(self):
+        check(lib.tpg_prof_reset(self.h))
+
+    def prof_get(self, prefix: str):
+        ms = C.c_double()
+        n = C.c_int64()
+        check(lib.tpg_prof_get(self.h, prefix.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def prof_dump(self) -> dict:
+        buf = C.create_string_buffer(1 << 16)
+        check(lib.tpg_prof_dump(self.h, buf, C.c_size_t(len(buf))))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split("\t")
+            out[name] = (int(n), float(ms))
+        return out
+
+    def close(self):
+        if self.h:
+            lib.tpg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class FBM:
+    """Genotype bytes resident in HBM (the role bigstatsr's mmapped FBM.code256 plays)."""
+
+    def __init__(self, ctx: Context, handle, nrow: int, ncol: int, code256=None):
+        self.ctx, self.h, self.nrow, self.ncol = ctx, handle, nrow, ncol
+        self.code256 = CODE_012 if code256 is None else np.asarray(code256, dtype=float)
+
+    @classmethod
+    def from_numpy(cls, bytes_2d, ctx: Optional[Context] = None, code256=None) -> "FBM":
+        ctx = ctx or default_context()
+        a = np.asarray(bytes_2d)
+        if a.dtype != np.uint8 or a.ndim != 2:
+            raise TypeError("FBM bytes must be a 2-D uint8 array (individuals x loci)")
+        a = np.asfortranarray(a)
+        h = C.c_void_p()
+        check(lib.tpg_fbm_from_host(ctx.h, _ptr(a), C.c_int64(a.shape[0]), C.c_int64(a.shape[1]), C.byref(h)))
+        return cls(ctx, h, a.shape[0], a.shape[1], code256)
+
+    @classmethod
+    def open_bk(cls, path: str, nrow: int, ncol: int, ctx: Optional[Context] = None, code256=None) -> "FBM":
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib.tpg_fbm_open_bk(ctx.h, path.encode(), C.c_int64(nrow), C.c_int64(ncol), C.byref(h)))
+        return cls(ctx, h, nrow, ncol, code256)
+
+    @classmethod
+    def synth(cls, seed: int, nrow: int, ncol: int, j0: int = 0, npop: int = 51, miss: float = 0.02,
+              imputed_bytes: bool = False, ctx: Optional[Context] = None, code256=None) -> "FBM":
+        ctx = ctx or default_context()
+        thr = min(int(round(miss * 2 ** 32)), 2 ** 32 - 1)
+        h = C.c_void_p()
+        check(lib.tpg_fbm_synth(ctx.h, C.c_uint64(seed), C.c_int64(nrow), C.c_int64(ncol), C.c_int64(j0),
+                                C.c_int(npop), C.c_uint32(thr), C.c_int(int(imputed_bytes)), C.byref(h)))
+        return cls(ctx, h, nrow, ncol, code256)
+
+    def to_numpy(self) -> np.ndarray:
+        out = np.zeros((self.nrow, self.ncol), dtype=np.uint8, order="F")
+        check(lib.tpg_fbm_to_host(self.ctx.h, self.h, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib.tpg_fbm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class View:
+    """(FBM, rowInd, colInd, code256) packed to 2 bits in HBM (tpg_view)."""
+
+    def __init__(self, X: FBM, ind_row=None, ind_col=None, code256="fbm"):
+        self.X = X
+        self.ctx = X.ctx
+        r, c = _i32(ind_row), _i32(ind_col)
+        if isinstance(code256, str):
+            code = _f64(X.code256)
+        else:
+            code = _f64(code256)  # None = raw bytes
+        h = C.c_void_p()
+        check(lib.tpg_view_create(self.ctx.h, X.h, _ptr(r), C.c_int64(0 if r is None else len(r)), _ptr(c),
+                                  C.c_int64(0 if c is None else len(c)), _ptr(code), C.byref(h)))
+        self.h = h
+        self.n = int(lib.tpg_view_n(h))
+        self.m = int(lib.tpg_view_m(h))
+
+    def unpack(self) -> np.ndarray:
+        out = np.zeros((self.n, self.m), dtype=np.uint8, order="F")
+        check(lib.tpg_view_unpack(self.ctx.h, self.h, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib.tpg_view_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Pairwise:
+    """Integer N x N cross-product accumulators (tpg_pairwise)."""
+
+    def __init__(self, ctx: Context, n: int, ext_buffer: Optional[int] = None):
+        self.ctx, self.n = ctx, n
+        h = C.c_void_p()
+        check(lib.tpg_pairwise_create(ctx.h, C.c_int64(n), C.c_void_p(ext_buffer), C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def buffer_bytes(n: int) -> int:
+        return int(lib.tpg_pairwise_buffer_bytes(C.c_int64(n)))
+
+    def zero(self):
+        check(lib.tpg_pairwise_zero(self.ctx.h, self.h))
+
+    def accumulate(self, view: View, col_begin: int = 0, col_end: int = -1):
+        check(lib.tpg_pairwise_accumulate(self.ctx.h, self.h, view.h, C.c_int64(col_begin), C.c_int64(col_end)))
+
+    def _mat(self):
+        return np.zeros((self.n, self.n), order="F")
+
+    def counts(self, which=("ibs", "ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den")) -> dict:
+        names = ("ibs", "ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den")
+        outs = {k: self._mat() for k in which}
+        check(lib.tpg_pairwise_counts(self.ctx.h, self.h, *[_ptr(outs.get(k)) for k in names]))
+        return outs
+
+    def ibs(self, type: str = "proportion", m: int = 0) -> np.ndarray:
+        out = self._mat()
+        check(lib.tpg_pairwise_ibs(self.ctx.h, self.h, C.c_int(0 if type == "proportion" else 1), C.c_int64(m), _ptr(out)))
+        return out
+
+    def king(self) -> np.ndarray:
+        out = self._mat()
+        check(lib.tpg_pairwise_king(self.ctx.h, self.h, _ptr(out)))
+        return out
+
+    def allele_sharing(self) -> np.ndarray:
+        out = self._mat()
+        check(lib.tpg_pairwise_allele_sharing(self.ctx.h, self.h, _ptr(out)))
+        return out
+
+    def grm(self) -> np.ndarray:
+        out = self._mat()
+        check(lib.tpg_pairwise_grm(self.ctx.h, self.h, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib.tpg_pairwise_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+# R-level functions
+
+def _raw_view(X: FBM, ind_row, ind_col) -> View:
+    # increment_{ibs,king,as}_counts compare the RAW bytes with 0/1/2 (src/snp_ibs.cpp:47-54)
+    return View(X, ind_row, ind_col, code256=None)
+
+
+def _pairwise_pass(X: FBM, ind_row, ind_col):
+    v = _raw_view(X, ind_row, ind_col)
+    pw = Pairwise(X.ctx, v.n)
+    pw.accumulate(v)
+    return v, pw
+
+
+def snp_ibs(X: FBM, ind_row=None, ind_col=None, type: str = "proportion", block_size=None):
+    """R/snp_ibs.R:42-104.  block_size is accepted for signature compatibility; the whole locus
+    range is swept in one device pass (results do not depend on it)."""
+    if type not in ("proportion", "adjusted_counts", "raw_counts"):
+        raise ValueError("'arg' should be one of 'proportion', 'adjusted_counts', 'raw_counts'")
+    v, pw = _pairwise_pass(X, ind_row, ind_col)
+    if type == "raw_counts":
+        c = pw.counts(("ibs", "ibs_valid"))
+        return dict(ibs=c["ibs"], valid_n=c["ibs_valid"])
+    return pw.ibs(type, v.m)
+
+
+def snp_king(X: FBM, ind_row=None, ind_col=None, block_size=None):
+    """R/snp_king.R:32-103"""
+    _, pw = _pairwise_pass(X, ind_row, ind_col)
+    return pw.king()
+
+
+def snp_allele_sharing(X: FBM, ind_row=None, ind_col=None, block_size=None):
+    """R/snp_allele_sharing.R:33-82 (the mathematically intended value; reference quirk Q1 of
+    SURVEY.md §8a is NOT reproduced)."""
+    _, pw = _pairwise_pass(X, ind_row, ind_col)
+    return pw.allele_sharing()
+
+
+def pairwise_grm(X: FBM, ind_row=None, ind_col=None, block_size=None):
+    """R/pairwise_grm.R:30-51 on top of snp_allele_sharing"""
+    _, pw = _pairwise_pass(X, ind_row, ind_col)
+    return pw.grm()
+
+
+def increment_ibs_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] = None):
+    """Literal mirror of src/snp_ibs.cpp:22-74 (k, k2 are incremented in place; X_bytes is the host FBM)."""
+    return _increment(lib.tpg_increment_ibs_counts, k, k2, X_bytes, rowInd, colInd, ctx)
+
+
+def increment_king_numerator(k, n_Aa_i, X_bytes, rowInd, colInd, ctx: Optional[Context] = None):
+    """Literal mirror of src/snp_king.cpp:21-74"""
+    return _increment(lib.tpg_increment_king_numerator, k, n_Aa_i, X_bytes, rowInd, colInd, ctx)
+
+
+def increment_as_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] = None):
+    """Literal mirror of src/snp_as.cpp:22-67"""
+    return _increment(lib.tpg_increment_as_counts, k, k2, X_bytes, rowInd, colInd, ctx)
+
+
+def _increment(fn, a, b, X_bytes, rowInd, colInd, ctx):
+    ctx = ctx or default_context()
+    X_bytes = np.asarray(X_bytes)
+    assert X_bytes.dtype == np.uint8 and X_bytes.flags.f_contiguous
+    assert a.flags.f_contiguous and b.flags.f_contiguous and a.dtype == np.float64 and b.dtype == np.float64
+    r, c = _i32(rowInd), _i32(colInd)
+    check(fn(ctx.h, _ptr(a), _ptr(b), _ptr(X_bytes), C.c_int64(X_bytes.shape[0]), C.c_int64(X_bytes.shape[1]),
+             _ptr(r), C.c_int64(len(r)), _ptr(c), C.c_int64(len(c))))
+
+
+def _ploidy(v: View, ploidy):
+    return np.full(v.n, 2.0) if ploidy is None else _f64(ploidy)
+
+
+def loci_counts(v: View) -> np.ndarray:
+    out = np.zeros((v.m, 4), dtype=np.int32)
+    check(lib.tpg_loci_counts(v.ctx.h, v.h, _ptr(out)))
+    return out
+
+
+def alt_freq_dip_pseudo_cpp(v: View, ploidy=None, as_counts: bool = False) -> np.ndarray:
+    """src/alt_freq_dip_pseudo_cpp.cpp:8-58 -> (m, 2)"""
+    out = np.zeros((v.m, 2), order="F")
+    check(lib.tpg_alt_freq_dip_pseudo(v.ctx.h, v.h, _ptr(_ploidy(v, ploidy)), C.c_int(int(as_counts)), _ptr(out)))
+    return out
+
+
+def loci_alt_freq(X: FBM, ind_row=None, ind_col=None, ploidy=None, as_counts: bool = False, block_size=None):
+    """R/loci_alt_freq.R:328-379"""
+    v = View(X, ind_row, ind_col)
+    freq = alt_freq_dip_pseudo_cpp(v, ploidy, as_counts)
+    return freq if as_counts else freq[:, 0]
+
+
+def loci_missingness(X: FBM, ind_row=None, ind_col=None, as_counts: bool = False, block_size=None):
+    """R/loci_missingness.R:97-134"""
+    v = View(X, ind_row, ind_col)
+    n_na = loci_counts(v)[:, 3].astype(float)
+    return n_na if as_counts else n_na / v.n
+
+
+def grouped_alt_freq_dip_pseudo_cpp(v: View, groupIds, ngroups: int, ploidy=None, as_counts: bool = False):
+    """src/grouped_alt_freq_dip_pseudo_cpp.cpp:8-58 -> (m, 2G)"""
+    out = np.zeros((v.m, 2 * ngroups), order="F")
+    check(lib.tpg_grouped_alt_freq_dip_pseudo(v.ctx.h, v.h, _ptr(_i32(groupIds)), C.c_int(ngroups),
+                                              _ptr(_ploidy(v, ploidy)), C.c_int(int(as_counts)), _ptr(out)))
+    return out
+
+
+def grouped_missingness_cpp(v: View, groupIds, ngroups: int):
+    """src/grouped_missingness_cpp.cpp:8-33 -> (m, G)"""
+    out = np.zeros((v.m, ngroups), order="F")
+    check(lib.tpg_grouped_missingness(v.ctx.h, v.h, _ptr(_i32(groupIds)), C.c_int(ngroups), _ptr(out)))
+    return out
+
+
+def grouped_summaries_dip_pseudo_cpp(v: View, groupIds, ngroups: int, ploidy=None) -> dict:
+    """src/grouped_summaries_dip_pseudo_cpp.cpp:11-63"""
+    outs = [np.zeros((v.m, ngroups), order="F") for _ in range(4)]
+    check(lib.tpg_grouped_summaries_dip_pseudo(v.ctx.h, v.h, _ptr(_i32(groupIds)), C.c_int(ngroups),
+                                               _ptr(_ploidy(v, ploidy)), *[_ptr(o) for o in outs]))
+    return dict(freq_alt=outs[0], freq_ref=outs[1], n=outs[2], het_obs=outs[3])
+
+
+def combn2(G: int) -> np.ndarray:
+    """utils::combn(G, 2) (R/pairwise_pop_fst.R:119): 2 x P, 1-based"""
+    cols = [(a, b) for a in range(1, G + 1) for b in range(a + 1, G + 1)]
+    return np.array(cols, dtype=np.int32).T.reshape(2, -1)
+
+
+def _fst_outputs(m, P, by_locus, return_num_dem):
+    tot = np.zeros(P)
+    a = np.zeros((m, P), order="F") if by_locus else None
+    b = np.zeros((m, P), order="F") if return_num_dem else None
+    return tot, a, b
+
+
+def _fst_result(tot, a, b, by_locus, return_num_dem):
+    if return_num_dem:
+        return dict(Fst_by_locus_num=a, Fst_by_locus_den=b)
+    return dict(fst_locus=a if by_locus else np.zeros((0, 0)), fst_tot=tot)
+
+
+def pairwise_pop_fst(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=None, method: str = "Hudson",
+                     by_locus: bool = False, return_num_dem: bool = False, pairwise_combn=None):
+    """R/pairwise_pop_fst.R:71-161 (numeric part; the tidy / matrix formatting is out of scope)"""
+    if method not in FST_METHODS:
+        raise ValueError("'arg' should be one of 'Hudson', 'Nei87', 'WC84'")
+    if not isinstance(return_num_dem, (bool, np.bool_)):
+        raise ValueError("return_num_dem must be a logical value (TRUE or FALSE)")
+    if return_num_dem:
+        by_locus = True
+    v = View(X, ind_row, ind_col)
+    pairs = combn2(ngroups) if pairwise_combn is None else np.asarray(pairwise_combn, dtype=np.int32)
+    pairs_c = np.ascontiguousarray(pairs.T)  # (P, 2) row-major == 2 x P column-major
+    P = pairs_c.shape[0]
+    tot, a, b = _fst_outputs(v.m, P, by_locus, return_num_dem)
+    check(lib.tpg_pairwise_pop_fst(v.ctx.h, v.h, _ptr(_i32(groupIds)), C.c_int(ngroups), _ptr(_ploidy(v, ploidy)),
+                                   C.c_int(FST_METHODS[method]), _ptr(pairs_c), C.c_int(P), C.c_int(int(by_locus)),
+                                   C.c_int(int(return_num_dem)), _ptr(tot), _ptr(a), _ptr(b)))
+    return _fst_result(tot, a, b, by_locus, return_num_dem)
+
+
+def _fst_loop(method, pairwise_combn, n, freq_alt, freq_ref, het_obs, by_locus, return_num_dem, ctx):
+    ctx = ctx or default_context()
+    pairs_c = np.ascontiguousarray(np.asarray(pairwise_combn, dtype=np.int32).T)
+    P = pairs_c.shape[0]
+    n = np.asfortranarray(n, dtype=float)
+    m, G = n.shape
+    mats = [None if x is None else np.asfortranarray(x, dtype=float) for x in (freq_alt, freq_ref, het_obs)]
+    tot, a, b = _fst_outputs(m, P, by_locus or return_num_dem, return_num_dem)
+    check(lib.tpg_pairwise_fst_loop(ctx.h, C.c_int(FST_METHODS[method]), _ptr(pairs_c), C.c_int(P), C.c_int64(m),
+                                    C.c_int(G), _ptr(n), *[_ptr(x) for x in mats], C.c_int(int(by_locus)),
+                                    C.c_int(int(return_num_dem)), _ptr(tot), _ptr(a), _ptr(b)))
+    return _fst_result(tot, a, b, by_locus or return_num_dem, return_num_dem)
+
+
+def pairwise_fst_hudson_loop(pairwise_combn, n, freq_alt, freq_ref, by_locus=False, return_num_dem=False, ctx=None):
+    """src/pairwise_fst_hudson_loop.cpp:5-63"""
+    return _fst_loop("Hudson", pairwise_combn, n, freq_alt, freq_ref, None, by_locus, return_num_dem, ctx)
+
+
+def pairwise_fst_wc84_loop(pairwise_combn, n, freq_alt, het_obs, by_locus=False, return_num_dem=False, ctx=None):
+    """src/pairwise_fst_wc84_loop.cpp:5-121"""
+    return _fst_loop("WC84", pairwise_combn, n, freq_alt, None, het_obs, by_locus, return_num_dem, ctx)
+
+
+def pairwise_fst_nei87_loop(pairwise_combn, n, het_obs, freq_alt, freq_ref, by_locus=False, return_num_dem=False,
+                            ctx=None):
+    """src/pairwise_fst_nei87_loop.cpp:5-115"""
+    return _fst_loop("Nei87", pairwise_combn, n, freq_alt, freq_ref, het_obs, by_locus, return_num_dem, ctx)
+
+
+# ---------------------------------------------------------------------------
+# PCA
+
+def pca_center_scale(v: View):
+    center, scale = np.zeros(v.m), np.zeros(v.m)
+    check(lib.tpg_pca_center_scale(v.ctx.h, v.h, _ptr(center), _ptr(scale)))
+    return center, scale
+
+
+def pca_gram(v: View, center, scale) -> np.ndarray:
+    K = np.zeros((v.n, v.n), order="F")
+    check(lib.tpg_pca_gram(v.ctx.h, v.h, _ptr(_f64(center)), _ptr(_f64(scale)), _ptr(K)))
+    return K
+
+
+def gt_pca_partialSVD(X: FBM, ind_row=None, ind_col=None, k: int = 10, total_var: bool = True,
+                      code256=CODE_IMPUTE_PRED) -> dict:
+    """R/gt_pca_partialSVD.R:67-108: the imputed code table is switched on (:74-77), then
+    bigstatsr::big_SVD with bigsnpr::snp_scaleBinom."""
+    v = View(X, ind_row, ind_col, code256=code256)
+    d = np.zeros(k)
+    u = np.zeros((v.n, k), order="F")
+    vl = np.zeros((v.m, k), order="F")
+    center, scale = np.zeros(v.m), np.zeros(v.m)
+    fro = C.c_double()
+    check(lib.tpg_pca_partial_svd(v.ctx.h, v.h, C.c_int(k), _ptr(d), _ptr(u), _ptr(vl), _ptr(center), _ptr(scale),
+                                  C.byref(fro) if total_var else None))
+    out = dict(d=d, u=u, v=vl, center=center, scale=scale, method="partialSVD")
+    if total_var:
+        out["square_frobenius"] = fro.value
+    return out
+
+
+def fbm256_prod_and_rowSumsSq(X: FBM, ind_row, ind_col, center, scale, V, code256="fbm"):
+    """src/fbm_prod_and_rowSumSq.cpp:10-47 -> (XV (n, K), rowSumsSq (n,))"""
+    v = View(X, ind_row, ind_col, code256=code256)
+    V = np.asfortranarray(V, dtype=float)
+    if V.shape[0] != v.m:
+        raise ValueError("Incompatibility between dimensions.")  # bigstatsr myassert_size
+    XV = np.zeros((v.n, V.shape[1]), order="F")
+    rss = np.zeros(v.n)
+    check(lib.tpg_fbm256_prod_and_rowSumsSq(v.ctx.h, v.h, _ptr(_f64(center)), _ptr(_f64(scale)), _ptr(V),
+                                            C.c_int(V.shape[1]), _ptr(XV), _ptr(rss)))
+    return XV, rss
+
+
+def square_frobenius(X: FBM, ind_row, ind_col, center, scale, code256=CODE_IMPUTE_PRED) -> float:
+    """R/square_frobenius.R:19-35"""
+    v = View(X, ind_row, ind_col, code256=code256)
+    center, scale = _f64(center), _f64(scale)
+    if len(center) != v.m or len(scale) != v.m:
+        raise ValueError("center and scale must be the same length as the number of columns in the matrix")
+    out = C.c_double()
+    check(lib.tpg_square_frobenius(v.ctx.h, v.h, _ptr(center), _ptr(scale), C.byref(out)))
+    return out.value
+
+
+def block_size(n: int, ncores: int = 1) -> int:
+    """bigstatsr::block_size (recalled)"""
+    return max(1, int(math.floor(1024.0 ** 3 / (8.0 * n * ncores))))

@@ -1,0 +1,167 @@
+// common.h -- internal declarations shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tpg.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing (nothing throws across the C ABI)
+void tpg_set_error(const char* fmt, ...);
+
+#define TPG_HIP(call)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (call);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      tpg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e));     \
+      return TPG_EHIP;                                                                       \
+    }                                                                                        \
+  } while (0)
+
+#define TPG_REQUIRE(cond, code, ...)  \
+  do {                                \
+    if (!(cond)) {                    \
+      tpg_set_error(__VA_ARGS__);     \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+#define TPG_TRY(call)          \
+  do {                         \
+    int _rc = (call);          \
+    if (_rc != TPG_OK) return _rc; \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+struct ProfRec {
+  std::string name;
+  hipEvent_t start, stop;
+};
+
+struct tpg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool prof = false;
+  std::vector<ProfRec> prof_pending;
+  std::map<std::string, std::pair<double, int64_t>> prof_acc;  // name -> (ms, launches)
+  std::vector<hipEvent_t> event_pool;
+  int num_cu = 256;
+};
+
+struct ProfScope {
+  tpg_ctx* ctx;
+  ProfRec rec;
+  bool on;
+  ProfScope(tpg_ctx* c, const char* name);
+  ~ProfScope();
+};
+int tpg_prof_resolve(tpg_ctx* ctx);
+
+// Launch a kernel on the context's stream, bracketed by HIP events when profiling is on.
+#define TPG_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                          \
+  do {                                                                                  \
+    ProfScope _ps((ctx), (name));                                                       \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);        \
+  } while (0)
+
+#define TPG_CHECK_LAUNCH() TPG_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------
+// HBM layout of a packed view (see DESIGN.md "Data layout").
+//
+// A *fragment block* is 1 KiB = 64 lanes x 16 B.  Lane l = (r = l & 31, h = l >> 5)
+// holds 4 dwords s = 0..3; dword s packs 16 two-bit codes, element e = 4k + b stored at
+// bits [8b + 2k, 8b + 2k + 1], so that (w >> 2k) & 0x03030303 is the 4 code bytes of MFMA
+// operand register k.  One dword is exactly the 16-deep K slice that lane (r, h) feeds to
+// v_mfma_i32_32x32x32_i8 for row/column r.
+//
+//   T ("individual-tiled", contraction over loci: pairwise N x N, PCA Gram, Z.V):
+//     block (rt, kg): lane (r,h), dword s, element e  <->  individual 32 rt + r,
+//     locus 128 kg + 32 s + 16 h + e.          address: ((rt * KG + kg) * 64 + lane) * 16 B
+//   L ("locus-tiled", contraction over individuals: per-locus / per-group counts, Z'u):
+//     block (lt, q):  lane (r,h), dword s, element e  <->  locus 32 lt + r,
+//     individual 128 q + 32 s + 16 h + e.      address: ((lt * Q + q) * 64 + lane) * 16 B
+//
+// Codes: 0,1,2 = alt-allele dosage, 3 = missing.  Padding (individuals >= n, loci >= m) is 3.
+struct tpg_fbm {
+  tpg_ctx* ctx;
+  uint8_t* d_bytes;
+  int64_t nrow, ncol;
+};
+
+struct tpg_view {
+  tpg_ctx* ctx;
+  int64_t n, m;    // kept individuals / loci
+  int64_t Q, KG;   // ceil(n/128), ceil(m/128)
+  uint4* T;        // (4Q) row tiles x KG blocks
+  uint4* L;        // (4KG) locus tiles x Q blocks
+  size_t bytes_each;
+};
+
+// tile-packed int32 accumulators of the pairwise kernel: per unit (64-row super-tile I, 32-column
+// tile jt >= 2I) 5 products x 2 sub-tiles x 16 accumulator registers x 64 lanes (MFMA C/D order)
+#define TPG_PW_PRODUCTS 5  // V, D, H, HV (= A[i][j]), VH (= A[j][i])
+#define TPG_PW_TILE_INTS (TPG_PW_PRODUCTS * 2 * 16 * 64)
+struct tpg_pairwise {
+  tpg_ctx* ctx;
+  int64_t n;
+  int64_t nst;  // super-tiles of 64 individuals
+  int64_t ntp;  // number of (I, jt) units = nst*(nst+1)
+  int32_t* acc;
+  bool owns;
+};
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// device allocation helpers
+template <typename T>
+static inline int tpg_dmalloc(T** p, size_t count) {
+  TPG_HIP(hipMalloc((void**)p, count * sizeof(T) > 0 ? count * sizeof(T) : 16));
+  return TPG_OK;
+}
+
+// Output buffer that may be host or device memory: kernels write to dev(); commit() copies back
+// if the user's pointer is not device memory.
+bool tpg_is_device_ptr(const void* p);
+struct OutBuf {
+  void* user = nullptr;
+  void* d = nullptr;
+  size_t bytes = 0;
+  bool owned = false;
+  int init(void* user_ptr, size_t nbytes);
+  int commit(tpg_ctx* ctx);  // async copy on ctx stream (+ sync) when user is host memory
+  ~OutBuf();
+  template <typename T> T* dev() { return (T*)d; }
+};
+// Input buffer: host or device pointer -> device pointer
+struct InBuf {
+  const void* d = nullptr;
+  void* owned_ptr = nullptr;
+  int init(tpg_ctx* ctx, const void* user_ptr, size_t nbytes);
+  ~InBuf();
+  template <typename T> const T* dev() { return (const T*)d; }
+};
+
+// ---- cross-TU entry points (one per .hip file) -----------------------------
+int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,
+                    const uint8_t* d_lut, tpg_view* v);
+int tpg_launch_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* d_codes, int from_L);
+int tpg_launch_synth(tpg_ctx* ctx, uint8_t* d_bytes, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0,
+                     int npop, uint32_t miss_thresh, int imputed_bytes);
+
+// per-locus
+int tpg_launch_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* d_counts /* m x 4 */);
+// class-wise counts via MFMA: d_cls[n] in [0, nclass) ; out cnt[3][Mpad][Cpad] (n1, n2, nvalid)
+struct GroupedCounts {
+  int32_t* cnt = nullptr;
+  int64_t Mpad = 0;  // 32 * n_lt
+  int Cpad = 0;      // 32 * ceil(nclass/32)
+  int nclass = 0;
+  ~GroupedCounts();
+};
+int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, int nclass, GroupedCounts* out);

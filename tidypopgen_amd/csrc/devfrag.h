@@ -1,0 +1,28 @@
+// devfrag.h -- device-side helpers for the 2-bit fragment layout (see common.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// v_perm_b32 used as a 4-entry byte lookup: selector bytes 0..3 pick bytes of `lut`.
+// LUT byte c = value for code c (0,1,2 = dosage, 3 = missing).
+#define TPG_LUT_V 0x00010101u   // valid:        1,1,1,0
+#define TPG_LUT_H 0x00000100u   // heterozygous: 0,1,0,0
+#define TPG_LUT_E2 0x00010000u  // hom alt:      0,0,1,0
+#define TPG_LUT_D 0x000100FFu   // dosage - 1:  -1,0,1,0
+#define TPG_LUT_G 0x00020100u   // dosage:       0,1,2,0
+
+__device__ __forceinline__ uint32_t tpg_codes(uint32_t w, int k) { return (w >> (2 * k)) & 0x03030303u; }
+
+__device__ __forceinline__ int tpg_lut(uint32_t lut, uint32_t codes) {
+  return (int)__builtin_amdgcn_perm(0u, lut, codes);
+}
+
+// bit position of element e (0..15) inside a packed dword
+__host__ __device__ __forceinline__ int tpg_elem_shift(int e) { return 8 * (e & 3) + 2 * (e >> 2); }
+
+// MFMA 32x32 C/D register -> row inside the 32x32 tile (col = lane & 31)
+__device__ __forceinline__ int tpg_cd_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }

@@ -1,0 +1,280 @@
+// fst.hip -- pairwise population Fst (Hudson / WC84 / Nei87).
+//
+// Replaces pairwise_fst_hudson_loop (src/pairwise_fst_hudson_loop.cpp:5-63),
+// pairwise_fst_wc84_loop (src/pairwise_fst_wc84_loop.cpp:5-121), pairwise_fst_nei87_loop
+// (src/pairwise_fst_nei87_loop.cpp:5-115) and, in the fused entry point, the m x G summary
+// matrices of grouped_summaries_dip_pseudo_cpp that feed them (R/pairwise_pop_fst.R:123-161).
+//
+// The per-locus per-pair arithmetic is the reference's, statement for statement, in FP64 with
+// FMA contraction off (this file is compiled with -ffp-contract=off), so by-locus values match
+// bit for bit; only the order of the sum over loci differs (fixed: locus chunks are summed per
+// workgroup in ascending order, workgroup partials are summed in ascending order by one thread).
+//
+// Work decomposition: a workgroup stages the (n, p, h) doubles of LB loci x G populations in LDS
+// (layout [locus][population]: threads of a wave hold consecutive pairs, i.e. the same pop1
+// (broadcast) and consecutive pop2 (conflict-free)), then every thread owns one population pair
+// and walks the LB loci.  FP64-VALU bound (about 12 / 45 / 60 flops per pair-locus for
+// Hudson / WC84 / Nei87), not HBM bound: the counts it reads are 12 B per locus-population.
+#include <math.h>
+
+#include "common.h"
+
+#define FST_NAN __longlong_as_double(0x7FF8000000000000ll)
+
+template <int METHOD>
+__device__ __forceinline__ void fst_terms(double n1, double p1, double h1, double n2, double p2, double h2,
+                                          double& num, double& den) {
+  if (METHOD == TPG_FST_HUDSON) {
+    // src/pairwise_fst_hudson_loop.cpp:27-32
+    const double q1 = 1 - p1, q2 = 1 - p2;  // freq_ref = 1 - freq_alt (grouped_summaries :53)
+    const double d = p1 - p2;
+    num = d * d - (p1 * q1) / (n1 - 1) - (p2 * q2) / (n2 - 1);
+    den = p1 * q2 + p2 * q1;
+  } else if (METHOD == TPG_FST_WC84) {
+    // src/pairwise_fst_wc84_loop.cpp:41-99 with r = 2
+    const double r = 2.0;
+    const double ni1 = n1 / 2.0, ni2 = n2 / 2.0;
+    double sum_n = 0.0, sum_sq = 0.0;
+    sum_n += ni1; sum_sq += ni1 * ni1;
+    sum_n += ni2; sum_sq += ni2 * ni2;
+    const double n_total = sum_n, n_bar = sum_n / 2;
+    const double n_c = (sum_n - sum_sq / sum_n) / (2 - 1);
+    double sum_pn = 0.0, sum_h = 0.0;
+    sum_pn += p1 * ni1; sum_h += h1 * ni1;
+    sum_pn += p2 * ni2; sum_h += h2 * ni2;
+    const double p_bar = sum_pn / n_total, h_bar = sum_h / n_total;
+    double sum_sq_diff = 0.0;
+    sum_sq_diff += (p1 - p_bar) * (p1 - p_bar) * ni1;
+    sum_sq_diff += (p2 - p_bar) * (p2 - p_bar) * ni2;
+    const double s2 = sum_sq_diff / (n_bar * (2 - 1));
+    const double a = n_bar / n_c * (s2 - (1.0 / (n_bar - 1.0)) * (p_bar * (1 - p_bar) - ((r - 1.0) / r) * s2 - h_bar / 4.0));
+    const double b = n_bar / (n_bar - 1.0) *
+                     (p_bar * (1 - p_bar) - ((r - 1.0) / r) * s2 - ((2 * n_bar - 1.0) / (4.0 * n_bar)) * h_bar);
+    const double c = h_bar / 2.0;
+    num = a;
+    den = a + b + c;
+  } else {
+    // src/pairwise_fst_nei87_loop.cpp:45-80
+    const double q1 = 1 - p1, q2 = 1 - p2;
+    const double np1 = n1 / 2.0, np2 = n2 / 2.0;
+    int valid = 0;
+    double nsum = 0.0, inv_nsum = 0.0, ho_sum = 0.0;
+    if (np1 == np1) { valid++; ho_sum += h1; nsum += 1.0; inv_nsum += 1.0 / np1; }
+    if (np2 == np2) { valid++; ho_sum += h2; nsum += 1.0; inv_nsum += 1.0 / np2; }
+    const double np = valid;
+    const double mn = (inv_nsum > 0) ? nsum / inv_nsum : FST_NAN;
+    const double mHo = ho_sum / valid;
+    const double sp2a = p1 * p1 + p2 * p2;
+    const double sp2r = q1 * q1 + q2 * q2;
+    const double sp2 = sp2a + sp2r;
+    const double msp2 = sp2 / 2.0;
+    const double fAm = (p1 + p2) / 2.0, fRm = (q1 + q2) / 2.0;
+    const double mp2 = fAm * fAm + fRm * fRm;
+    const double mHs = mn / (mn - 1.0) * (1.0 - msp2 - mHo / (2.0 * mn));
+    const double Ht = 1.0 - mp2 + mHs / (mn * np) - mHo / (2.0 * mn * np);
+    const double Dst = Ht - mHs;
+    const double Dstp = (np / (np - 1.0)) * Dst;
+    num = Dstp;
+    den = mHs + Dstp;
+  }
+}
+
+struct FstSrc {
+  // either class counts (fused path) ...
+  const int32_t* cnt;
+  int64_t Mpad;
+  int Cpad;
+  int has_hap;
+  // ... or the reference's m x G matrices (loop mirror)
+  const double* n;
+  const double* p;
+  const double* q;  // freq_ref; only used to honour a caller-supplied matrix in the mirror
+  const double* h;
+};
+
+template <int METHOD>
+__global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int G, int LB,
+                                                      const int32_t* __restrict__ pairs0, int P, int by_locus,
+                                                      int return_num_dem, double* __restrict__ part,
+                                                      double* __restrict__ out_a, double* __restrict__ out_b) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* sh_n = sh;
+  double* sh_p = sh + (size_t)LB * G;
+  double* sh_h = sh + 2 * (size_t)LB * G;
+  const int pi = blockIdx.y * 256 + threadIdx.x;
+  int g1 = 0, g2 = 0;
+  if (pi < P) { g1 = pairs0[2 * pi]; g2 = pairs0[2 * pi + 1]; }
+  double sum_num = 0.0, sum_den = 0.0;
+  const int64_t nchunks = (m + LB - 1) / LB;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t j0 = ch * LB;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < LB * G; idx += 256) {
+      const int l = idx / G, g = idx % G;
+      const int64_t j = j0 + l;
+      double vn = FST_NAN, vp = FST_NAN, vh = FST_NAN;
+      if (j < m) {
+        if (src.cnt) {
+          const int64_t plane = src.Mpad * src.Cpad;
+          if (!src.has_hap) {
+            const int64_t o = j * src.Cpad + g;
+            const int n1 = src.cnt[o], n2 = src.cnt[plane + o], nv = src.cnt[2 * plane + o];
+            vn = (double)(2 * nv);
+            vp = (double)(n1 + 2 * n2) / vn;
+            vh = (double)(2 * n1) / vn;
+          } else {
+            const int64_t o = j * src.Cpad + 2 * g;
+            const int n1d = src.cnt[o], n2d = src.cnt[plane + o], nvd = src.cnt[2 * plane + o];
+            const int n1h = src.cnt[o + 1], n2h = src.cnt[plane + o + 1], nvh = src.cnt[2 * plane + o + 1];
+            vn = (double)(2 * nvd + nvh);
+            vp = ((double)(n1d + 2 * n2d) + 0.5 * (double)(n1h + 2 * n2h)) / vn;
+            vh = (double)(2 * (n1d + n1h)) / vn;
+          }
+        } else {
+          vn = src.n[j + (int64_t)g * m];
+          vp = src.p[j + (int64_t)g * m];
+          vh = src.h ? src.h[j + (int64_t)g * m] : 0.0;
+        }
+      }
+      sh_n[idx] = vn; sh_p[idx] = vp; sh_h[idx] = vh;
+    }
+    __syncthreads();
+    if (pi < P) {
+      const int lmax = (int)((m - j0) < LB ? (m - j0) : LB);
+      for (int l = 0; l < lmax; l++) {
+        const int o1 = l * G + g1, o2 = l * G + g2;
+        double num, den;
+        fst_terms<METHOD>(sh_n[o1], sh_p[o1], sh_h[o1], sh_n[o2], sh_p[o2], sh_h[o2], num, den);
+        if (by_locus) {
+          const int64_t o = (j0 + l) + (int64_t)pi * m;
+          if (!return_num_dem) out_a[o] = num / den;
+          else { out_a[o] = num; out_b[o] = den; }
+        }
+        if (num == num && den == den) { sum_num += num; sum_den += den; }  // !is_na(num) && !is_na(den)
+      }
+    }
+  }
+  if (pi < P) {
+    part[((int64_t)blockIdx.x * P + pi) * 2] = sum_num;
+    part[((int64_t)blockIdx.x * P + pi) * 2 + 1] = sum_den;
+  }
+}
+
+__global__ void tpg_fst_reduce_kernel(const double* __restrict__ part, int nblocks, int P, double* __restrict__ fst_tot) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= P) return;
+  double sn = 0.0, sd = 0.0;
+  for (int b = 0; b < nblocks; b++) { sn += part[((int64_t)b * P + pi) * 2]; sd += part[((int64_t)b * P + pi) * 2 + 1]; }
+  fst_tot[pi] = sn / sd;
+}
+
+static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const int32_t* pairs1, int P, int by_locus,
+                   int return_num_dem, double* fst_tot, double* out_a, double* out_b) {
+  TPG_REQUIRE(method == TPG_FST_HUDSON || method == TPG_FST_NEI87 || method == TPG_FST_WC84, TPG_EINVAL,
+              "unknown Fst method %d", method);
+  TPG_REQUIRE(P > 0 && pairs1, TPG_EINVAL, "no population pairs");
+  if (return_num_dem) by_locus = 1;  // R/pairwise_pop_fst.R:103-106
+  TPG_REQUIRE(!by_locus || out_a, TPG_EINVAL, "by_locus output requested but out_a is NULL");
+  TPG_REQUIRE(!return_num_dem || out_b, TPG_EINVAL, "return_num_dem requested but out_b is NULL");
+  TPG_REQUIRE(return_num_dem || fst_tot, TPG_EINVAL, "fst_tot is NULL");
+  std::vector<int32_t> p0((size_t)2 * P);
+  for (int k = 0; k < 2 * P; k++) {
+    TPG_REQUIRE(pairs1[k] >= 1 && pairs1[k] <= G, TPG_EINVAL, "pairwise_combn[%d] = %d out of [1,%d]", k, pairs1[k], G);
+    p0[(size_t)k] = pairs1[k] - 1;
+  }
+  InBuf pb;
+  TPG_TRY(pb.init(ctx, p0.data(), sizeof(int32_t) * 2 * (size_t)P));
+  int LB = 32;
+  while (LB > 1 && (size_t)LB * G * 3 * sizeof(double) > 96 * 1024) LB /= 2;
+  TPG_REQUIRE((size_t)LB * G * 3 * sizeof(double) <= 150 * 1024, TPG_EUNSUPPORTED, "too many populations (%d)", G);
+  const size_t shmem = (size_t)LB * G * 3 * sizeof(double);
+  const int64_t nchunks = ceil_div(m, LB);
+  const int ypass = (int)ceil_div(P, 256);
+  int nblocks = (int)(nchunks < 4 * ctx->num_cu ? nchunks : 4 * ctx->num_cu);
+  if (nblocks < 1) nblocks = 1;
+  double* d_part = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_part, sizeof(double) * 2 * (size_t)nblocks * (size_t)P));
+  OutBuf ot, oa, ob;
+  int rc = TPG_OK;
+  const size_t mp = sizeof(double) * (size_t)m * (size_t)P;
+  if (rc == TPG_OK && fst_tot) rc = ot.init(fst_tot, sizeof(double) * (size_t)P);
+  if (rc == TPG_OK && by_locus) rc = oa.init(out_a, mp);
+  if (rc == TPG_OK && return_num_dem) rc = ob.init(out_b, mp);
+  if (rc == TPG_OK) {
+    dim3 grid((unsigned)nblocks, (unsigned)ypass);
+#define FST_LAUNCH(M, NAME)                                                                                      \
+  do {                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)tpg_fst_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    TPG_LAUNCH(ctx, NAME, tpg_fst_kernel<M>, grid, dim3(256), shmem, src, m, G, LB, pb.dev<int32_t>(), P, by_locus, \
+               return_num_dem, d_part, oa.dev<double>(), ob.dev<double>());                                      \
+  } while (0)
+    if (method == TPG_FST_HUDSON) FST_LAUNCH(TPG_FST_HUDSON, "fst_hudson");
+    else if (method == TPG_FST_WC84) FST_LAUNCH(TPG_FST_WC84, "fst_wc84");
+    else FST_LAUNCH(TPG_FST_NEI87, "fst_nei87");
+#undef FST_LAUNCH
+    if (fst_tot)
+      TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, d_part,
+                 nblocks, P, ot.dev<double>());
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { tpg_set_error("fst kernels: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  }
+  (void)hipFree(d_part);
+  TPG_TRY(rc);
+  if (fst_tot) TPG_TRY(ot.commit(ctx));
+  if (by_locus) TPG_TRY(oa.commit(ctx));
+  if (return_num_dem) TPG_TRY(ob.commit(ctx));
+  return TPG_OK;
+}
+
+extern "C" int tpg_pairwise_fst_loop(tpg_ctx* ctx, int method, const int32_t* pairs1, int P, int64_t m, int G,
+                                     const double* n, const double* freq_alt, const double* freq_ref,
+                                     const double* het_obs, int by_locus, int return_num_dem, double* fst_tot,
+                                     double* out_a, double* out_b) {
+  TPG_REQUIRE(ctx && n && freq_alt, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(m > 0 && G > 0, TPG_EINVAL, "empty input");
+  TPG_REQUIRE(method == TPG_FST_HUDSON || het_obs, TPG_EINVAL, "het_obs is required for WC84 / Nei87");
+  // freq_ref is 1 - freq_alt by construction (src/grouped_summaries_dip_pseudo_cpp.cpp:53); the device
+  // code recomputes it, so a caller-supplied freq_ref is accepted but not read.
+  (void)freq_ref;
+  const size_t bytes = sizeof(double) * (size_t)m * (size_t)G;
+  InBuf bn, bp, bh;
+  TPG_TRY(bn.init(ctx, n, bytes));
+  TPG_TRY(bp.init(ctx, freq_alt, bytes));
+  if (het_obs) TPG_TRY(bh.init(ctx, het_obs, bytes));
+  FstSrc src{nullptr, 0, 0, 0, bn.dev<double>(), bp.dev<double>(), nullptr, het_obs ? bh.dev<double>() : nullptr};
+  return run_fst(ctx, method, src, m, G, pairs1, P, by_locus, return_num_dem, fst_tot, out_a, out_b);
+}
+
+// class plan shared with loci.hip
+struct ClassPlanF {
+  std::vector<int32_t> cls;
+  int nclass, has_hap;
+};
+
+extern "C" int tpg_pairwise_pop_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                                    const double* ploidy, int method, const int32_t* pairs1, int P, int by_locus,
+                                    int return_num_dem, double* fst_tot, double* out_a, double* out_b) {
+  TPG_REQUIRE(ctx && v && groupIds0, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(ngroups > 0, TPG_EINVAL, "ngroups must be positive");
+  int has_hap = 0;
+  if (ploidy)
+    for (int64_t i = 0; i < v->n; i++) {
+      TPG_REQUIRE(ploidy[i] == 1.0 || ploidy[i] == 2.0, TPG_EUNSUPPORTED, "ploidy[%lld] = %g unsupported",
+                  (long long)i, ploidy[i]);
+      if (ploidy[i] == 1.0) has_hap = 1;
+    }
+  // R/pairwise_pop_fst.R:110-115: pseudohaploids only with Hudson
+  TPG_REQUIRE(!has_hap || method == TPG_FST_HUDSON, TPG_EINVAL,
+              "only method = Hudson is valid when the data include pseudohaploids");
+  std::vector<int32_t> cls((size_t)v->n);
+  for (int64_t i = 0; i < v->n; i++) {
+    TPG_REQUIRE(groupIds0[i] >= 0 && groupIds0[i] < ngroups, TPG_EINVAL, "groupIds[%lld] = %d out of [0,%d)",
+                (long long)i, groupIds0[i], ngroups);
+    cls[(size_t)i] = has_hap ? 2 * groupIds0[i] + (ploidy[i] == 1.0 ? 1 : 0) : groupIds0[i];
+  }
+  GroupedCounts gc;
+  TPG_TRY(tpg_grouped_counts(ctx, v, cls.data(), ngroups * (has_hap ? 2 : 1), &gc));
+  FstSrc src{gc.cnt, gc.Mpad, gc.Cpad, has_hap, nullptr, nullptr, nullptr, nullptr};
+  return run_fst(ctx, method, src, v->m, ngroups, pairs1, P, by_locus, return_num_dem, fst_tot, out_a, out_b);
+}

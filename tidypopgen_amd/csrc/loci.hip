@@ -1,0 +1,384 @@
+// loci.hip -- per-locus sweeps over the locus-tiled layout L.
+//
+//  * tpg_loci_counts_kernel: genotype counts per locus (n0,n1,n2,nNA).  One wave per 32-locus
+//    tile streams that tile's Q contiguous 1-KiB blocks with 16-B coalesced loads; lane (r,h)
+//    owns locus r and popcounts its own dwords, so the only cross-lane step is one lane^32
+//    exchange at the end.  HBM-bound: n/4 bytes per locus in, 16 B out.
+//  * tpg_grouped_counts_kernel: per locus x class counts as an int8 MFMA contraction over
+//    individuals, D[locus][class] = sum_i plane[i][locus] * onehot[i][class] for the planes
+//    {het, hom-alt, valid}.  Exact in int32, arbitrary class assignment, no atomics.
+//  * finalize kernels turn counts into the doubles the reference returns
+//    (src/alt_freq_dip_pseudo_cpp.cpp:43-57, src/grouped_alt_freq_dip_pseudo_cpp.cpp:46-55,
+//    src/grouped_missingness_cpp.cpp:23-31, src/grouped_summaries_dip_pseudo_cpp.cpp:50-57).
+//    The reference's sums of x*mult and ploidy are sums of {0, 0.5, 1, 2}-multiples, exact in
+//    double in any order, so integer counts + one conversion reproduce them bit for bit.
+#include "common.h"
+#include "devfrag.h"
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tpg_loci_counts_kernel(const uint4* __restrict__ L, int64_t n_lt,
+                                                              int64_t Q, int64_t n, int64_t m,
+                                                              int4* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (lt >= n_lt) return;
+  const uint4* p = L + (lt * Q) * 64 + lane;
+  int c_lo = 0, c_hi = 0, c_both = 0;
+  auto acc = [&](uint32_t w) {
+    const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+    c_lo += __popc(lo);
+    c_hi += __popc(hi);
+    c_both += __popc(lo & hi);
+  };
+  int64_t q = 0;
+  for (; q + 4 <= Q; q += 4) {
+    uint4 a0 = p[(q + 0) * 64], a1 = p[(q + 1) * 64], a2 = p[(q + 2) * 64], a3 = p[(q + 3) * 64];
+    acc(a0.x); acc(a0.y); acc(a0.z); acc(a0.w);
+    acc(a1.x); acc(a1.y); acc(a1.z); acc(a1.w);
+    acc(a2.x); acc(a2.y); acc(a2.z); acc(a2.w);
+    acc(a3.x); acc(a3.y); acc(a3.z); acc(a3.w);
+  }
+  for (; q < Q; q++) {
+    uint4 a0 = p[q * 64];
+    acc(a0.x); acc(a0.y); acc(a0.z); acc(a0.w);
+  }
+  c_lo += __shfl_xor(c_lo, 32);
+  c_hi += __shfl_xor(c_hi, 32);
+  c_both += __shfl_xor(c_both, 32);
+  const int64_t j = lt * 32 + (lane & 31);
+  if (lane < 32 && j < m) {
+    const int n3 = c_both, n1 = c_lo - c_both, n2 = c_hi - c_both;
+    const int npad = (int)(Q * 128 - n);
+    out[j] = make_int4((int)(Q * 128) - n1 - n2 - n3, n1, n2, n3 - npad);
+  }
+}
+
+int tpg_launch_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* d_counts) {
+  const int64_t n_lt = v->KG * 4;
+  TPG_LAUNCH(ctx, "loci_counts", tpg_loci_counts_kernel, dim3((unsigned)ceil_div(n_lt, 4)), dim3(256), 0,
+             (const uint4*)v->L, n_lt, v->Q, v->n, v->m, (int4*)d_counts);
+  TPG_CHECK_LAUNCH();
+  return TPG_OK;
+}
+
+extern "C" int tpg_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out) {
+  TPG_REQUIRE(ctx && v && out, TPG_EINVAL, "null argument");
+  OutBuf o;
+  TPG_TRY(o.init(out, sizeof(int32_t) * 4 * (size_t)v->m));
+  TPG_TRY(tpg_launch_loci_counts(ctx, v, o.dev<int32_t>()));
+  return o.commit(ctx);
+}
+
+// ---------------------------------------------------------------------------
+// one-hot B fragments: OH[q][s][gt][lane = (c,h)][16 B], element e <-> individual
+// 128 q + 32 s + 16 h + e, byte = (cls[individual] == 32 gt + c)
+__global__ void tpg_onehot_kernel(const int32_t* __restrict__ cls, int64_t n, int64_t Q, int GT,
+                                  uint4* __restrict__ OH) {
+  const int64_t total = Q * 4 * GT * 64;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    const int64_t t = idx >> 6;
+    const int gt = (int)(t % GT);
+    const int64_t qs = t / GT;
+    const int s = (int)(qs & 3);
+    const int64_t q = qs >> 2;
+    const int c = 32 * gt + (lane & 31), h = lane >> 5;
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int e = 0; e < 16; e++) {
+      const int64_t i = 128 * q + 32 * s + 16 * h + e;
+      if (i < n && cls[i] == c) w[e >> 2] |= 1u << (8 * (e & 3));
+    }
+    OH[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// cnt[plane][locus][class] (row-major by locus, Cpad classes), planes: 0 het, 1 hom-alt, 2 valid
+template <int GT>
+__global__ __launch_bounds__(256) void tpg_grouped_counts_kernel(const uint4* __restrict__ L,
+                                                                 const uint4* __restrict__ OH, int64_t n_lt,
+                                                                 int64_t Q, int gt0, int GT_total,
+                                                                 int32_t* __restrict__ cnt, int64_t Mpad,
+                                                                 int Cpad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (lt >= n_lt) return;
+  v16i acc[3][GT];
+#pragma unroll
+  for (int p = 0; p < 3; p++)
+#pragma unroll
+    for (int g = 0; g < GT; g++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[p][g][r] = 0;
+  const uint4* pa = L + (lt * Q) * 64 + lane;
+  for (int64_t q = 0; q < Q; q++) {
+    const uint4 a = pa[q * 64];
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      v4i fh, f2, fv;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t c = tpg_codes(aw[s], k);
+        fh[k] = tpg_lut(TPG_LUT_H, c);
+        f2[k] = tpg_lut(TPG_LUT_E2, c);
+        fv[k] = tpg_lut(TPG_LUT_V, c);
+      }
+#pragma unroll
+      for (int g = 0; g < GT; g++) {
+        const uint4 b = OH[((q * 4 + s) * GT_total + gt0 + g) * 64 + lane];
+        v4i fb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+        acc[0][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fh, fb, acc[0][g], 0, 0, 0);
+        acc[1][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f2, fb, acc[1][g], 0, 0, 0);
+        acc[2][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fv, fb, acc[2][g], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 3; p++)
+#pragma unroll
+    for (int g = 0; g < GT; g++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int64_t row = lt * 32 + tpg_cd_row(r, lane);
+        cnt[((int64_t)p * Mpad + row) * Cpad + 32 * (gt0 + g) + (lane & 31)] = acc[p][g][r];
+      }
+}
+
+GroupedCounts::~GroupedCounts() {
+  if (cnt) (void)hipFree(cnt);
+}
+
+int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, int nclass, GroupedCounts* out) {
+  TPG_REQUIRE(nclass > 0, TPG_EINVAL, "no classes");
+  for (int64_t i = 0; i < v->n; i++)
+    TPG_REQUIRE(h_cls[i] >= 0 && h_cls[i] < nclass, TPG_EINVAL, "class id %d of individual %lld out of [0,%d)",
+                h_cls[i], (long long)i, nclass);
+  const int GT = (int)ceil_div(nclass, 32);
+  const int64_t n_lt = v->KG * 4;
+  out->Mpad = n_lt * 32;
+  out->Cpad = GT * 32;
+  out->nclass = nclass;
+  TPG_HIP(hipMalloc((void**)&out->cnt, sizeof(int32_t) * 3 * (size_t)out->Mpad * (size_t)out->Cpad));
+  int32_t* d_cls = nullptr;
+  uint4* d_oh = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_cls, sizeof(int32_t) * (size_t)v->n));
+  hipError_t e = hipMalloc((void**)&d_oh, (size_t)v->Q * 4 * GT * 1024);
+  if (e != hipSuccess) { (void)hipFree(d_cls); tpg_set_error("hipMalloc one-hot: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  int rc = TPG_OK;
+  e = hipMemcpyAsync(d_cls, h_cls, sizeof(int32_t) * (size_t)v->n, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) { tpg_set_error("class upload: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  if (rc == TPG_OK) {
+    TPG_LAUNCH(ctx, "onehot", tpg_onehot_kernel, dim3(1024), dim3(256), 0, d_cls, v->n, v->Q, GT, d_oh);
+    const unsigned grid = (unsigned)ceil_div(n_lt, 4);
+    int g0 = 0;
+    while (g0 < GT) {
+      if (GT - g0 >= 2) {
+        TPG_LAUNCH(ctx, "grouped_counts", tpg_grouped_counts_kernel<2>, dim3(grid), dim3(256), 0, (const uint4*)v->L,
+                   (const uint4*)d_oh, n_lt, v->Q, g0, GT, out->cnt, out->Mpad, out->Cpad);
+        g0 += 2;
+      } else {
+        TPG_LAUNCH(ctx, "grouped_counts", tpg_grouped_counts_kernel<1>, dim3(grid), dim3(256), 0, (const uint4*)v->L,
+                   (const uint4*)d_oh, n_lt, v->Q, g0, GT, out->cnt, out->Mpad, out->Cpad);
+        g0 += 1;
+      }
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // d_cls / d_oh are freed below
+    if (e != hipSuccess) { tpg_set_error("grouped counts: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  }
+  (void)hipFree(d_cls);
+  (void)hipFree(d_oh);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// Class scheme shared by the grouped entry points: with pseudohaploids present class = 2*g + (ploidy==1),
+// otherwise class = g.  (ploidy is 1 or 2: the reference's dip_pseudo kernels assume it too.)
+struct ClassPlan {
+  std::vector<int32_t> cls;
+  std::vector<int32_t> group_size;
+  int nclass = 0;
+  int has_hap = 0;
+};
+
+static int make_class_plan(const tpg_view* v, const int32_t* groupIds0, int ngroups, const double* ploidy,
+                           ClassPlan* cp) {
+  TPG_REQUIRE(ngroups > 0, TPG_EINVAL, "ngroups must be positive");
+  cp->has_hap = 0;
+  if (ploidy)
+    for (int64_t i = 0; i < v->n; i++) {
+      TPG_REQUIRE(ploidy[i] == 1.0 || ploidy[i] == 2.0, TPG_EUNSUPPORTED,
+                  "ploidy[%lld] = %g: only diploid (2) and pseudohaploid (1) individuals are supported",
+                  (long long)i, ploidy[i]);
+      if (ploidy[i] == 1.0) cp->has_hap = 1;
+    }
+  cp->nclass = ngroups * (cp->has_hap ? 2 : 1);
+  cp->cls.resize((size_t)v->n);
+  cp->group_size.assign((size_t)ngroups, 0);
+  for (int64_t i = 0; i < v->n; i++) {
+    const int g = groupIds0 ? groupIds0[i] : 0;
+    TPG_REQUIRE(g >= 0 && g < ngroups, TPG_EINVAL, "groupIds[%lld] = %d out of [0,%d)", (long long)i, g, ngroups);
+    cp->group_size[(size_t)g]++;
+    cp->cls[(size_t)i] = cp->has_hap ? 2 * g + (ploidy[i] == 1.0 ? 1 : 0) : g;
+  }
+  return TPG_OK;
+}
+
+struct GroupVals {
+  double alt, valid, het2, nvalid_ind;
+};
+
+__device__ __forceinline__ GroupVals tpg_group_vals(const int32_t* __restrict__ cnt, int64_t Mpad, int Cpad,
+                                                    int64_t j, int g, int has_hap) {
+  GroupVals r;
+  const int64_t plane = Mpad * Cpad;
+  if (!has_hap) {
+    const int64_t o = j * Cpad + g;
+    const int n1 = cnt[o], n2 = cnt[plane + o], nv = cnt[2 * plane + o];
+    r.alt = (double)(n1 + 2 * n2);
+    r.valid = (double)(2 * nv);
+    r.het2 = (double)(2 * n1);
+    r.nvalid_ind = (double)nv;
+  } else {
+    const int64_t o = j * Cpad + 2 * g;
+    const int n1d = cnt[o], n2d = cnt[plane + o], nvd = cnt[2 * plane + o];
+    const int n1h = cnt[o + 1], n2h = cnt[plane + o + 1], nvh = cnt[2 * plane + o + 1];
+    r.alt = (double)(n1d + 2 * n2d) + 0.5 * (double)(n1h + 2 * n2h);  // x * 1/(3-ploidy)
+    r.valid = (double)(2 * nvd + nvh);                                 // sum of ploidy
+    r.het2 = (double)(2 * (n1d + n1h));                                // +2 per x == 1
+    r.nvalid_ind = (double)(nvd + nvh);
+  }
+  return r;
+}
+
+// mode 0: grouped_alt_freq (out m x 2G; as_counts), 1: grouped_missingness (out m x G),
+// 2: grouped_summaries (o0..o3 m x G, each may be null)
+__global__ void tpg_grouped_finalize_kernel(const int32_t* __restrict__ cnt, int64_t Mpad, int Cpad, int64_t m,
+                                            int G, int has_hap, int mode, int as_counts,
+                                            const int32_t* __restrict__ group_size, double* __restrict__ o0,
+                                            double* __restrict__ o1, double* __restrict__ o2,
+                                            double* __restrict__ o3) {
+  const int64_t total = m * G;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = idx % m;
+    const int g = (int)(idx / m);
+    const GroupVals gv = tpg_group_vals(cnt, Mpad, Cpad, j, g, has_hap);
+    if (mode == 0) {
+      o0[j + (int64_t)g * m] = as_counts ? gv.alt : gv.alt / gv.valid;
+      o0[j + (int64_t)(G + g) * m] = gv.valid;
+    } else if (mode == 1) {
+      o0[idx] = (double)group_size[g] - gv.nvalid_ind;
+    } else {
+      const double f = gv.alt / gv.valid;
+      if (o0) o0[idx] = f;
+      if (o1) o1[idx] = 1 - f;
+      if (o2) o2[idx] = gv.valid;
+      if (o3) o3[idx] = gv.het2 / gv.valid;
+    }
+  }
+}
+
+// ungrouped diploid: counts (m x 4) -> m x 2 doubles
+__global__ void tpg_alt_freq_finalize_kernel(const int4* __restrict__ counts, int64_t m, int as_counts,
+                                             double* __restrict__ out) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = counts[j];
+    const double alt = (double)(c.y + 2 * c.z), valid = (double)(2 * (c.x + c.y + c.z));
+    double f = alt;
+    if (!as_counts) f = valid > 0 ? alt / valid : __longlong_as_double(0x7FF8000000000000ll);
+    out[j] = f;
+    out[m + j] = valid;
+  }
+}
+
+extern "C" int tpg_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const double* ploidy, int as_counts,
+                                       double* out) {
+  TPG_REQUIRE(ctx && v && out, TPG_EINVAL, "null argument");
+  bool all_dip = true;
+  if (ploidy)
+    for (int64_t i = 0; i < v->n; i++) {
+      TPG_REQUIRE(ploidy[i] == 1.0 || ploidy[i] == 2.0, TPG_EUNSUPPORTED,
+                  "ploidy[%lld] = %g: only 1 and 2 are supported", (long long)i, ploidy[i]);
+      if (ploidy[i] != 2.0) all_dip = false;
+    }
+  OutBuf o;
+  TPG_TRY(o.init(out, sizeof(double) * 2 * (size_t)v->m));
+  if (all_dip) {
+    int32_t* d_counts = nullptr;
+    TPG_HIP(hipMalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
+    int rc = tpg_launch_loci_counts(ctx, v, d_counts);
+    if (rc == TPG_OK) {
+      TPG_LAUNCH(ctx, "alt_freq_finalize", tpg_alt_freq_finalize_kernel, dim3(1024), dim3(256), 0,
+                 (const int4*)d_counts, v->m, as_counts, o.dev<double>());
+      hipError_t e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) { tpg_set_error("alt_freq: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+    }
+    (void)hipFree(d_counts);
+    TPG_TRY(rc);
+    return o.commit(ctx);
+  }
+  // mixed ploidy: one group, two ploidy classes
+  ClassPlan cp;
+  TPG_TRY(make_class_plan(v, nullptr, 1, ploidy, &cp));
+  GroupedCounts gc;
+  TPG_TRY(tpg_grouped_counts(ctx, v, cp.cls.data(), cp.nclass, &gc));
+  // reuse the grouped finalize (mode 0 with G = 1 has the m x 2 layout wanted), then NA guard on the host side
+  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3(1024), dim3(256), 0, gc.cnt, gc.Mpad,
+             gc.Cpad, v->m, 1, cp.has_hap, 0, as_counts, (const int32_t*)nullptr, o.dev<double>(),
+             (double*)nullptr, (double*)nullptr, (double*)nullptr);
+  TPG_CHECK_LAUNCH();
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  // 0/0 is already NaN, which is what the ungrouped reference returns as NA_REAL (:52)
+  return o.commit(ctx);
+}
+
+static int grouped_common(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                          const double* ploidy, int mode, int as_counts, double* o0, size_t o0_count, double* o1,
+                          double* o2, double* o3) {
+  ClassPlan cp;
+  TPG_TRY(make_class_plan(v, groupIds0, ngroups, ploidy, &cp));
+  GroupedCounts gc;
+  TPG_TRY(tpg_grouped_counts(ctx, v, cp.cls.data(), cp.nclass, &gc));
+  const size_t mg = (size_t)v->m * (size_t)ngroups;
+  OutBuf b0, b1, b2, b3;
+  if (o0) TPG_TRY(b0.init(o0, sizeof(double) * o0_count));
+  if (o1) TPG_TRY(b1.init(o1, sizeof(double) * mg));
+  if (o2) TPG_TRY(b2.init(o2, sizeof(double) * mg));
+  if (o3) TPG_TRY(b3.init(o3, sizeof(double) * mg));
+  InBuf gs;
+  TPG_TRY(gs.init(ctx, cp.group_size.data(), sizeof(int32_t) * (size_t)ngroups));
+  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3(2048), dim3(256), 0, gc.cnt, gc.Mpad,
+             gc.Cpad, v->m, ngroups, cp.has_hap, mode, as_counts, gs.dev<int32_t>(), b0.dev<double>(),
+             b1.dev<double>(), b2.dev<double>(), b3.dev<double>());
+  TPG_CHECK_LAUNCH();
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  if (o0) TPG_TRY(b0.commit(ctx));
+  if (o1) TPG_TRY(b1.commit(ctx));
+  if (o2) TPG_TRY(b2.commit(ctx));
+  if (o3) TPG_TRY(b3.commit(ctx));
+  return TPG_OK;
+}
+
+extern "C" int tpg_grouped_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0,
+                                               int ngroups, const double* ploidy, int as_counts, double* out) {
+  TPG_REQUIRE(ctx && v && groupIds0 && out, TPG_EINVAL, "null argument");
+  return grouped_common(ctx, v, groupIds0, ngroups, ploidy, 0, as_counts, out, (size_t)v->m * 2 * (size_t)ngroups,
+                        nullptr, nullptr, nullptr);
+}
+
+extern "C" int tpg_grouped_missingness(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                                       double* out) {
+  TPG_REQUIRE(ctx && v && groupIds0 && out, TPG_EINVAL, "null argument");
+  return grouped_common(ctx, v, groupIds0, ngroups, nullptr, 1, 0, out, (size_t)v->m * (size_t)ngroups, nullptr,
+                        nullptr, nullptr);
+}
+
+extern "C" int tpg_grouped_summaries_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0,
+                                                int ngroups, const double* ploidy, double* freq_alt,
+                                                double* freq_ref, double* n, double* het_obs) {
+  TPG_REQUIRE(ctx && v && groupIds0, TPG_EINVAL, "null argument");
+  return grouped_common(ctx, v, groupIds0, ngroups, ploidy, 2, 0, freq_alt, (size_t)v->m * (size_t)ngroups,
+                        freq_ref, n, het_obs);
+}

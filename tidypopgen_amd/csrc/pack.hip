@@ -1,0 +1,140 @@
+// pack.hip -- FBM bytes -> 2-bit fragment layouts T and L (common.h), unpack, synthetic panel.
+//
+// pack: one workgroup per 128 individuals x 128 loci tile.  The tile's bytes are gathered
+// through (rowInd, colInd), decoded by the 256-entry byte -> 2-bit table held in LDS, kept as
+// one code byte per genotype in LDS, then emitted twice: four 1-KiB T blocks (contraction over
+// loci) and four 1-KiB L blocks (contraction over individuals).  HBM-bound: reads n*m bytes,
+// writes n*m/2 bytes.  Replaces the per-block byte decode loops of the reference
+// (src/snp_ibs.cpp:45-55, src/snp_king.cpp:45-58, src/snp_as.cpp:44-53 and the
+// SubBMCode256Acc accessor in src/alt_freq_dip_pseudo_cpp.cpp:15-16).
+#include "common.h"
+#include "devfrag.h"
+#include "synth_common.h"
+
+#define TILE 128
+#define LDS_STRIDE 132  // bytes per locus row in LDS (128 + 4 pad)
+
+__global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict__ fbm, int64_t nrow,
+                                                       const int32_t* __restrict__ rows,
+                                                       const int32_t* __restrict__ cols, uint8_t* lut_and_flag,
+                                                       int64_t n, int64_t m, int64_t Q, int64_t KG,
+                                                       uint32_t* __restrict__ T, uint32_t* __restrict__ L) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[256 + TILE * LDS_STRIDE];
+  uint8_t* lut = smem;
+  uint8_t* codes = smem + 256;  // codes[locus][individual]
+  const int tid = threadIdx.x;
+  const int64_t bj = blockIdx.x;  // locus group (kg)
+  const int64_t bi = blockIdx.y;  // individual chunk (q)
+  lut[tid] = lut_and_flag[tid];
+  __syncthreads();
+
+  const int ii = tid & 127;
+  const int64_t i = bi * TILE + ii;
+  int64_t src_row = -1;
+  if (i < n) src_row = rows ? (int64_t)rows[i] - 1 : i;
+  bool bad = false;
+  for (int l = tid >> 7; l < TILE; l += 2) {
+    const int64_t j = bj * TILE + l;
+    uint8_t c = 3;
+    if (src_row >= 0 && j < m) {
+      const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
+      c = lut[fbm[src_row + src_col * nrow]];
+      if (c == 0xFF) { bad = true; c = 3; }
+    }
+    codes[l * LDS_STRIDE + ii] = c;
+  }
+  if (bad) atomicOr((unsigned int*)(lut_and_flag + 256), 1u);
+  __syncthreads();
+
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int idx = tid + 256 * it;
+    const int s = idx & 3, lane = (idx >> 2) & 63, tl = idx >> 8;
+    const int r = lane & 31, h = lane >> 5;
+    // T: individual 32 tl + r, loci 32 s + 16 h + e
+    {
+      const int ind = 32 * tl + r;
+      uint32_t w = 0;
+#pragma unroll
+      for (int e = 0; e < 16; e++) w |= (uint32_t)codes[(32 * s + 16 * h + e) * LDS_STRIDE + ind] << tpg_elem_shift(e);
+      const int64_t rt = bi * 4 + tl;
+      T[((rt * KG + bj) * 64 + lane) * 4 + s] = w;
+    }
+    // L: locus 32 tl + r, individuals 32 s + 16 h + e
+    {
+      const int loc = 32 * tl + r;
+      uint32_t w = 0;
+#pragma unroll
+      for (int e = 0; e < 16; e++) w |= (uint32_t)codes[loc * LDS_STRIDE + 32 * s + 16 * h + e] << tpg_elem_shift(e);
+      const int64_t lt = bj * 4 + tl;
+      L[((lt * Q + bi) * 64 + lane) * 4 + s] = w;
+    }
+  }
+}
+
+int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,
+                    const uint8_t* d_lut, tpg_view* v) {
+  TPG_REQUIRE(v->KG < 2147483647ll && v->Q <= 65535, TPG_EINVAL, "view too large for the pack grid");
+  dim3 grid((unsigned)v->KG, (unsigned)v->Q);
+  TPG_LAUNCH(ctx, "pack", tpg_pack_kernel, grid, dim3(256), 0, fbm->d_bytes, fbm->nrow, d_rows, d_cols,
+             (uint8_t*)d_lut, v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L);
+  TPG_CHECK_LAUNCH();
+  return TPG_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void tpg_unpack_kernel(const uint32_t* __restrict__ T, const uint32_t* __restrict__ L, int from_L,
+                                  int64_t n, int64_t m, int64_t Q, int64_t KG, uint8_t* __restrict__ out) {
+  const int64_t total = n * m;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx % n, j = idx / n;
+    uint32_t w;
+    int e;
+    if (!from_L) {
+      const int64_t rt = i >> 5, kg = j >> 7;
+      const int r = (int)(i & 31), jj = (int)(j & 127);
+      const int s = jj >> 5, h = (jj >> 4) & 1;
+      e = jj & 15;
+      w = T[((rt * KG + kg) * 64 + (r + 32 * h)) * 4 + s];
+    } else {
+      const int64_t lt = j >> 5, q = i >> 7;
+      const int r = (int)(j & 31), ii = (int)(i & 127);
+      const int s = ii >> 5, h = (ii >> 4) & 1;
+      e = ii & 15;
+      w = L[((lt * Q + q) * 64 + (r + 32 * h)) * 4 + s];
+    }
+    out[idx] = (uint8_t)((w >> tpg_elem_shift(e)) & 3u);
+  }
+}
+
+int tpg_launch_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* d_codes, int from_L) {
+  TPG_LAUNCH(ctx, "unpack", tpg_unpack_kernel, dim3(2048), dim3(256), 0, (const uint32_t*)v->T,
+             (const uint32_t*)v->L, from_L, v->n, v->m, v->Q, v->KG, d_codes);
+  TPG_CHECK_LAUNCH();
+  return TPG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// One workgroup per locus: the npop population frequencies are computed once into LDS.
+__global__ __launch_bounds__(256) void tpg_synth_kernel(uint8_t* __restrict__ out, uint64_t seed, int64_t nrow,
+                                                        int64_t ncol, int64_t j0, int npop, uint32_t miss_thresh,
+                                                        int imputed_bytes) {
+  __shared__ uint32_t pjg[1024];
+  for (int64_t j = blockIdx.x; j < ncol; j += gridDim.x) {
+    __syncthreads();
+    for (int g = threadIdx.x; g < npop; g += blockDim.x) pjg[g] = tpg_synth_pjg(seed, (uint64_t)(j0 + j), (uint32_t)g);
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < nrow; i += blockDim.x)
+      out[i + j * nrow] = tpg_synth_geno(seed, (uint64_t)i, (uint64_t)(j0 + j), pjg[i % npop], miss_thresh, imputed_bytes);
+  }
+}
+
+int tpg_launch_synth(tpg_ctx* ctx, uint8_t* d_bytes, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0,
+                     int npop, uint32_t miss_thresh, int imputed_bytes) {
+  unsigned grid = (unsigned)(ncol < 65536 ? ncol : 65536);
+  TPG_LAUNCH(ctx, "synth", tpg_synth_kernel, dim3(grid), dim3(256), 0, d_bytes, seed, nrow, ncol, j0, npop,
+             miss_thresh, imputed_bytes);
+  TPG_CHECK_LAUNCH();
+  return TPG_OK;
+}

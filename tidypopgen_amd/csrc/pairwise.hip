@@ -1,0 +1,407 @@
+// pairwise.hip -- N x N individual cross-products on int8 MFMA (IBS / KING / allele sharing / GRM).
+//
+// Replaces the dense FP64 products of increment_ibs_counts (src/snp_ibs.cpp:67-72),
+// increment_king_numerator (src/snp_king.cpp:70-72) and increment_as_counts (src/snp_as.cpp:64-65)
+// and the R block loops around them (R/snp_ibs.R:69-82, R/snp_king.R:63-77,
+// R/snp_allele_sharing.R:58-70).
+//
+// Per genotype three int8 features are decoded from the 2-bit code: v (valid), d (dosage-1, 0 if
+// missing), h (heterozygous).  With V = vv', D = dd', H = hh', A = hv' (A not symmetric) every count
+// matrix of the reference is an integer combination (derivation in DESIGN.md):
+//   IBS        = V + D + H          IBS_valid = 2 V
+//   KING_num   = D - V + A + A'     N_Aa_i    = A
+//   AS_num     = D                  AS_den    = V
+// so the fused pass needs 3 symmetric + 1 general product = 2.5 N^2 M MACs instead of the
+// reference's 12 N^2 M FP64 flops for IBS+KING+AS.
+//
+// Kernel: one wave owns a 64 x 64 output tile (2 x 2 MFMA 32x32 tiles) of a super-tile pair
+// (I <= J) and a K range; it keeps 5 products x 4 sub-tiles = 20 int32 accumulator tiles (320
+// registers, one wave per SIMD), streams its four operand row tiles from T with 16-B coalesced
+// loads (1 KiB per wave instruction, next K group prefetched), decodes each 16-locus slice with
+// 7 bit ops + 12 v_perm_b32 per fragment, and issues 20 v_mfma_i32_32x32x32_i8 per 32 loci.
+// No LDS, no barriers.  Partial tiles are added to HBM with integer atomics (exact, order
+// independent) into a tile-packed buffer in MFMA register order, so each atomic wave instruction
+// is 256 contiguous bytes.  That buffer is what a multi-GPU run all-reduces.
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+#include "devfrag.h"
+
+#define MFMA_I8(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8((a), (b), (c), 0, 0, 0)
+
+struct Frag3 {
+  v4i v, d, h;
+};
+
+__device__ __forceinline__ Frag3 tpg_decode3(uint32_t w) {
+  Frag3 f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t c = tpg_codes(w, k);
+    f.v[k] = tpg_lut(TPG_LUT_V, c);
+    f.d[k] = tpg_lut(TPG_LUT_D, c);
+    f.h[k] = tpg_lut(TPG_LUT_H, c);
+  }
+  return f;
+}
+
+// unit (I, jt): rows = super-tile I (row tiles 2I, 2I+1), columns = row tile jt >= 2I.
+// slab index u = 2 (I nst - I (I-1)/2) + (jt - 2I); slab = [product][ta][reg][lane] int32.
+__device__ __forceinline__ int64_t tpg_pw_unit_index(int nst, int I, int jt) {
+  return 2 * ((int64_t)I * nst - ((int64_t)I * (I - 1)) / 2) + (jt - 2 * I);
+}
+
+__global__ __launch_bounds__(256, 2) void tpg_pairwise_kernel(const uint4* __restrict__ T, int64_t KG,
+                                                              int64_t kg_begin, int64_t kg_end, int nst,
+                                                              int64_t ntp, int S, int32_t* __restrict__ acc_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t nunits = ntp * S;
+  const int64_t kgs = kg_end - kg_begin;
+
+  for (int64_t unit = wave; unit < nunits; unit += nwaves) {
+    int64_t tp = unit % ntp;
+    const int ks = (int)(unit / ntp);
+    const int64_t tp0 = tp;
+    int I = 0;
+    while (tp >= 2 * (nst - I)) { tp -= 2 * (nst - I); I++; }
+    const int jt = 2 * I + (int)tp;
+    const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
+
+    const uint4* pa0 = T + ((int64_t)(2 * I) * KG) * 64 + lane;
+    const uint4* pa1 = T + ((int64_t)(2 * I + 1) * KG) * 64 + lane;
+    const uint4* pb0 = T + ((int64_t)jt * KG) * 64 + lane;
+
+    v16i cV[2], cD[2], cH[2], cHV[2], cVH[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { cV[t][r] = 0; cD[t][r] = 0; cH[t][r] = 0; cHV[t][r] = 0; cVH[t][r] = 0; }
+
+    if (k0 < k1) {
+      uint4 na0 = pa0[k0 * 64], na1 = pa1[k0 * 64], nb0 = pb0[k0 * 64];
+      for (int64_t kg = k0; kg < k1; kg++) {
+        const uint4 a0 = na0, a1 = na1, b0 = nb0;
+        const int64_t kn = (kg + 1 < k1) ? kg + 1 : kg;
+        na0 = pa0[kn * 64]; na1 = pa1[kn * 64]; nb0 = pb0[kn * 64];
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this K group's MFMAs
+        const uint32_t wa0[4] = {a0.x, a0.y, a0.z, a0.w}, wa1[4] = {a1.x, a1.y, a1.z, a1.w};
+        const uint32_t wb0[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const Frag3 A[2] = {tpg_decode3(wa0[s]), tpg_decode3(wa1[s])};
+          const Frag3 B = tpg_decode3(wb0[s]);
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            cV[t] = MFMA_I8(A[t].v, B.v, cV[t]);
+            cD[t] = MFMA_I8(A[t].d, B.d, cD[t]);
+            cH[t] = MFMA_I8(A[t].h, B.h, cH[t]);
+            cHV[t] = MFMA_I8(A[t].h, B.v, cHV[t]);
+            cVH[t] = MFMA_I8(A[t].v, B.h, cVH[t]);
+          }
+        }
+      }
+    }
+    int32_t* slab = acc_out + tp0 * TPG_PW_TILE_INTS + lane;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int o = (t * 16 + r) * 64;
+        atomicAdd(slab + 0 * 2048 + o, cV[t][r]);
+        atomicAdd(slab + 1 * 2048 + o, cD[t][r]);
+        atomicAdd(slab + 2 * 2048 + o, cH[t][r]);
+        atomicAdd(slab + 3 * 2048 + o, cHV[t][r]);
+        atomicAdd(slab + 4 * 2048 + o, cVH[t][r]);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+extern "C" size_t tpg_pairwise_buffer_bytes(int64_t n) {
+  const int64_t nst = ceil_div(n, 64);
+  return (size_t)(nst * (nst + 1)) * TPG_PW_TILE_INTS * sizeof(int32_t);
+}
+
+extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tpg_pairwise** out) {
+  TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(n > 0 && n < (1 << 22), TPG_EINVAL, "bad n = %lld", (long long)n);
+  TPG_HIP(hipSetDevice(ctx->device));
+  tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 64), 0, nullptr, false};
+  pw->ntp = pw->nst * (pw->nst + 1);
+  if (ext_buffer) {
+    if (!tpg_is_device_ptr(ext_buffer)) { delete pw; tpg_set_error("ext_buffer is not device memory"); return TPG_EINVAL; }
+    pw->acc = (int32_t*)ext_buffer;
+  } else {
+    hipError_t e = hipMalloc((void**)&pw->acc, tpg_pairwise_buffer_bytes(n));
+    if (e != hipSuccess) { delete pw; tpg_set_error("hipMalloc pairwise buffer: %s", hipGetErrorString(e)); return TPG_EHIP; }
+    pw->owns = true;
+  }
+  int rc = tpg_pairwise_zero(ctx, pw);
+  if (rc != TPG_OK) { tpg_pairwise_free(pw); return rc; }
+  *out = pw;
+  return TPG_OK;
+}
+
+extern "C" void tpg_pairwise_free(tpg_pairwise* pw) {
+  if (!pw) return;
+  if (pw->owns && pw->acc) (void)hipFree(pw->acc);
+  delete pw;
+}
+
+extern "C" int tpg_pairwise_zero(tpg_ctx* ctx, tpg_pairwise* pw) {
+  TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
+  ProfScope ps(ctx, "pairwise_zero");
+  TPG_HIP(hipMemsetAsync(pw->acc, 0, tpg_pairwise_buffer_bytes(pw->n), ctx->stream));
+  return TPG_OK;
+}
+
+extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
+                                       int64_t col_end) {
+  TPG_REQUIRE(ctx && pw && v, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(pw->n == v->n, TPG_EINVAL, "pairwise n = %lld but view n = %lld", (long long)pw->n, (long long)v->n);
+  if (col_end < 0) col_end = v->m;
+  TPG_REQUIRE(col_begin >= 0 && col_begin <= col_end && col_end <= v->m, TPG_EINVAL, "bad locus range [%lld,%lld)",
+              (long long)col_begin, (long long)col_end);
+  // the kernel works on whole 128-locus groups; a range that is not aligned would need masking
+  TPG_REQUIRE(col_begin % 128 == 0 && (col_end % 128 == 0 || col_end == v->m), TPG_EINVAL,
+              "locus range must start on a multiple of 128 and end on one (or at m)");
+  if (col_begin == col_end) return TPG_OK;
+  const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
+  const int64_t kgs = kg1 - kg0;
+  const int64_t nwaves = (int64_t)ctx->num_cu * 8;
+  // K split: make ntp * S fill the resident waves evenly, keep >= 8 K groups (1024 loci) per unit
+  int bestS = 1;
+  double best = -1;
+  const int64_t maxS = kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1;
+  for (int64_t S = 1; S <= maxS; S++) {
+    const int64_t U = pw->ntp * S;
+    const double eff = (double)U / (double)(ceil_div(U, nwaves) * nwaves);
+    if (eff > best + 0.01) { best = eff; bestS = (int)S; }
+  }
+  const int64_t U = pw->ntp * bestS;
+  const unsigned grid = (unsigned)(ceil_div(U, 4) < 2 * ctx->num_cu ? ceil_div(U, 4) : 2 * ctx->num_cu);
+  TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG, kg0,
+             kg1, (int)pw->nst, pw->ntp, bestS, pw->acc);
+  TPG_CHECK_LAUNCH();
+  return TPG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// epilogues.  FP64 arithmetic follows the R drivers' operation order (file compiled with
+// -ffp-contract=off).
+struct PwCounts {
+  int V, D, H, Aij, Aji;
+};
+
+__device__ __forceinline__ PwCounts tpg_pw_fetch(const int32_t* __restrict__ acc, int nst, int i, int j) {
+  bool sw = (j >> 5) < 2 * (i >> 6);  // below the stored band: read the mirrored element
+  if (sw) { int t = i; i = j; j = t; }
+  const int I = i >> 6, jt = j >> 5;
+  const int64_t u = tpg_pw_unit_index(nst, I, jt);
+  const int ta = (i >> 5) & 1;
+  const int row = i & 31, col = j & 31;
+  const int lane = col + 32 * ((row >> 2) & 1);
+  const int reg = (row & 3) + 4 * (row >> 3);
+  const int32_t* p = acc + u * TPG_PW_TILE_INTS + (ta * 16 + reg) * 64 + lane;
+  PwCounts c;
+  c.V = p[0];
+  c.D = p[2048];
+  c.H = p[2 * 2048];
+  const int hv = p[3 * 2048], vh = p[4 * 2048];
+  c.Aij = sw ? vh : hv;
+  c.Aji = sw ? hv : vh;
+  return c;
+}
+
+#define TPG_NAN __longlong_as_double(0x7FF8000000000000ll)
+
+// mode: 0 raw counts (six optional outputs), 1 IBS proportion / adjusted counts (scale), 2 KING,
+// 3 allele sharing
+__global__ void tpg_pairwise_epilogue_kernel(const int32_t* __restrict__ acc, int nst, int n, int mode,
+                                             double scale, double* __restrict__ o0, double* __restrict__ o1,
+                                             double* __restrict__ o2, double* __restrict__ o3,
+                                             double* __restrict__ o4, double* __restrict__ o5) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % n), j = (int)(idx / n);
+    const PwCounts c = tpg_pw_fetch(acc, nst, i, j);
+    if (mode == 0) {
+      if (o0) o0[idx] = (double)(c.V + c.D + c.H);
+      if (o1) o1[idx] = (double)(2 * c.V);
+      if (o2) o2[idx] = (double)(c.D - c.V + c.Aij + c.Aji);
+      if (o3) o3[idx] = (double)c.Aij;
+      if (o4) o4[idx] = (double)c.D;
+      if (o5) o5[idx] = (double)c.V;
+    } else if (mode == 1) {
+      const double prop = (double)(c.V + c.D + c.H) / (double)(2 * c.V);  // R/snp_ibs.R:88-95
+      o0[idx] = scale == 1.0 ? prop : prop * scale;                        // :100
+    } else if (mode == 2) {
+      const double K = (double)(c.D - c.V + c.Aij + c.Aji), Ni = (double)c.Aij, Nj = (double)c.Aji;
+      const double mn = Ni < Nj ? Ni : Nj;
+      o0[idx] = K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn;  // R/snp_king.R:86-89
+    } else {
+      const double num = (double)c.D, den = (double)c.V;
+      o0[idx] = c.V == 0 ? TPG_NAN : 0.5 * (1 + num / den);  // R/snp_allele_sharing.R:79-80
+    }
+  }
+}
+
+static int run_epilogue(tpg_ctx* ctx, const tpg_pairwise* pw, int mode, double scale, double* outs[6]) {
+  const size_t bytes = sizeof(double) * (size_t)pw->n * (size_t)pw->n;
+  OutBuf b[6];
+  for (int k = 0; k < 6; k++)
+    if (outs[k]) TPG_TRY(b[k].init(outs[k], bytes));
+  TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(2048), dim3(256), 0,
+             (const int32_t*)pw->acc, (int)pw->nst, (int)pw->n, mode, scale, b[0].dev<double>(), b[1].dev<double>(),
+             b[2].dev<double>(), b[3].dev<double>(), b[4].dev<double>(), b[5].dev<double>());
+  TPG_CHECK_LAUNCH();
+  for (int k = 0; k < 6; k++)
+    if (outs[k]) TPG_TRY(b[k].commit(ctx));
+  return TPG_OK;
+}
+
+extern "C" int tpg_pairwise_counts(tpg_ctx* ctx, const tpg_pairwise* pw, double* ibs, double* ibs_valid,
+                                   double* king_num, double* n_Aa_i, double* as_num, double* as_den) {
+  TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
+  double* outs[6] = {ibs, ibs_valid, king_num, n_Aa_i, as_num, as_den};
+  return run_epilogue(ctx, pw, 0, 1.0, outs);
+}
+
+extern "C" int tpg_pairwise_ibs(tpg_ctx* ctx, const tpg_pairwise* pw, int type, int64_t m, double* out) {
+  TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(type == TPG_IBS_PROPORTION || type == TPG_IBS_ADJUSTED_COUNTS, TPG_EINVAL, "bad IBS type %d", type);
+  double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
+  return run_epilogue(ctx, pw, 1, type == TPG_IBS_PROPORTION ? 1.0 : (double)m, outs);
+}
+
+extern "C" int tpg_pairwise_king(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
+  TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
+  double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
+  return run_epilogue(ctx, pw, 2, 1.0, outs);
+}
+
+extern "C" int tpg_pairwise_allele_sharing(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
+  TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
+  double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
+  return run_epilogue(ctx, pw, 3, 1.0, outs);
+}
+
+// GRM (R/pairwise_grm.R:42-50): mb = mean of the off-diagonal allele-sharing values (na.rm), then
+// 2 (M - mb) / (1 - mb).  The mean is reduced per block in double and finished on the host in long
+// double (R's mean() accumulates in long double too).
+__global__ __launch_bounds__(256) void tpg_offdiag_sum_kernel(const double* __restrict__ M, int n,
+                                                              double* __restrict__ part_sum,
+                                                              unsigned long long* __restrict__ part_cnt) {
+  __shared__ double ssum[256];
+  __shared__ unsigned long long scnt[256];
+  double s = 0;
+  unsigned long long c = 0;
+  const int64_t total = (int64_t)n * n;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % n), j = (int)(idx / n);
+    const double x = M[idx];
+    if (i != j && x == x) { s += x; c++; }
+  }
+  ssum[threadIdx.x] = s;
+  scnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { ssum[threadIdx.x] += ssum[threadIdx.x + w]; scnt[threadIdx.x] += scnt[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part_sum[blockIdx.x] = ssum[0]; part_cnt[blockIdx.x] = scnt[0]; }
+}
+
+__global__ void tpg_grm_kernel(double* __restrict__ M, int64_t total, double mb) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x)
+    M[idx] = (M[idx] - mb) / (1 - mb) * 2;
+}
+
+extern "C" int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
+  TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
+  const int n = (int)pw->n;
+  OutBuf o;
+  TPG_TRY(o.init(out, sizeof(double) * (size_t)n * (size_t)n));
+  double* nulls[6] = {o.dev<double>(), nullptr, nullptr, nullptr, nullptr, nullptr};
+  TPG_TRY(run_epilogue(ctx, pw, 3, 1.0, nulls));  // allele sharing straight into the device buffer
+  const int NB = 512;
+  double* d_sum = nullptr;
+  unsigned long long* d_cnt = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_sum, sizeof(double) * NB));
+  hipError_t e = hipMalloc((void**)&d_cnt, sizeof(unsigned long long) * NB);
+  if (e != hipSuccess) { (void)hipFree(d_sum); tpg_set_error("hipMalloc: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_offdiag_sum_kernel, dim3(NB), dim3(256), 0, o.dev<double>(), n, d_sum,
+             d_cnt);
+  std::vector<double> hs(NB);
+  std::vector<unsigned long long> hc(NB);
+  e = hipMemcpyAsync(hs.data(), d_sum, sizeof(double) * NB, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(hc.data(), d_cnt, sizeof(unsigned long long) * NB, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_sum);
+  (void)hipFree(d_cnt);
+  if (e != hipSuccess) { tpg_set_error("grm reduce: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  long double s = 0;
+  unsigned long long c = 0;
+  for (int b = 0; b < NB; b++) { s += hs[b]; c += hc[b]; }
+  const double mb = c ? (double)(s / (long double)c) : NAN;
+  TPG_LAUNCH(ctx, "grm_scale", tpg_grm_kernel, dim3(2048), dim3(256), 0, o.dev<double>(), (int64_t)n * n, mb);
+  TPG_CHECK_LAUNCH();
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return o.commit(ctx);
+}
+
+// ---------------------------------------------------------------------------
+// literal per-block mirrors of increment_{ibs,king,as}_counts
+static int increment_common(tpg_ctx* ctx, int which, double* A, double* B, const uint8_t* fbm_bytes, int64_t nrow,
+                            int64_t ncol, const int32_t* rowInd1, int64_t n, const int32_t* colInd1, int64_t m) {
+  TPG_REQUIRE(ctx && A && B && fbm_bytes && rowInd1 && colInd1, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty block");
+  // gather the block's columns (each is nrow contiguous bytes of the mmapped FBM)
+  std::vector<uint8_t> cols((size_t)nrow * (size_t)m);
+  for (int64_t j = 0; j < m; j++) {
+    TPG_REQUIRE(colInd1[j] >= 1 && colInd1[j] <= ncol, TPG_EINVAL, "colInd[%lld] = %d out of range", (long long)j,
+                colInd1[j]);
+    memcpy(cols.data() + (size_t)j * (size_t)nrow, fbm_bytes + (size_t)(colInd1[j] - 1) * (size_t)nrow, (size_t)nrow);
+  }
+  tpg_fbm* f = nullptr;
+  tpg_view* v = nullptr;
+  tpg_pairwise* pw = nullptr;
+  int rc = tpg_fbm_from_host(ctx, cols.data(), nrow, m, &f);
+  if (rc == TPG_OK) rc = tpg_view_create(ctx, f, rowInd1, n, nullptr, m, nullptr, &v);
+  if (rc == TPG_OK) rc = tpg_pairwise_create(ctx, n, nullptr, &pw);
+  if (rc == TPG_OK) rc = tpg_pairwise_accumulate(ctx, pw, v, 0, -1);
+  std::vector<double> a((size_t)n * (size_t)n), b((size_t)n * (size_t)n);
+  if (rc == TPG_OK) {
+    if (which == 0) rc = tpg_pairwise_counts(ctx, pw, a.data(), b.data(), nullptr, nullptr, nullptr, nullptr);
+    else if (which == 1) rc = tpg_pairwise_counts(ctx, pw, nullptr, nullptr, a.data(), b.data(), nullptr, nullptr);
+    else rc = tpg_pairwise_counts(ctx, pw, nullptr, nullptr, nullptr, nullptr, a.data(), b.data());
+  }
+  if (rc == TPG_OK)
+    for (size_t k = 0; k < a.size(); k++) { A[k] += a[k]; B[k] += b[k]; }
+  tpg_pairwise_free(pw);
+  tpg_view_free(v);
+  tpg_fbm_free(f);
+  return rc;
+}
+
+extern "C" int tpg_increment_ibs_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes, int64_t nrow,
+                                        int64_t ncol, const int32_t* rowInd1, int64_t n, const int32_t* colInd1,
+                                        int64_t m) {
+  return increment_common(ctx, 0, K, K2, fbm_bytes, nrow, ncol, rowInd1, n, colInd1, m);
+}
+extern "C" int tpg_increment_king_numerator(tpg_ctx* ctx, double* K, double* N_Aa_i, const uint8_t* fbm_bytes,
+                                            int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
+                                            const int32_t* colInd1, int64_t m) {
+  return increment_common(ctx, 1, K, N_Aa_i, fbm_bytes, nrow, ncol, rowInd1, n, colInd1, m);
+}
+extern "C" int tpg_increment_as_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes, int64_t nrow,
+                                       int64_t ncol, const int32_t* rowInd1, int64_t n, const int32_t* colInd1,
+                                       int64_t m) {
+  return increment_common(ctx, 2, K, K2, fbm_bytes, nrow, ncol, rowInd1, n, colInd1, m);
+}

@@ -1,0 +1,374 @@
+// runtime.hip -- context, error state, HIP-event profiling, FBM residency, view creation.
+#include <fcntl.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void tpg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* tpg_last_error(void) { return g_err; }
+extern "C" const char* tpg_version(void) { return "tidypopgen_amd 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------
+ProfScope::ProfScope(tpg_ctx* c, const char* name) : ctx(c), on(c->prof) {
+  if (!on) return;
+  rec.name = name;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+  };
+  rec.start = get();
+  rec.stop = get();
+  (void)hipEventRecord(rec.start, ctx->stream);
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  (void)hipEventRecord(rec.stop, ctx->stream);
+  ctx->prof_pending.push_back(rec);
+}
+
+int tpg_prof_resolve(tpg_ctx* ctx) {
+  if (ctx->prof_pending.empty()) return TPG_OK;
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->prof_pending) {
+    float ms = 0;
+    TPG_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
+    auto& a = ctx->prof_acc[r.name];
+    a.first += ms;
+    a.second += 1;
+    ctx->event_pool.push_back(r.start);
+    ctx->event_pool.push_back(r.stop);
+  }
+  ctx->prof_pending.clear();
+  return TPG_OK;
+}
+
+extern "C" int tpg_prof_enable(tpg_ctx* ctx, int on) {
+  TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
+  TPG_TRY(tpg_prof_resolve(ctx));
+  ctx->prof = on != 0;
+  return TPG_OK;
+}
+extern "C" int tpg_prof_reset(tpg_ctx* ctx) {
+  TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
+  TPG_TRY(tpg_prof_resolve(ctx));
+  ctx->prof_acc.clear();
+  return TPG_OK;
+}
+extern "C" int tpg_prof_get(tpg_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches) {
+  TPG_REQUIRE(ctx && prefix, TPG_EINVAL, "null argument");
+  TPG_TRY(tpg_prof_resolve(ctx));
+  double ms = 0;
+  int64_t n = 0;
+  size_t pl = strlen(prefix);
+  for (auto& kv : ctx->prof_acc)
+    if (kv.first.compare(0, pl, prefix) == 0) { ms += kv.second.first; n += kv.second.second; }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  return TPG_OK;
+}
+extern "C" int tpg_prof_dump(tpg_ctx* ctx, char* buf, size_t cap) {
+  TPG_REQUIRE(ctx && buf && cap > 0, TPG_EINVAL, "null argument");
+  TPG_TRY(tpg_prof_resolve(ctx));
+  size_t off = 0;
+  buf[0] = 0;
+  for (auto& kv : ctx->prof_acc) {
+    int w = snprintf(buf + off, cap - off, "%s\t%lld\t%.6f\n", kv.first.c_str(), (long long)kv.second.second,
+                     kv.second.first);
+    if (w < 0 || (size_t)w >= cap - off) break;
+    off += (size_t)w;
+  }
+  return TPG_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int tpg_ctx_create(int device, tpg_ctx** out) {
+  TPG_REQUIRE(out, TPG_EINVAL, "null out");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    tpg_set_error("no HIP device available (%s); this library has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return TPG_EHIP;
+  }
+  TPG_REQUIRE(device >= 0 && device < count, TPG_EINVAL, "device %d out of range [0,%d)", device, count);
+  TPG_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  TPG_HIP(hipGetDeviceProperties(&prop, device));
+  tpg_ctx* c = new tpg_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  TPG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  *out = c;
+  return TPG_OK;
+}
+
+extern "C" void tpg_ctx_destroy(tpg_ctx* ctx) {
+  if (!ctx) return;
+  (void)tpg_prof_resolve(ctx);
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int tpg_ctx_set_stream(tpg_ctx* ctx, void* hip_stream) {
+  TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
+  TPG_TRY(tpg_prof_resolve(ctx));
+  if (ctx->own_stream && ctx->stream) {
+    TPG_HIP(hipStreamSynchronize(ctx->stream));
+    TPG_HIP(hipStreamDestroy(ctx->stream));
+  }
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+  } else {
+    TPG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  return TPG_OK;
+}
+
+extern "C" int tpg_ctx_sync(tpg_ctx* ctx) {
+  TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return TPG_OK;
+}
+
+// ---------------------------------------------------------------------------
+bool tpg_is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // clear the sticky "invalid value" for plain host memory
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice;
+}
+
+int OutBuf::init(void* user_ptr, size_t nbytes) {
+  user = user_ptr;
+  bytes = nbytes;
+  if (tpg_is_device_ptr(user_ptr)) {
+    d = user_ptr;
+    owned = false;
+  } else {
+    TPG_HIP(hipMalloc(&d, nbytes > 0 ? nbytes : 16));
+    owned = true;
+  }
+  return TPG_OK;
+}
+int OutBuf::commit(tpg_ctx* ctx) {
+  if (owned && user && bytes) {
+    TPG_HIP(hipMemcpyAsync(user, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TPG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return TPG_OK;
+}
+OutBuf::~OutBuf() {
+  if (owned && d) (void)hipFree(d);
+}
+
+int InBuf::init(tpg_ctx* ctx, const void* user_ptr, size_t nbytes) {
+  if (tpg_is_device_ptr(user_ptr)) {
+    d = user_ptr;
+    return TPG_OK;
+  }
+  TPG_HIP(hipMalloc(&owned_ptr, nbytes > 0 ? nbytes : 16));
+  if (nbytes) TPG_HIP(hipMemcpyAsync(owned_ptr, user_ptr, nbytes, hipMemcpyHostToDevice, ctx->stream));
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  d = owned_ptr;
+  return TPG_OK;
+}
+InBuf::~InBuf() {
+  if (owned_ptr) (void)hipFree(owned_ptr);
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, tpg_fbm** out) {
+  TPG_REQUIRE(ctx && bytes && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(nrow > 0 && ncol > 0, TPG_EINVAL, "empty FBM (%lld x %lld)", (long long)nrow, (long long)ncol);
+  TPG_HIP(hipSetDevice(ctx->device));
+  tpg_fbm* f = new tpg_fbm{ctx, nullptr, nrow, ncol};
+  size_t sz = (size_t)nrow * (size_t)ncol;
+  hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
+  if (e != hipSuccess) { delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
+  e = hipMemcpyAsync(f->d_bytes, bytes, sz, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { (void)hipFree(f->d_bytes); delete f; tpg_set_error("FBM upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  *out = f;
+  return TPG_OK;
+}
+
+extern "C" int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int64_t ncol, tpg_fbm** out) {
+  TPG_REQUIRE(ctx && path && out, TPG_EINVAL, "null argument");
+  int fd = open(path, O_RDONLY);
+  TPG_REQUIRE(fd >= 0, TPG_EINVAL, "cannot open backing file %s", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (int64_t)st.st_size < nrow * ncol) {
+    close(fd);
+    tpg_set_error("backing file %s is smaller than %lld x %lld bytes", path, (long long)nrow, (long long)ncol);
+    return TPG_EINVAL;
+  }
+  size_t sz = (size_t)nrow * (size_t)ncol;
+  void* p = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  TPG_REQUIRE(p != MAP_FAILED, TPG_EINVAL, "mmap of %s failed", path);
+  int rc = tpg_fbm_from_host(ctx, (const uint8_t*)p, nrow, ncol, out);
+  munmap(p, sz);
+  return rc;
+}
+
+extern "C" int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0, int npop,
+                             uint32_t miss_thresh, int imputed_bytes, tpg_fbm** out) {
+  TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(nrow > 0 && ncol > 0 && npop > 0 && npop <= 1024, TPG_EINVAL, "bad synth shape");
+  TPG_HIP(hipSetDevice(ctx->device));
+  tpg_fbm* f = new tpg_fbm{ctx, nullptr, nrow, ncol};
+  size_t sz = (size_t)nrow * (size_t)ncol;
+  hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
+  if (e != hipSuccess) { delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
+  int rc = tpg_launch_synth(ctx, f->d_bytes, seed, nrow, ncol, j0, npop, miss_thresh, imputed_bytes);
+  if (rc != TPG_OK) { (void)hipFree(f->d_bytes); delete f; return rc; }
+  *out = f;
+  return TPG_OK;
+}
+
+extern "C" int tpg_fbm_to_host(tpg_ctx* ctx, const tpg_fbm* fbm, uint8_t* bytes) {
+  TPG_REQUIRE(ctx && fbm && bytes, TPG_EINVAL, "null argument");
+  TPG_HIP(hipMemcpyAsync(bytes, fbm->d_bytes, (size_t)fbm->nrow * (size_t)fbm->ncol, hipMemcpyDeviceToHost, ctx->stream));
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return TPG_OK;
+}
+
+extern "C" void tpg_fbm_free(tpg_fbm* fbm) {
+  if (!fbm) return;
+  if (fbm->d_bytes) (void)hipFree(fbm->d_bytes);
+  delete fbm;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n,
+                               const int32_t* colInd1, int64_t m, const double* code256, tpg_view** out) {
+  TPG_REQUIRE(ctx && fbm && out, TPG_EINVAL, "null argument");
+  if (!rowInd1) n = fbm->nrow;
+  if (!colInd1) m = fbm->ncol;
+  TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty view (%lld x %lld)", (long long)n, (long long)m);
+  TPG_REQUIRE(n < (1ll << 24), TPG_EINVAL, "n = %lld too large", (long long)n);
+  // index validation on the host (bigstatsr's accessors bounds-check too)
+  if (rowInd1)
+    for (int64_t i = 0; i < n; i++)
+      TPG_REQUIRE(rowInd1[i] >= 1 && rowInd1[i] <= fbm->nrow, TPG_EINVAL, "rowInd[%lld] = %d out of [1,%lld]",
+                  (long long)i, rowInd1[i], (long long)fbm->nrow);
+  if (colInd1)
+    for (int64_t j = 0; j < m; j++)
+      TPG_REQUIRE(colInd1[j] >= 1 && colInd1[j] <= fbm->ncol, TPG_EINVAL, "colInd[%lld] = %d out of [1,%lld]",
+                  (long long)j, colInd1[j], (long long)fbm->ncol);
+  // byte -> 2-bit code table
+  uint8_t lut[256];
+  for (int b = 0; b < 256; b++) {
+    if (!code256) { lut[b] = b < 3 ? (uint8_t)b : 3; continue; }
+    double x = code256[b];
+    if (!(x > -1)) lut[b] = 3;  // NA (NaN), same test as the reference
+    else if (x == 0.0) lut[b] = 0;
+    else if (x == 1.0) lut[b] = 1;
+    else if (x == 2.0) lut[b] = 2;
+    else lut[b] = 0xFF;  // unsupported value: flagged by the pack kernel only if it occurs
+  }
+  TPG_HIP(hipSetDevice(ctx->device));
+  tpg_view* v = new tpg_view{ctx, n, m, ceil_div(n, 128), ceil_div(m, 128), nullptr, nullptr, 0};
+  v->bytes_each = (size_t)v->Q * (size_t)v->KG * 4096;
+  int32_t *d_rows = nullptr, *d_cols = nullptr;
+  uint8_t* d_lut = nullptr;
+  int rc = TPG_OK;
+  auto fail = [&](int code) {
+    if (d_rows) (void)hipFree(d_rows);
+    if (d_cols) (void)hipFree(d_cols);
+    if (d_lut) (void)hipFree(d_lut);
+    tpg_view_free(v);
+    return code;
+  };
+#define VHIP(call)                                                                       \
+  do {                                                                                   \
+    hipError_t _e = (call);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      tpg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+      return fail(TPG_EHIP);                                                             \
+    }                                                                                    \
+  } while (0)
+  VHIP(hipMalloc((void**)&v->T, v->bytes_each));
+  VHIP(hipMalloc((void**)&v->L, v->bytes_each));
+  VHIP(hipMalloc((void**)&d_lut, 256 + 16));
+  VHIP(hipMemcpyAsync(d_lut, lut, 256, hipMemcpyHostToDevice, ctx->stream));
+  VHIP(hipMemsetAsync(d_lut + 256, 0, 16, ctx->stream));
+  if (rowInd1) {
+    VHIP(hipMalloc((void**)&d_rows, sizeof(int32_t) * (size_t)n));
+    VHIP(hipMemcpyAsync(d_rows, rowInd1, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (colInd1) {
+    VHIP(hipMalloc((void**)&d_cols, sizeof(int32_t) * (size_t)m));
+    VHIP(hipMemcpyAsync(d_cols, colInd1, sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+  }
+  rc = tpg_launch_pack(ctx, fbm, d_rows, d_cols, d_lut, v);
+  if (rc != TPG_OK) return fail(rc);
+  int32_t bad = 0;
+  VHIP(hipMemcpyAsync(&bad, d_lut + 256, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VHIP(hipStreamSynchronize(ctx->stream));
+#undef VHIP
+  if (bad) {
+    tpg_set_error("code256 maps an occurring FBM byte to a value outside {0,1,2,NA}; the 2-bit device path cannot represent it");
+    return fail(TPG_EUNSUPPORTED);
+  }
+  if (d_rows) (void)hipFree(d_rows);
+  if (d_cols) (void)hipFree(d_cols);
+  (void)hipFree(d_lut);
+  *out = v;
+  return TPG_OK;
+}
+
+extern "C" void tpg_view_free(tpg_view* v) {
+  if (!v) return;
+  if (v->T) (void)hipFree(v->T);
+  if (v->L) (void)hipFree(v->L);
+  delete v;
+}
+extern "C" int64_t tpg_view_n(const tpg_view* v) { return v ? v->n : 0; }
+extern "C" int64_t tpg_view_m(const tpg_view* v) { return v ? v->m : 0; }
+
+extern "C" int tpg_view_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* codes) {
+  TPG_REQUIRE(ctx && v && codes, TPG_EINVAL, "null argument");
+  // codes from T, cross-checked against L on the device: both layouts must agree
+  OutBuf o;
+  TPG_TRY(o.init(codes, (size_t)v->n * (size_t)v->m));
+  TPG_TRY(tpg_launch_unpack(ctx, v, o.dev<uint8_t>(), 0));
+  uint8_t* d2 = nullptr;
+  TPG_HIP(hipMalloc((void**)&d2, (size_t)v->n * (size_t)v->m));
+  int rc = tpg_launch_unpack(ctx, v, d2, 1);
+  std::vector<uint8_t> a((size_t)v->n * (size_t)v->m), b((size_t)v->n * (size_t)v->m);
+  if (rc == TPG_OK) {
+    hipError_t e = hipMemcpyAsync(a.data(), o.dev<uint8_t>(), a.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b.data(), d2, b.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { tpg_set_error("unpack copy failed: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  }
+  (void)hipFree(d2);
+  TPG_TRY(rc);
+  TPG_REQUIRE(a == b, TPG_EHIP, "internal error: T and L layouts of the view disagree");
+  return o.commit(ctx);
+}
