@@ -164,7 +164,7 @@ def test_allele_sharing_and_grm_reference_cases(tpg):
 
 
 @pytest.mark.parametrize("n,m,miss", [(64, 128, 0.0), (65, 129, 0.05), (200, 3000, 0.02), (333, 5001, 0.3),
-                                      (700, 20000, 0.02)])
+                                      (500, 8000, 0.02)])
 def test_pairwise_counts_bit_exact_and_epilogues(tpg, n, m, miss):
     fbm = orc.synth_fbm(31, n, m, npop=9, miss=miss, imputed_bytes=(n == 333))
     X = tpg.FBM.from_numpy(fbm)

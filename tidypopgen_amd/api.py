@@ -37,7 +37,8 @@ FST_METHODS = {"Hudson": 0, "Nei87": 1, "WC84": 2}
 
 
 def _ptr(x):
-    """numpy array -> its data pointer; int -> raw (device) pointer; None -> NULL."""
+    """numpy array -> its data pointer; int -> raw (device) pointer; None -> NULL.
+    The caller must keep the array referenced until the C call returns (never pass a temporary)."""
     if x is None:
         return C.c_void_p(None)
     if isinstance(x, (int, np.integer)):
@@ -342,7 +343,8 @@ def loci_counts(v: View) -> np.ndarray:
 def alt_freq_dip_pseudo_cpp(v: View, ploidy=None, as_counts: bool = False) -> np.ndarray:
     """src/alt_freq_dip_pseudo_cpp.cpp:8-58 -> (m, 2)"""
     out = np.zeros((v.m, 2), order="F")
-    check(lib.tpg_alt_freq_dip_pseudo(v.ctx.h, v.h, _ptr(_ploidy(v, ploidy)), C.c_int(int(as_counts)), _ptr(out)))
+    pl = _ploidy(v, ploidy)
+    check(lib.tpg_alt_freq_dip_pseudo(v.ctx.h, v.h, _ptr(pl), C.c_int(int(as_counts)), _ptr(out)))
     return out
 
 
@@ -363,23 +365,26 @@ def loci_missingness(X: FBM, ind_row=None, ind_col=None, as_counts: bool = False
 def grouped_alt_freq_dip_pseudo_cpp(v: View, groupIds, ngroups: int, ploidy=None, as_counts: bool = False):
     """src/grouped_alt_freq_dip_pseudo_cpp.cpp:8-58 -> (m, 2G)"""
     out = np.zeros((v.m, 2 * ngroups), order="F")
-    check(lib.tpg_grouped_alt_freq_dip_pseudo(v.ctx.h, v.h, _ptr(_i32(groupIds)), C.c_int(ngroups),
-                                              _ptr(_ploidy(v, ploidy)), C.c_int(int(as_counts)), _ptr(out)))
+    gid, pl = _i32(groupIds), _ploidy(v, ploidy)
+    check(lib.tpg_grouped_alt_freq_dip_pseudo(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pl),
+                                              C.c_int(int(as_counts)), _ptr(out)))
     return out
 
 
 def grouped_missingness_cpp(v: View, groupIds, ngroups: int):
     """src/grouped_missingness_cpp.cpp:8-33 -> (m, G)"""
     out = np.zeros((v.m, ngroups), order="F")
-    check(lib.tpg_grouped_missingness(v.ctx.h, v.h, _ptr(_i32(groupIds)), C.c_int(ngroups), _ptr(out)))
+    gid = _i32(groupIds)
+    check(lib.tpg_grouped_missingness(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(out)))
     return out
 
 
 def grouped_summaries_dip_pseudo_cpp(v: View, groupIds, ngroups: int, ploidy=None) -> dict:
     """src/grouped_summaries_dip_pseudo_cpp.cpp:11-63"""
     outs = [np.zeros((v.m, ngroups), order="F") for _ in range(4)]
-    check(lib.tpg_grouped_summaries_dip_pseudo(v.ctx.h, v.h, _ptr(_i32(groupIds)), C.c_int(ngroups),
-                                               _ptr(_ploidy(v, ploidy)), *[_ptr(o) for o in outs]))
+    gid, pl = _i32(groupIds), _ploidy(v, ploidy)
+    check(lib.tpg_grouped_summaries_dip_pseudo(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pl),
+                                               *[_ptr(o) for o in outs]))
     return dict(freq_alt=outs[0], freq_ref=outs[1], n=outs[2], het_obs=outs[3])
 
 
@@ -416,7 +421,8 @@ def pairwise_pop_fst(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=No
     pairs_c = np.ascontiguousarray(pairs.T)  # (P, 2) row-major == 2 x P column-major
     P = pairs_c.shape[0]
     tot, a, b = _fst_outputs(v.m, P, by_locus, return_num_dem)
-    check(lib.tpg_pairwise_pop_fst(v.ctx.h, v.h, _ptr(_i32(groupIds)), C.c_int(ngroups), _ptr(_ploidy(v, ploidy)),
+    gid, pl = _i32(groupIds), _ploidy(v, ploidy)
+    check(lib.tpg_pairwise_pop_fst(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pl),
                                    C.c_int(FST_METHODS[method]), _ptr(pairs_c), C.c_int(P), C.c_int(int(by_locus)),
                                    C.c_int(int(return_num_dem)), _ptr(tot), _ptr(a), _ptr(b)))
     return _fst_result(tot, a, b, by_locus, return_num_dem)
@@ -463,7 +469,8 @@ def pca_center_scale(v: View):
 
 def pca_gram(v: View, center, scale) -> np.ndarray:
     K = np.zeros((v.n, v.n), order="F")
-    check(lib.tpg_pca_gram(v.ctx.h, v.h, _ptr(_f64(center)), _ptr(_f64(scale)), _ptr(K)))
+    center, scale = _f64(center), _f64(scale)
+    check(lib.tpg_pca_gram(v.ctx.h, v.h, _ptr(center), _ptr(scale), _ptr(K)))
     return K
 
 
@@ -493,7 +500,8 @@ def fbm256_prod_and_rowSumsSq(X: FBM, ind_row, ind_col, center, scale, V, code25
         raise ValueError("Incompatibility between dimensions.")  # bigstatsr myassert_size
     XV = np.zeros((v.n, V.shape[1]), order="F")
     rss = np.zeros(v.n)
-    check(lib.tpg_fbm256_prod_and_rowSumsSq(v.ctx.h, v.h, _ptr(_f64(center)), _ptr(_f64(scale)), _ptr(V),
+    center, scale = _f64(center), _f64(scale)
+    check(lib.tpg_fbm256_prod_and_rowSumsSq(v.ctx.h, v.h, _ptr(center), _ptr(scale), _ptr(V),
                                             C.c_int(V.shape[1]), _ptr(XV), _ptr(rss)))
     return XV, rss
 
