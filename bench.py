@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the tidypopgen genotype-matrix hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one synthetic SNP panel that is already
+resident in HBM as FBM bytes (5 000 individuals x 1 000 000 SNPs per GPU, 51 populations, 2 %
+missing kept as imputed bytes -- BASELINE.json configs[2..4]):
+
+    pack (raw view)  -> loci_alt_freq / missingness counts -> grouped_alt_freq (51 pops)
+    -> pairwise_pop_fst Hudson + WC84 -> IBS + KING + allele-sharing/GRM cross-products (int8 MFMA)
+    -> [N > 1: all-reduce of the integer N x N partials and of the Fst numerator/denominator sums]
+    -> IBS / KING / GRM epilogues
+    -> pack (imputed view) -> gt_pca_partialSVD (k = 20): center/scale, Gram, eigen, loadings
+
+Multi-GPU: SNP blocks shard across ranks (weak scaling: every rank owns 1 000 000 loci of a panel
+that is world_size times longer); one process per GPU, torch.distributed (RCCL).
+Rank 0 prints ONE JSON line.  `value` = N*M_total genotypes / wall second of the whole step.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=5000, help="individuals")
+    ap.add_argument("--m", type=int, default=1000000, help="SNPs per GPU")
+    ap.add_argument("--pops", type=int, default=51)
+    ap.add_argument("--k", type=int, default=20, help="principal components")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-loci", type=int, default=4096)
+    return ap.parse_args()
+
+
+class Step:
+    """Holds the resident panel and runs one pass of the hot path through the C ABI."""
+
+    def __init__(self, args, rank, world, local_rank):
+        import tidypopgen_amd as tpg
+        from tidypopgen_amd import api
+
+        self.tpg, self.api, self.lib = tpg, api, tpg._lib.lib
+        self.args, self.rank, self.world = args, rank, world
+        self.torch = None
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+
+            self.torch, self.dist = torch, dist
+            torch.cuda.set_device(local_rank)
+        self.ctx = tpg.Context(local_rank)
+        n, m, G = args.n, args.m, args.pops
+        # FBM bytes resident in HBM before the timed region (the "input"); imputed bytes 4..6 where missing
+        self.X = tpg.FBM.synth(3, n, m, j0=rank * m, npop=G, miss=0.02, imputed_bytes=True, ctx=self.ctx,
+                               code256=tpg.CODE_012)
+        self.gid = (np.arange(n) % G).astype(np.int32)
+        self.ploidy = np.full(n, 2.0)
+        self.pairs = np.ascontiguousarray(api.combn2(G).T)
+        self.P = self.pairs.shape[0]
+        self.code_imp = np.ascontiguousarray(tpg.CODE_IMPUTE_PRED)
+        self.code_012 = np.ascontiguousarray(tpg.CODE_012)
+        # device-resident outputs (PCIe excluded from `value`; see DESIGN.md for the inclusive rate)
+        self.d_freq = self._dalloc(8 * 2 * m)
+        self.d_gfreq = self._dalloc(8 * 2 * G * m)
+        self.d_nn = [self._dalloc(8 * n * n) for _ in range(3)]  # IBS, KING, GRM
+        self.pw_bytes = tpg.Pairwise.buffer_bytes(n)
+        if self.torch is not None:
+            self.pw_tensor = self.torch.zeros(self.pw_bytes // 4, dtype=self.torch.int32, device="cuda")
+            self.pw = tpg.Pairwise(self.ctx, n, ext_buffer=self.pw_tensor.data_ptr())
+        else:
+            self.pw = tpg.Pairwise(self.ctx, n)
+        self.fst = {}
+        self.has_pca = True
+
+    def _dalloc(self, nbytes):
+        p = C.c_void_p()
+        self.tpg._lib.check(self.lib.tpg_dev_alloc(self.ctx.h, C.c_size_t(nbytes), C.byref(p)))
+        return p
+
+    def barrier_sync(self):
+        self.ctx.sync()
+        if self.torch is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def run(self):
+        tpg, api, lib, ctx, a = self.tpg, self.api, self.lib, self.ctx, self.args
+        chk = tpg._lib.check
+        n, m, G = a.n, a.m, a.pops
+        P = self.P
+        # ---- raw view (bytes 0/1/2 valid, the rest missing) ----
+        v = api.View(self.X, None, None, code256=self.code_012)
+        chk(lib.tpg_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(self.ploidy), C.c_int(0), self.d_freq))
+        chk(lib.tpg_grouped_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(self.gid), C.c_int(G), api._ptr(self.ploidy),
+                                                C.c_int(0), self.d_gfreq))
+        sums = {}
+        for name, code in (("Hudson", 0), ("WC84", 2)):
+            sn, sd = np.zeros(P), np.zeros(P)
+            chk(lib.tpg_pairwise_pop_fst_sums(ctx.h, v.h, api._ptr(self.gid), C.c_int(G), api._ptr(self.ploidy),
+                                              C.c_int(code), api._ptr(self.pairs), C.c_int(P), api._ptr(sn),
+                                              api._ptr(sd)))
+            sums[name] = (sn, sd)
+        self.pw.zero()
+        self.pw.accumulate(v)
+        if self.torch is not None:
+            # the only data-path exchange: integer N x N partials (exact, order independent) and 4P doubles
+            ctx.sync()
+            self.dist.all_reduce(self.pw_tensor)
+            t = self.torch.from_numpy(np.concatenate([sums["Hudson"][0], sums["Hudson"][1], sums["WC84"][0],
+                                                      sums["WC84"][1]])).cuda()
+            self.dist.all_reduce(t)
+            self.torch.cuda.synchronize()
+            t = t.cpu().numpy()
+            sums = {"Hudson": (t[:P], t[P:2 * P]), "WC84": (t[2 * P:3 * P], t[3 * P:])}
+        for name in sums:
+            self.fst[name] = sums[name][0] / sums[name][1]
+        chk(lib.tpg_pairwise_ibs(ctx.h, self.pw.h, C.c_int(0), C.c_int64(m * self.world), self.d_nn[0]))
+        chk(lib.tpg_pairwise_king(ctx.h, self.pw.h, self.d_nn[1]))
+        chk(lib.tpg_pairwise_grm(ctx.h, self.pw.h, self.d_nn[2]))
+        v.free()
+        # ---- imputed view + PCA ----
+        if self.has_pca:
+            try:
+                self.pca = self._pca()
+            except tpg._lib.TpgError as e:
+                if e.code != 3:
+                    raise
+                self.has_pca = False
+        ctx.sync()
+
+    def _pca(self):
+        # single-GPU path; the sharded Gram all-reduce lands with the PCA kernels
+        return self.api.gt_pca_partialSVD(self.X, None, None, k=self.args.k, total_var=True, code256=self.code_imp)
+
+
+def cpu_baseline(args):
+    """The oracle's "as the reference does it" path (oracle/oracle.py: dense FP64 one-hot blocks + BLAS
+    products for IBS/KING/AS, C loops for the per-locus statistics and Fst, numpy Gram for PCA), timed on
+    this host's cores over a bounded sample of the same workload."""
+    from oracle import oracle as orc
+
+    n, G, B = args.n, args.pops, args.cpu_sample_loci
+    fbm = orc.synth_fbm(3, n, B, npop=G, miss=0.02, imputed_bytes=True)
+    r = np.arange(1, n + 1, dtype=np.int32)
+    c = np.arange(1, B + 1, dtype=np.int32)
+    gid = (np.arange(n) % G).astype(np.int32)
+    ploidy = np.full(n, 2.0)
+    t0 = time.time()
+    K = [np.zeros((n, n)) for _ in range(6)]
+    orc.blas_increment_ibs(K[0], K[1], fbm, r, c)
+    orc.blas_increment_king(K[2], K[3], fbm, r, c)
+    orc.blas_increment_as(K[4], K[5], fbm, r, c)
+    orc.king_epilogue(K[2], K[3])
+    orc.pairwise_grm(orc.as_epilogue(K[4], K[5]))
+    orc.alt_freq_dip_pseudo_cpp(fbm, r, c, ploidy)
+    orc.grouped_alt_freq_dip_pseudo_cpp(fbm, r, c, gid, G, ploidy)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        orc.pairwise_pop_fst(fbm, r, c, gid, G, method="Hudson")
+        orc.pairwise_pop_fst(fbm, r, c, gid, G, method="WC84")
+    # PCA Gram of the sample (K = Z Z' through BLAS), as bigstatsr::big_SVD accumulates it per block
+    X = orc.CODE_IMPUTE_PRED[fbm]
+    center = X.mean(axis=0)
+    p = center / 2
+    scale = np.sqrt(2 * p * (1 - p))
+    keep = scale > 0
+    Z = (X[:, keep] - center[keep]) / scale[keep]
+    Z @ Z.T
+    dt = time.time() - t0
+    return {"value": n * B / dt, "unit": "SNP-genotypes/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} x {B} loci of the same synthetic panel, IBS+KING+AS via numpy/BLAS FP64 one-hot products "
+                      f"(reference's 6/4/2 products per block), per-locus + Fst (Hudson, WC84) C loops, PCA Gram via BLAS; "
+                      f"{dt:.1f} s; eigen step excluded"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl")
+    st = Step(args, rank, world, local_rank)
+    for _ in range(args.warmup):
+        st.run()
+    st.ctx.prof_enable(True)
+    st.ctx.prof_reset()
+    st.barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st.run()
+    st.barrier_sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch
+
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        st.dist.all_reduce(t, op=st.dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = st.ctx.prof_dump()
+    if rank == 0:
+        n, m = args.n, args.m
+        total_genotypes = n * m * world
+        ms_per_step = dt / args.steps * 1e3
+        # dominant kernel: the int8 MFMA cross-product pass.  Algorithmic ops per launch: the fused
+        # IBS+KING+AS pass needs 3 symmetric + 1 general product = 2.5 N^2 M MACs = 5 N^2 M ops.
+        cnt, ms = prof.get("pairwise_mfma", (0, 0.0))
+        roof = None
+        if cnt:
+            avg_s = ms / cnt * 1e-3
+            achieved = 5.0 * n * n * m / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": "tpg_pairwise_kernel (v_mfma_i32_32x32x32_i8)", "achieved": achieved,
+                    "peak": 5000.0, "unit": "TOP/s", "frac": achieved / 5000.0, "traffic": None,
+                    "avg_launch_ms": ms / cnt, "algorithmic_ops_per_launch": 5.0 * n * n * m}
+        analyses = ["pack", "loci_alt_freq", "grouped_alt_freq", "fst_hudson", "fst_wc84", "ibs", "king", "grm"]
+        if st.has_pca:
+            analyses.append(f"pca_partialSVD_k{args.k}")
+        out = {
+            "metric": "SNP-genotypes/s (N x M) for IBS+KING+GRM+Fst+PCA",
+            "value": total_genotypes / (dt / args.steps),
+            "unit": "SNP-genotypes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8 MFMA / int32 accumulate for counts and cross-products, f64 for statistics",
+            "data": "synthetic",
+            "config": {"workload": f"{n} individuals x {m} SNPs per GPU ({world} GPU), 51 populations, 2% missing "
+                                   f"(imputed bytes), seed 3 [BASELINE configs 2-4]",
+                       "analyses": analyses, "pca_included": bool(st.has_pca)},
+            "roofline": roof,
+            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items())},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        st.dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

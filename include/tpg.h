@@ -64,6 +64,11 @@ int tpg_prof_get(tpg_ctx* ctx, const char* prefix, double* total_ms, int64_t* la
 /* writes "name\tlaunches\ttotal_ms\n" lines into buf (truncated to cap) */
 int tpg_prof_dump(tpg_ctx* ctx, char* buf, size_t cap);
 
+/* plain device buffers for callers without their own allocator (outputs may be device memory) */
+int tpg_dev_alloc(tpg_ctx* ctx, size_t bytes, void** out);
+void tpg_dev_free(void* p);
+int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+
 /* ---- genotype store (replaces the mmapped FBM) -------- */
 int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, tpg_fbm** out);
 /* mmap bigstatsr's <backingfile>.bk and upload it */
@@ -117,6 +122,12 @@ int tpg_grouped_summaries_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const int3
 int tpg_pairwise_pop_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                          const double* ploidy, int method, const int32_t* pairs1, int P, int by_locus,
                          int return_num_dem, double* fst_tot, double* out_a, double* out_b);
+/* Same sweep, but returns the sums over this view's loci of numerator and denominator
+ * (sum_num[P], sum_den[P]) instead of their ratio: SNP-block shards on different GPUs add these
+ * (one all-reduce of 2P doubles) before dividing. */
+int tpg_pairwise_pop_fst_sums(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                              const double* ploidy, int method, const int32_t* pairs1, int P,
+                              double* sum_num, double* sum_den);
 /* Literal mirrors of the three loop functions (src/pairwise_fst_hudson_loop.cpp:5-63,
  * src/pairwise_fst_wc84_loop.cpp:5-121, src/pairwise_fst_nei87_loop.cpp:5-115): inputs are
  * the m x G double matrices the reference passes; unused ones may be NULL. */

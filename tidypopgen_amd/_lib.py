@@ -52,14 +52,15 @@ lib.tpg_view_n.restype = C.c_int64
 lib.tpg_view_m.restype = C.c_int64
 lib.tpg_view_n.argtypes = [vp]
 lib.tpg_view_m.argtypes = [vp]
-for _name in ("tpg_ctx_destroy", "tpg_fbm_free", "tpg_view_free", "tpg_pairwise_free"):
+for _name in ("tpg_ctx_destroy", "tpg_fbm_free", "tpg_view_free", "tpg_pairwise_free", "tpg_dev_free"):
     getattr(lib, _name).restype = None
     getattr(lib, _name).argtypes = [vp]
 
 # every symbol include/tpg.h declares (checked by tests/test_abi.py against the header)
 SYMBOLS = [
     "tpg_last_error", "tpg_version", "tpg_ctx_create", "tpg_ctx_destroy", "tpg_ctx_set_stream", "tpg_ctx_sync",
-    "tpg_prof_enable", "tpg_prof_reset", "tpg_prof_get", "tpg_prof_dump", "tpg_fbm_from_host", "tpg_fbm_open_bk",
+    "tpg_prof_enable", "tpg_prof_reset", "tpg_prof_get", "tpg_prof_dump", "tpg_dev_alloc", "tpg_dev_free",
+    "tpg_dev_to_host", "tpg_pairwise_pop_fst_sums", "tpg_fbm_from_host", "tpg_fbm_open_bk",
     "tpg_fbm_synth", "tpg_fbm_to_host", "tpg_fbm_free", "tpg_view_create", "tpg_view_free", "tpg_view_n",
     "tpg_view_m", "tpg_view_unpack", "tpg_loci_counts", "tpg_alt_freq_dip_pseudo",
     "tpg_grouped_alt_freq_dip_pseudo", "tpg_grouped_missingness", "tpg_grouped_summaries_dip_pseudo",

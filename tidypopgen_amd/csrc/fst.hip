@@ -160,23 +160,27 @@ __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int
   }
 }
 
-__global__ void tpg_fst_reduce_kernel(const double* __restrict__ part, int nblocks, int P, double* __restrict__ fst_tot) {
+__global__ void tpg_fst_reduce_kernel(const double* __restrict__ part, int nblocks, int P, double* __restrict__ fst_tot,
+                                      double* __restrict__ sum_num, double* __restrict__ sum_den) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= P) return;
   double sn = 0.0, sd = 0.0;
   for (int b = 0; b < nblocks; b++) { sn += part[((int64_t)b * P + pi) * 2]; sd += part[((int64_t)b * P + pi) * 2 + 1]; }
-  fst_tot[pi] = sn / sd;
+  if (fst_tot) fst_tot[pi] = sn / sd;
+  if (sum_num) { sum_num[pi] = sn; sum_den[pi] = sd; }
 }
 
 static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const int32_t* pairs1, int P, int by_locus,
-                   int return_num_dem, double* fst_tot, double* out_a, double* out_b) {
+                   int return_num_dem, double* fst_tot, double* out_a, double* out_b, double* sum_num = nullptr,
+                   double* sum_den = nullptr) {
   TPG_REQUIRE(method == TPG_FST_HUDSON || method == TPG_FST_NEI87 || method == TPG_FST_WC84, TPG_EINVAL,
               "unknown Fst method %d", method);
   TPG_REQUIRE(P > 0 && pairs1, TPG_EINVAL, "no population pairs");
   if (return_num_dem) by_locus = 1;  // R/pairwise_pop_fst.R:103-106
   TPG_REQUIRE(!by_locus || out_a, TPG_EINVAL, "by_locus output requested but out_a is NULL");
   TPG_REQUIRE(!return_num_dem || out_b, TPG_EINVAL, "return_num_dem requested but out_b is NULL");
-  TPG_REQUIRE(return_num_dem || fst_tot, TPG_EINVAL, "fst_tot is NULL");
+  TPG_REQUIRE(return_num_dem || fst_tot || sum_num, TPG_EINVAL, "fst_tot is NULL");
+  TPG_REQUIRE((sum_num == nullptr) == (sum_den == nullptr), TPG_EINVAL, "sum_num and sum_den go together");
   std::vector<int32_t> p0((size_t)2 * P);
   for (int k = 0; k < 2 * P; k++) {
     TPG_REQUIRE(pairs1[k] >= 1 && pairs1[k] <= G, TPG_EINVAL, "pairwise_combn[%d] = %d out of [1,%d]", k, pairs1[k], G);
@@ -194,8 +198,9 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   if (nblocks < 1) nblocks = 1;
   double* d_part = nullptr;
   TPG_HIP(hipMalloc((void**)&d_part, sizeof(double) * 2 * (size_t)nblocks * (size_t)P));
-  OutBuf ot, oa, ob;
+  OutBuf ot, oa, ob, osn, osd;
   int rc = TPG_OK;
+  if (sum_num) { rc = osn.init(sum_num, sizeof(double) * (size_t)P); if (rc == TPG_OK) rc = osd.init(sum_den, sizeof(double) * (size_t)P); }
   const size_t mp = sizeof(double) * (size_t)m * (size_t)P;
   if (rc == TPG_OK && fst_tot) rc = ot.init(fst_tot, sizeof(double) * (size_t)P);
   if (rc == TPG_OK && by_locus) rc = oa.init(out_a, mp);
@@ -212,9 +217,9 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
     else if (method == TPG_FST_WC84) FST_LAUNCH(TPG_FST_WC84, "fst_wc84");
     else FST_LAUNCH(TPG_FST_NEI87, "fst_nei87");
 #undef FST_LAUNCH
-    if (fst_tot)
+    if (fst_tot || sum_num)
       TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, d_part,
-                 nblocks, P, ot.dev<double>());
+                 nblocks, P, ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { tpg_set_error("fst kernels: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
@@ -222,6 +227,7 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   (void)hipFree(d_part);
   TPG_TRY(rc);
   if (fst_tot) TPG_TRY(ot.commit(ctx));
+  if (sum_num) { TPG_TRY(osn.commit(ctx)); TPG_TRY(osd.commit(ctx)); }
   if (by_locus) TPG_TRY(oa.commit(ctx));
   if (return_num_dem) TPG_TRY(ob.commit(ctx));
   return TPG_OK;
@@ -246,15 +252,9 @@ extern "C" int tpg_pairwise_fst_loop(tpg_ctx* ctx, int method, const int32_t* pa
   return run_fst(ctx, method, src, m, G, pairs1, P, by_locus, return_num_dem, fst_tot, out_a, out_b);
 }
 
-// class plan shared with loci.hip
-struct ClassPlanF {
-  std::vector<int32_t> cls;
-  int nclass, has_hap;
-};
-
-extern "C" int tpg_pairwise_pop_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
-                                    const double* ploidy, int method, const int32_t* pairs1, int P, int by_locus,
-                                    int return_num_dem, double* fst_tot, double* out_a, double* out_b) {
+static int fused_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups, const double* ploidy,
+                     int method, const int32_t* pairs1, int P, int by_locus, int return_num_dem, double* fst_tot,
+                     double* out_a, double* out_b, double* sum_num, double* sum_den) {
   TPG_REQUIRE(ctx && v && groupIds0, TPG_EINVAL, "null argument");
   TPG_REQUIRE(ngroups > 0, TPG_EINVAL, "ngroups must be positive");
   int has_hap = 0;
@@ -276,5 +276,21 @@ extern "C" int tpg_pairwise_pop_fst(tpg_ctx* ctx, const tpg_view* v, const int32
   GroupedCounts gc;
   TPG_TRY(tpg_grouped_counts(ctx, v, cls.data(), ngroups * (has_hap ? 2 : 1), &gc));
   FstSrc src{gc.cnt, gc.Mpad, gc.Cpad, has_hap, nullptr, nullptr, nullptr, nullptr};
-  return run_fst(ctx, method, src, v->m, ngroups, pairs1, P, by_locus, return_num_dem, fst_tot, out_a, out_b);
+  return run_fst(ctx, method, src, v->m, ngroups, pairs1, P, by_locus, return_num_dem, fst_tot, out_a, out_b, sum_num,
+                 sum_den);
+}
+
+extern "C" int tpg_pairwise_pop_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                                    const double* ploidy, int method, const int32_t* pairs1, int P, int by_locus,
+                                    int return_num_dem, double* fst_tot, double* out_a, double* out_b) {
+  return fused_fst(ctx, v, groupIds0, ngroups, ploidy, method, pairs1, P, by_locus, return_num_dem, fst_tot, out_a,
+                   out_b, nullptr, nullptr);
+}
+
+extern "C" int tpg_pairwise_pop_fst_sums(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                                         const double* ploidy, int method, const int32_t* pairs1, int P,
+                                         double* sum_num, double* sum_den) {
+  TPG_REQUIRE(sum_num && sum_den, TPG_EINVAL, "null output");
+  return fused_fst(ctx, v, groupIds0, ngroups, ploidy, method, pairs1, P, 0, 0, nullptr, nullptr, nullptr, sum_num,
+                   sum_den);
 }

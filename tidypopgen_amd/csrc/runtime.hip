@@ -150,6 +150,22 @@ extern "C" int tpg_ctx_sync(tpg_ctx* ctx) {
   return TPG_OK;
 }
 
+extern "C" int tpg_dev_alloc(tpg_ctx* ctx, size_t bytes, void** out) {
+  TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
+  TPG_HIP(hipSetDevice(ctx->device));
+  TPG_HIP(hipMalloc(out, bytes > 0 ? bytes : 16));
+  return TPG_OK;
+}
+extern "C" void tpg_dev_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+extern "C" int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+  TPG_REQUIRE(ctx && host_dst && dev_src, TPG_EINVAL, "null argument");
+  TPG_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return TPG_OK;
+}
+
 // ---------------------------------------------------------------------------
 bool tpg_is_device_ptr(const void* p) {
   if (!p) return false;
