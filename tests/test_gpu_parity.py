@@ -291,3 +291,76 @@ def test_fst_pseudohaploid_hudson_only(tpg):
     assert np.allclose(tpg.pairwise_pop_fst(X, None, None, gid, G, ploidy=ploidy, method="Hudson")["fst_tot"], o, rtol=1e-12)
     with pytest.raises(tpg._lib.TpgError):  # R/pairwise_pop_fst.R:113-115
         tpg.pairwise_pop_fst(X, None, None, gid, G, ploidy=ploidy, method="WC84")
+
+
+# ---------------------------------------------------------------- PCA
+def _align_sign(a, b):
+    """flip the columns of a so that they correlate positively with b"""
+    s = np.sign((a * b).sum(axis=0))
+    s[s == 0] = 1
+    return a * s
+
+
+def test_pca_families_against_prcomp_definition(tpg):
+    # tests/testthat/test_gt_pca.R:320-374: std.dev = d / sqrt(n - 1) and percent = d^2 / ||Z||_F^2 at 1e-4
+    fam = fx.families_fbm()
+    Xf = fam.astype(float)
+    keep = np.where(((Xf == 3).sum(axis=0) == 0))[0]
+    maf = Xf[:, keep].sum(axis=0) / 24
+    maf = np.minimum(maf, 1 - maf)
+    keep = keep[maf > 0.01]
+    cols = (keep + 1).astype(np.int32)
+    X = tpg.FBM.from_numpy(fam)
+    res = tpg.gt_pca_partialSVD(X, None, cols, k=10, code256=tpg.CODE_012)
+    Z = (Xf[:, keep] - res["center"]) / res["scale"]
+    s = np.linalg.svd(Z, compute_uv=False)
+    assert np.allclose(res["d"] / np.sqrt(11), s[:10] / np.sqrt(11), rtol=1e-6)
+    assert res["square_frobenius"] == pytest.approx((Z ** 2).sum(), rel=1e-12)
+    o = orc.gt_pca_partialSVD(fam, None, cols, k=10, code256=orc.CODE_012)
+    assert np.array_equal(res["center"], o["center"]) and np.array_equal(res["scale"], o["scale"])
+    assert np.allclose(res["d"], o["d"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,m,G,k", [(60, 500, 3, 5), (300, 4000, 6, 10), (500, 6000, 12, 20)])
+def test_pca_vs_oracle(tpg, n, m, G, k):
+    fbm = orc.synth_fbm(71, n, m, npop=G, miss=0.03, imputed_bytes=True)
+    # drop monomorphic loci (big_SVD stops on a zero scale)
+    dec = np.where(fbm > 3, fbm - 4, fbm)
+    cols = (np.where((dec.sum(axis=0) > 0) & (dec.sum(axis=0) < 2 * n))[0] + 1).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    o = orc.gt_pca_partialSVD(fbm, None, cols, k=k)
+    r = tpg.gt_pca_partialSVD(X, None, cols, k=k)
+    assert np.array_equal(r["center"], o["center"]) and np.array_equal(r["scale"], o["scale"])
+    assert r["square_frobenius"] == pytest.approx(o["square_frobenius"], rel=1e-12)
+    assert np.allclose(r["d"], o["d"], rtol=1e-6, atol=0)  # tolerance of BASELINE.json: 1e-6 relative
+    # scores u*d and loadings v, sign aligned (eigenvectors are defined up to sign)
+    so, sr = o["u"] * o["d"], _align_sign(r["u"] * r["d"], o["u"] * o["d"])
+    assert np.max(np.abs(sr - so)) <= 1e-6 * np.max(np.abs(so))
+    vr = _align_sign(r["v"], o["v"])
+    assert np.max(np.abs(vr - o["v"])) <= 1e-6 * np.max(np.abs(o["v"]))
+    # Gram matrix itself
+    v = tpg.View(X, None, cols, code256=tpg.CODE_IMPUTE_PRED)
+    c, s = tpg.pca_center_scale(v)
+    K = tpg.pca_gram(v, c, s)
+    _, _, Ko = orc.pca_gram(fbm, None, cols)
+    assert np.max(np.abs(K - Ko)) <= 1e-6 * np.max(np.abs(Ko))
+    assert np.array_equal(K, K.T)
+    # projection kernel (src/fbm_prod_and_rowSumSq.cpp), incl. missing values -> 0 under CODE_012
+    XV, rss = tpg.fbm256_prod_and_rowSumsSq(X, None, cols, o["center"], o["scale"], o["v"], code256=tpg.CODE_012)
+    XVo, rsso = orc.fbm256_prod_and_rowSumsSq(fbm, None, cols, o["center"], o["scale"], o["v"], code256=orc.CODE_012)
+    assert np.allclose(XV, XVo, rtol=1e-9, atol=1e-9 * np.max(np.abs(XVo)))
+    assert np.allclose(rss, rsso, rtol=1e-10)
+    assert tpg.square_frobenius(X, None, cols, o["center"], o["scale"]) == pytest.approx(o["square_frobenius"], rel=1e-12)
+
+
+def test_pca_errors_like_big_svd(tpg):
+    fbm = orc.synth_fbm(72, 50, 300, npop=2, miss=0.05)
+    X = tpg.FBM.from_numpy(fbm)
+    with pytest.raises(tpg._lib.TpgError) as e:  # missing values (CODE_012 keeps byte 3 missing)
+        tpg.gt_pca_partialSVD(X, k=3, code256=tpg.CODE_012)
+    assert e.value.code == 4
+    mono = orc.synth_fbm(72, 50, 300, npop=2, miss=0.0)
+    mono[:, 7] = 0
+    with pytest.raises(tpg._lib.TpgError) as e:  # zero scale
+        tpg.gt_pca_partialSVD(tpg.FBM.from_numpy(mono), k=3)
+    assert e.value.code == 4

@@ -1,10 +1,966 @@
-// pca.hip -- PCA Gram / partial SVD / projections (placeholder until the kernels land).
+// pca.hip -- gt_pca_partialSVD on the device: center/scale, Gram matrix, top-k eigenpairs,
+// loadings, projections and the squared Frobenius norm.
+//
+// Replaces the arithmetic behind R/gt_pca_partialSVD.R:82-89 (bigstatsr::big_SVD with
+// bigsnpr::snp_scaleBinom -- third-party, recalled: center_j = sum_i x_ij / n, p = center/2,
+// scale_j = sqrt(2 p (1-p)), K = sum_j z_j z_j', eigen(K), d = sqrt(lambda), v = Z'u/d),
+// R/square_frobenius.R:19-35 and fbm256_prod_and_rowSumsSq (src/fbm_prod_and_rowSumSq.cpp:10-47).
+//
+// Gram matrix on int8 MFMA.  z_ij = (g_ij - c_j)/s_j with g in {0,1,2} (no missing values), so
+//     K_ik = sum_j w_j g_ij g_kj  -  r_i  -  r_k  +  C,      w_j = 1/s_j^2,
+//     r_i  = sum_j w_j c_j g_ij,   C = sum_j w_j c_j^2.
+// The weights are rounded to fixed point, W_j = round(w_j 2^F), and written in balanced base-128
+// digits W_j = sum_t D_t[j] 128^t, D_t in [-64, 63].  Then sum_j W_j g_ij g_kj is a sum of T exact
+// int8 x int8 -> int32 MFMA contractions with A = D_t[j] * g_ij (|.| <= 128) and B = g_kj.  The only
+// approximation is the rounding of w_j (relative error <= 2^-(F+1)/w_min <= 2^-(F+2)): K-hat is the
+// exact Gram matrix of data whose per-locus scale is perturbed by that relative amount, so every
+// eigenvalue moves by at most that relative amount.  F is chosen as large as 4 digits allow
+// (F = 22 for w_max < 32, i.e. relative 6e-8); more digits are added when rare alleles need them.
+// r and C are FP64 sweeps that use the same rounded weights, which keeps K-hat exactly symmetric PSD
+// up to FP64 rounding.
+//
+// A-side fragment of digit t: one v_perm_b32 per register selects, per byte, D_t (genotype 1),
+// 2 D_t (genotype 2) or 0 (genotype 0) with a selector computed once per register from the codes.
+//
+// Eigen step: Chebyshev-filtered subspace iteration (Zhou & Saad) on the N x N matrix in HBM; all
+// N-sized work (K Q products, projections, residuals) runs in FP64 kernels here, only b x b
+// (b = k + 12) factorizations run on the host.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
 #include "common.h"
+#include "devfrag.h"
 
-#define TPG_NOT_YET(name) do { tpg_set_error(name ": not implemented yet"); return TPG_EUNSUPPORTED; } while (0)
+#define MFMA_I8(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8((a), (b), (c), 0, 0, 0)
+#define PCA_NAN __longlong_as_double(0x7FF8000000000000ll)
 
-extern "C" int tpg_pca_center_scale(tpg_ctx*, const tpg_view*, double*, double*) { TPG_NOT_YET("tpg_pca_center_scale"); }
-extern "C" int tpg_pca_gram(tpg_ctx*, const tpg_view*, const double*, const double*, double*) { TPG_NOT_YET("tpg_pca_gram"); }
-extern "C" int tpg_pca_partial_svd(tpg_ctx*, const tpg_view*, int, double*, double*, double*, double*, double*, double*) { TPG_NOT_YET("tpg_pca_partial_svd"); }
-extern "C" int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx*, const tpg_view*, const double*, const double*, const double*, int, double*, double*) { TPG_NOT_YET("tpg_fbm256_prod_and_rowSumsSq"); }
-extern "C" int tpg_square_frobenius(tpg_ctx*, const tpg_view*, const double*, const double*, double*) { TPG_NOT_YET("tpg_square_frobenius"); }
+// ---------------------------------------------------------------------------
+// center / scale from genotype counts; flags[0] = missing value met, flags[1] = zero scale met
+__global__ void tpg_pca_center_scale_kernel(const int4* __restrict__ counts, int64_t m, int64_t n,
+                                            double* __restrict__ center, double* __restrict__ scale,
+                                            int* __restrict__ flags) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = counts[j];
+    if (c.w != 0) flags[0] = 1;
+    const double mean = (double)(c.y + 2 * c.z) / (double)n;  // big_colstats()$sum / n
+    const double p = mean / 2;
+    const double sd = sqrt(2 * p * (1 - p));
+    if (!(sd > 0)) flags[1] = 1;
+    center[j] = mean;
+    scale[j] = sd;
+  }
+}
+
+// R/square_frobenius.R:32-34 from the counts: sum_j ((n-1) var_j + n (mean_j - center_j)^2) / scale_j^2,
+// var_j the sample variance (bigstatsr::big_colstats, recalled).  Per-block partial sums.
+__global__ __launch_bounds__(256) void tpg_pca_frobenius_kernel(const int4* __restrict__ counts, int64_t m, int64_t n,
+                                                                const double* __restrict__ center,
+                                                                const double* __restrict__ scale,
+                                                                double* __restrict__ part) {
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = counts[j];
+    const double s = (double)(c.y + 2 * c.z), ss = (double)(c.y + 4 * c.z);
+    const double nn = (double)n;
+    const double var = (ss - s * s / nn) / (nn - 1);
+    const double dm = s / nn - center[j];
+    acc += ((nn - 1) * var + nn * dm * dm) / (scale[j] * scale[j]);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+static int pca_counts_center_scale(tpg_ctx* ctx, const tpg_view* v, int32_t* d_counts, double* d_center,
+                                   double* d_scale) {
+  TPG_TRY(tpg_launch_loci_counts(ctx, v, d_counts));
+  int* d_flags = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_flags, 2 * sizeof(int)));
+  hipError_t e = hipMemsetAsync(d_flags, 0, 2 * sizeof(int), ctx->stream);
+  int flags[2] = {0, 0};
+  if (e == hipSuccess) {
+    TPG_LAUNCH(ctx, "pca_center_scale", tpg_pca_center_scale_kernel, dim3(1024), dim3(256), 0, (const int4*)d_counts,
+               v->m, v->n, d_center, d_scale, d_flags);
+    e = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_flags);
+  if (e != hipSuccess) { tpg_set_error("pca center/scale: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  // bigstatsr::big_SVD stops on missing values and on a zero scale
+  TPG_REQUIRE(!flags[0], TPG_ENUMERIC, "You can't have missing values in 'X'.");
+  TPG_REQUIRE(!flags[1], TPG_ENUMERIC, "Some variables have a zero scaling; remove them before attempting to scale variables.");
+  return TPG_OK;
+}
+
+extern "C" int tpg_pca_center_scale(tpg_ctx* ctx, const tpg_view* v, double* center, double* scale) {
+  TPG_REQUIRE(ctx && v && center && scale, TPG_EINVAL, "null argument");
+  OutBuf oc, os;
+  TPG_TRY(oc.init(center, sizeof(double) * (size_t)v->m));
+  TPG_TRY(os.init(scale, sizeof(double) * (size_t)v->m));
+  int32_t* d_counts = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
+  int rc = pca_counts_center_scale(ctx, v, d_counts, oc.dev<double>(), os.dev<double>());
+  (void)hipFree(d_counts);
+  TPG_TRY(rc);
+  TPG_TRY(oc.commit(ctx));
+  return os.commit(ctx);
+}
+
+static int frobenius_from_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* d_counts, const double* d_center,
+                                 const double* d_scale, double* out_host) {
+  const int NB = 512;
+  double* d_part = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_part, sizeof(double) * NB));
+  TPG_LAUNCH(ctx, "pca_frobenius", tpg_pca_frobenius_kernel, dim3(NB), dim3(256), 0, (const int4*)d_counts, v->m, v->n,
+             d_center, d_scale, d_part);
+  std::vector<double> hp(NB);
+  hipError_t e = hipMemcpyAsync(hp.data(), d_part, sizeof(double) * NB, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_part);
+  if (e != hipSuccess) { tpg_set_error("frobenius: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  long double s = 0;
+  for (int b = 0; b < NB; b++) s += hp[b];
+  *out_host = (double)s;
+  return TPG_OK;
+}
+
+extern "C" int tpg_square_frobenius(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale,
+                                    double* out) {
+  TPG_REQUIRE(ctx && v && center && scale && out, TPG_EINVAL, "null argument");
+  InBuf ic, is;
+  TPG_TRY(ic.init(ctx, center, sizeof(double) * (size_t)v->m));
+  TPG_TRY(is.init(ctx, scale, sizeof(double) * (size_t)v->m));
+  int32_t* d_counts = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
+  int rc = tpg_launch_loci_counts(ctx, v, d_counts);
+  if (rc == TPG_OK) rc = frobenius_from_counts(ctx, v, d_counts, ic.dev<double>(), is.dev<double>(), out);
+  (void)hipFree(d_counts);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// Skinny FP64 sweeps over a fragment layout (T: rows = individuals, columns = loci;
+// L: rows = loci, columns = individuals):
+//     out[row][k] = sum_col z(row,col) * Tab[col][k],   rss[row] = sum_col z(row,col)^2
+// with z = (g - center) * inv_scale for typed genotypes and 0 for missing ones.
+//   COLSCALE: center / inv_scale belong to the column (T layout: XV = Z V, src/fbm_prod_and_rowSumSq.cpp:30-44)
+//   ROWSCALE: they belong to the row (L layout: Z'U of the big_SVD second sweep)
+//   RAW:      z = g, no centering (the r_i sums of the Gram correction)
+// One wave per 32-row tile; the 128-column slice of Tab for the current block is staged in LDS and
+// shared by the workgroup's 4 waves.  KC (<= 8) output columns per pass.
+enum { SW_COLSCALE = 0, SW_ROWSCALE = 1, SW_RAW = 2 };
+
+template <int KC, int MODE>
+__global__ __launch_bounds__(256) void tpg_sweep_kernel(const uint4* __restrict__ P, int64_t nrowtiles, int64_t nblocks,
+                                                        int S, int64_t nrows, int64_t ncols,
+                                                        const double* __restrict__ center,
+                                                        const double* __restrict__ inv_scale,
+                                                        const double* __restrict__ Tab, int64_t ldtab, int kc,
+                                                        double* __restrict__ part, double* __restrict__ rss_part) {
+  __shared__ double tab[128][KC];
+  __shared__ double cs[128][2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t rt = (int64_t)blockIdx.x * 4 + wv;
+  const int split = blockIdx.y;
+  const int64_t b0 = nblocks * split / S, b1 = nblocks * (split + 1) / S;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t row = rt * 32 + r;
+  double acc[KC];
+#pragma unroll
+  for (int k = 0; k < KC; k++) acc[k] = 0;
+  double rss = 0;
+  double rc = 0, ris = 1;
+  if (MODE == SW_ROWSCALE && row < nrows) { rc = center[row]; ris = inv_scale[row]; }
+  const uint4* p = P + (rt * nblocks) * 64 + lane;
+  for (int64_t b = b0; b < b1; b++) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 128 * KC; idx += 256) {
+      const int cl = idx / KC, k = idx % KC;
+      const int64_t col = b * 128 + cl;
+      tab[cl][k] = (col < ncols && k < kc) ? Tab[col + (int64_t)k * ldtab] : 0.0;
+    }
+    if (MODE == SW_COLSCALE && threadIdx.x < 128) {
+      const int64_t col = b * 128 + threadIdx.x;
+      cs[threadIdx.x][0] = col < ncols ? center[col] : 0.0;
+      cs[threadIdx.x][1] = col < ncols ? inv_scale[col] : 0.0;
+    }
+    __syncthreads();
+    if (rt < nrowtiles) {
+      const uint4 a = p[b * 64];
+      const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int code = (w[s] >> tpg_elem_shift(e)) & 3;
+          const int cl = 32 * s + 16 * h + e;
+          double z;
+          if (MODE == SW_COLSCALE) z = ((double)code - cs[cl][0]) * cs[cl][1];
+          else if (MODE == SW_ROWSCALE) z = ((double)code - rc) * ris;
+          else z = (double)code;
+          if (code == 3) z = 0;
+          rss += z * z;
+#pragma unroll
+          for (int k = 0; k < KC; k++) acc[k] += z * tab[cl][k];
+        }
+      }
+    }
+  }
+  // the two halves of a row
+#pragma unroll
+  for (int k = 0; k < KC; k++) acc[k] += __shfl_xor(acc[k], 32);
+  rss += __shfl_xor(rss, 32);
+  if (rt < nrowtiles && lane < 32) {
+    const int64_t rows_pad = nrowtiles * 32;
+#pragma unroll
+    for (int k = 0; k < KC; k++) part[((int64_t)split * KC + k) * rows_pad + row] = acc[k];
+    if (rss_part) rss_part[(int64_t)split * rows_pad + row] = rss;
+  }
+}
+
+// out[row + (k0+k)*ldout] = scale_k * sum_split part[split][k][row]
+__global__ void tpg_sweep_reduce_kernel(const double* __restrict__ part, const double* __restrict__ rss_part, int S,
+                                        int KC, int kc, int64_t rows_pad, int64_t nrows, double* __restrict__ out,
+                                        int64_t ldout, int k0, const double* __restrict__ col_div,
+                                        double* __restrict__ rss_out) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < nrows * (kc + 1);
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx % nrows;
+    const int k = (int)(idx / nrows);
+    if (k < kc) {
+      double s = 0;
+      for (int sp = 0; sp < S; sp++) s += part[((int64_t)sp * KC + k) * rows_pad + row];
+      if (col_div) s = s / col_div[k0 + k];
+      out[row + (int64_t)(k0 + k) * ldout] = s;
+    } else if (rss_out && rss_part) {
+      double s = 0;
+      for (int sp = 0; sp < S; sp++) s += rss_part[(int64_t)sp * rows_pad + row];
+      rss_out[row] = s;
+    }
+  }
+}
+
+// out (nrows x K, column-major, ld = nrows) ; Tab is ncols x K column-major (ld = ldtab)
+static int run_sweep(tpg_ctx* ctx, int mode, const uint4* P, int64_t nrowtiles, int64_t nblocks, int64_t nrows,
+                     int64_t ncols, const double* d_center, const double* d_inv_scale, const double* d_Tab,
+                     int64_t ldtab, int K, double* d_out, const double* d_col_div, double* d_rss) {
+  const int KC = 8;
+  const int64_t rows_pad = nrowtiles * 32;
+  // split the column range so that the grid fills the chip (rows alone may be few: N/32 tiles)
+  int64_t S = 1;
+  const int64_t row_blocks = ceil_div(nrowtiles, 4);
+  while (row_blocks * S < 4 * ctx->num_cu && S * 2 <= nblocks && S < 64) S *= 2;
+  double *d_part = nullptr, *d_rsp = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_part, sizeof(double) * (size_t)S * KC * (size_t)rows_pad));
+  hipError_t e = hipMalloc((void**)&d_rsp, sizeof(double) * (size_t)S * (size_t)rows_pad);
+  if (e != hipSuccess) { (void)hipFree(d_part); tpg_set_error("hipMalloc sweep: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  dim3 grid((unsigned)row_blocks, (unsigned)S);
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kc = K - k0 < KC ? K - k0 : KC;
+    const double* tabp = d_Tab + (int64_t)k0 * ldtab;
+    double* rsp = (k0 == 0 && d_rss) ? d_rsp : nullptr;
+    if (mode == SW_COLSCALE)
+      TPG_LAUNCH(ctx, "sweep_colscale", (tpg_sweep_kernel<8, SW_COLSCALE>), grid, dim3(256), 0, P, nrowtiles, nblocks,
+                 (int)S, nrows, ncols, d_center, d_inv_scale, tabp, ldtab, kc, d_part, rsp);
+    else if (mode == SW_ROWSCALE)
+      TPG_LAUNCH(ctx, "sweep_rowscale", (tpg_sweep_kernel<8, SW_ROWSCALE>), grid, dim3(256), 0, P, nrowtiles, nblocks,
+                 (int)S, nrows, ncols, d_center, d_inv_scale, tabp, ldtab, kc, d_part, rsp);
+    else
+      TPG_LAUNCH(ctx, "sweep_raw", (tpg_sweep_kernel<8, SW_RAW>), grid, dim3(256), 0, P, nrowtiles, nblocks, (int)S,
+                 nrows, ncols, d_center, d_inv_scale, tabp, ldtab, kc, d_part, rsp);
+    TPG_LAUNCH(ctx, "sweep_reduce", tpg_sweep_reduce_kernel, dim3(512), dim3(256), 0, d_part, rsp, (int)S, KC, kc,
+               rows_pad, nrows, d_out, nrows, k0, d_col_div, rsp ? d_rss : nullptr);
+  }
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_part);
+  (void)hipFree(d_rsp);
+  if (e != hipSuccess) { tpg_set_error("sweep: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  return TPG_OK;
+}
+
+__global__ void tpg_inv_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ y) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = 1.0 / x[i];
+}
+
+extern "C" int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx* ctx, const tpg_view* v, const double* center,
+                                             const double* scale, const double* V, int K, double* XV, double* rss) {
+  TPG_REQUIRE(ctx && v && center && scale && V && XV && rss, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(K > 0, TPG_EINVAL, "V has no columns");
+  InBuf ic, is, iv;
+  TPG_TRY(ic.init(ctx, center, sizeof(double) * (size_t)v->m));
+  TPG_TRY(is.init(ctx, scale, sizeof(double) * (size_t)v->m));
+  TPG_TRY(iv.init(ctx, V, sizeof(double) * (size_t)v->m * (size_t)K));
+  OutBuf oxv, orss;
+  TPG_TRY(oxv.init(XV, sizeof(double) * (size_t)v->n * (size_t)K));
+  TPG_TRY(orss.init(rss, sizeof(double) * (size_t)v->n));
+  double* d_inv = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_inv, sizeof(double) * (size_t)v->m));
+  TPG_LAUNCH(ctx, "inv_scale", tpg_inv_kernel, dim3(1024), dim3(256), 0, is.dev<double>(), v->m, d_inv);
+  int rc = run_sweep(ctx, SW_COLSCALE, v->T, v->Q * 4, v->KG, v->n, v->m, ic.dev<double>(), d_inv, iv.dev<double>(),
+                     v->m, K, oxv.dev<double>(), nullptr, orss.dev<double>());
+  (void)hipFree(d_inv);
+  TPG_TRY(rc);
+  TPG_TRY(oxv.commit(ctx));
+  return orss.commit(ctx);
+}
+
+// ---------------------------------------------------------------------------
+// Gram matrix: weight digits
+//
+// DG layout: for K group kg, K step s, lane half h, digit t: 8 dwords = D (4 dwords) then 2D (4 dwords);
+// byte b of dword k belongs to locus 128 kg + 32 s + 16 h + 4 k + b.
+__global__ void tpg_pca_digits_kernel(const double* __restrict__ scale, const double* __restrict__ center, int64_t m,
+                                      int64_t KG, int F, int T, uint32_t* __restrict__ DG, double* __restrict__ what,
+                                      double* __restrict__ wc) {
+  const int64_t total = KG * 4 * 2 * 4;  // (kg, s, h, k)
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx & 3), h = (int)((idx >> 2) & 1), s = (int)((idx >> 3) & 3);
+    const int64_t kg = idx >> 5;
+    uint32_t d[8], d2[8];
+    for (int t = 0; t < 8; t++) { d[t] = 0; d2[t] = 0; }
+    for (int b = 0; b < 4; b++) {
+      const int64_t j = kg * 128 + 32 * s + 16 * h + 4 * k + b;
+      if (j >= m) continue;
+      const double w = 1.0 / (scale[j] * scale[j]);
+      long long W = llrint(ldexp(w, F));
+      const double wh = ldexp((double)W, -F);
+      what[j] = wh;
+      wc[j] = wh * center[j];
+      for (int t = 0; t < T; t++) {
+        long long dig = W & 127;
+        if (dig >= 64) dig -= 128;
+        W = (W - dig) >> 7;
+        d[t] |= (uint32_t)((int)dig & 0xFF) << (8 * b);
+        d2[t] |= (uint32_t)((int)(2 * dig) & 0xFF) << (8 * b);
+      }
+    }
+    const int64_t base = (((kg * 4 + s) * 2 + h) * T) * 8;
+    for (int t = 0; t < T; t++) {
+      DG[base + t * 8 + k] = d[t];
+      DG[base + t * 8 + 4 + k] = d2[t];
+    }
+  }
+}
+
+// unit (ia, jb): A row tile ia (32 individuals, weighted digit planes) x B super-tile jb (4 row tiles = 128
+// individuals, plain dosage), jb >= ia/4.  Combined int64 slab per unit: [tb][reg][lane].
+#define PCA_SLAB_INTS (4 * 16 * 64)
+
+__device__ __forceinline__ int64_t tpg_gram_unit_index(int nsb, int ia, int jb) {
+  const int a = ia >> 2, r = ia & 3;
+  return 4 * ((int64_t)a * nsb - ((int64_t)a * (a - 1)) / 2) + (int64_t)r * (nsb - a) + (jb - a);
+}
+
+template <int TD>  // digits handled by this pass (<= 4)
+__global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
+                                                              int64_t kg_begin, int64_t kg_end,
+                                                              const uint4* __restrict__ DG, int Ttot, int t0, int nrt,
+                                                              int nsb, int64_t nun, int S,
+                                                              long long* __restrict__ slabs) {
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t kgs = kg_end - kg_begin;
+  for (int64_t unit = wave; unit < nun * S; unit += nwaves) {
+    int64_t u = unit % nun;
+    const int ks = (int)(unit / nun);
+    const int64_t u0 = u;
+    // decode u -> (ia, jb)
+    int a = 0;
+    while (u >= 4 * (int64_t)(nsb - a)) { u -= 4 * (int64_t)(nsb - a); a++; }
+    const int r = (int)(u / (nsb - a));
+    const int jb = a + (int)(u % (nsb - a));
+    const int ia = 4 * a + r;
+    const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
+
+    const uint4* pa = Tl + ((int64_t)ia * KG) * 64 + lane;
+    const uint4* pb[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; tb++) pb[tb] = Tl + ((int64_t)(4 * jb + tb) * KG) * 64 + lane;
+
+    v16i acc[TD][4];
+#pragma unroll
+    for (int t = 0; t < TD; t++)
+#pragma unroll
+      for (int tb = 0; tb < 4; tb++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[t][tb][q] = 0;
+
+    for (int64_t kg = k0; kg < k1; kg++) {
+      const uint4 A = pa[kg * 64];
+      uint4 B[4];
+#pragma unroll
+      for (int tb = 0; tb < 4; tb++) B[tb] = pb[tb][kg * 64];
+      const uint32_t wa[4] = {A.x, A.y, A.z, A.w};
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        // selector per register: genotype 1 -> byte b of D (S1), genotype 2 -> byte b of 2D (S0), else 0
+        uint32_t sel[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t c = tpg_codes(wa[s], k);
+          const uint32_t base = (uint32_t)tpg_lut(0x0C04000Cu, c);
+          const uint32_t mv = (uint32_t)tpg_lut(0x00FFFF00u, c);
+          sel[k] = (0x03020100u & mv) | base;
+        }
+        v4i fb[4];
+#pragma unroll
+        for (int tb = 0; tb < 4; tb++) {
+          const uint32_t wb = s == 0 ? B[tb].x : s == 1 ? B[tb].y : s == 2 ? B[tb].z : B[tb].w;
+#pragma unroll
+          for (int k = 0; k < 4; k++) fb[tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wb, k));
+        }
+        const uint4* dg = DG + ((((kg * 4 + s) * 2 + h) * (int64_t)Ttot) + t0) * 2;
+#pragma unroll
+        for (int t = 0; t < TD; t++) {
+          const uint4 d1 = dg[t * 2], d2 = dg[t * 2 + 1];
+          v4i fa;
+          fa[0] = (int)__builtin_amdgcn_perm(d2.x, d1.x, sel[0]);
+          fa[1] = (int)__builtin_amdgcn_perm(d2.y, d1.y, sel[1]);
+          fa[2] = (int)__builtin_amdgcn_perm(d2.z, d1.z, sel[2]);
+          fa[3] = (int)__builtin_amdgcn_perm(d2.w, d1.w, sel[3]);
+#pragma unroll
+          for (int tb = 0; tb < 4; tb++) acc[t][tb] = MFMA_I8(fa, fb[tb], acc[t][tb]);
+        }
+      }
+    }
+    long long* slab = slabs + u0 * PCA_SLAB_INTS + lane;
+#pragma unroll
+    for (int tb = 0; tb < 4; tb++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        long long c = 0;
+#pragma unroll
+        for (int t = 0; t < TD; t++) c += (long long)acc[t][tb][q] << (7 * t);
+        c <<= 7 * t0;  // wrapping shift is fine: two's complement, |c| stays far below 2^62
+        atomicAdd((unsigned long long*)(slab + (tb * 16 + q) * 64), (unsigned long long)c);
+      }
+  }
+}
+
+// K[i + k n] = 2^-F S[i][k] - r_i - r_k + C  (both triangles)
+__global__ void tpg_pca_assemble_kernel(const long long* __restrict__ slabs, int nsb, int n, int F,
+                                        const double* __restrict__ rvec, double Cc, double* __restrict__ K) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int i = (int)(idx % n), k = (int)(idx / n);
+    const int oi = i, ok = k;
+    if ((k >> 7) < (i >> 7)) { int t = i; i = k; k = t; }
+    const int ia = i >> 5, jb = k >> 7;
+    const int tb = (k & 127) >> 5, row = i & 31, col = k & 31;
+    const int lane = col + 32 * ((row >> 2) & 1);
+    const int reg = (row & 3) + 4 * (row >> 3);
+    const long long s = slabs[tpg_gram_unit_index(nsb, ia, jb) * PCA_SLAB_INTS + (tb * 16 + reg) * 64 + lane];
+    K[idx] = ldexp((double)s, -F) - rvec[oi] - rvec[ok] + Cc;
+  }
+}
+
+__global__ __launch_bounds__(256) void tpg_dot_kernel(const double* __restrict__ a, const double* __restrict__ b,
+                                                      int64_t n, double* __restrict__ part) {
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+    acc += a[j] * b[j];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+// Gram matrix into d_K (device, n x n column-major) given device center / scale.
+static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_center, const double* d_scale,
+                           double* d_K) {
+  const int64_t n = v->n, m = v->m;
+  // weight range decides the number of digits
+  std::vector<double> hs((size_t)m);
+  TPG_HIP(hipMemcpyAsync(hs.data(), d_scale, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  double wmax = 0;
+  for (int64_t j = 0; j < m; j++) {
+    TPG_REQUIRE(hs[(size_t)j] > 0, TPG_ENUMERIC, "zero or negative scale at locus %lld", (long long)j);
+    wmax = std::max(wmax, 1.0 / (hs[(size_t)j] * hs[(size_t)j]));
+  }
+  const int F_TARGET = 22;
+  const int wbits = (int)ceil(log2(wmax + 1.0));
+  int T = (wbits + F_TARGET + 1 + 6) / 7;
+  if (T < 4) T = 4;
+  TPG_REQUIRE(T <= 8, TPG_ENUMERIC, "per-locus weight range too wide (max 1/scale^2 = %g)", wmax);
+  const int F = 7 * T - 1 - wbits;
+
+  const int nsb = (int)v->Q, nrt = (int)(v->Q * 4);
+  const int64_t nun = 4 * ((int64_t)nsb * (nsb + 1) / 2);
+  uint32_t* d_DG = nullptr;
+  double *d_what = nullptr, *d_wc = nullptr, *d_r = nullptr, *d_part = nullptr;
+  long long* d_slabs = nullptr;
+  int rc = TPG_OK;
+  hipError_t e = hipSuccess;
+#define GHIP(call) do { if (e == hipSuccess) { e = (call); if (e != hipSuccess) tpg_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e)); } } while (0)
+  GHIP(hipMalloc((void**)&d_DG, (size_t)v->KG * 4 * 2 * T * 8 * sizeof(uint32_t)));
+  GHIP(hipMalloc((void**)&d_what, sizeof(double) * (size_t)m));
+  GHIP(hipMalloc((void**)&d_wc, sizeof(double) * (size_t)m));
+  GHIP(hipMalloc((void**)&d_r, sizeof(double) * (size_t)n));
+  GHIP(hipMalloc((void**)&d_part, sizeof(double) * 512));
+  GHIP(hipMalloc((void**)&d_slabs, sizeof(long long) * (size_t)nun * PCA_SLAB_INTS));
+  GHIP(hipMemsetAsync(d_slabs, 0, sizeof(long long) * (size_t)nun * PCA_SLAB_INTS, ctx->stream));
+  if (e == hipSuccess) {
+    TPG_LAUNCH(ctx, "pca_digits", tpg_pca_digits_kernel, dim3(1024), dim3(256), 0, d_scale, d_center, m, v->KG, F, T,
+               d_DG, d_what, d_wc);
+    // K-split as in the pairwise kernel: fill the resident waves (1 wave per SIMD)
+    const int64_t nwaves = (int64_t)ctx->num_cu * 4;
+    int bestS = 1;
+    double best = -1;
+    const int64_t maxS = v->KG / 8 > 0 ? (v->KG / 8 < 96 ? v->KG / 8 : 96) : 1;
+    for (int64_t S = 1; S <= maxS; S++) {
+      const int64_t U = nun * S;
+      const double eff = (double)U / (double)(ceil_div(U, nwaves) * nwaves);
+      if (eff > best + 0.01) { best = eff; bestS = (int)S; }
+    }
+    const int64_t U = nun * bestS;
+    const unsigned grid = (unsigned)(ceil_div(U, 4) < ctx->num_cu ? ceil_div(U, 4) : ctx->num_cu);
+    for (int t0 = 0; t0 < T; t0 += 4) {
+      const int td = T - t0 < 4 ? T - t0 : 4;
+#define GRAM_LAUNCH(TD)                                                                                              \
+  TPG_LAUNCH(ctx, "pca_gram_mfma", tpg_pca_gram_kernel<TD>, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG,      \
+             (int64_t)0, v->KG, (const uint4*)d_DG, T, t0, nrt, nsb, nun, bestS, d_slabs)
+      if (td == 4) GRAM_LAUNCH(4);
+      else if (td == 3) GRAM_LAUNCH(3);
+      else if (td == 2) GRAM_LAUNCH(2);
+      else GRAM_LAUNCH(1);
+#undef GRAM_LAUNCH
+    }
+    GHIP(hipGetLastError());
+  }
+  if (e == hipSuccess) {
+    // r_i = sum_j what_j c_j g_ij  (RAW sweep with a one-column table), C = sum_j what_j c_j^2
+    rc = run_sweep(ctx, SW_RAW, v->T, v->Q * 4, v->KG, n, m, nullptr, nullptr, d_wc, m, 1, d_r, nullptr, nullptr);
+  }
+  double Cc = 0;
+  if (e == hipSuccess && rc == TPG_OK) {
+    TPG_LAUNCH(ctx, "pca_dot", tpg_dot_kernel, dim3(512), dim3(256), 0, d_wc, d_center, m, d_part);
+    std::vector<double> hp(512);
+    GHIP(hipMemcpyAsync(hp.data(), d_part, sizeof(double) * 512, hipMemcpyDeviceToHost, ctx->stream));
+    GHIP(hipStreamSynchronize(ctx->stream));
+    long double s = 0;
+    for (int b = 0; b < 512; b++) s += hp[(size_t)b];
+    Cc = (double)s;
+  }
+  if (e == hipSuccess && rc == TPG_OK) {
+    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, nsb, (int)n, F, d_r, Cc,
+               d_K);
+    GHIP(hipGetLastError());
+    GHIP(hipStreamSynchronize(ctx->stream));
+  }
+#undef GHIP
+  (void)hipFree(d_DG); (void)hipFree(d_what); (void)hipFree(d_wc); (void)hipFree(d_r); (void)hipFree(d_part);
+  (void)hipFree(d_slabs);
+  if (e != hipSuccess) return TPG_EHIP;
+  return rc;
+}
+
+extern "C" int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale, double* K) {
+  TPG_REQUIRE(ctx && v && center && scale && K, TPG_EINVAL, "null argument");
+  InBuf ic, is;
+  TPG_TRY(ic.init(ctx, center, sizeof(double) * (size_t)v->m));
+  TPG_TRY(is.init(ctx, scale, sizeof(double) * (size_t)v->m));
+  OutBuf ok;
+  TPG_TRY(ok.init(K, sizeof(double) * (size_t)v->n * (size_t)v->n));
+  TPG_TRY(pca_gram_device(ctx, v, ic.dev<double>(), is.dev<double>(), ok.dev<double>()));
+  return ok.commit(ctx);
+}
+
+// ---------------------------------------------------------------------------
+// dense FP64 helpers for the eigen solver (all matrices column-major)
+
+// part[split][row][c] = sum_{k in split} K[row + k n] * Q[k + c n]   (c < b <= 64)
+__global__ __launch_bounds__(256) void tpg_symm_apply_kernel(const double* __restrict__ K, int n,
+                                                             const double* __restrict__ Q, int b, int S,
+                                                             double* __restrict__ part) {
+  __shared__ double qs[64][65];  // 64 k x b columns
+  const int r = threadIdx.x & 63, cg = threadIdx.x >> 6;  // 4 column groups of 16
+  const int row = blockIdx.x * 64 + r;
+  const int split = blockIdx.y;
+  const int kbeg = (int)((int64_t)n * split / S), kend = (int)((int64_t)n * (split + 1) / S);
+  double acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) acc[c] = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += 64) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * b; idx += 256) {
+      const int kk = idx & 63, c = idx >> 6;
+      qs[kk][c] = (k0 + kk < kend) ? Q[(k0 + kk) + (int64_t)c * n] : 0.0;
+    }
+    __syncthreads();
+    if (row < n) {
+      const int kmax = kend - k0 < 64 ? kend - k0 : 64;
+      for (int kk = 0; kk < kmax; kk++) {
+        const double kv = K[row + (int64_t)(k0 + kk) * n];
+#pragma unroll
+        for (int c = 0; c < 16; c++) acc[c] += kv * qs[kk][cg * 16 + c];
+      }
+    }
+  }
+  if (row < n)
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+      if (cg * 16 + c < b) part[((int64_t)split * b + cg * 16 + c) * n + row] = acc[c];
+}
+
+// Y = alpha * sum_split part + beta * Y1 + gamma * Y0   (Y1 / Y0 may be null)
+__global__ void tpg_combine_kernel(const double* __restrict__ part, int S, int64_t nb, double alpha,
+                                   const double* __restrict__ Y1, double beta, const double* __restrict__ Y0,
+                                   double gamma, double* __restrict__ Y) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < nb; idx += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0;
+    for (int sp = 0; sp < S; sp++) s += part[(int64_t)sp * nb + idx];
+    double y = alpha * s;
+    if (Y1) y += beta * Y1[idx];
+    if (Y0) y += gamma * Y0[idx];
+    Y[idx] = y;
+  }
+}
+
+// partial[chunk][i + j p] = sum_{rows in chunk} A[row + i n] * B[row + j n]   (p, b <= 64)
+__global__ __launch_bounds__(256) void tpg_gram_small_kernel(const double* __restrict__ A, int p,
+                                                             const double* __restrict__ B, int b, int n,
+                                                             int rows_per_chunk, double* __restrict__ part) {
+  __shared__ double as[64][33], bs[64][33];
+  const int chunk = blockIdx.x;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = r0 + rows_per_chunk < n ? r0 + rows_per_chunk : n;
+  // each thread owns outputs (i, j) with i = tid & 63 (< p), j = (tid >> 6) + 4 jj
+  const int i = threadIdx.x & 63, jq = threadIdx.x >> 6;
+  double acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) acc[c] = 0;
+  for (int rr = r0; rr < r1; rr += 32) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+      const int col = idx >> 5, dr = idx & 31;
+      as[col][dr] = (col < p && rr + dr < r1) ? A[(rr + dr) + (int64_t)col * n] : 0.0;
+      bs[col][dr] = (col < b && rr + dr < r1) ? B[(rr + dr) + (int64_t)col * n] : 0.0;
+    }
+    __syncthreads();
+    for (int dr = 0; dr < 32; dr++) {
+      const double av = as[i][dr];
+#pragma unroll
+      for (int c = 0; c < 16; c++) acc[c] += av * bs[jq + 4 * c][dr];
+    }
+  }
+  if (i < p)
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const int j = jq + 4 * c;
+      if (j < b) part[(int64_t)chunk * p * b + i + (int64_t)j * p] = acc[c];
+    }
+}
+
+// Y[row + j n] = sum_i A[row + i n] * X[i + j p]   (X small, p <= 64, b2 <= 64); optional residual
+// form: Y = A X - Bm * diag(theta) is done by the caller through two calls / combine.
+__global__ void tpg_right_mult_kernel(const double* __restrict__ A, int n, int p, const double* __restrict__ X, int b2,
+                                      double* __restrict__ Y) {
+  __shared__ double xs[64 * 64];
+  for (int idx = threadIdx.x; idx < p * b2; idx += blockDim.x) xs[idx] = X[idx];
+  __syncthreads();
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  double a[64];
+  for (int i = 0; i < p; i++) a[i] = A[row + (int64_t)i * n];
+  for (int j = 0; j < b2; j++) {
+    double s = 0;
+    for (int i = 0; i < p; i++) s += a[i] * xs[i + j * p];
+    Y[row + (int64_t)j * n] = s;
+  }
+}
+
+__global__ void tpg_fill_random_kernel(double* __restrict__ Q, int64_t total, uint64_t seed) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t x = (uint64_t)idx * 0x9E3779B97F4A7C15ull + seed;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    Q[idx] = (double)(int64_t)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  }
+}
+
+// ---- small host linear algebra (b <= 64) ----
+static bool host_cholesky_upper(std::vector<double>& G, int b) {  // G = R'R, R upper, in place (column-major)
+  for (int j = 0; j < b; j++) {
+    double s = G[j + (size_t)j * b];
+    for (int k = 0; k < j; k++) s -= G[k + (size_t)j * b] * G[k + (size_t)j * b];
+    if (!(s > 0)) return false;
+    const double rjj = sqrt(s);
+    G[j + (size_t)j * b] = rjj;
+    for (int c = j + 1; c < b; c++) {
+      double t = G[j + (size_t)c * b];
+      for (int k = 0; k < j; k++) t -= G[k + (size_t)j * b] * G[k + (size_t)c * b];
+      G[j + (size_t)c * b] = t / rjj;
+    }
+    for (int i = j + 1; i < b; i++) G[i + (size_t)j * b] = 0;
+  }
+  return true;
+}
+
+static void host_upper_inverse(const std::vector<double>& R, int b, std::vector<double>& Ri) {
+  Ri.assign((size_t)b * b, 0.0);
+  for (int j = 0; j < b; j++) {
+    Ri[j + (size_t)j * b] = 1.0 / R[j + (size_t)j * b];
+    for (int i = j - 1; i >= 0; i--) {
+      double s = 0;
+      for (int k = i + 1; k <= j; k++) s += R[i + (size_t)k * b] * Ri[k + (size_t)j * b];
+      Ri[i + (size_t)j * b] = -s / R[i + (size_t)i * b];
+    }
+  }
+}
+
+// cyclic Jacobi for a symmetric b x b matrix: eigenvalues (descending) and eigenvectors (columns of X)
+static void host_jacobi_eig(std::vector<double> H, int b, std::vector<double>& theta, std::vector<double>& X) {
+  X.assign((size_t)b * b, 0.0);
+  for (int i = 0; i < b; i++) X[i + (size_t)i * b] = 1.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < b; i++) {
+      diag += H[i + (size_t)i * b] * H[i + (size_t)i * b];
+      for (int j = i + 1; j < b; j++) off += H[i + (size_t)j * b] * H[i + (size_t)j * b];
+    }
+    if (off <= 1e-30 * diag) break;
+    for (int p = 0; p < b - 1; p++)
+      for (int q = p + 1; q < b; q++) {
+        const double apq = H[p + (size_t)q * b];
+        if (apq == 0) continue;
+        const double app = H[p + (size_t)p * b], aqq = H[q + (size_t)q * b];
+        const double tau = (aqq - app) / (2 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
+        const double c = 1 / sqrt(1 + t * t), s = t * c;
+        for (int k = 0; k < b; k++) {
+          const double hkp = H[k + (size_t)p * b], hkq = H[k + (size_t)q * b];
+          H[k + (size_t)p * b] = c * hkp - s * hkq;
+          H[k + (size_t)q * b] = s * hkp + c * hkq;
+        }
+        for (int k = 0; k < b; k++) {
+          const double hpk = H[p + (size_t)k * b], hqk = H[q + (size_t)k * b];
+          H[p + (size_t)k * b] = c * hpk - s * hqk;
+          H[q + (size_t)k * b] = s * hpk + c * hqk;
+        }
+        for (int k = 0; k < b; k++) {
+          const double xkp = X[k + (size_t)p * b], xkq = X[k + (size_t)q * b];
+          X[k + (size_t)p * b] = c * xkp - s * xkq;
+          X[k + (size_t)q * b] = s * xkp + c * xkq;
+        }
+      }
+  }
+  std::vector<int> ord((size_t)b);
+  for (int i = 0; i < b; i++) ord[(size_t)i] = i;
+  std::sort(ord.begin(), ord.end(), [&](int x, int y) { return H[x + (size_t)x * b] > H[y + (size_t)y * b]; });
+  theta.resize((size_t)b);
+  std::vector<double> Xs((size_t)b * b);
+  for (int j = 0; j < b; j++) {
+    theta[(size_t)j] = H[ord[(size_t)j] + (size_t)ord[(size_t)j] * b];
+    for (int i = 0; i < b; i++) Xs[i + (size_t)j * b] = X[i + (size_t)ord[(size_t)j] * b];
+  }
+  X.swap(Xs);
+}
+
+struct EigWork {
+  tpg_ctx* ctx;
+  const double* K;
+  int n, b, S;
+  double *part = nullptr, *gpart = nullptr, *xsmall = nullptr;
+  int nchunks, rows_per_chunk;
+  int init() {
+    S = 1;
+    const int row_blocks = (n + 63) / 64;
+    while (row_blocks * S < 2 * ctx->num_cu && S < 32 && n / (S * 2) >= 64) S *= 2;
+    rows_per_chunk = 256;
+    nchunks = (n + rows_per_chunk - 1) / rows_per_chunk;
+    TPG_HIP(hipMalloc((void**)&part, sizeof(double) * (size_t)S * (size_t)b * (size_t)n));
+    TPG_HIP(hipMalloc((void**)&gpart, sizeof(double) * (size_t)nchunks * 64 * 64));
+    TPG_HIP(hipMalloc((void**)&xsmall, sizeof(double) * 64 * 64));
+    return TPG_OK;
+  }
+  ~EigWork() {
+    if (part) (void)hipFree(part);
+    if (gpart) (void)hipFree(gpart);
+    if (xsmall) (void)hipFree(xsmall);
+  }
+  // Y = alpha K Q + beta Y1 + gamma Y0
+  int apply(const double* Q, double alpha, const double* Y1, double beta, const double* Y0, double gamma, double* Y) {
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)S);
+    TPG_LAUNCH(ctx, "eig_symm_apply", tpg_symm_apply_kernel, grid, dim3(256), 0, K, n, Q, b, S, part);
+    TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, (const double*)part, S,
+               (int64_t)n * b, alpha, Y1, beta, Y0, gamma, Y);
+    TPG_CHECK_LAUNCH();
+    return TPG_OK;
+  }
+  // C (p x bb, host, column-major) = A' B
+  int gram(const double* A, int p, const double* B, int bb, std::vector<double>& C) {
+    TPG_LAUNCH(ctx, "eig_gram_small", tpg_gram_small_kernel, dim3((unsigned)nchunks), dim3(256), 0, A, p, B, bb, n,
+               rows_per_chunk, gpart);
+    std::vector<double> hp((size_t)nchunks * p * bb);
+    TPG_HIP(hipMemcpyAsync(hp.data(), gpart, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, ctx->stream));
+    TPG_HIP(hipStreamSynchronize(ctx->stream));
+    C.assign((size_t)p * bb, 0.0);
+    for (int c = 0; c < nchunks; c++)
+      for (size_t t = 0; t < (size_t)p * bb; t++) C[t] += hp[(size_t)c * p * bb + t];
+    return TPG_OK;
+  }
+  // Y = A X  (X host p x b2)
+  int rmult(const double* A, int p, const std::vector<double>& X, int b2, double* Y) {
+    TPG_HIP(hipMemcpyAsync(xsmall, X.data(), sizeof(double) * (size_t)p * b2, hipMemcpyHostToDevice, ctx->stream));
+    TPG_LAUNCH(ctx, "eig_right_mult", tpg_right_mult_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, A, n, p,
+               xsmall, b2, Y);
+    TPG_CHECK_LAUNCH();
+    TPG_HIP(hipStreamSynchronize(ctx->stream));  // X may go out of scope on the host
+    return TPG_OK;
+  }
+};
+
+// Top-k eigenpairs of the symmetric PSD matrix d_K (n x n, device).  lambda[k] (descending), d_U n x k.
+static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambda_host, double* d_U) {
+  int b = k + 12;
+  if (b > 64) b = 64;
+  if (b > n) b = n;
+  TPG_REQUIRE(k <= b, TPG_EINVAL, "k = %d too large (at most %d components)", k, b);
+  EigWork w{ctx, d_K, n, b, 1};
+  TPG_TRY(w.init());
+  double *Q = nullptr, *Y = nullptr, *Y0 = nullptr, *Y1 = nullptr;
+  const size_t nb = sizeof(double) * (size_t)n * (size_t)b;
+  TPG_HIP(hipMalloc((void**)&Q, nb));
+  TPG_HIP(hipMalloc((void**)&Y, nb));
+  TPG_HIP(hipMalloc((void**)&Y0, nb));
+  TPG_HIP(hipMalloc((void**)&Y1, nb));
+  struct Free { double *a, *b, *c, *d; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); } } fr{Q, Y, Y0, Y1};
+
+  auto orthonormalize = [&](double* A, double* tmp) -> int {  // CholQR, twice; result back in A
+    for (int pass = 0; pass < 2; pass++) {
+      std::vector<double> G, Ri;
+      TPG_TRY(w.gram(A, b, A, b, G));
+      // column scaling first keeps the Gram matrix well conditioned when columns differ in norm
+      std::vector<double> D((size_t)b);
+      for (int j = 0; j < b; j++) D[(size_t)j] = G[j + (size_t)j * b] > 0 ? 1.0 / sqrt(G[j + (size_t)j * b]) : 1.0;
+      for (int j = 0; j < b; j++)
+        for (int i = 0; i < b; i++) G[i + (size_t)j * b] *= D[(size_t)i] * D[(size_t)j];
+      if (!host_cholesky_upper(G, b)) {
+        // numerically rank deficient block: add a tiny ridge (happens only if n < b or K has rank < b)
+        for (int j = 0; j < b; j++) G[j + (size_t)j * b] += 1e-12;
+        if (!host_cholesky_upper(G, b)) { tpg_set_error("eigen solver: block lost rank"); return TPG_ENUMERIC; }
+      }
+      host_upper_inverse(G, b, Ri);
+      for (int j = 0; j < b; j++)
+        for (int i = 0; i < b; i++) Ri[i + (size_t)j * b] *= D[(size_t)i];
+      TPG_TRY(w.rmult(A, b, Ri, b, tmp));
+      TPG_HIP(hipMemcpyAsync(A, tmp, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return TPG_OK;
+  };
+
+  TPG_LAUNCH(ctx, "eig_random", tpg_fill_random_kernel, dim3(512), dim3(256), 0, Q, (int64_t)n * b, (uint64_t)0x5EED);
+  TPG_TRY(orthonormalize(Q, Y));
+  std::vector<double> theta, X, H;
+  const int DEG = 12, MAXIT = 40;
+  const double TOL = 1e-11;
+  bool converged = false;
+  for (int it = 0; it < MAXIT; it++) {
+    // Rayleigh-Ritz
+    TPG_TRY(w.apply(Q, 1.0, nullptr, 0, nullptr, 0, Y));  // Y = K Q
+    TPG_TRY(w.gram(Q, b, Y, b, H));
+    for (int i = 0; i < b; i++)
+      for (int j = i + 1; j < b; j++) { const double s = 0.5 * (H[i + (size_t)j * b] + H[j + (size_t)i * b]); H[i + (size_t)j * b] = s; H[j + (size_t)i * b] = s; }
+    host_jacobi_eig(H, b, theta, X);
+    TPG_TRY(w.rmult(Q, b, X, b, Y0));  // Ritz vectors
+    TPG_TRY(w.rmult(Y, b, X, b, Y1));  // K * Ritz vectors
+    TPG_HIP(hipMemcpyAsync(Q, Y0, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    // residual norms of the first k pairs: R = K q - theta q
+    std::vector<double> negtheta((size_t)b * b, 0.0);
+    for (int j = 0; j < b; j++) negtheta[j + (size_t)j * b] = -theta[(size_t)j];
+    TPG_TRY(w.rmult(Q, b, negtheta, b, Y));
+    TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, (const double*)Y, 1, (int64_t)n * b,
+               1.0, (const double*)Y1, 1.0, (const double*)nullptr, 0.0, Y);
+    std::vector<double> RR;
+    TPG_TRY(w.gram(Y, b, Y, b, RR));
+    double worst = 0;
+    for (int j = 0; j < k; j++) worst = std::max(worst, sqrt(std::max(0.0, RR[j + (size_t)j * b])) / fabs(theta[0]));
+    if (worst < TOL) { converged = true; break; }
+    // Chebyshev filter of degree DEG damping [0, theta_b], scaled at theta_1 (Zhou & Saad 2007)
+    const double lo = 0.0, up = std::max(theta[(size_t)b - 1], 1e-300);
+    const double ec = (up - lo) / 2, cc = (up + lo) / 2;
+    double sigma = ec / (theta[0] - cc);
+    const double sigma1 = sigma;
+    // Y1 currently holds K Q: first step Ynew = (sigma1/e)(K Q - c Q)
+    TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, (const double*)Y1, 1, (int64_t)n * b,
+               sigma1 / ec, (const double*)Q, -cc * sigma1 / ec, (const double*)nullptr, 0.0, Y);
+    TPG_HIP(hipMemcpyAsync(Y0, Q, nb, hipMemcpyDeviceToDevice, ctx->stream));  // Y0 = previous, Y = current
+    double* prev = Y0;
+    double* cur = Y;
+    double* nxt = Y1;
+    for (int dgr = 2; dgr <= DEG; dgr++) {
+      const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
+      // nxt = (2 sigma2 / e)(K cur - c cur) - sigma sigma2 prev
+      TPG_TRY(w.apply(cur, 2 * sigma2 / ec, cur, -2 * sigma2 * cc / ec, prev, -sigma * sigma2, nxt));
+      double* t = prev; prev = cur; cur = nxt; nxt = t;
+      sigma = sigma2;
+    }
+    if (cur != Q) TPG_HIP(hipMemcpyAsync(Q, cur, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    TPG_TRY(orthonormalize(Q, cur == Y ? Y0 : Y));
+  }
+  TPG_REQUIRE(converged, TPG_ENUMERIC, "eigen solver did not converge");
+  for (int j = 0; j < k; j++) lambda_host[j] = theta[(size_t)j];
+  TPG_HIP(hipMemcpyAsync(d_U, Q, sizeof(double) * (size_t)n * (size_t)k, hipMemcpyDeviceToDevice, ctx->stream));
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return TPG_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,
+                                   double* center, double* scale, double* square_frobenius) {
+  TPG_REQUIRE(ctx && v && d && u && vload && center && scale, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(k >= 1 && k <= 52 && k <= v->n && k <= v->m, TPG_EINVAL, "k = %d out of range", k);
+  const int64_t n = v->n, m = v->m;
+  OutBuf oc, os, ou, ov;
+  TPG_TRY(oc.init(center, sizeof(double) * (size_t)m));
+  TPG_TRY(os.init(scale, sizeof(double) * (size_t)m));
+  TPG_TRY(ou.init(u, sizeof(double) * (size_t)n * (size_t)k));
+  TPG_TRY(ov.init(vload, sizeof(double) * (size_t)m * (size_t)k));
+  int32_t* d_counts = nullptr;
+  double *d_K = nullptr, *d_inv = nullptr, *d_dk = nullptr;
+  TPG_HIP(hipMalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)m));
+  struct Free { void *a, *b, *c, *d; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); } } fr{d_counts, nullptr, nullptr, nullptr};
+  TPG_TRY(pca_counts_center_scale(ctx, v, d_counts, oc.dev<double>(), os.dev<double>()));
+  if (square_frobenius) TPG_TRY(frobenius_from_counts(ctx, v, d_counts, oc.dev<double>(), os.dev<double>(), square_frobenius));
+  TPG_HIP(hipMalloc((void**)&d_K, sizeof(double) * (size_t)n * (size_t)n));
+  fr.b = d_K;
+  TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K));
+  std::vector<double> lam((size_t)k);
+  TPG_TRY(eig_topk(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>()));
+  std::vector<double> dh((size_t)k);
+  for (int j = 0; j < k; j++) dh[(size_t)j] = sqrt(lam[(size_t)j] > 0 ? lam[(size_t)j] : 0.0);
+  TPG_HIP(hipMalloc((void**)&d_inv, sizeof(double) * (size_t)m));
+  fr.c = d_inv;
+  TPG_HIP(hipMalloc((void**)&d_dk, sizeof(double) * (size_t)k));
+  fr.d = d_dk;
+  TPG_HIP(hipMemcpyAsync(d_dk, dh.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
+  TPG_LAUNCH(ctx, "inv_scale", tpg_inv_kernel, dim3(1024), dim3(256), 0, (const double*)os.dev<double>(), m, d_inv);
+  // v = Z'u / d: rows = loci (L layout), table = u (n x k)
+  TPG_TRY(run_sweep(ctx, SW_ROWSCALE, v->L, v->KG * 4, v->Q, m, n, oc.dev<double>(), d_inv, ou.dev<double>(), n, k,
+                    ov.dev<double>(), d_dk, nullptr));
+  if (tpg_is_device_ptr(d)) TPG_HIP(hipMemcpyAsync(d, dh.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
+  else memcpy(d, dh.data(), sizeof(double) * (size_t)k);
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  TPG_TRY(oc.commit(ctx));
+  TPG_TRY(os.commit(ctx));
+  TPG_TRY(ou.commit(ctx));
+  return ov.commit(ctx);
+}
