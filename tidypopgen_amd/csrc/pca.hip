@@ -829,6 +829,13 @@ struct EigWork {
 };
 
 // Top-k eigenpairs of the symmetric PSD matrix d_K (n x n, device).  lambda[k] (descending), d_U n x k.
+//
+// Chebyshev-filtered subspace iteration with locking: a block of b = k + 12 vectors; every outer
+// iteration does Rayleigh-Ritz on the active (not yet converged) columns, locks the leading Ritz pairs
+// whose residual is below TOL * lambda_1, then applies a Chebyshev polynomial of K that damps
+// [0, smallest active Ritz value].  The degree is capped so that the amplification spread inside the
+// block stays below 1e7 (otherwise the trailing columns drown in rounding noise of the leading
+// directions and the block loses rank); locking shrinks that spread as the large eigenvalues converge.
 static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambda_host, double* d_U) {
   int b = k + 12;
   if (b > 64) b = 64;
@@ -837,88 +844,118 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
   EigWork w{ctx, d_K, n, b, 1};
   TPG_TRY(w.init());
   double *Q = nullptr, *Y = nullptr, *Y0 = nullptr, *Y1 = nullptr;
-  const size_t nb = sizeof(double) * (size_t)n * (size_t)b;
-  TPG_HIP(hipMalloc((void**)&Q, nb));
-  TPG_HIP(hipMalloc((void**)&Y, nb));
-  TPG_HIP(hipMalloc((void**)&Y0, nb));
-  TPG_HIP(hipMalloc((void**)&Y1, nb));
+  const size_t nbytes = sizeof(double) * (size_t)n * (size_t)b;
+  TPG_HIP(hipMalloc((void**)&Q, nbytes));
+  TPG_HIP(hipMalloc((void**)&Y, nbytes));
+  TPG_HIP(hipMalloc((void**)&Y0, nbytes));
+  TPG_HIP(hipMalloc((void**)&Y1, nbytes));
   struct Free { double *a, *b, *c, *d; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); } } fr{Q, Y, Y0, Y1};
+  auto colbytes = [&](int cols) { return sizeof(double) * (size_t)n * (size_t)cols; };
+  auto axpby = [&](const double* x, double alpha, const double* y, double beta, double* out, int cols) -> int {
+    TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, x, 1, (int64_t)n * cols, alpha, y,
+               beta, (const double*)nullptr, 0.0, out);
+    TPG_CHECK_LAUNCH();
+    return TPG_OK;
+  };
 
-  auto orthonormalize = [&](double* A, double* tmp) -> int {  // CholQR, twice; result back in A
+  // CholQR (twice) of the `act` columns at A, after projecting out the `nl` locked columns at L
+  auto orthonormalize = [&](double* A, int act, const double* L, int nl, double* tmp) -> int {
     for (int pass = 0; pass < 2; pass++) {
-      std::vector<double> G, Ri;
-      TPG_TRY(w.gram(A, b, A, b, G));
-      // column scaling first keeps the Gram matrix well conditioned when columns differ in norm
-      std::vector<double> D((size_t)b);
-      for (int j = 0; j < b; j++) D[(size_t)j] = G[j + (size_t)j * b] > 0 ? 1.0 / sqrt(G[j + (size_t)j * b]) : 1.0;
-      for (int j = 0; j < b; j++)
-        for (int i = 0; i < b; i++) G[i + (size_t)j * b] *= D[(size_t)i] * D[(size_t)j];
-      if (!host_cholesky_upper(G, b)) {
-        // numerically rank deficient block: add a tiny ridge (happens only if n < b or K has rank < b)
-        for (int j = 0; j < b; j++) G[j + (size_t)j * b] += 1e-12;
-        if (!host_cholesky_upper(G, b)) { tpg_set_error("eigen solver: block lost rank"); return TPG_ENUMERIC; }
+      if (nl > 0) {
+        std::vector<double> Cm;
+        TPG_TRY(w.gram(L, nl, A, act, Cm));      // nl x act
+        TPG_TRY(w.rmult(L, nl, Cm, act, tmp));   // L (L'A)
+        TPG_TRY(axpby(tmp, -1.0, A, 1.0, A, act));
       }
-      host_upper_inverse(G, b, Ri);
-      for (int j = 0; j < b; j++)
-        for (int i = 0; i < b; i++) Ri[i + (size_t)j * b] *= D[(size_t)i];
-      TPG_TRY(w.rmult(A, b, Ri, b, tmp));
-      TPG_HIP(hipMemcpyAsync(A, tmp, nb, hipMemcpyDeviceToDevice, ctx->stream));
+      std::vector<double> G, Ri;
+      TPG_TRY(w.gram(A, act, A, act, G));
+      std::vector<double> D((size_t)act);
+      for (int j = 0; j < act; j++) D[(size_t)j] = G[j + (size_t)j * act] > 0 ? 1.0 / sqrt(G[j + (size_t)j * act]) : 1.0;
+      for (int j = 0; j < act; j++)
+        for (int i = 0; i < act; i++) G[i + (size_t)j * act] *= D[(size_t)i] * D[(size_t)j];
+      if (!host_cholesky_upper(G, act)) { tpg_set_error("eigen solver: block lost rank"); return TPG_ENUMERIC; }
+      host_upper_inverse(G, act, Ri);
+      for (int j = 0; j < act; j++)
+        for (int i = 0; i < act; i++) Ri[i + (size_t)j * act] *= D[(size_t)i];
+      TPG_TRY(w.rmult(A, act, Ri, act, tmp));
+      TPG_HIP(hipMemcpyAsync(A, tmp, colbytes(act), hipMemcpyDeviceToDevice, ctx->stream));
     }
     return TPG_OK;
   };
 
   TPG_LAUNCH(ctx, "eig_random", tpg_fill_random_kernel, dim3(512), dim3(256), 0, Q, (int64_t)n * b, (uint64_t)0x5EED);
-  TPG_TRY(orthonormalize(Q, Y));
-  std::vector<double> theta, X, H;
-  const int DEG = 12, MAXIT = 40;
-  const double TOL = 1e-11;
-  bool converged = false;
-  for (int it = 0; it < MAXIT; it++) {
-    // Rayleigh-Ritz
-    TPG_TRY(w.apply(Q, 1.0, nullptr, 0, nullptr, 0, Y));  // Y = K Q
-    TPG_TRY(w.gram(Q, b, Y, b, H));
-    for (int i = 0; i < b; i++)
-      for (int j = i + 1; j < b; j++) { const double s = 0.5 * (H[i + (size_t)j * b] + H[j + (size_t)i * b]); H[i + (size_t)j * b] = s; H[j + (size_t)i * b] = s; }
-    host_jacobi_eig(H, b, theta, X);
-    TPG_TRY(w.rmult(Q, b, X, b, Y0));  // Ritz vectors
-    TPG_TRY(w.rmult(Y, b, X, b, Y1));  // K * Ritz vectors
-    TPG_HIP(hipMemcpyAsync(Q, Y0, nb, hipMemcpyDeviceToDevice, ctx->stream));
-    // residual norms of the first k pairs: R = K q - theta q
-    std::vector<double> negtheta((size_t)b * b, 0.0);
-    for (int j = 0; j < b; j++) negtheta[j + (size_t)j * b] = -theta[(size_t)j];
-    TPG_TRY(w.rmult(Q, b, negtheta, b, Y));
-    TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, (const double*)Y, 1, (int64_t)n * b,
-               1.0, (const double*)Y1, 1.0, (const double*)nullptr, 0.0, Y);
+  TPG_TRY(orthonormalize(Q, b, nullptr, 0, Y));
+  std::vector<double> lam((size_t)b, 0.0), theta, X, H;
+  int nl = 0;
+  const int MAXIT = 200;
+  const double TOL = 1e-12, AMP = 1e7;
+  double lam1 = 0;
+  for (int it = 0; it < MAXIT && nl < k; it++) {
+    const int act = b - nl;
+    double* A = Q + (size_t)n * nl;
+    w.b = act;
+    // Rayleigh-Ritz on the active columns
+    TPG_TRY(w.apply(A, 1.0, nullptr, 0, nullptr, 0, Y));  // Y = K A
+    TPG_TRY(w.gram(A, act, Y, act, H));
+    for (int i = 0; i < act; i++)
+      for (int j = i + 1; j < act; j++) {
+        const double sy = 0.5 * (H[i + (size_t)j * act] + H[j + (size_t)i * act]);
+        H[i + (size_t)j * act] = sy;
+        H[j + (size_t)i * act] = sy;
+      }
+    host_jacobi_eig(H, act, theta, X);
+    TPG_TRY(w.rmult(A, act, X, act, Y0));  // Ritz vectors
+    TPG_TRY(w.rmult(Y, act, X, act, Y1));  // K * Ritz vectors
+    TPG_HIP(hipMemcpyAsync(A, Y0, colbytes(act), hipMemcpyDeviceToDevice, ctx->stream));
+    if (nl == 0) lam1 = fabs(theta[0]) > 0 ? fabs(theta[0]) : 1.0;
+    // residuals R = K a - theta a
+    std::vector<double> negtheta((size_t)act * act, 0.0);
+    for (int j = 0; j < act; j++) negtheta[j + (size_t)j * act] = -theta[(size_t)j];
+    TPG_TRY(w.rmult(A, act, negtheta, act, Y));
+    TPG_TRY(axpby(Y, 1.0, Y1, 1.0, Y, act));
     std::vector<double> RR;
-    TPG_TRY(w.gram(Y, b, Y, b, RR));
-    double worst = 0;
-    for (int j = 0; j < k; j++) worst = std::max(worst, sqrt(std::max(0.0, RR[j + (size_t)j * b])) / fabs(theta[0]));
-    if (worst < TOL) { converged = true; break; }
-    // Chebyshev filter of degree DEG damping [0, theta_b], scaled at theta_1 (Zhou & Saad 2007)
-    const double lo = 0.0, up = std::max(theta[(size_t)b - 1], 1e-300);
+    TPG_TRY(w.gram(Y, act, Y, act, RR));
+    int newly = 0;
+    while (newly < act && nl + newly < k && sqrt(std::max(0.0, RR[newly + (size_t)newly * act])) < TOL * lam1) newly++;
+    for (int j = 0; j < newly; j++) lam[(size_t)(nl + j)] = theta[(size_t)j];
+    nl += newly;
+    if (nl >= k) break;
+    const int act2 = b - nl;
+    TPG_REQUIRE(act2 >= 2, TPG_ENUMERIC, "eigen solver ran out of active vectors");
+    double* A2 = Q + (size_t)n * nl;
+    const double* KA2 = Y1 + (size_t)n * newly;  // K * (active Ritz vectors), still valid
+    // Chebyshev filter damping [0, smallest active Ritz value], scaled at the largest active one
+    const double up = std::max(theta[(size_t)act - 1], 1e-300 * lam1), lo = 0.0;
+    const double a0 = std::max(theta[(size_t)newly], up * (1 + 1e-8));
     const double ec = (up - lo) / 2, cc = (up + lo) / 2;
-    double sigma = ec / (theta[0] - cc);
+    const double x0 = (a0 - cc) / ec;
+    int deg = 20;
+    if (x0 > 1.0 + 1e-12) {
+      const double dmax = log(2 * AMP) / acosh(x0);
+      deg = dmax < 2 ? 2 : (dmax > 20 ? 20 : (int)dmax);
+    }
+    w.b = act2;
+    double sigma = ec / (a0 - cc);
     const double sigma1 = sigma;
-    // Y1 currently holds K Q: first step Ynew = (sigma1/e)(K Q - c Q)
-    TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, (const double*)Y1, 1, (int64_t)n * b,
-               sigma1 / ec, (const double*)Q, -cc * sigma1 / ec, (const double*)nullptr, 0.0, Y);
-    TPG_HIP(hipMemcpyAsync(Y0, Q, nb, hipMemcpyDeviceToDevice, ctx->stream));  // Y0 = previous, Y = current
+    // first step: cur = (sigma1/e)(K A2 - c A2), prev = A2
     double* prev = Y0;
     double* cur = Y;
     double* nxt = Y1;
-    for (int dgr = 2; dgr <= DEG; dgr++) {
+    TPG_HIP(hipMemcpyAsync(prev, A2, colbytes(act2), hipMemcpyDeviceToDevice, ctx->stream));
+    TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, KA2, 1, (int64_t)n * act2,
+               sigma1 / ec, (const double*)prev, -cc * sigma1 / ec, (const double*)nullptr, 0.0, cur);
+    for (int dgr = 2; dgr <= deg; dgr++) {
       const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
-      // nxt = (2 sigma2 / e)(K cur - c cur) - sigma sigma2 prev
       TPG_TRY(w.apply(cur, 2 * sigma2 / ec, cur, -2 * sigma2 * cc / ec, prev, -sigma * sigma2, nxt));
       double* t = prev; prev = cur; cur = nxt; nxt = t;
       sigma = sigma2;
     }
-    if (cur != Q) TPG_HIP(hipMemcpyAsync(Q, cur, nb, hipMemcpyDeviceToDevice, ctx->stream));
-    TPG_TRY(orthonormalize(Q, cur == Y ? Y0 : Y));
+    TPG_HIP(hipMemcpyAsync(A2, cur, colbytes(act2), hipMemcpyDeviceToDevice, ctx->stream));
+    TPG_TRY(orthonormalize(A2, act2, Q, nl, prev));
   }
-  TPG_REQUIRE(converged, TPG_ENUMERIC, "eigen solver did not converge");
-  for (int j = 0; j < k; j++) lambda_host[j] = theta[(size_t)j];
-  TPG_HIP(hipMemcpyAsync(d_U, Q, sizeof(double) * (size_t)n * (size_t)k, hipMemcpyDeviceToDevice, ctx->stream));
+  TPG_REQUIRE(nl >= k, TPG_ENUMERIC, "eigen solver did not converge (%d of %d pairs)", nl, k);
+  for (int j = 0; j < k; j++) lambda_host[j] = lam[(size_t)j];
+  TPG_HIP(hipMemcpyAsync(d_U, Q, colbytes(k), hipMemcpyDeviceToDevice, ctx->stream));
   TPG_HIP(hipStreamSynchronize(ctx->stream));
   return TPG_OK;
 }
