@@ -619,13 +619,14 @@ __global__ __launch_bounds__(256) void tpg_symm_apply_kernel(const double* __res
       if (cg * 16 + c < b) part[((int64_t)split * b + cg * 16 + c) * n + row] = acc[c];
 }
 
-// Y = alpha * sum_split part + beta * Y1 + gamma * Y0   (Y1 / Y0 may be null)
+// Y = alpha * (sum_split part - Dm) + beta * Y1 + gamma * Y0   (Dm / Y1 / Y0 may be null)
 __global__ void tpg_combine_kernel(const double* __restrict__ part, int S, int64_t nb, double alpha,
                                    const double* __restrict__ Y1, double beta, const double* __restrict__ Y0,
-                                   double gamma, double* __restrict__ Y) {
+                                   double gamma, double* __restrict__ Y, const double* __restrict__ Dm = nullptr) {
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < nb; idx += (int64_t)gridDim.x * blockDim.x) {
     double s = 0;
     for (int sp = 0; sp < S; sp++) s += part[(int64_t)sp * nb + idx];
+    if (Dm) s -= Dm[idx];
     double y = alpha * s;
     if (Y1) y += beta * Y1[idx];
     if (Y0) y += gamma * Y0[idx];
@@ -666,6 +667,17 @@ __global__ __launch_bounds__(256) void tpg_gram_small_kernel(const double* __res
       const int j = jq + 4 * c;
       if (j < b) part[(int64_t)chunk * p * b + i + (int64_t)j * p] = acc[c];
     }
+}
+
+// C[i + j p] = rowscale[i] * sum_chunks part[chunk][i + j p]   (device-side finish of gram_small)
+__global__ void tpg_gram_reduce_kernel(const double* __restrict__ part, int nchunks, int p, int b,
+                                       const double* __restrict__ rowscale, double* __restrict__ Cm) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p * b) return;
+  double s = 0;
+  for (int c = 0; c < nchunks; c++) s += part[(int64_t)c * p * b + idx];
+  if (rowscale) s *= rowscale[idx % p];
+  Cm[idx] = s;
 }
 
 // Y[row + j n] = sum_i A[row + i n] * X[i + j p]   (X small, p <= 64, b2 <= 64); optional residual
@@ -780,6 +792,10 @@ struct EigWork {
   int n, b, S;
   double *part = nullptr, *gpart = nullptr, *xsmall = nullptr;
   int nchunks, rows_per_chunk;
+  // deflation: K' = K - L diag(lam) L' for the nl locked eigenpairs (L = first nl columns of the block)
+  const double* L = nullptr;
+  int nl = 0;
+  double *lam_dev = nullptr, *cdev = nullptr, *dtmp = nullptr;
   int init() {
     S = 1;
     const int row_blocks = (n + 63) / 64;
@@ -789,19 +805,44 @@ struct EigWork {
     TPG_HIP(hipMalloc((void**)&part, sizeof(double) * (size_t)S * (size_t)b * (size_t)n));
     TPG_HIP(hipMalloc((void**)&gpart, sizeof(double) * (size_t)nchunks * 64 * 64));
     TPG_HIP(hipMalloc((void**)&xsmall, sizeof(double) * 64 * 64));
+    TPG_HIP(hipMalloc((void**)&lam_dev, sizeof(double) * 64));
+    TPG_HIP(hipMalloc((void**)&cdev, sizeof(double) * 64 * 64));
+    TPG_HIP(hipMalloc((void**)&dtmp, sizeof(double) * (size_t)b * (size_t)n));
     return TPG_OK;
   }
   ~EigWork() {
     if (part) (void)hipFree(part);
     if (gpart) (void)hipFree(gpart);
     if (xsmall) (void)hipFree(xsmall);
+    if (lam_dev) (void)hipFree(lam_dev);
+    if (cdev) (void)hipFree(cdev);
+    if (dtmp) (void)hipFree(dtmp);
   }
-  // Y = alpha K Q + beta Y1 + gamma Y0
+  int set_locked(const double* Lptr, int count, const double* lam_host) {
+    L = Lptr;
+    nl = count;
+    if (count > 0) {
+      TPG_HIP(hipMemcpyAsync(lam_dev, lam_host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+      TPG_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return TPG_OK;
+  }
+  // Y = alpha K' Q + beta Y1 + gamma Y0   with K' = K - L diag(lam) L'; no host synchronisation
   int apply(const double* Q, double alpha, const double* Y1, double beta, const double* Y0, double gamma, double* Y) {
     dim3 grid((unsigned)((n + 63) / 64), (unsigned)S);
     TPG_LAUNCH(ctx, "eig_symm_apply", tpg_symm_apply_kernel, grid, dim3(256), 0, K, n, Q, b, S, part);
+    const double* Dm = nullptr;
+    if (nl > 0) {
+      TPG_LAUNCH(ctx, "eig_gram_small", tpg_gram_small_kernel, dim3((unsigned)nchunks), dim3(256), 0, L, nl, Q, b, n,
+                 rows_per_chunk, gpart);
+      TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((nl * b + 255) / 256)), dim3(256), 0,
+                 (const double*)gpart, nchunks, nl, b, (const double*)lam_dev, cdev);
+      TPG_LAUNCH(ctx, "eig_right_mult", tpg_right_mult_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, L, n, nl,
+                 (const double*)cdev, b, dtmp);
+      Dm = dtmp;
+    }
     TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, (const double*)part, S,
-               (int64_t)n * b, alpha, Y1, beta, Y0, gamma, Y);
+               (int64_t)n * b, alpha, Y1, beta, Y0, gamma, Y, Dm);
     TPG_CHECK_LAUNCH();
     return TPG_OK;
   }
@@ -853,7 +894,7 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
   auto colbytes = [&](int cols) { return sizeof(double) * (size_t)n * (size_t)cols; };
   auto axpby = [&](const double* x, double alpha, const double* y, double beta, double* out, int cols) -> int {
     TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, x, 1, (int64_t)n * cols, alpha, y,
-               beta, (const double*)nullptr, 0.0, out);
+               beta, (const double*)nullptr, 0.0, out, (const double*)nullptr);
     TPG_CHECK_LAUNCH();
     return TPG_OK;
   };
@@ -894,8 +935,9 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
     const int act = b - nl;
     double* A = Q + (size_t)n * nl;
     w.b = act;
-    // Rayleigh-Ritz on the active columns
-    TPG_TRY(w.apply(A, 1.0, nullptr, 0, nullptr, 0, Y));  // Y = K A
+    TPG_TRY(w.set_locked(Q, nl, lam.data()));
+    // Rayleigh-Ritz on the active columns (deflated operator)
+    TPG_TRY(w.apply(A, 1.0, nullptr, 0, nullptr, 0, Y));  // Y = K' A
     TPG_TRY(w.gram(A, act, Y, act, H));
     for (int i = 0; i < act; i++)
       for (int j = i + 1; j < act; j++) {
@@ -935,6 +977,9 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
       deg = dmax < 2 ? 2 : (dmax > 20 ? 20 : (int)dmax);
     }
     w.b = act2;
+    TPG_TRY(w.set_locked(Q, nl, lam.data()));
+    // KA2 was formed with the previous deflation; the newly locked directions are (numerically)
+    // orthogonal to the remaining Ritz vectors, so K' A2 = K'_old A2 up to rounding.
     double sigma = ec / (a0 - cc);
     const double sigma1 = sigma;
     // first step: cur = (sigma1/e)(K A2 - c A2), prev = A2
@@ -943,7 +988,8 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
     double* nxt = Y1;
     TPG_HIP(hipMemcpyAsync(prev, A2, colbytes(act2), hipMemcpyDeviceToDevice, ctx->stream));
     TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, KA2, 1, (int64_t)n * act2,
-               sigma1 / ec, (const double*)prev, -cc * sigma1 / ec, (const double*)nullptr, 0.0, cur);
+               sigma1 / ec, (const double*)prev, -cc * sigma1 / ec, (const double*)nullptr, 0.0, cur,
+               (const double*)nullptr);
     for (int dgr = 2; dgr <= deg; dgr++) {
       const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
       TPG_TRY(w.apply(cur, 2 * sigma2 / ec, cur, -2 * sigma2 * cc / ec, prev, -sigma * sigma2, nxt));
