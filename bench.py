@@ -83,6 +83,20 @@ class Step:
             self.pw = tpg.Pairwise(self.ctx, n)
         self.fst = {}
         self.has_pca = True
+        # PCA setup (untimed): big_SVD stops on a zero scale, so monomorphic loci are dropped beforehand,
+        # as a MAF filter does in the reference workflow (vignettes/articles/benchmark_hgdp.Rmd)
+        vi = api.View(self.X, None, None, code256=self.code_imp)
+        cnt = api.loci_counts(vi)
+        vi.free()
+        alt = cnt[:, 1] + 2 * cnt[:, 2]
+        poly = (alt > 0) & (alt < 2 * n)
+        self.pca_cols = None if poly.all() else (np.where(poly)[0] + 1).astype(np.int32)
+        self.m_pca = int(poly.sum())
+        k = args.k
+        self.d_pca = {"u": self._dalloc(8 * n * k), "v": self._dalloc(8 * self.m_pca * k),
+                      "center": self._dalloc(8 * self.m_pca), "scale": self._dalloc(8 * self.m_pca)}
+        self.pca_d = np.zeros(k)
+        self.pca_fro = C.c_double()
 
     def _dalloc(self, nbytes):
         p = C.c_void_p()
@@ -141,8 +155,14 @@ class Step:
         ctx.sync()
 
     def _pca(self):
-        # single-GPU path; the sharded Gram all-reduce lands with the PCA kernels
-        return self.api.gt_pca_partialSVD(self.X, None, None, k=self.args.k, total_var=True, code256=self.code_imp)
+        # single-GPU path; the sharded Gram all-reduce lands in a later round (DESIGN.md "Multi-GPU")
+        api, lib, ctx = self.api, self.lib, self.ctx
+        v = api.View(self.X, None, self.pca_cols, code256=self.code_imp)
+        self.tpg._lib.check(lib.tpg_pca_partial_svd(ctx.h, v.h, C.c_int(self.args.k), api._ptr(self.pca_d),
+                                                    self.d_pca["u"], self.d_pca["v"], self.d_pca["center"],
+                                                    self.d_pca["scale"], C.byref(self.pca_fro)))
+        v.free()
+        return self.pca_d
 
 
 def cpu_baseline(args):
