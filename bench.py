@@ -260,7 +260,8 @@ def main():
                                    f"(imputed bytes), seed 3 [BASELINE configs 2-4]",
                        "analyses": analyses, "pca_included": bool(st.has_pca)},
             "roofline": roof,
-            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items())},
+            "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
+            "kernel_launches_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)

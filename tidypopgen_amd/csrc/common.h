@@ -118,6 +118,14 @@ struct tpg_pairwise {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Size-bucketed cache of device allocations (hipMalloc / hipFree cost milliseconds and synchronise
+// the device; a step of the hot path needs ~40 scratch buffers).  Blocks are reused in stream order:
+// the library issues all work of a context on one stream, and a process is expected to drive one
+// context per device.  tpg_pfree() of a pointer the pool does not know falls back to hipFree().
+hipError_t tpg_pmalloc(void** p, size_t bytes);
+void tpg_pfree(void* p);
+void tpg_pool_trim(void);
+
 // device allocation helpers
 template <typename T>
 static inline int tpg_dmalloc(T** p, size_t count) {

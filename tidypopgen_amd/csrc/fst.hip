@@ -197,7 +197,7 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   int nblocks = (int)(nchunks < 4 * ctx->num_cu ? nchunks : 4 * ctx->num_cu);
   if (nblocks < 1) nblocks = 1;
   double* d_part = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_part, sizeof(double) * 2 * (size_t)nblocks * (size_t)P));
+  TPG_HIP(tpg_pmalloc((void**)&d_part, sizeof(double) * 2 * (size_t)nblocks * (size_t)P));
   OutBuf ot, oa, ob, osn, osd;
   int rc = TPG_OK;
   if (sum_num) { rc = osn.init(sum_num, sizeof(double) * (size_t)P); if (rc == TPG_OK) rc = osd.init(sum_den, sizeof(double) * (size_t)P); }
@@ -224,7 +224,7 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { tpg_set_error("fst kernels: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   }
-  (void)hipFree(d_part);
+  tpg_pfree(d_part);
   TPG_TRY(rc);
   if (fst_tot) TPG_TRY(ot.commit(ctx));
   if (sum_num) { TPG_TRY(osn.commit(ctx)); TPG_TRY(osd.commit(ctx)); }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void tpg_grouped_counts_kernel(const uint4* __
 }
 
 GroupedCounts::~GroupedCounts() {
-  if (cnt) (void)hipFree(cnt);
+  if (cnt) tpg_pfree(cnt);
 }
 
 int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, int nclass, GroupedCounts* out) {
@@ -159,12 +159,12 @@ int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, in
   out->Mpad = n_lt * 32;
   out->Cpad = GT * 32;
   out->nclass = nclass;
-  TPG_HIP(hipMalloc((void**)&out->cnt, sizeof(int32_t) * 3 * (size_t)out->Mpad * (size_t)out->Cpad));
+  TPG_HIP(tpg_pmalloc((void**)&out->cnt, sizeof(int32_t) * 3 * (size_t)out->Mpad * (size_t)out->Cpad));
   int32_t* d_cls = nullptr;
   uint4* d_oh = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_cls, sizeof(int32_t) * (size_t)v->n));
-  hipError_t e = hipMalloc((void**)&d_oh, (size_t)v->Q * 4 * GT * 1024);
-  if (e != hipSuccess) { (void)hipFree(d_cls); tpg_set_error("hipMalloc one-hot: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  TPG_HIP(tpg_pmalloc((void**)&d_cls, sizeof(int32_t) * (size_t)v->n));
+  hipError_t e = tpg_pmalloc((void**)&d_oh, (size_t)v->Q * 4 * GT * 1024);
+  if (e != hipSuccess) { tpg_pfree(d_cls); tpg_set_error("hipMalloc one-hot: %s", hipGetErrorString(e)); return TPG_EHIP; }
   int rc = TPG_OK;
   e = hipMemcpyAsync(d_cls, h_cls, sizeof(int32_t) * (size_t)v->n, hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) { tpg_set_error("class upload: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
@@ -187,8 +187,8 @@ int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, in
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // d_cls / d_oh are freed below
     if (e != hipSuccess) { tpg_set_error("grouped counts: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   }
-  (void)hipFree(d_cls);
-  (void)hipFree(d_oh);
+  tpg_pfree(d_cls);
+  tpg_pfree(d_oh);
   return rc;
 }
 
@@ -307,7 +307,7 @@ extern "C" int tpg_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const do
   TPG_TRY(o.init(out, sizeof(double) * 2 * (size_t)v->m));
   if (all_dip) {
     int32_t* d_counts = nullptr;
-    TPG_HIP(hipMalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
+    TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
     int rc = tpg_launch_loci_counts(ctx, v, d_counts);
     if (rc == TPG_OK) {
       TPG_LAUNCH(ctx, "alt_freq_finalize", tpg_alt_freq_finalize_kernel, dim3(1024), dim3(256), 0,
@@ -315,7 +315,7 @@ extern "C" int tpg_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const do
       hipError_t e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess) { tpg_set_error("alt_freq: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
     }
-    (void)hipFree(d_counts);
+    tpg_pfree(d_counts);
     TPG_TRY(rc);
     return o.commit(ctx);
   }

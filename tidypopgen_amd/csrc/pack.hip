@@ -28,20 +28,51 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
   lut[tid] = lut_and_flag[tid];
   __syncthreads();
 
-  const int ii = tid & 127;
-  const int64_t i = bi * TILE + ii;
-  int64_t src_row = -1;
-  if (i < n) src_row = rows ? (int64_t)rows[i] - 1 : i;
   bool bad = false;
-  for (int l = tid >> 7; l < TILE; l += 2) {
-    const int64_t j = bj * TILE + l;
-    uint8_t c = 3;
-    if (src_row >= 0 && j < m) {
-      const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
-      c = lut[fbm[src_row + src_col * nrow]];
-      if (c == 0xFF) { bad = true; c = 3; }
+  // fast path: identity rows, whole tile inside the FBM rows, columns 8-byte aligned -> 8-byte loads,
+  // 8 independent loads per thread in flight
+  const bool fast = (rows == nullptr) && (bi * TILE + TILE <= n) && ((nrow & 7) == 0) &&
+                    ((((uintptr_t)fbm) & 7) == 0);
+  if (fast) {
+    const int c8 = tid & 15;  // 8-byte chunk of the tile's 128 individuals
+    uint2 v[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int64_t j = bj * TILE + (tid >> 4) + 16 * it;
+      v[it] = make_uint2(0, 0);
+      if (j < m) {
+        const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
+        v[it] = *reinterpret_cast<const uint2*>(fbm + bi * TILE + 8 * c8 + src_col * nrow);
+      }
     }
-    codes[l * LDS_STRIDE + ii] = c;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int l = (tid >> 4) + 16 * it;
+      const bool inside = bj * TILE + l < m;
+      uint8_t* dst = codes + l * LDS_STRIDE + 8 * c8;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t word = q < 4 ? v[it].x : v[it].y;
+        uint8_t c = inside ? lut[(word >> (8 * (q & 3))) & 0xFFu] : (uint8_t)3;
+        if (c == 0xFF) { bad = true; c = 3; }
+        dst[q] = c;
+      }
+    }
+  } else {
+    const int ii = tid & 127;
+    const int64_t i = bi * TILE + ii;
+    int64_t src_row = -1;
+    if (i < n) src_row = rows ? (int64_t)rows[i] - 1 : i;
+    for (int l = tid >> 7; l < TILE; l += 2) {
+      const int64_t j = bj * TILE + l;
+      uint8_t c = 3;
+      if (src_row >= 0 && j < m) {
+        const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
+        c = lut[fbm[src_row + src_col * nrow]];
+        if (c == 0xFF) { bad = true; c = 3; }
+      }
+      codes[l * LDS_STRIDE + ii] = c;
+    }
   }
   if (bad) atomicOr((unsigned int*)(lut_and_flag + 256), 1u);
   __syncthreads();

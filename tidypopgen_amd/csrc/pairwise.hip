@@ -135,7 +135,7 @@ extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tp
     if (!tpg_is_device_ptr(ext_buffer)) { delete pw; tpg_set_error("ext_buffer is not device memory"); return TPG_EINVAL; }
     pw->acc = (int32_t*)ext_buffer;
   } else {
-    hipError_t e = hipMalloc((void**)&pw->acc, tpg_pairwise_buffer_bytes(n));
+    hipError_t e = tpg_pmalloc((void**)&pw->acc, tpg_pairwise_buffer_bytes(n));
     if (e != hipSuccess) { delete pw; tpg_set_error("hipMalloc pairwise buffer: %s", hipGetErrorString(e)); return TPG_EHIP; }
     pw->owns = true;
   }
@@ -147,7 +147,7 @@ extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tp
 
 extern "C" void tpg_pairwise_free(tpg_pairwise* pw) {
   if (!pw) return;
-  if (pw->owns && pw->acc) (void)hipFree(pw->acc);
+  if (pw->owns && pw->acc) tpg_pfree(pw->acc);
   delete pw;
 }
 
@@ -333,9 +333,9 @@ extern "C" int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* ou
   const int NB = 512;
   double* d_sum = nullptr;
   unsigned long long* d_cnt = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_sum, sizeof(double) * NB));
-  hipError_t e = hipMalloc((void**)&d_cnt, sizeof(unsigned long long) * NB);
-  if (e != hipSuccess) { (void)hipFree(d_sum); tpg_set_error("hipMalloc: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  TPG_HIP(tpg_pmalloc((void**)&d_sum, sizeof(double) * NB));
+  hipError_t e = tpg_pmalloc((void**)&d_cnt, sizeof(unsigned long long) * NB);
+  if (e != hipSuccess) { tpg_pfree(d_sum); tpg_set_error("hipMalloc: %s", hipGetErrorString(e)); return TPG_EHIP; }
   TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_offdiag_sum_kernel, dim3(NB), dim3(256), 0, o.dev<double>(), n, d_sum,
              d_cnt);
   std::vector<double> hs(NB);
@@ -343,8 +343,8 @@ extern "C" int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* ou
   e = hipMemcpyAsync(hs.data(), d_sum, sizeof(double) * NB, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(hc.data(), d_cnt, sizeof(unsigned long long) * NB, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_sum);
-  (void)hipFree(d_cnt);
+  tpg_pfree(d_sum);
+  tpg_pfree(d_cnt);
   if (e != hipSuccess) { tpg_set_error("grm reduce: %s", hipGetErrorString(e)); return TPG_EHIP; }
   long double s = 0;
   unsigned long long c = 0;

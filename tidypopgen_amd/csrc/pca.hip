@@ -82,7 +82,7 @@ static int pca_counts_center_scale(tpg_ctx* ctx, const tpg_view* v, int32_t* d_c
                                    double* d_scale) {
   TPG_TRY(tpg_launch_loci_counts(ctx, v, d_counts));
   int* d_flags = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_flags, 2 * sizeof(int)));
+  TPG_HIP(tpg_pmalloc((void**)&d_flags, 2 * sizeof(int)));
   hipError_t e = hipMemsetAsync(d_flags, 0, 2 * sizeof(int), ctx->stream);
   int flags[2] = {0, 0};
   if (e == hipSuccess) {
@@ -91,7 +91,7 @@ static int pca_counts_center_scale(tpg_ctx* ctx, const tpg_view* v, int32_t* d_c
     e = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_flags);
+  tpg_pfree(d_flags);
   if (e != hipSuccess) { tpg_set_error("pca center/scale: %s", hipGetErrorString(e)); return TPG_EHIP; }
   // bigstatsr::big_SVD stops on missing values and on a zero scale
   TPG_REQUIRE(!flags[0], TPG_ENUMERIC, "You can't have missing values in 'X'.");
@@ -105,9 +105,9 @@ extern "C" int tpg_pca_center_scale(tpg_ctx* ctx, const tpg_view* v, double* cen
   TPG_TRY(oc.init(center, sizeof(double) * (size_t)v->m));
   TPG_TRY(os.init(scale, sizeof(double) * (size_t)v->m));
   int32_t* d_counts = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
+  TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
   int rc = pca_counts_center_scale(ctx, v, d_counts, oc.dev<double>(), os.dev<double>());
-  (void)hipFree(d_counts);
+  tpg_pfree(d_counts);
   TPG_TRY(rc);
   TPG_TRY(oc.commit(ctx));
   return os.commit(ctx);
@@ -117,13 +117,13 @@ static int frobenius_from_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t*
                                  const double* d_scale, double* out_host) {
   const int NB = 512;
   double* d_part = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_part, sizeof(double) * NB));
+  TPG_HIP(tpg_pmalloc((void**)&d_part, sizeof(double) * NB));
   TPG_LAUNCH(ctx, "pca_frobenius", tpg_pca_frobenius_kernel, dim3(NB), dim3(256), 0, (const int4*)d_counts, v->m, v->n,
              d_center, d_scale, d_part);
   std::vector<double> hp(NB);
   hipError_t e = hipMemcpyAsync(hp.data(), d_part, sizeof(double) * NB, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_part);
+  tpg_pfree(d_part);
   if (e != hipSuccess) { tpg_set_error("frobenius: %s", hipGetErrorString(e)); return TPG_EHIP; }
   long double s = 0;
   for (int b = 0; b < NB; b++) s += hp[b];
@@ -138,10 +138,10 @@ extern "C" int tpg_square_frobenius(tpg_ctx* ctx, const tpg_view* v, const doubl
   TPG_TRY(ic.init(ctx, center, sizeof(double) * (size_t)v->m));
   TPG_TRY(is.init(ctx, scale, sizeof(double) * (size_t)v->m));
   int32_t* d_counts = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
+  TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
   int rc = tpg_launch_loci_counts(ctx, v, d_counts);
   if (rc == TPG_OK) rc = frobenius_from_counts(ctx, v, d_counts, ic.dev<double>(), is.dev<double>(), out);
-  (void)hipFree(d_counts);
+  tpg_pfree(d_counts);
   return rc;
 }
 
@@ -251,37 +251,41 @@ __global__ void tpg_sweep_reduce_kernel(const double* __restrict__ part, const d
 static int run_sweep(tpg_ctx* ctx, int mode, const uint4* P, int64_t nrowtiles, int64_t nblocks, int64_t nrows,
                      int64_t ncols, const double* d_center, const double* d_inv_scale, const double* d_Tab,
                      int64_t ldtab, int K, double* d_out, const double* d_col_div, double* d_rss) {
-  const int KC = 8;
+  const int KC = K <= 4 ? 4 : 20;
   const int64_t rows_pad = nrowtiles * 32;
   // split the column range so that the grid fills the chip (rows alone may be few: N/32 tiles)
   int64_t S = 1;
   const int64_t row_blocks = ceil_div(nrowtiles, 4);
   while (row_blocks * S < 4 * ctx->num_cu && S * 2 <= nblocks && S < 64) S *= 2;
   double *d_part = nullptr, *d_rsp = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_part, sizeof(double) * (size_t)S * KC * (size_t)rows_pad));
-  hipError_t e = hipMalloc((void**)&d_rsp, sizeof(double) * (size_t)S * (size_t)rows_pad);
-  if (e != hipSuccess) { (void)hipFree(d_part); tpg_set_error("hipMalloc sweep: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  TPG_HIP(tpg_pmalloc((void**)&d_part, sizeof(double) * (size_t)S * KC * (size_t)rows_pad));
+  hipError_t e = tpg_pmalloc((void**)&d_rsp, sizeof(double) * (size_t)S * (size_t)rows_pad);
+  if (e != hipSuccess) { tpg_pfree(d_part); tpg_set_error("hipMalloc sweep: %s", hipGetErrorString(e)); return TPG_EHIP; }
   dim3 grid((unsigned)row_blocks, (unsigned)S);
   for (int k0 = 0; k0 < K; k0 += KC) {
     const int kc = K - k0 < KC ? K - k0 : KC;
     const double* tabp = d_Tab + (int64_t)k0 * ldtab;
     double* rsp = (k0 == 0 && d_rss) ? d_rsp : nullptr;
-    if (mode == SW_COLSCALE)
-      TPG_LAUNCH(ctx, "sweep_colscale", (tpg_sweep_kernel<8, SW_COLSCALE>), grid, dim3(256), 0, P, nrowtiles, nblocks,
-                 (int)S, nrows, ncols, d_center, d_inv_scale, tabp, ldtab, kc, d_part, rsp);
-    else if (mode == SW_ROWSCALE)
-      TPG_LAUNCH(ctx, "sweep_rowscale", (tpg_sweep_kernel<8, SW_ROWSCALE>), grid, dim3(256), 0, P, nrowtiles, nblocks,
-                 (int)S, nrows, ncols, d_center, d_inv_scale, tabp, ldtab, kc, d_part, rsp);
-    else
-      TPG_LAUNCH(ctx, "sweep_raw", (tpg_sweep_kernel<8, SW_RAW>), grid, dim3(256), 0, P, nrowtiles, nblocks, (int)S,
-                 nrows, ncols, d_center, d_inv_scale, tabp, ldtab, kc, d_part, rsp);
+#define SWEEP_LAUNCH(KCV, MODEV, NAME)                                                                              \
+  TPG_LAUNCH(ctx, NAME, (tpg_sweep_kernel<KCV, MODEV>), grid, dim3(256), 0, P, nrowtiles, nblocks, (int)S, nrows,   \
+             ncols, d_center, d_inv_scale, tabp, ldtab, kc, d_part, rsp)
+    if (KC == 4) {
+      if (mode == SW_COLSCALE) SWEEP_LAUNCH(4, SW_COLSCALE, "sweep_colscale");
+      else if (mode == SW_ROWSCALE) SWEEP_LAUNCH(4, SW_ROWSCALE, "sweep_rowscale");
+      else SWEEP_LAUNCH(4, SW_RAW, "sweep_raw");
+    } else {
+      if (mode == SW_COLSCALE) SWEEP_LAUNCH(20, SW_COLSCALE, "sweep_colscale");
+      else if (mode == SW_ROWSCALE) SWEEP_LAUNCH(20, SW_ROWSCALE, "sweep_rowscale");
+      else SWEEP_LAUNCH(20, SW_RAW, "sweep_raw");
+    }
+#undef SWEEP_LAUNCH
     TPG_LAUNCH(ctx, "sweep_reduce", tpg_sweep_reduce_kernel, dim3(512), dim3(256), 0, d_part, rsp, (int)S, KC, kc,
                rows_pad, nrows, d_out, nrows, k0, d_col_div, rsp ? d_rss : nullptr);
   }
   e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_part);
-  (void)hipFree(d_rsp);
+  tpg_pfree(d_part);
+  tpg_pfree(d_rsp);
   if (e != hipSuccess) { tpg_set_error("sweep: %s", hipGetErrorString(e)); return TPG_EHIP; }
   return TPG_OK;
 }
@@ -302,11 +306,11 @@ extern "C" int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx* ctx, const tpg_view* v, co
   TPG_TRY(oxv.init(XV, sizeof(double) * (size_t)v->n * (size_t)K));
   TPG_TRY(orss.init(rss, sizeof(double) * (size_t)v->n));
   double* d_inv = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_inv, sizeof(double) * (size_t)v->m));
+  TPG_HIP(tpg_pmalloc((void**)&d_inv, sizeof(double) * (size_t)v->m));
   TPG_LAUNCH(ctx, "inv_scale", tpg_inv_kernel, dim3(1024), dim3(256), 0, is.dev<double>(), v->m, d_inv);
   int rc = run_sweep(ctx, SW_COLSCALE, v->T, v->Q * 4, v->KG, v->n, v->m, ic.dev<double>(), d_inv, iv.dev<double>(),
                      v->m, K, oxv.dev<double>(), nullptr, orss.dev<double>());
-  (void)hipFree(d_inv);
+  tpg_pfree(d_inv);
   TPG_TRY(rc);
   TPG_TRY(oxv.commit(ctx));
   return orss.commit(ctx);
@@ -396,41 +400,64 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[t][tb][q] = 0;
 
-    for (int64_t kg = k0; kg < k1; kg++) {
-      const uint4 A = pa[kg * 64];
-      uint4 B[4];
+    if (k0 < k1) {
+      uint4 nA = pa[k0 * 64], nB[4];
 #pragma unroll
-      for (int tb = 0; tb < 4; tb++) B[tb] = pb[tb][kg * 64];
-      const uint32_t wa[4] = {A.x, A.y, A.z, A.w};
+      for (int tb = 0; tb < 4; tb++) nB[tb] = pb[tb][k0 * 64];
+      for (int64_t kg = k0; kg < k1; kg++) {
+        const uint4 A = nA;
+        uint4 B[4];
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
-        // selector per register: genotype 1 -> byte b of D (S1), genotype 2 -> byte b of 2D (S0), else 0
-        uint32_t sel[4];
+        for (int tb = 0; tb < 4; tb++) B[tb] = nB[tb];
+        const int64_t kn = (kg + 1 < k1) ? kg + 1 : kg;
+        nA = pa[kn * 64];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t c = tpg_codes(wa[s], k);
-          const uint32_t base = (uint32_t)tpg_lut(0x0C04000Cu, c);
-          const uint32_t mv = (uint32_t)tpg_lut(0x00FFFF00u, c);
-          sel[k] = (0x03020100u & mv) | base;
-        }
-        v4i fb[4];
+        for (int tb = 0; tb < 4; tb++) nB[tb] = pb[tb][kn * 64];
+        // digits of K step 0 of this group; later steps are fetched one step ahead
+        const uint4* dgbase = DG + (((kg * 4) * 2 + h) * (int64_t)Ttot + t0) * 2;
+        uint4 dcur[TD][2], dnxt[TD][2];
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) {
-          const uint32_t wb = s == 0 ? B[tb].x : s == 1 ? B[tb].y : s == 2 ? B[tb].z : B[tb].w;
+        for (int t = 0; t < TD; t++) { dcur[t][0] = dgbase[t * 2]; dcur[t][1] = dgbase[t * 2 + 1]; }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's MFMAs
+        const uint32_t wa[4] = {A.x, A.y, A.z, A.w};
 #pragma unroll
-          for (int k = 0; k < 4; k++) fb[tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wb, k));
-        }
-        const uint4* dg = DG + ((((kg * 4 + s) * 2 + h) * (int64_t)Ttot) + t0) * 2;
+        for (int s = 0; s < 4; s++) {
+          if (s < 3) {
+            const uint4* dgn = dgbase + (int64_t)(s + 1) * 2 * Ttot * 2;
 #pragma unroll
-        for (int t = 0; t < TD; t++) {
-          const uint4 d1 = dg[t * 2], d2 = dg[t * 2 + 1];
-          v4i fa;
-          fa[0] = (int)__builtin_amdgcn_perm(d2.x, d1.x, sel[0]);
-          fa[1] = (int)__builtin_amdgcn_perm(d2.y, d1.y, sel[1]);
-          fa[2] = (int)__builtin_amdgcn_perm(d2.z, d1.z, sel[2]);
-          fa[3] = (int)__builtin_amdgcn_perm(d2.w, d1.w, sel[3]);
+            for (int t = 0; t < TD; t++) { dnxt[t][0] = dgn[t * 2]; dnxt[t][1] = dgn[t * 2 + 1]; }
+          }
+          // selector per register: genotype 1 -> byte b of D (S1), genotype 2 -> byte b of 2D (S0), else 0
+          uint32_t sel[4];
 #pragma unroll
-          for (int tb = 0; tb < 4; tb++) acc[t][tb] = MFMA_I8(fa, fb[tb], acc[t][tb]);
+          for (int k = 0; k < 4; k++) {
+            const uint32_t c = tpg_codes(wa[s], k);
+            const uint32_t base = (uint32_t)tpg_lut(0x0C04000Cu, c);
+            const uint32_t mv = (uint32_t)tpg_lut(0x00FFFF00u, c);
+            sel[k] = (0x03020100u & mv) | base;
+          }
+          v4i fb[4];
+#pragma unroll
+          for (int tb = 0; tb < 4; tb++) {
+            const uint32_t wb = s == 0 ? B[tb].x : s == 1 ? B[tb].y : s == 2 ? B[tb].z : B[tb].w;
+#pragma unroll
+            for (int k = 0; k < 4; k++) fb[tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wb, k));
+          }
+#pragma unroll
+          for (int t = 0; t < TD; t++) {
+            const uint4 d1 = dcur[t][0], d2 = dcur[t][1];
+            v4i fa;
+            fa[0] = (int)__builtin_amdgcn_perm(d2.x, d1.x, sel[0]);
+            fa[1] = (int)__builtin_amdgcn_perm(d2.y, d1.y, sel[1]);
+            fa[2] = (int)__builtin_amdgcn_perm(d2.z, d1.z, sel[2]);
+            fa[3] = (int)__builtin_amdgcn_perm(d2.w, d1.w, sel[3]);
+#pragma unroll
+            for (int tb = 0; tb < 4; tb++) acc[t][tb] = MFMA_I8(fa, fb[tb], acc[t][tb]);
+          }
+          if (s < 3) {
+#pragma unroll
+            for (int t = 0; t < TD; t++) { dcur[t][0] = dnxt[t][0]; dcur[t][1] = dnxt[t][1]; }
+          }
         }
       }
     }
@@ -509,12 +536,12 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   int rc = TPG_OK;
   hipError_t e = hipSuccess;
 #define GHIP(call) do { if (e == hipSuccess) { e = (call); if (e != hipSuccess) tpg_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e)); } } while (0)
-  GHIP(hipMalloc((void**)&d_DG, (size_t)v->KG * 4 * 2 * T * 8 * sizeof(uint32_t)));
-  GHIP(hipMalloc((void**)&d_what, sizeof(double) * (size_t)m));
-  GHIP(hipMalloc((void**)&d_wc, sizeof(double) * (size_t)m));
-  GHIP(hipMalloc((void**)&d_r, sizeof(double) * (size_t)n));
-  GHIP(hipMalloc((void**)&d_part, sizeof(double) * 512));
-  GHIP(hipMalloc((void**)&d_slabs, sizeof(long long) * (size_t)nun * PCA_SLAB_INTS));
+  GHIP(tpg_pmalloc((void**)&d_DG, (size_t)v->KG * 4 * 2 * T * 8 * sizeof(uint32_t)));
+  GHIP(tpg_pmalloc((void**)&d_what, sizeof(double) * (size_t)m));
+  GHIP(tpg_pmalloc((void**)&d_wc, sizeof(double) * (size_t)m));
+  GHIP(tpg_pmalloc((void**)&d_r, sizeof(double) * (size_t)n));
+  GHIP(tpg_pmalloc((void**)&d_part, sizeof(double) * 512));
+  GHIP(tpg_pmalloc((void**)&d_slabs, sizeof(long long) * (size_t)nun * PCA_SLAB_INTS));
   GHIP(hipMemsetAsync(d_slabs, 0, sizeof(long long) * (size_t)nun * PCA_SLAB_INTS, ctx->stream));
   if (e == hipSuccess) {
     TPG_LAUNCH(ctx, "pca_digits", tpg_pca_digits_kernel, dim3(1024), dim3(256), 0, d_scale, d_center, m, v->KG, F, T,
@@ -565,8 +592,8 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     GHIP(hipStreamSynchronize(ctx->stream));
   }
 #undef GHIP
-  (void)hipFree(d_DG); (void)hipFree(d_what); (void)hipFree(d_wc); (void)hipFree(d_r); (void)hipFree(d_part);
-  (void)hipFree(d_slabs);
+  tpg_pfree(d_DG); tpg_pfree(d_what); tpg_pfree(d_wc); tpg_pfree(d_r); tpg_pfree(d_part);
+  tpg_pfree(d_slabs);
   if (e != hipSuccess) return TPG_EHIP;
   return rc;
 }
@@ -606,10 +633,15 @@ __global__ __launch_bounds__(256) void tpg_symm_apply_kernel(const double* __res
     __syncthreads();
     if (row < n) {
       const int kmax = kend - k0 < 64 ? kend - k0 : 64;
-      for (int kk = 0; kk < kmax; kk++) {
-        const double kv = K[row + (int64_t)(k0 + kk) * n];
+      const double* kp = K + row + (int64_t)k0 * n;
+      for (int kb = 0; kb < 64; kb += 16) {
+        double kv[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) acc[c] += kv * qs[kk][cg * 16 + c];
+        for (int u = 0; u < 16; u++) kv[u] = (kb + u < kmax) ? kp[(int64_t)(kb + u) * n] : 0.0;  // 16 loads in flight
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+#pragma unroll
+          for (int c = 0; c < 16; c++) acc[c] += kv[u] * qs[kb + u][cg * 16 + c];
       }
     }
   }
@@ -802,21 +834,21 @@ struct EigWork {
     while (row_blocks * S < 2 * ctx->num_cu && S < 32 && n / (S * 2) >= 64) S *= 2;
     rows_per_chunk = 256;
     nchunks = (n + rows_per_chunk - 1) / rows_per_chunk;
-    TPG_HIP(hipMalloc((void**)&part, sizeof(double) * (size_t)S * (size_t)b * (size_t)n));
-    TPG_HIP(hipMalloc((void**)&gpart, sizeof(double) * (size_t)nchunks * 64 * 64));
-    TPG_HIP(hipMalloc((void**)&xsmall, sizeof(double) * 64 * 64));
-    TPG_HIP(hipMalloc((void**)&lam_dev, sizeof(double) * 64));
-    TPG_HIP(hipMalloc((void**)&cdev, sizeof(double) * 64 * 64));
-    TPG_HIP(hipMalloc((void**)&dtmp, sizeof(double) * (size_t)b * (size_t)n));
+    TPG_HIP(tpg_pmalloc((void**)&part, sizeof(double) * (size_t)S * (size_t)b * (size_t)n));
+    TPG_HIP(tpg_pmalloc((void**)&gpart, sizeof(double) * (size_t)nchunks * 64 * 64));
+    TPG_HIP(tpg_pmalloc((void**)&xsmall, sizeof(double) * 64 * 64));
+    TPG_HIP(tpg_pmalloc((void**)&lam_dev, sizeof(double) * 64));
+    TPG_HIP(tpg_pmalloc((void**)&cdev, sizeof(double) * 64 * 64));
+    TPG_HIP(tpg_pmalloc((void**)&dtmp, sizeof(double) * (size_t)b * (size_t)n));
     return TPG_OK;
   }
   ~EigWork() {
-    if (part) (void)hipFree(part);
-    if (gpart) (void)hipFree(gpart);
-    if (xsmall) (void)hipFree(xsmall);
-    if (lam_dev) (void)hipFree(lam_dev);
-    if (cdev) (void)hipFree(cdev);
-    if (dtmp) (void)hipFree(dtmp);
+    if (part) tpg_pfree(part);
+    if (gpart) tpg_pfree(gpart);
+    if (xsmall) tpg_pfree(xsmall);
+    if (lam_dev) tpg_pfree(lam_dev);
+    if (cdev) tpg_pfree(cdev);
+    if (dtmp) tpg_pfree(dtmp);
   }
   int set_locked(const double* Lptr, int count, const double* lam_host) {
     L = Lptr;
@@ -886,11 +918,11 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
   TPG_TRY(w.init());
   double *Q = nullptr, *Y = nullptr, *Y0 = nullptr, *Y1 = nullptr;
   const size_t nbytes = sizeof(double) * (size_t)n * (size_t)b;
-  TPG_HIP(hipMalloc((void**)&Q, nbytes));
-  TPG_HIP(hipMalloc((void**)&Y, nbytes));
-  TPG_HIP(hipMalloc((void**)&Y0, nbytes));
-  TPG_HIP(hipMalloc((void**)&Y1, nbytes));
-  struct Free { double *a, *b, *c, *d; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); } } fr{Q, Y, Y0, Y1};
+  TPG_HIP(tpg_pmalloc((void**)&Q, nbytes));
+  TPG_HIP(tpg_pmalloc((void**)&Y, nbytes));
+  TPG_HIP(tpg_pmalloc((void**)&Y0, nbytes));
+  TPG_HIP(tpg_pmalloc((void**)&Y1, nbytes));
+  struct Free { double *a, *b, *c, *d; ~Free() { tpg_pfree(a); tpg_pfree(b); tpg_pfree(c); tpg_pfree(d); } } fr{Q, Y, Y0, Y1};
   auto colbytes = [&](int cols) { return sizeof(double) * (size_t)n * (size_t)cols; };
   auto axpby = [&](const double* x, double alpha, const double* y, double beta, double* out, int cols) -> int {
     TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, x, 1, (int64_t)n * cols, alpha, y,
@@ -1019,20 +1051,20 @@ extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, doubl
   TPG_TRY(ov.init(vload, sizeof(double) * (size_t)m * (size_t)k));
   int32_t* d_counts = nullptr;
   double *d_K = nullptr, *d_inv = nullptr, *d_dk = nullptr;
-  TPG_HIP(hipMalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)m));
-  struct Free { void *a, *b, *c, *d; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); } } fr{d_counts, nullptr, nullptr, nullptr};
+  TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)m));
+  struct Free { void *a, *b, *c, *d; ~Free() { tpg_pfree(a); tpg_pfree(b); tpg_pfree(c); tpg_pfree(d); } } fr{d_counts, nullptr, nullptr, nullptr};
   TPG_TRY(pca_counts_center_scale(ctx, v, d_counts, oc.dev<double>(), os.dev<double>()));
   if (square_frobenius) TPG_TRY(frobenius_from_counts(ctx, v, d_counts, oc.dev<double>(), os.dev<double>(), square_frobenius));
-  TPG_HIP(hipMalloc((void**)&d_K, sizeof(double) * (size_t)n * (size_t)n));
+  TPG_HIP(tpg_pmalloc((void**)&d_K, sizeof(double) * (size_t)n * (size_t)n));
   fr.b = d_K;
   TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K));
   std::vector<double> lam((size_t)k);
   TPG_TRY(eig_topk(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>()));
   std::vector<double> dh((size_t)k);
   for (int j = 0; j < k; j++) dh[(size_t)j] = sqrt(lam[(size_t)j] > 0 ? lam[(size_t)j] : 0.0);
-  TPG_HIP(hipMalloc((void**)&d_inv, sizeof(double) * (size_t)m));
+  TPG_HIP(tpg_pmalloc((void**)&d_inv, sizeof(double) * (size_t)m));
   fr.c = d_inv;
-  TPG_HIP(hipMalloc((void**)&d_dk, sizeof(double) * (size_t)k));
+  TPG_HIP(tpg_pmalloc((void**)&d_dk, sizeof(double) * (size_t)k));
   fr.d = d_dk;
   TPG_HIP(hipMemcpyAsync(d_dk, dh.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
   TPG_LAUNCH(ctx, "inv_scale", tpg_inv_kernel, dim3(1024), dim3(256), 0, (const double*)os.dev<double>(), m, d_inv);

@@ -10,7 +10,77 @@
 
 #include "common.h"
 
+#include <mutex>
+#include <unordered_map>
+
 static thread_local char g_err[1024] = "";
+
+// ---------------------------------------------------------------------------
+static std::mutex g_pool_mu;
+static std::multimap<size_t, void*> g_pool_free;       // rounded size -> block
+static std::unordered_map<void*, size_t> g_pool_live;  // block -> rounded size
+static size_t g_pool_cached_bytes = 0;
+static const size_t POOL_MAX_CACHED = (size_t)48 << 30;
+
+static size_t pool_round(size_t b) {
+  if (b < 256) return 256;
+  if (b < ((size_t)1 << 20)) return (b + 255) & ~(size_t)255;
+  return (b + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+}
+
+hipError_t tpg_pmalloc(void** p, size_t bytes) {
+  const size_t rb = pool_round(bytes);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_free.find(rb);
+    if (it != g_pool_free.end()) {
+      *p = it->second;
+      g_pool_free.erase(it);
+      g_pool_cached_bytes -= rb;
+      g_pool_live[*p] = rb;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, rb);
+  if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+    (void)hipGetLastError();
+    tpg_pool_trim();
+    e = hipMalloc(p, rb);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool_live[*p] = rb;
+  return hipSuccess;
+}
+
+void tpg_pfree(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_live.find(p);
+    if (it != g_pool_live.end()) {
+      const size_t rb = it->second;
+      g_pool_live.erase(it);
+      if (g_pool_cached_bytes + rb <= POOL_MAX_CACHED) {
+        g_pool_free.emplace(rb, p);
+        g_pool_cached_bytes += rb;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+
+void tpg_pool_trim(void) {
+  std::vector<void*> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto& kv : g_pool_free) blocks.push_back(kv.second);
+    g_pool_free.clear();
+    g_pool_cached_bytes = 0;
+  }
+  for (void* b : blocks) (void)hipFree(b);
+}
 
 void tpg_set_error(const char* fmt, ...) {
   va_list ap;
@@ -123,6 +193,8 @@ extern "C" void tpg_ctx_destroy(tpg_ctx* ctx) {
   if (!ctx) return;
   (void)tpg_prof_resolve(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  tpg_pool_trim();
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -153,11 +225,11 @@ extern "C" int tpg_ctx_sync(tpg_ctx* ctx) {
 extern "C" int tpg_dev_alloc(tpg_ctx* ctx, size_t bytes, void** out) {
   TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
   TPG_HIP(hipSetDevice(ctx->device));
-  TPG_HIP(hipMalloc(out, bytes > 0 ? bytes : 16));
+  TPG_HIP(tpg_pmalloc(out, bytes > 0 ? bytes : 16));
   return TPG_OK;
 }
 extern "C" void tpg_dev_free(void* p) {
-  if (p) (void)hipFree(p);
+  if (p) tpg_pfree(p);
 }
 extern "C" int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
   TPG_REQUIRE(ctx && host_dst && dev_src, TPG_EINVAL, "null argument");
@@ -185,7 +257,7 @@ int OutBuf::init(void* user_ptr, size_t nbytes) {
     d = user_ptr;
     owned = false;
   } else {
-    TPG_HIP(hipMalloc(&d, nbytes > 0 ? nbytes : 16));
+    TPG_HIP(tpg_pmalloc(&d, nbytes > 0 ? nbytes : 16));
     owned = true;
   }
   return TPG_OK;
@@ -198,7 +270,7 @@ int OutBuf::commit(tpg_ctx* ctx) {
   return TPG_OK;
 }
 OutBuf::~OutBuf() {
-  if (owned && d) (void)hipFree(d);
+  if (owned && d) tpg_pfree(d);
 }
 
 int InBuf::init(tpg_ctx* ctx, const void* user_ptr, size_t nbytes) {
@@ -206,14 +278,14 @@ int InBuf::init(tpg_ctx* ctx, const void* user_ptr, size_t nbytes) {
     d = user_ptr;
     return TPG_OK;
   }
-  TPG_HIP(hipMalloc(&owned_ptr, nbytes > 0 ? nbytes : 16));
+  TPG_HIP(tpg_pmalloc(&owned_ptr, nbytes > 0 ? nbytes : 16));
   if (nbytes) TPG_HIP(hipMemcpyAsync(owned_ptr, user_ptr, nbytes, hipMemcpyHostToDevice, ctx->stream));
   TPG_HIP(hipStreamSynchronize(ctx->stream));
   d = owned_ptr;
   return TPG_OK;
 }
 InBuf::~InBuf() {
-  if (owned_ptr) (void)hipFree(owned_ptr);
+  if (owned_ptr) tpg_pfree(owned_ptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -224,7 +296,7 @@ extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nro
   tpg_fbm* f = new tpg_fbm{ctx, nullptr, nrow, ncol};
   size_t sz = (size_t)nrow * (size_t)ncol;
   hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
-  if (e != hipSuccess) { delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
+  if (e != hipSuccess) { delete f; tpg_set_error("tpg_pmalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
   e = hipMemcpyAsync(f->d_bytes, bytes, sz, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { (void)hipFree(f->d_bytes); delete f; tpg_set_error("FBM upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
@@ -259,7 +331,7 @@ extern "C" int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t 
   tpg_fbm* f = new tpg_fbm{ctx, nullptr, nrow, ncol};
   size_t sz = (size_t)nrow * (size_t)ncol;
   hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
-  if (e != hipSuccess) { delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
+  if (e != hipSuccess) { delete f; tpg_set_error("tpg_pmalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
   int rc = tpg_launch_synth(ctx, f->d_bytes, seed, nrow, ncol, j0, npop, miss_thresh, imputed_bytes);
   if (rc != TPG_OK) { (void)hipFree(f->d_bytes); delete f; return rc; }
   *out = f;
@@ -314,9 +386,9 @@ extern "C" int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* 
   uint8_t* d_lut = nullptr;
   int rc = TPG_OK;
   auto fail = [&](int code) {
-    if (d_rows) (void)hipFree(d_rows);
-    if (d_cols) (void)hipFree(d_cols);
-    if (d_lut) (void)hipFree(d_lut);
+    if (d_rows) tpg_pfree(d_rows);
+    if (d_cols) tpg_pfree(d_cols);
+    if (d_lut) tpg_pfree(d_lut);
     tpg_view_free(v);
     return code;
   };
@@ -328,17 +400,17 @@ extern "C" int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* 
       return fail(TPG_EHIP);                                                             \
     }                                                                                    \
   } while (0)
-  VHIP(hipMalloc((void**)&v->T, v->bytes_each));
-  VHIP(hipMalloc((void**)&v->L, v->bytes_each));
-  VHIP(hipMalloc((void**)&d_lut, 256 + 16));
+  VHIP(tpg_pmalloc((void**)&v->T, v->bytes_each));
+  VHIP(tpg_pmalloc((void**)&v->L, v->bytes_each));
+  VHIP(tpg_pmalloc((void**)&d_lut, 256 + 16));
   VHIP(hipMemcpyAsync(d_lut, lut, 256, hipMemcpyHostToDevice, ctx->stream));
   VHIP(hipMemsetAsync(d_lut + 256, 0, 16, ctx->stream));
   if (rowInd1) {
-    VHIP(hipMalloc((void**)&d_rows, sizeof(int32_t) * (size_t)n));
+    VHIP(tpg_pmalloc((void**)&d_rows, sizeof(int32_t) * (size_t)n));
     VHIP(hipMemcpyAsync(d_rows, rowInd1, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   }
   if (colInd1) {
-    VHIP(hipMalloc((void**)&d_cols, sizeof(int32_t) * (size_t)m));
+    VHIP(tpg_pmalloc((void**)&d_cols, sizeof(int32_t) * (size_t)m));
     VHIP(hipMemcpyAsync(d_cols, colInd1, sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
   }
   rc = tpg_launch_pack(ctx, fbm, d_rows, d_cols, d_lut, v);
@@ -351,17 +423,17 @@ extern "C" int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* 
     tpg_set_error("code256 maps an occurring FBM byte to a value outside {0,1,2,NA}; the 2-bit device path cannot represent it");
     return fail(TPG_EUNSUPPORTED);
   }
-  if (d_rows) (void)hipFree(d_rows);
-  if (d_cols) (void)hipFree(d_cols);
-  (void)hipFree(d_lut);
+  if (d_rows) tpg_pfree(d_rows);
+  if (d_cols) tpg_pfree(d_cols);
+  tpg_pfree(d_lut);
   *out = v;
   return TPG_OK;
 }
 
 extern "C" void tpg_view_free(tpg_view* v) {
   if (!v) return;
-  if (v->T) (void)hipFree(v->T);
-  if (v->L) (void)hipFree(v->L);
+  if (v->T) tpg_pfree(v->T);
+  if (v->L) tpg_pfree(v->L);
   delete v;
 }
 extern "C" int64_t tpg_view_n(const tpg_view* v) { return v ? v->n : 0; }
@@ -374,7 +446,7 @@ extern "C" int tpg_view_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* codes) 
   TPG_TRY(o.init(codes, (size_t)v->n * (size_t)v->m));
   TPG_TRY(tpg_launch_unpack(ctx, v, o.dev<uint8_t>(), 0));
   uint8_t* d2 = nullptr;
-  TPG_HIP(hipMalloc((void**)&d2, (size_t)v->n * (size_t)v->m));
+  TPG_HIP(tpg_pmalloc((void**)&d2, (size_t)v->n * (size_t)v->m));
   int rc = tpg_launch_unpack(ctx, v, d2, 1);
   std::vector<uint8_t> a((size_t)v->n * (size_t)v->m), b((size_t)v->n * (size_t)v->m);
   if (rc == TPG_OK) {
@@ -383,7 +455,7 @@ extern "C" int tpg_view_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* codes) 
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { tpg_set_error("unpack copy failed: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   }
-  (void)hipFree(d2);
+  tpg_pfree(d2);
   TPG_TRY(rc);
   TPG_REQUIRE(a == b, TPG_EHIP, "internal error: T and L layouts of the view disagree");
   return o.commit(ctx);
