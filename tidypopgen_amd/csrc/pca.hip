@@ -319,12 +319,14 @@ extern "C" int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx* ctx, const tpg_view* v, co
 // ---------------------------------------------------------------------------
 // Gram matrix: weight digits
 //
-// DG layout: for K group kg, K step s, lane half h, digit t: 8 dwords = D (4 dwords) then 2D (4 dwords);
-// byte b of dword k belongs to locus 128 kg + 32 s + 16 h + 4 k + b.
+// DG layout (per pass of <= 4 digits, TD digits in the pass): K group kg owns TD * 256 contiguous bytes:
+// for K step s, lane half h, digit t: 8 dwords = D (4 dwords) then 2D (4 dwords); byte b of dword k
+// belongs to locus 128 kg + 32 s + 16 h + 4 k + b.  dword index = (((kg*4 + s)*2 + h)*TD + t)*8 + which*4 + k.
 __global__ void tpg_pca_digits_kernel(const double* __restrict__ scale, const double* __restrict__ center, int64_t m,
                                       int64_t KG, int F, int T, uint32_t* __restrict__ DG, double* __restrict__ what,
                                       double* __restrict__ wc) {
   const int64_t total = KG * 4 * 2 * 4;  // (kg, s, h, k)
+  const int npass = (T + 3) / 4;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(idx & 3), h = (int)((idx >> 2) & 1), s = (int)((idx >> 3) & 3);
@@ -347,10 +349,15 @@ __global__ void tpg_pca_digits_kernel(const double* __restrict__ scale, const do
         d2[t] |= (uint32_t)((int)(2 * dig) & 0xFF) << (8 * b);
       }
     }
-    const int64_t base = (((kg * 4 + s) * 2 + h) * T) * 8;
-    for (int t = 0; t < T; t++) {
-      DG[base + t * 8 + k] = d[t];
-      DG[base + t * 8 + 4 + k] = d2[t];
+    int64_t pass_base = 0;  // dwords before this pass's table
+    for (int p = 0; p < npass; p++) {
+      const int td = T - 4 * p < 4 ? T - 4 * p : 4;
+      const int64_t base = pass_base + (((kg * 4 + s) * 2 + h) * td) * 8;
+      for (int t = 0; t < td; t++) {
+        DG[base + t * 8 + k] = d[4 * p + t];
+        DG[base + t * 8 + 4 + k] = d2[4 * p + t];
+      }
+      pass_base += KG * 4 * 2 * td * 8;
     }
   }
 }
@@ -364,22 +371,24 @@ __device__ __forceinline__ int64_t tpg_gram_unit_index(int nsb, int ia, int jb) 
   return 4 * ((int64_t)a * nsb - ((int64_t)a * (a - 1)) / 2) + (int64_t)r * (nsb - a) + (jb - a);
 }
 
-template <int TD>  // digits handled by this pass (<= 4)
+template <int TD>  // digits handled by this pass (<= 4); DG holds exactly these TD digits per locus
 __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
                                                               int64_t kg_begin, int64_t kg_end,
-                                                              const uint4* __restrict__ DG, int Ttot, int t0, int nrt,
+                                                              const uint4* __restrict__ DG, int t0, int nrt,
                                                               int nsb, int64_t nun, int S,
                                                               long long* __restrict__ slabs) {
+  // per wave: two buffers of one K group's digit table (TD * 256 B each)
+  __shared__ __attribute__((aligned(16))) uint4 dgs[4][2][TD * 16];
   const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   const int h = lane >> 5;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int64_t kgs = kg_end - kg_begin;
   for (int64_t unit = wave; unit < nun * S; unit += nwaves) {
     int64_t u = unit % nun;
     const int ks = (int)(unit / nun);
     const int64_t u0 = u;
-    // decode u -> (ia, jb)
     int a = 0;
     while (u >= 4 * (int64_t)(nsb - a)) { u -= 4 * (int64_t)(nsb - a); a++; }
     const int r = (int)(u / (nsb - a));
@@ -401,32 +410,30 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
         for (int q = 0; q < 16; q++) acc[t][tb][q] = 0;
 
     if (k0 < k1) {
-      uint4 nA = pa[k0 * 64], nB[4];
+      const bool dlane = lane < TD * 16;  // lanes that carry a piece of the digit table
+      uint4 nA = pa[k0 * 64], nB[4], nD = make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int tb = 0; tb < 4; tb++) nB[tb] = pb[tb][k0 * 64];
+      if (dlane) nD = DG[k0 * (TD * 16) + lane];
+      int buf = 0;
       for (int64_t kg = k0; kg < k1; kg++) {
         const uint4 A = nA;
         uint4 B[4];
 #pragma unroll
         for (int tb = 0; tb < 4; tb++) B[tb] = nB[tb];
+        if (dlane) dgs[wv][buf][lane] = nD;
         const int64_t kn = (kg + 1 < k1) ? kg + 1 : kg;
         nA = pa[kn * 64];
 #pragma unroll
         for (int tb = 0; tb < 4; tb++) nB[tb] = pb[tb][kn * 64];
-        // digits of K step 0 of this group; later steps are fetched one step ahead
-        const uint4* dgbase = DG + (((kg * 4) * 2 + h) * (int64_t)Ttot + t0) * 2;
-        uint4 dcur[TD][2], dnxt[TD][2];
-#pragma unroll
-        for (int t = 0; t < TD; t++) { dcur[t][0] = dgbase[t * 2]; dcur[t][1] = dgbase[t * 2 + 1]; }
+        if (dlane) nD = DG[kn * (TD * 16) + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's MFMAs
         const uint32_t wa[4] = {A.x, A.y, A.z, A.w};
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-          if (s < 3) {
-            const uint4* dgn = dgbase + (int64_t)(s + 1) * 2 * Ttot * 2;
-#pragma unroll
-            for (int t = 0; t < TD; t++) { dnxt[t][0] = dgn[t * 2]; dnxt[t][1] = dgn[t * 2 + 1]; }
-          }
           // selector per register: genotype 1 -> byte b of D (S1), genotype 2 -> byte b of 2D (S0), else 0
           uint32_t sel[4];
 #pragma unroll
@@ -443,9 +450,10 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
 #pragma unroll
             for (int k = 0; k < 4; k++) fb[tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wb, k));
           }
+          const uint4* dl = &dgs[wv][buf][((s * 2 + h) * TD) * 2];
 #pragma unroll
           for (int t = 0; t < TD; t++) {
-            const uint4 d1 = dcur[t][0], d2 = dcur[t][1];
+            const uint4 d1 = dl[t * 2], d2 = dl[t * 2 + 1];
             v4i fa;
             fa[0] = (int)__builtin_amdgcn_perm(d2.x, d1.x, sel[0]);
             fa[1] = (int)__builtin_amdgcn_perm(d2.y, d1.y, sel[1]);
@@ -454,11 +462,8 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
 #pragma unroll
             for (int tb = 0; tb < 4; tb++) acc[t][tb] = MFMA_I8(fa, fb[tb], acc[t][tb]);
           }
-          if (s < 3) {
-#pragma unroll
-            for (int t = 0; t < TD; t++) { dcur[t][0] = dnxt[t][0]; dcur[t][1] = dnxt[t][1]; }
-          }
         }
+        buf ^= 1;
       }
     }
     long long* slab = slabs + u0 * PCA_SLAB_INTS + lane;
@@ -558,16 +563,19 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     }
     const int64_t U = nun * bestS;
     const unsigned grid = (unsigned)(ceil_div(U, 4) < ctx->num_cu ? ceil_div(U, 4) : ctx->num_cu);
+    int64_t pass_base = 0;  // dwords
     for (int t0 = 0; t0 < T; t0 += 4) {
       const int td = T - t0 < 4 ? T - t0 : 4;
+      const uint4* dgp = (const uint4*)(d_DG + pass_base);
 #define GRAM_LAUNCH(TD)                                                                                              \
   TPG_LAUNCH(ctx, "pca_gram_mfma", tpg_pca_gram_kernel<TD>, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG,      \
-             (int64_t)0, v->KG, (const uint4*)d_DG, T, t0, nrt, nsb, nun, bestS, d_slabs)
+             (int64_t)0, v->KG, dgp, t0, nrt, nsb, nun, bestS, d_slabs)
       if (td == 4) GRAM_LAUNCH(4);
       else if (td == 3) GRAM_LAUNCH(3);
       else if (td == 2) GRAM_LAUNCH(2);
       else GRAM_LAUNCH(1);
 #undef GRAM_LAUNCH
+      pass_base += v->KG * 4 * 2 * td * 8;
     }
     GHIP(hipGetLastError());
   }
@@ -612,43 +620,56 @@ extern "C" int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* cente
 // ---------------------------------------------------------------------------
 // dense FP64 helpers for the eigen solver (all matrices column-major)
 
-// part[split][row][c] = sum_{k in split} K[row + k n] * Q[k + c n]   (c < b <= 64)
+// part[split][row + c n] = sum_{k in split} K[row + k n] * Q[k + c n]   (c < b <= 64)
+// FP64 MFMA (v_mfma_f64_16x16x4_f64): one wave owns 16 rows x 64 columns (4 accumulator tiles), so every
+// element of K is read exactly once per product; the workgroup's 4 waves share the 64-deep slice of Q
+// staged in LDS.  A = K[row0 + (l & 15)][k + (l >> 4)], B = Q[k + (l >> 4)][col + (l & 15)];
+// C/D: col = l & 15, row = (l >> 4) + 4 reg.
 __global__ __launch_bounds__(256) void tpg_symm_apply_kernel(const double* __restrict__ K, int n,
                                                              const double* __restrict__ Q, int b, int S,
                                                              double* __restrict__ part) {
-  __shared__ double qs[64][65];  // 64 k x b columns
-  const int r = threadIdx.x & 63, cg = threadIdx.x >> 6;  // 4 column groups of 16
-  const int row = blockIdx.x * 64 + r;
+  __shared__ double qs[64][65];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + wv) * 16;
+  const int row = row0 + r16;
   const int split = blockIdx.y;
-  const int kbeg = (int)((int64_t)n * split / S), kend = (int)((int64_t)n * (split + 1) / S);
-  double acc[16];
+  // split boundaries on multiples of 64 so that chunks never straddle
+  const int nchunk = (n + 63) / 64;
+  const int cbeg = (int)((int64_t)nchunk * split / S), cend = (int)((int64_t)nchunk * (split + 1) / S);
+  v4d acc[4];
 #pragma unroll
-  for (int c = 0; c < 16; c++) acc[c] = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += 64) {
+  for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0, 0, 0, 0};
+  for (int ch = cbeg; ch < cend; ch++) {
+    const int k0 = ch * 64;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * b; idx += 256) {
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
       const int kk = idx & 63, c = idx >> 6;
-      qs[kk][c] = (k0 + kk < kend) ? Q[(k0 + kk) + (int64_t)c * n] : 0.0;
+      qs[kk][c] = (k0 + kk < n && c < b) ? Q[(k0 + kk) + (int64_t)c * n] : 0.0;
     }
     __syncthreads();
-    if (row < n) {
-      const int kmax = kend - k0 < 64 ? kend - k0 : 64;
-      const double* kp = K + row + (int64_t)k0 * n;
-      for (int kb = 0; kb < 64; kb += 16) {
-        double kv[16];
+    double av[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) kv[u] = (kb + u < kmax) ? kp[(int64_t)(kb + u) * n] : 0.0;  // 16 loads in flight
+    for (int u = 0; u < 16; u++) {
+      const int k = k0 + 4 * u + kq;
+      av[u] = (row < n && k < n) ? K[row + (int64_t)k * n] : 0.0;
+    }
 #pragma unroll
-        for (int u = 0; u < 16; u++)
+    for (int u = 0; u < 16; u++) {
 #pragma unroll
-          for (int c = 0; c < 16; c++) acc[c] += kv[u] * qs[kb + u][cg * 16 + c];
-      }
+      for (int ct = 0; ct < 4; ct++)
+        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], qs[4 * u + kq][ct * 16 + r16], acc[ct], 0, 0, 0);
     }
   }
-  if (row < n)
 #pragma unroll
-    for (int c = 0; c < 16; c++)
-      if (cg * 16 + c < b) part[((int64_t)split * b + cg * 16 + c) * n + row] = acc[c];
+  for (int ct = 0; ct < 4; ct++) {
+    const int col = ct * 16 + r16;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int orow = row0 + kq + 4 * reg;
+      if (orow < n && col < b) part[((int64_t)split * b + col) * n + orow] = acc[ct][reg];
+    }
+  }
 }
 
 // Y = alpha * (sum_split part - Dm) + beta * Y1 + gamma * Y0   (Dm / Y1 / Y0 may be null)
@@ -714,19 +735,30 @@ __global__ void tpg_gram_reduce_kernel(const double* __restrict__ part, int nchu
 
 // Y[row + j n] = sum_i A[row + i n] * X[i + j p]   (X small, p <= 64, b2 <= 64); optional residual
 // form: Y = A X - Bm * diag(theta) is done by the caller through two calls / combine.
-__global__ void tpg_right_mult_kernel(const double* __restrict__ A, int n, int p, const double* __restrict__ X, int b2,
-                                      double* __restrict__ Y) {
+__global__ __launch_bounds__(256) void tpg_right_mult_kernel(const double* __restrict__ A, int n, int p,
+                                                             const double* __restrict__ X, int b2,
+                                                             double* __restrict__ Y) {
   __shared__ double xs[64 * 64];
-  for (int idx = threadIdx.x; idx < p * b2; idx += blockDim.x) xs[idx] = X[idx];
+  for (int idx = threadIdx.x; idx < p * b2; idx += 256) xs[idx] = X[idx];
   __syncthreads();
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int cg = threadIdx.x >> 5;  // 8 groups of 8 columns
   if (row >= n) return;
-  double a[64];
-  for (int i = 0; i < p; i++) a[i] = A[row + (int64_t)i * n];
-  for (int j = 0; j < b2; j++) {
-    double s = 0;
-    for (int i = 0; i < p; i++) s += a[i] * xs[i + j * p];
-    Y[row + (int64_t)j * n] = s;
+  double acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) acc[c] = 0;
+  for (int i = 0; i < p; i++) {
+    const double a = A[row + (int64_t)i * n];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int j = cg * 8 + c;
+      acc[c] += a * (j < b2 ? xs[i + j * p] : 0.0);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const int j = cg * 8 + c;
+    if (j < b2) Y[row + (int64_t)j * n] = acc[c];
   }
 }
 
@@ -831,11 +863,11 @@ struct EigWork {
   int init() {
     S = 1;
     const int row_blocks = (n + 63) / 64;
-    while (row_blocks * S < 2 * ctx->num_cu && S < 32 && n / (S * 2) >= 64) S *= 2;
-    rows_per_chunk = 256;
+    while (row_blocks * S < 4 * ctx->num_cu && S < 32 && n / (S * 2) >= 128) S *= 2;
+    rows_per_chunk = 32;
     nchunks = (n + rows_per_chunk - 1) / rows_per_chunk;
     TPG_HIP(tpg_pmalloc((void**)&part, sizeof(double) * (size_t)S * (size_t)b * (size_t)n));
-    TPG_HIP(tpg_pmalloc((void**)&gpart, sizeof(double) * (size_t)nchunks * 64 * 64));
+    TPG_HIP(tpg_pmalloc((void**)&gpart, sizeof(double) * (size_t)nchunks * 64 * 64));  // nchunks = n/32
     TPG_HIP(tpg_pmalloc((void**)&xsmall, sizeof(double) * 64 * 64));
     TPG_HIP(tpg_pmalloc((void**)&lam_dev, sizeof(double) * 64));
     TPG_HIP(tpg_pmalloc((void**)&cdev, sizeof(double) * 64 * 64));
@@ -861,7 +893,7 @@ struct EigWork {
   }
   // Y = alpha K' Q + beta Y1 + gamma Y0   with K' = K - L diag(lam) L'; no host synchronisation
   int apply(const double* Q, double alpha, const double* Y1, double beta, const double* Y0, double gamma, double* Y) {
-    dim3 grid((unsigned)((n + 63) / 64), (unsigned)S);
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)S);  // 4 waves x 16 rows per workgroup
     TPG_LAUNCH(ctx, "eig_symm_apply", tpg_symm_apply_kernel, grid, dim3(256), 0, K, n, Q, b, S, part);
     const double* Dm = nullptr;
     if (nl > 0) {
@@ -869,7 +901,7 @@ struct EigWork {
                  rows_per_chunk, gpart);
       TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((nl * b + 255) / 256)), dim3(256), 0,
                  (const double*)gpart, nchunks, nl, b, (const double*)lam_dev, cdev);
-      TPG_LAUNCH(ctx, "eig_right_mult", tpg_right_mult_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, L, n, nl,
+      TPG_LAUNCH(ctx, "eig_right_mult", tpg_right_mult_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, L, n, nl,
                  (const double*)cdev, b, dtmp);
       Dm = dtmp;
     }
@@ -878,23 +910,22 @@ struct EigWork {
     TPG_CHECK_LAUNCH();
     return TPG_OK;
   }
-  // C (p x bb, host, column-major) = A' B
+  // C (p x bb, host, column-major) = A' B   (partials reduced on the device, p*bb doubles copied back)
   int gram(const double* A, int p, const double* B, int bb, std::vector<double>& C) {
     TPG_LAUNCH(ctx, "eig_gram_small", tpg_gram_small_kernel, dim3((unsigned)nchunks), dim3(256), 0, A, p, B, bb, n,
                rows_per_chunk, gpart);
-    std::vector<double> hp((size_t)nchunks * p * bb);
-    TPG_HIP(hipMemcpyAsync(hp.data(), gpart, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, ctx->stream));
-    TPG_HIP(hipStreamSynchronize(ctx->stream));
+    TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((p * bb + 255) / 256)), dim3(256), 0,
+               (const double*)gpart, nchunks, p, bb, (const double*)nullptr, cdev);
     C.assign((size_t)p * bb, 0.0);
-    for (int c = 0; c < nchunks; c++)
-      for (size_t t = 0; t < (size_t)p * bb; t++) C[t] += hp[(size_t)c * p * bb + t];
+    TPG_HIP(hipMemcpyAsync(C.data(), cdev, sizeof(double) * (size_t)p * bb, hipMemcpyDeviceToHost, ctx->stream));
+    TPG_HIP(hipStreamSynchronize(ctx->stream));
     return TPG_OK;
   }
   // Y = A X  (X host p x b2)
   int rmult(const double* A, int p, const std::vector<double>& X, int b2, double* Y) {
     TPG_HIP(hipMemcpyAsync(xsmall, X.data(), sizeof(double) * (size_t)p * b2, hipMemcpyHostToDevice, ctx->stream));
-    TPG_LAUNCH(ctx, "eig_right_mult", tpg_right_mult_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, A, n, p,
-               xsmall, b2, Y);
+    TPG_LAUNCH(ctx, "eig_right_mult", tpg_right_mult_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, A, n, p,
+               (const double*)xsmall, b2, Y);
     TPG_CHECK_LAUNCH();
     TPG_HIP(hipStreamSynchronize(ctx->stream));  // X may go out of scope on the host
     return TPG_OK;
@@ -910,7 +941,10 @@ struct EigWork {
 // block stays below 1e7 (otherwise the trailing columns drown in rounding noise of the leading
 // directions and the block loses rank); locking shrinks that spread as the large eigenvalues converge.
 static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambda_host, double* d_U) {
-  int b = k + 12;
+  // K Q costs about the same for 32 and 64 columns (K is streamed once either way), while a wider
+  // block puts lambda_{b+1} deeper into the bulk of the spectrum and converges in far fewer sweeps
+  int b = 2 * k + 24;
+  if (b < k + 12) b = k + 12;
   if (b > 64) b = 64;
   if (b > n) b = n;
   TPG_REQUIRE(k <= b, TPG_EINVAL, "k = %d too large (at most %d components)", k, b);
