@@ -941,10 +941,7 @@ struct EigWork {
 // block stays below 1e7 (otherwise the trailing columns drown in rounding noise of the leading
 // directions and the block loses rank); locking shrinks that spread as the large eigenvalues converge.
 static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambda_host, double* d_U) {
-  // K Q costs about the same for 32 and 64 columns (K is streamed once either way), while a wider
-  // block puts lambda_{b+1} deeper into the bulk of the spectrum and converges in far fewer sweeps
-  int b = 2 * k + 24;
-  if (b < k + 12) b = k + 12;
+  int b = k + 12;
   if (b > 64) b = 64;
   if (b > n) b = n;
   TPG_REQUIRE(k <= b, TPG_EINVAL, "k = %d too large (at most %d components)", k, b);
@@ -967,6 +964,7 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
 
   // CholQR (twice) of the `act` columns at A, after projecting out the `nl` locked columns at L
   auto orthonormalize = [&](double* A, int act, const double* L, int nl, double* tmp) -> int {
+    int extra_passes = 0;
     for (int pass = 0; pass < 2; pass++) {
       if (nl > 0) {
         std::vector<double> Cm;
@@ -980,8 +978,24 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
       for (int j = 0; j < act; j++) D[(size_t)j] = G[j + (size_t)j * act] > 0 ? 1.0 / sqrt(G[j + (size_t)j * act]) : 1.0;
       for (int j = 0; j < act; j++)
         for (int i = 0; i < act; i++) G[i + (size_t)j * act] *= D[(size_t)i] * D[(size_t)j];
-      if (!host_cholesky_upper(G, act)) { tpg_set_error("eigen solver: block lost rank"); return TPG_ENUMERIC; }
-      host_upper_inverse(G, act, Ri);
+      std::vector<double> Gsave = G;
+      if (host_cholesky_upper(G, act)) {
+        host_upper_inverse(G, act, Ri);
+      } else {
+        // ill-conditioned block: whiten with the eigen-decomposition of the Gram matrix instead
+        // (G = V diag(lam) V', A <- A V diag(lam^-1/2), tiny lam clamped); the next pass restores
+        // orthogonality to rounding.
+        std::vector<double> lamg, Vg;
+        host_jacobi_eig(Gsave, act, lamg, Vg);
+        const double floor_ = std::max(lamg[0], 1e-300) * 1e-14;
+        Ri.assign((size_t)act * act, 0.0);
+        for (int j = 0; j < act; j++) {
+          const double sc = 1.0 / sqrt(std::max(lamg[(size_t)j], floor_));
+          for (int i = 0; i < act; i++) Ri[i + (size_t)j * act] = Vg[i + (size_t)j * act] * sc;
+        }
+        if (pass == 1) pass = 0, extra_passes++;  // one more clean-up pass
+        if (extra_passes > 3) { tpg_set_error("eigen solver: block lost rank"); return TPG_ENUMERIC; }
+      }
       for (int j = 0; j < act; j++)
         for (int i = 0; i < act; i++) Ri[i + (size_t)j * act] *= D[(size_t)i];
       TPG_TRY(w.rmult(A, act, Ri, act, tmp));
@@ -995,7 +1009,7 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
   std::vector<double> lam((size_t)b, 0.0), theta, X, H;
   int nl = 0;
   const int MAXIT = 200;
-  const double TOL = 1e-12, AMP = 1e7;
+  const double TOL = 1e-12, AMP = 1e6;
   double lam1 = 0;
   for (int it = 0; it < MAXIT && nl < k; it++) {
     const int act = b - nl;
