@@ -434,7 +434,7 @@ void orc_synth_fbm(uint64_t seed, int64_t n, int64_t m, int64_t j0, int npop, ui
                    int imputed_bytes, uint8_t* out /* n x m column-major */) {
   uint32_t* pjg = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)npop);
   for (int64_t j = 0; j < m; j++) {
-    for (int g = 0; g < npop; g++) pjg[g] = tpg_synth_pjg(seed, (uint64_t)(j0 + j), (uint32_t)g);
+    for (int g = 0; g < npop; g++) pjg[g] = tpg_synth_pjg(seed, (uint64_t)(j0 + j), (uint32_t)g, (uint32_t)npop);
     for (int64_t i = 0; i < n; i++)
       out[(size_t)i + (size_t)j * (size_t)n] =
           tpg_synth_geno(seed, (uint64_t)i, (uint64_t)(j0 + j), pjg[i % npop], miss_thresh, imputed_bytes);

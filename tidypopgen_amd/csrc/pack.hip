@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void tpg_synth_kernel(uint8_t* __restrict__ ou
   __shared__ uint32_t pjg[1024];
   for (int64_t j = blockIdx.x; j < ncol; j += gridDim.x) {
     __syncthreads();
-    for (int g = threadIdx.x; g < npop; g += blockDim.x) pjg[g] = tpg_synth_pjg(seed, (uint64_t)(j0 + j), (uint32_t)g);
+    for (int g = threadIdx.x; g < npop; g += blockDim.x) pjg[g] = tpg_synth_pjg(seed, (uint64_t)(j0 + j), (uint32_t)g, (uint32_t)npop);
     __syncthreads();
     for (int64_t i = threadIdx.x; i < nrow; i += blockDim.x)
       out[i + j * nrow] = tpg_synth_geno(seed, (uint64_t)i, (uint64_t)(j0 + j), pjg[i % npop], miss_thresh, imputed_bytes);

@@ -26,6 +26,8 @@
 // N-sized work (K Q products, projections, residuals) runs in FP64 kernels here, only b x b
 // (b = k + 12) factorizations run on the host.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -864,7 +866,7 @@ struct EigWork {
     S = 1;
     const int row_blocks = (n + 63) / 64;
     while (row_blocks * S < 4 * ctx->num_cu && S < 32 && n / (S * 2) >= 128) S *= 2;
-    rows_per_chunk = 32;
+    rows_per_chunk = 128;
     nchunks = (n + rows_per_chunk - 1) / rows_per_chunk;
     TPG_HIP(tpg_pmalloc((void**)&part, sizeof(double) * (size_t)S * (size_t)b * (size_t)n));
     TPG_HIP(tpg_pmalloc((void**)&gpart, sizeof(double) * (size_t)nchunks * 64 * 64));  // nchunks = n/32
@@ -1056,6 +1058,10 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
       const double dmax = log(2 * AMP) / acosh(x0);
       deg = dmax < 2 ? 2 : (dmax > 20 ? 20 : (int)dmax);
     }
+    if (getenv("TPG_DEBUG"))
+      fprintf(stderr, "[eig] it %d act %d locked %d (+%d) deg %d theta_first %.4g theta_last %.4g lam1 %.4g res0 %.3g\n", it,
+              act, nl, newly, deg, theta[(size_t)newly], theta[(size_t)act - 1], lam1,
+              sqrt(std::max(0.0, RR[newly + (size_t)newly * act])) / lam1);
     w.b = act2;
     TPG_TRY(w.set_locked(Q, nl, lam.data()));
     // KA2 was formed with the previous deflation; the newly locked directions are (numerically)

@@ -7,8 +7,10 @@
 // there is no libm / FMA difference between host and device.
 //
 // Model: ancestral frequency p_j ~ U(0.05, 0.95); population frequency
-// p_jg = clamp(p_j + sd_j * z_jg, 0.001, 0.999) with sd_j = sqrt(F p_j (1-p_j)),
-// F = 0.05 and z_jg an Irwin-Hall(12) approximation of N(0,1) -- the normal
+// p_jg = clamp(p_j + sd_jg * z_jg, 0.001, 0.999) with sd_jg = sqrt(F_g p_j (1-p_j)),
+// population-specific drift F_g rising linearly from 0.01 (g = 0) to 0.20 (g = npop-1) -- equal F for
+// all populations would give npop-1 nearly equal leading eigenvalues, a degenerate spectrum that real
+// panels (HGDP-like hierarchical structure) do not have -- and z_jg an Irwin-Hall(12) approximation of N(0,1) -- the normal
 // approximation of the Balding-Nichols Beta with the same mean and variance
 // (documented deviation from the Beta draw named in SURVEY.md §8d: a Beta
 // sampler needs floating-point transcendental functions, which would break the
@@ -46,10 +48,11 @@ TPG_HD uint64_t tpg_isqrt64(uint64_t v) {  // floor(sqrt(v)), bitwise (no fp)
 }
 
 // population allele frequency of locus j in population g, Q32 fixed point
-TPG_HD uint32_t tpg_synth_pjg(uint64_t seed, uint64_t j, uint32_t g) {
+TPG_HD uint32_t tpg_synth_pjg(uint64_t seed, uint64_t j, uint32_t g, uint32_t npop) {
   const uint64_t LO = 214748365ull;    // 0.05 * 2^32
   const uint64_t RANGE = 3865470566ull;  // 0.90 * 2^32
-  const uint64_t F = 214748365ull;     // 0.05 * 2^32
+  const uint64_t FMIN = 42949673ull, FSPAN = 816043786ull;  // 0.01, 0.19 (* 2^32)
+  const uint64_t F = FMIN + (npop > 1 ? (FSPAN * (uint64_t)g) / (uint64_t)(npop - 1) : 0);
   uint64_t hj = tpg_mix64(seed ^ tpg_mix64(j * 2 + 1));
   uint64_t p = LO + (((hj >> 32) * RANGE) >> 32);          // Q32
   uint64_t pq = (p * (4294967296ull - p)) >> 32;           // Q32
@@ -82,6 +85,6 @@ TPG_HD uint8_t tpg_synth_geno(uint64_t seed, uint64_t i, uint64_t j, uint32_t pj
 
 TPG_HD uint8_t tpg_synth_byte(uint64_t seed, uint64_t i, uint64_t j, int npop, uint32_t miss_thresh,
                               int imputed_bytes) {
-  uint32_t pjg = tpg_synth_pjg(seed, j, (uint32_t)(i % (uint64_t)npop));
+  uint32_t pjg = tpg_synth_pjg(seed, j, (uint32_t)(i % (uint64_t)npop), (uint32_t)npop);
   return tpg_synth_geno(seed, i, j, pjg, miss_thresh, imputed_bytes);
 }
