@@ -364,23 +364,25 @@ __global__ void tpg_pca_digits_kernel(const double* __restrict__ scale, const do
   }
 }
 
-// unit (ia, jb): A row tile ia (32 individuals, weighted digit planes) x B super-tile jb (4 row tiles = 128
-// individuals, plain dosage), jb >= ia/4.  Combined int64 slab per unit: [tb][reg][lane].
-#define PCA_SLAB_INTS (4 * 16 * 64)
+// unit (ia, jb): A row tile ia (32 individuals, weighted digit planes) x B super-tile jb (PCA_TB row tiles,
+// plain dosage), jb >= ia / PCA_TB.  Combined int64 slab per unit: [tb][reg][lane].
+#define PCA_TB 2  // B row tiles per unit: 32 x 64 wave tile, 8 accumulator tiles, 2 waves per SIMD
+#define PCA_SLAB_INTS (PCA_TB * 16 * 64)
 
 __device__ __forceinline__ int64_t tpg_gram_unit_index(int nsb, int ia, int jb) {
-  const int a = ia >> 2, r = ia & 3;
-  return 4 * ((int64_t)a * nsb - ((int64_t)a * (a - 1)) / 2) + (int64_t)r * (nsb - a) + (jb - a);
+  const int a = ia / PCA_TB, r = ia % PCA_TB;
+  return PCA_TB * ((int64_t)a * nsb - ((int64_t)a * (a - 1)) / 2) + (int64_t)r * (nsb - a) + (jb - a);
 }
 
 template <int TD>  // digits handled by this pass (<= 4); DG holds exactly these TD digits per locus
-__global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
+__global__ __launch_bounds__(256, 2) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
                                                               int64_t kg_begin, int64_t kg_end,
                                                               const uint4* __restrict__ DG, int t0, int nrt,
                                                               int nsb, int64_t nun, int S,
                                                               long long* __restrict__ slabs) {
   // per wave: two buffers of one K group's digit table (TD * 256 B each)
   __shared__ __attribute__((aligned(16))) uint4 dgs[4][2][TD * 16];
+  constexpr int TB = PCA_TB;
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int h = lane >> 5;
@@ -392,42 +394,42 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
     const int ks = (int)(unit / nun);
     const int64_t u0 = u;
     int a = 0;
-    while (u >= 4 * (int64_t)(nsb - a)) { u -= 4 * (int64_t)(nsb - a); a++; }
+    while (u >= TB * (int64_t)(nsb - a)) { u -= TB * (int64_t)(nsb - a); a++; }
     const int r = (int)(u / (nsb - a));
     const int jb = a + (int)(u % (nsb - a));
-    const int ia = 4 * a + r;
+    const int ia = TB * a + r;
     const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
 
     const uint4* pa = Tl + ((int64_t)ia * KG) * 64 + lane;
-    const uint4* pb[4];
+    const uint4* pb[TB];
 #pragma unroll
-    for (int tb = 0; tb < 4; tb++) pb[tb] = Tl + ((int64_t)(4 * jb + tb) * KG) * 64 + lane;
+    for (int tb = 0; tb < TB; tb++) pb[tb] = Tl + ((int64_t)(TB * jb + tb) * KG) * 64 + lane;
 
-    v16i acc[TD][4];
+    v16i acc[TD][TB];
 #pragma unroll
     for (int t = 0; t < TD; t++)
 #pragma unroll
-      for (int tb = 0; tb < 4; tb++)
+      for (int tb = 0; tb < TB; tb++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[t][tb][q] = 0;
 
     if (k0 < k1) {
       const bool dlane = lane < TD * 16;  // lanes that carry a piece of the digit table
-      uint4 nA = pa[k0 * 64], nB[4], nD = make_uint4(0, 0, 0, 0);
+      uint4 nA = pa[k0 * 64], nB[TB], nD = make_uint4(0, 0, 0, 0);
 #pragma unroll
-      for (int tb = 0; tb < 4; tb++) nB[tb] = pb[tb][k0 * 64];
+      for (int tb = 0; tb < TB; tb++) nB[tb] = pb[tb][k0 * 64];
       if (dlane) nD = DG[k0 * (TD * 16) + lane];
       int buf = 0;
       for (int64_t kg = k0; kg < k1; kg++) {
         const uint4 A = nA;
-        uint4 B[4];
+        uint4 B[TB];
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) B[tb] = nB[tb];
+        for (int tb = 0; tb < TB; tb++) B[tb] = nB[tb];
         if (dlane) dgs[wv][buf][lane] = nD;
         const int64_t kn = (kg + 1 < k1) ? kg + 1 : kg;
         nA = pa[kn * 64];
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) nB[tb] = pb[tb][kn * 64];
+        for (int tb = 0; tb < TB; tb++) nB[tb] = pb[tb][kn * 64];
         if (dlane) nD = DG[kn * (TD * 16) + lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -445,9 +447,9 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
             const uint32_t mv = (uint32_t)tpg_lut(0x00FFFF00u, c);
             sel[k] = (0x03020100u & mv) | base;
           }
-          v4i fb[4];
+          v4i fb[TB];
 #pragma unroll
-          for (int tb = 0; tb < 4; tb++) {
+          for (int tb = 0; tb < TB; tb++) {
             const uint32_t wb = s == 0 ? B[tb].x : s == 1 ? B[tb].y : s == 2 ? B[tb].z : B[tb].w;
 #pragma unroll
             for (int k = 0; k < 4; k++) fb[tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wb, k));
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
             fa[2] = (int)__builtin_amdgcn_perm(d2.z, d1.z, sel[2]);
             fa[3] = (int)__builtin_amdgcn_perm(d2.w, d1.w, sel[3]);
 #pragma unroll
-            for (int tb = 0; tb < 4; tb++) acc[t][tb] = MFMA_I8(fa, fb[tb], acc[t][tb]);
+            for (int tb = 0; tb < TB; tb++) acc[t][tb] = MFMA_I8(fa, fb[tb], acc[t][tb]);
           }
         }
         buf ^= 1;
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
     }
     long long* slab = slabs + u0 * PCA_SLAB_INTS + lane;
 #pragma unroll
-    for (int tb = 0; tb < 4; tb++)
+    for (int tb = 0; tb < TB; tb++)
 #pragma unroll
       for (int q = 0; q < 16; q++) {
         long long c = 0;
@@ -490,9 +492,9 @@ __global__ void tpg_pca_assemble_kernel(const long long* __restrict__ slabs, int
        idx += (int64_t)gridDim.x * blockDim.x) {
     int i = (int)(idx % n), k = (int)(idx / n);
     const int oi = i, ok = k;
-    if ((k >> 7) < (i >> 7)) { int t = i; i = k; k = t; }
-    const int ia = i >> 5, jb = k >> 7;
-    const int tb = (k & 127) >> 5, row = i & 31, col = k & 31;
+    if ((k / (32 * PCA_TB)) < (i / (32 * PCA_TB))) { int t = i; i = k; k = t; }
+    const int ia = i >> 5, jb = k / (32 * PCA_TB);
+    const int tb = (k % (32 * PCA_TB)) >> 5, row = i & 31, col = k & 31;
     const int lane = col + 32 * ((row >> 2) & 1);
     const int reg = (row & 3) + 4 * (row >> 3);
     const long long s = slabs[tpg_gram_unit_index(nsb, ia, jb) * PCA_SLAB_INTS + (tb * 16 + reg) * 64 + lane];
@@ -535,8 +537,8 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   TPG_REQUIRE(T <= 8, TPG_ENUMERIC, "per-locus weight range too wide (max 1/scale^2 = %g)", wmax);
   const int F = 7 * T - 1 - wbits;
 
-  const int nsb = (int)v->Q, nrt = (int)(v->Q * 4);
-  const int64_t nun = 4 * ((int64_t)nsb * (nsb + 1) / 2);
+  const int nrt = (int)(v->Q * 4), nsb = nrt / PCA_TB;
+  const int64_t nun = PCA_TB * ((int64_t)nsb * (nsb + 1) / 2);
   uint32_t* d_DG = nullptr;
   double *d_what = nullptr, *d_wc = nullptr, *d_r = nullptr, *d_part = nullptr;
   long long* d_slabs = nullptr;
@@ -553,8 +555,8 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   if (e == hipSuccess) {
     TPG_LAUNCH(ctx, "pca_digits", tpg_pca_digits_kernel, dim3(1024), dim3(256), 0, d_scale, d_center, m, v->KG, F, T,
                d_DG, d_what, d_wc);
-    // K-split as in the pairwise kernel: fill the resident waves (1 wave per SIMD)
-    const int64_t nwaves = (int64_t)ctx->num_cu * 4;
+    // K-split as in the pairwise kernel: fill the resident waves (2 waves per SIMD)
+    const int64_t nwaves = (int64_t)ctx->num_cu * 8;
     int bestS = 1;
     double best = -1;
     const int64_t maxS = v->KG / 8 > 0 ? (v->KG / 8 < 96 ? v->KG / 8 : 96) : 1;
@@ -564,7 +566,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
       if (eff > best + 0.01) { best = eff; bestS = (int)S; }
     }
     const int64_t U = nun * bestS;
-    const unsigned grid = (unsigned)(ceil_div(U, 4) < ctx->num_cu ? ceil_div(U, 4) : ctx->num_cu);
+    const unsigned grid = (unsigned)(ceil_div(U, 4) < 2 * ctx->num_cu ? ceil_div(U, 4) : 2 * ctx->num_cu);
     int64_t pass_base = 0;  // dwords
     for (int t0 = 0; t0 < T; t0 += 4) {
       const int td = T - t0 < 4 ? T - t0 : 4;
