@@ -54,12 +54,19 @@ class Step:
         self.tpg, self.api, self.lib = tpg, api, tpg._lib.lib
         self.args, self.rank, self.world = args, rank, world
         self.torch = None
-        if world > 1:
+        self.backend = os.environ.get("TPG_BENCH_BACKEND", "nccl")
+        if os.environ.get("TPG_BENCH_SHARE_GPU") == "1":
+            local_rank = 0  # rehearsal: several ranks on one GPU (gloo only; RCCL refuses duplicate devices)
+        if world > 1 or os.environ.get("TPG_BENCH_FORCE_DIST") == "1":  # FORCE_DIST: rehearse the collective path on 1 rank
             import torch
             import torch.distributed as dist
 
             self.torch, self.dist = torch, dist
-            torch.cuda.set_device(local_rank)
+            if self.backend == "nccl":
+                torch.cuda.set_device(local_rank)
+        from tidypopgen_amd import sharding
+
+        self.sharding = sharding
         self.ctx = tpg.Context(local_rank)
         n, m, G = args.n, args.m, args.pops
         # FBM bytes resident in HBM before the timed region (the "input"); imputed bytes 4..6 where missing
@@ -76,11 +83,21 @@ class Step:
         self.d_gfreq = self._dalloc(8 * 2 * G * m)
         self.d_nn = [self._dalloc(8 * n * n) for _ in range(3)]  # IBS, KING, GRM
         self.pw_bytes = tpg.Pairwise.buffer_bytes(n)
-        if self.torch is not None:
+        self.pw_tensor = self.K_tensor = None
+        if self.torch is not None and self.backend == "nccl":
+            # collectives need torch tensors: the library accumulates straight into them
             self.pw_tensor = self.torch.zeros(self.pw_bytes // 4, dtype=self.torch.int32, device="cuda")
             self.pw = tpg.Pairwise(self.ctx, n, ext_buffer=self.pw_tensor.data_ptr())
+            self.K_tensor = self.torch.zeros(n * n, dtype=self.torch.float64, device="cuda")
+            self.d_K = C.c_void_p(self.K_tensor.data_ptr())
         else:
-            self.pw = tpg.Pairwise(self.ctx, n)
+            if self.torch is not None:  # gloo rehearsal: an external buffer whose address we know
+                self.pw_dev = self._dalloc(self.pw_bytes)
+                self.pw = tpg.Pairwise(self.ctx, n, ext_buffer=self.pw_dev.value)
+            else:
+                self.pw_dev = None
+                self.pw = tpg.Pairwise(self.ctx, n)
+            self.d_K = self._dalloc(8 * n * n)
         self.fst = {}
         self.has_pca = True
         # PCA setup (untimed): big_SVD stops on a zero scale, so monomorphic loci are dropped beforehand,
@@ -107,7 +124,21 @@ class Step:
         self.ctx.sync()
         if self.torch is not None:
             self.dist.barrier()
+            if self.backend == "nccl":
+                self.torch.cuda.synchronize()
+
+    def _all_reduce_dev(self, dptr, tensor, nbytes, dtype):
+        """sum a device buffer over ranks: RCCL on the aliasing torch tensor, or through host memory (gloo)"""
+        self.ctx.sync()
+        if tensor is not None:
+            self.dist.all_reduce(tensor)
             self.torch.cuda.synchronize()
+            return
+        host = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        chk = self.tpg._lib.check
+        chk(self.lib.tpg_dev_to_host(self.ctx.h, self.api._ptr(host), dptr, C.c_size_t(nbytes)))
+        self.sharding.all_reduce_numpy(host)
+        chk(self.lib.tpg_dev_from_host(self.ctx.h, dptr, self.api._ptr(host), C.c_size_t(nbytes)))
 
     def run(self):
         tpg, api, lib, ctx, a = self.tpg, self.api, self.lib, self.ctx, self.args
@@ -129,17 +160,11 @@ class Step:
         self.pw.zero()
         self.pw.accumulate(v)
         if self.torch is not None:
-            # the only data-path exchange: integer N x N partials (exact, order independent) and 4P doubles
-            ctx.sync()
-            self.dist.all_reduce(self.pw_tensor)
-            t = self.torch.from_numpy(np.concatenate([sums["Hudson"][0], sums["Hudson"][1], sums["WC84"][0],
-                                                      sums["WC84"][1]])).cuda()
-            self.dist.all_reduce(t)
-            self.torch.cuda.synchronize()
-            t = t.cpu().numpy()
-            sums = {"Hudson": (t[:P], t[P:2 * P]), "WC84": (t[2 * P:3 * P], t[3 * P:])}
-        for name in sums:
-            self.fst[name] = sums[name][0] / sums[name][1]
+            # data-path exchanges: integer N x N partials (exact, order independent) ...
+            pw_ptr = C.c_void_p(self.pw_tensor.data_ptr()) if self.pw_tensor is not None else self._pw_ptr()
+            self._all_reduce_dev(pw_ptr, self.pw_tensor, self.pw_bytes, np.int32)
+        for name in sums:  # ... and 2P doubles per Fst method (no-op on one rank)
+            self.fst[name] = self.sharding.fst_from_sums(sums[name][0], sums[name][1])
         chk(lib.tpg_pairwise_ibs(ctx.h, self.pw.h, C.c_int(0), C.c_int64(m * self.world), self.d_nn[0]))
         chk(lib.tpg_pairwise_king(ctx.h, self.pw.h, self.d_nn[1]))
         chk(lib.tpg_pairwise_grm(ctx.h, self.pw.h, self.d_nn[2]))
@@ -154,13 +179,33 @@ class Step:
                 self.has_pca = False
         ctx.sync()
 
+    def _pw_ptr(self):
+        if self.pw_dev is None:
+            # the library-owned accumulator: fetch its address once through the buffer-bytes contract
+            raise RuntimeError("gloo rehearsal needs an external pairwise buffer")
+        return self.pw_dev
+
     def _pca(self):
-        # single-GPU path; the sharded Gram all-reduce lands in a later round (DESIGN.md "Multi-GPU")
-        api, lib, ctx = self.api, self.lib, self.ctx
+        api, lib, ctx, k = self.api, self.lib, self.ctx, self.args.k
+        chk = self.tpg._lib.check
         v = api.View(self.X, None, self.pca_cols, code256=self.code_imp)
-        self.tpg._lib.check(lib.tpg_pca_partial_svd(ctx.h, v.h, C.c_int(self.args.k), api._ptr(self.pca_d),
-                                                    self.d_pca["u"], self.d_pca["v"], self.d_pca["center"],
-                                                    self.d_pca["scale"], C.byref(self.pca_fro)))
+        if self.torch is None:
+            chk(lib.tpg_pca_partial_svd(ctx.h, v.h, C.c_int(k), api._ptr(self.pca_d), self.d_pca["u"], self.d_pca["v"],
+                                        self.d_pca["center"], self.d_pca["scale"], C.byref(self.pca_fro)))
+        else:
+            # SNP shards: local center/scale and Gram, one N x N all-reduce, replicated eigen step, local loadings
+            n = self.args.n
+            chk(lib.tpg_pca_center_scale(ctx.h, v.h, self.d_pca["center"], self.d_pca["scale"]))
+            chk(lib.tpg_pca_gram(ctx.h, v.h, self.d_pca["center"], self.d_pca["scale"], self.d_K))
+            self._all_reduce_dev(self.d_K, self.K_tensor, 8 * n * n, np.float64)
+            lam = np.zeros(k)
+            chk(lib.tpg_sym_eig_topk(ctx.h, self.d_K, C.c_int64(n), C.c_int(k), api._ptr(lam), self.d_pca["u"]))
+            self.pca_d[:] = np.sqrt(np.maximum(lam, 0))
+            chk(lib.tpg_pca_loadings(ctx.h, v.h, self.d_pca["center"], self.d_pca["scale"], self.d_pca["u"],
+                                     api._ptr(self.pca_d), C.c_int(k), self.d_pca["v"]))
+            fro = C.c_double()
+            chk(lib.tpg_square_frobenius(ctx.h, v.h, self.d_pca["center"], self.d_pca["scale"], C.byref(fro)))
+            self.pca_fro.value = float(self.sharding.all_reduce_numpy(np.array([fro.value]))[0])
         v.free()
         return self.pca_d
 
@@ -209,10 +254,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or os.environ.get("TPG_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("TPG_BENCH_BACKEND", "nccl"))
     st = Step(args, rank, world, local_rank)
     for _ in range(args.warmup):
         st.run()
@@ -224,12 +270,8 @@ def main():
         st.run()
     st.barrier_sync()
     dt = time.perf_counter() - t0
-    if world > 1:
-        import torch
-
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        st.dist.all_reduce(t, op=st.dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if dist_on:
+        dt = float(st.sharding.all_reduce_numpy(np.array([dt]), op="max")[0])
     prof = st.ctx.prof_dump()
     if rank == 0:
         n, m = args.n, args.m
@@ -266,7 +308,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         st.dist.destroy_process_group()
 
 

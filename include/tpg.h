@@ -68,6 +68,7 @@ int tpg_prof_dump(tpg_ctx* ctx, char* buf, size_t cap);
 int tpg_dev_alloc(tpg_ctx* ctx, size_t bytes, void** out);
 void tpg_dev_free(void* p);
 int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+int tpg_dev_from_host(tpg_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
 
 /* ---- genotype store (replaces the mmapped FBM) -------- */
 int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, tpg_fbm** out);
@@ -185,6 +186,13 @@ int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* center, const do
  * (R/square_frobenius.R:19-35) */
 int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,
                         double* center, double* scale, double* square_frobenius);
+/* The pieces of tpg_pca_partial_svd for SNP-block shards on several GPUs: every rank computes the Gram
+ * matrix of its loci (tpg_pca_gram, additive over loci), the N x N partials are summed (one all-reduce),
+ * then tpg_sym_eig_topk gives lambda[k] (descending) and U (n x k) of the summed matrix and
+ * tpg_pca_loadings the rows of v = Z'u/d that belong to the rank's loci (d = sqrt(lambda)). */
+int tpg_sym_eig_topk(tpg_ctx* ctx, const double* K, int64_t n, int k, double* lambda, double* U);
+int tpg_pca_loadings(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale,
+                     const double* U, const double* d, int k, double* vload);
 /* replaces fbm256_prod_and_rowSumsSq (src/fbm_prod_and_rowSumSq.cpp:10-47): V m x K,
  * XV n x K, rss[n] */
 int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx* ctx, const tpg_view* v, const double* center,

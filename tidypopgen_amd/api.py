@@ -474,6 +474,26 @@ def pca_gram(v: View, center, scale) -> np.ndarray:
     return K
 
 
+def sym_eig_topk(K, k: int, ctx: Optional[Context] = None):
+    """top-k eigenpairs (descending) of a symmetric PSD matrix: (lambda[k], U n x k)"""
+    ctx = ctx or default_context()
+    K = np.asfortranarray(K, dtype=float)
+    n = K.shape[0]
+    lam, U = np.zeros(k), np.zeros((n, k), order="F")
+    check(lib.tpg_sym_eig_topk(ctx.h, _ptr(K), C.c_int64(n), C.c_int(k), _ptr(lam), _ptr(U)))
+    return lam, U
+
+
+def pca_loadings(v: View, center, scale, U, d) -> np.ndarray:
+    """v = Z'u/d for the loci of the view (second sweep of big_SVD)"""
+    center, scale, d = _f64(center), _f64(scale), _f64(d)
+    U = np.asfortranarray(U, dtype=float)
+    k = U.shape[1]
+    out = np.zeros((v.m, k), order="F")
+    check(lib.tpg_pca_loadings(v.ctx.h, v.h, _ptr(center), _ptr(scale), _ptr(U), _ptr(d), C.c_int(k), _ptr(out)))
+    return out
+
+
 def gt_pca_partialSVD(X: FBM, ind_row=None, ind_col=None, k: int = 10, total_var: bool = True,
                       code256=CODE_IMPUTE_PRED) -> dict:
     """R/gt_pca_partialSVD.R:67-108: the imputed code table is switched on (:74-77), then

@@ -1135,3 +1135,40 @@ extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, doubl
   TPG_TRY(ou.commit(ctx));
   return ov.commit(ctx);
 }
+
+extern "C" int tpg_sym_eig_topk(tpg_ctx* ctx, const double* K, int64_t n, int k, double* lambda, double* U) {
+  TPG_REQUIRE(ctx && K && lambda && U, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(n > 0 && k >= 1 && k <= 52 && k <= n, TPG_EINVAL, "bad n = %lld / k = %d", (long long)n, k);
+  InBuf ik;
+  TPG_TRY(ik.init(ctx, K, sizeof(double) * (size_t)n * (size_t)n));
+  OutBuf ou;
+  TPG_TRY(ou.init(U, sizeof(double) * (size_t)n * (size_t)k));
+  std::vector<double> lam((size_t)k);
+  TPG_TRY(eig_topk(ctx, ik.dev<double>(), (int)n, k, lam.data(), ou.dev<double>()));
+  if (tpg_is_device_ptr(lambda)) TPG_HIP(hipMemcpyAsync(lambda, lam.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
+  else memcpy(lambda, lam.data(), sizeof(double) * (size_t)k);
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return ou.commit(ctx);
+}
+
+extern "C" int tpg_pca_loadings(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale,
+                                const double* U, const double* d, int k, double* vload) {
+  TPG_REQUIRE(ctx && v && center && scale && U && d && vload, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(k >= 1, TPG_EINVAL, "k must be positive");
+  const int64_t n = v->n, m = v->m;
+  InBuf ic, is, iu, id;
+  TPG_TRY(ic.init(ctx, center, sizeof(double) * (size_t)m));
+  TPG_TRY(is.init(ctx, scale, sizeof(double) * (size_t)m));
+  TPG_TRY(iu.init(ctx, U, sizeof(double) * (size_t)n * (size_t)k));
+  TPG_TRY(id.init(ctx, d, sizeof(double) * (size_t)k));
+  OutBuf ov;
+  TPG_TRY(ov.init(vload, sizeof(double) * (size_t)m * (size_t)k));
+  double* d_inv = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_inv, sizeof(double) * (size_t)m));
+  TPG_LAUNCH(ctx, "inv_scale", tpg_inv_kernel, dim3(1024), dim3(256), 0, is.dev<double>(), m, d_inv);
+  int rc = run_sweep(ctx, SW_ROWSCALE, v->L, v->KG * 4, v->Q, m, n, ic.dev<double>(), d_inv, iu.dev<double>(), n, k,
+                     ov.dev<double>(), id.dev<double>(), nullptr);
+  tpg_pfree(d_inv);
+  TPG_TRY(rc);
+  return ov.commit(ctx);
+}

@@ -238,6 +238,13 @@ extern "C" int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src
   return TPG_OK;
 }
 
+extern "C" int tpg_dev_from_host(tpg_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+  TPG_REQUIRE(ctx && dev_dst && host_src, TPG_EINVAL, "null argument");
+  TPG_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return TPG_OK;
+}
+
 // ---------------------------------------------------------------------------
 bool tpg_is_device_ptr(const void* p) {
   if (!p) return false;
