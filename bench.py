@@ -35,8 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=5000, help="individuals")
-    ap.add_argument("--m", type=int, default=1000000, help="SNPs per GPU")
+    ap.add_argument("--indiv", "--n", dest="n", type=int, default=5000, help="individuals")
+    ap.add_argument("--snps", "--m", dest="m", type=int, default=1000000, help="SNPs per GPU")
     ap.add_argument("--pops", type=int, default=51)
     ap.add_argument("--k", type=int, default=20, help="principal components")
     ap.add_argument("--no-cpu-baseline", action="store_true")
