@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--k", type=int, default=20, help="principal components")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-loci", type=int, default=4096)
+    ap.add_argument("--digest", default=None, help="rank 0 writes a small JSON digest of the results (tests)")
     return ap.parse_args()
 
 
@@ -210,6 +211,24 @@ class Step:
         return self.pca_d
 
 
+def digest(st):
+    """A few numbers that pin every output of the step (used to compare sharded and unsharded runs)."""
+    n, k = st.args.n, st.args.k
+    chk = st.tpg._lib.check
+    out = {"fst_hudson": st.fst["Hudson"].tolist(), "fst_wc84": st.fst["WC84"].tolist(),
+           "pca_d": st.pca_d.tolist(), "pca_fro": st.pca_fro.value}
+    for name, dptr in zip(("ibs", "king", "grm"), st.d_nn):
+        a = np.zeros((n, n), order="F")
+        chk(st.lib.tpg_dev_to_host(st.ctx.h, st.api._ptr(a), dptr, C.c_size_t(8 * n * n)))
+        out[name + "_sum"] = float(np.nansum(a))
+        out[name + "_corner"] = a[:6, :6].tolist()
+        out[name + "_nan"] = int(np.isnan(a).sum())
+    u = np.zeros((n, k), order="F")
+    chk(st.lib.tpg_dev_to_host(st.ctx.h, st.api._ptr(u), st.d_pca["u"], C.c_size_t(8 * n * k)))
+    out["pca_u_abs_colsum"] = np.abs(u).sum(axis=0).tolist()
+    return out
+
+
 def cpu_baseline(args):
     """The oracle's "as the reference does it" path (oracle/oracle.py: dense FP64 one-hot blocks + BLAS
     products for IBS/KING/AS, C loops for the per-locus statistics and Fst, numpy Gram for PCA), timed on
@@ -273,6 +292,9 @@ def main():
     if dist_on:
         dt = float(st.sharding.all_reduce_numpy(np.array([dt]), op="max")[0])
     prof = st.ctx.prof_dump()
+    if rank == 0 and args.digest:
+        with open(args.digest, "w") as f:
+            json.dump(digest(st), f)
     if rank == 0:
         n, m = args.n, args.m
         total_genotypes = n * m * world
