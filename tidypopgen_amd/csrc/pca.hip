@@ -498,7 +498,60 @@ __global__ void tpg_pca_assemble_kernel(const long long* __restrict__ slabs, int
     const int lane = col + 32 * ((row >> 2) & 1);
     const int reg = (row & 3) + 4 * (row >> 3);
     const long long s = slabs[tpg_gram_unit_index(nsb, ia, jb) * PCA_SLAB_INTS + (tb * 16 + reg) * 64 + lane];
-    K[idx] = ldexp((double)s, -F) - rvec[oi] - rvec[ok] + Cc;
+    double val = ldexp((double)s, -F);
+    if (rvec) val = val - rvec[oi] - rvec[ok] + Cc;
+    K[idx] = val;
+  }
+}
+
+// Double centering K <- H K H, H = I - 11'/n.  With center_j = column mean of the SAME individuals,
+// Z = H G W^(1/2), so the Gram matrix is exactly the double-centered weighted cross-product S' = G W G':
+// r_i = row mean of S', C = grand mean.  Row means from the (symmetric) columns: coalesced.
+__global__ __launch_bounds__(256) void tpg_colmean_kernel(const double* __restrict__ K, int n, double* __restrict__ r) {
+  __shared__ double sh[256];
+  const int col = blockIdx.x;
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += K[i + (int64_t)col * n];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) r[col] = sh[0] / n;
+}
+
+__global__ __launch_bounds__(256) void tpg_mean_kernel(const double* __restrict__ r, int n, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += r[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0] / n;
+}
+
+__global__ void tpg_double_center_kernel(double* __restrict__ K, int n, const double* __restrict__ r,
+                                         const double* __restrict__ grand) {
+  const int64_t total = (int64_t)n * n;
+  const double C0 = grand[0];
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % n), k = (int)(idx / n);
+    K[idx] = K[idx] - r[i] - r[k] + C0;
+  }
+}
+
+// flags[0] |= (center_j != column mean from the counts)
+__global__ void tpg_center_is_mean_kernel(const int4* __restrict__ counts, const double* __restrict__ center,
+                                          int64_t m, int64_t n, int* __restrict__ flags) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = counts[j];
+    if (c.w != 0) flags[1] = 1;
+    if (center[j] != (double)(c.y + 2 * c.z) / (double)n) flags[0] = 1;
   }
 }
 
@@ -518,8 +571,10 @@ __global__ __launch_bounds__(256) void tpg_dot_kernel(const double* __restrict__
 }
 
 // Gram matrix into d_K (device, n x n column-major) given device center / scale.
+// own_center: center_j is the column mean over the view's own individuals (big_SVD's case) -> double centering;
+// otherwise the general form K = S' - r 1' - 1 r' + C with r_i = sum_j w_j c_j g_ij, C = sum_j w_j c_j^2.
 static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_center, const double* d_scale,
-                           double* d_K) {
+                           double* d_K, bool own_center) {
   const int64_t n = v->n, m = v->m;
   // weight range decides the number of digits
   std::vector<double> hs((size_t)m);
@@ -583,12 +638,22 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     }
     GHIP(hipGetLastError());
   }
-  if (e == hipSuccess) {
+  if (e == hipSuccess && own_center) {
+    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, nsb, (int)n, F,
+               (const double*)nullptr, 0.0, d_K);
+    TPG_LAUNCH(ctx, "pca_colmean", tpg_colmean_kernel, dim3((unsigned)n), dim3(256), 0, (const double*)d_K, (int)n, d_r);
+    TPG_LAUNCH(ctx, "pca_colmean", tpg_mean_kernel, dim3(1), dim3(256), 0, (const double*)d_r, (int)n, d_part);
+    TPG_LAUNCH(ctx, "pca_double_center", tpg_double_center_kernel, dim3(2048), dim3(256), 0, d_K, (int)n,
+               (const double*)d_r, (const double*)d_part);
+    GHIP(hipGetLastError());
+    GHIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (e == hipSuccess && !own_center) {
     // r_i = sum_j what_j c_j g_ij  (RAW sweep with a one-column table), C = sum_j what_j c_j^2
     rc = run_sweep(ctx, SW_RAW, v->T, v->Q * 4, v->KG, n, m, nullptr, nullptr, d_wc, m, 1, d_r, nullptr, nullptr);
   }
   double Cc = 0;
-  if (e == hipSuccess && rc == TPG_OK) {
+  if (e == hipSuccess && rc == TPG_OK && !own_center) {
     TPG_LAUNCH(ctx, "pca_dot", tpg_dot_kernel, dim3(512), dim3(256), 0, d_wc, d_center, m, d_part);
     std::vector<double> hp(512);
     GHIP(hipMemcpyAsync(hp.data(), d_part, sizeof(double) * 512, hipMemcpyDeviceToHost, ctx->stream));
@@ -597,9 +662,9 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     for (int b = 0; b < 512; b++) s += hp[(size_t)b];
     Cc = (double)s;
   }
-  if (e == hipSuccess && rc == TPG_OK) {
-    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, nsb, (int)n, F, d_r, Cc,
-               d_K);
+  if (e == hipSuccess && rc == TPG_OK && !own_center) {
+    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, nsb, (int)n, F,
+               (const double*)d_r, Cc, d_K);
     GHIP(hipGetLastError());
     GHIP(hipStreamSynchronize(ctx->stream));
   }
@@ -617,7 +682,26 @@ extern "C" int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* cente
   TPG_TRY(is.init(ctx, scale, sizeof(double) * (size_t)v->m));
   OutBuf ok;
   TPG_TRY(ok.init(K, sizeof(double) * (size_t)v->n * (size_t)v->n));
-  TPG_TRY(pca_gram_device(ctx, v, ic.dev<double>(), is.dev<double>(), ok.dev<double>()));
+  // is `center` the column mean of these individuals (what tpg_pca_center_scale returns)?
+  int32_t* d_counts = nullptr;
+  int* d_flag = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
+  hipError_t e = tpg_pmalloc((void**)&d_flag, 2 * sizeof(int));
+  int flag[2] = {1, 0};
+  int rc = e == hipSuccess ? tpg_launch_loci_counts(ctx, v, d_counts) : TPG_EHIP;
+  if (rc == TPG_OK) {
+    e = hipMemsetAsync(d_flag, 0, 2 * sizeof(int), ctx->stream);
+    TPG_LAUNCH(ctx, "pca_center_check", tpg_center_is_mean_kernel, dim3(1024), dim3(256), 0, (const int4*)d_counts,
+               ic.dev<double>(), v->m, v->n, d_flag);
+    if (e == hipSuccess) e = hipMemcpyAsync(flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { tpg_set_error("pca_gram: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  }
+  tpg_pfree(d_counts);
+  tpg_pfree(d_flag);
+  TPG_TRY(rc);
+  TPG_REQUIRE(!flag[1], TPG_ENUMERIC, "You can't have missing values in 'X'.");
+  TPG_TRY(pca_gram_device(ctx, v, ic.dev<double>(), is.dev<double>(), ok.dev<double>(), flag[0] == 0));
   return ok.commit(ctx);
 }
 
@@ -1094,6 +1178,9 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
   return TPG_OK;
 }
 
+static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_center, const double* d_scale,
+                               const double* d_U, const double* d_dk, int k, double* d_V);
+
 // ---------------------------------------------------------------------------
 extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,
                                    double* center, double* scale, double* square_frobenius) {
@@ -1106,27 +1193,23 @@ extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, doubl
   TPG_TRY(ou.init(u, sizeof(double) * (size_t)n * (size_t)k));
   TPG_TRY(ov.init(vload, sizeof(double) * (size_t)m * (size_t)k));
   int32_t* d_counts = nullptr;
-  double *d_K = nullptr, *d_inv = nullptr, *d_dk = nullptr;
+  double *d_K = nullptr, *d_dk = nullptr;
   TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)m));
   struct Free { void *a, *b, *c, *d; ~Free() { tpg_pfree(a); tpg_pfree(b); tpg_pfree(c); tpg_pfree(d); } } fr{d_counts, nullptr, nullptr, nullptr};
   TPG_TRY(pca_counts_center_scale(ctx, v, d_counts, oc.dev<double>(), os.dev<double>()));
   if (square_frobenius) TPG_TRY(frobenius_from_counts(ctx, v, d_counts, oc.dev<double>(), os.dev<double>(), square_frobenius));
   TPG_HIP(tpg_pmalloc((void**)&d_K, sizeof(double) * (size_t)n * (size_t)n));
   fr.b = d_K;
-  TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K));
+  TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true));
   std::vector<double> lam((size_t)k);
   TPG_TRY(eig_topk(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>()));
   std::vector<double> dh((size_t)k);
   for (int j = 0; j < k; j++) dh[(size_t)j] = sqrt(lam[(size_t)j] > 0 ? lam[(size_t)j] : 0.0);
-  TPG_HIP(tpg_pmalloc((void**)&d_inv, sizeof(double) * (size_t)m));
-  fr.c = d_inv;
   TPG_HIP(tpg_pmalloc((void**)&d_dk, sizeof(double) * (size_t)k));
   fr.d = d_dk;
   TPG_HIP(hipMemcpyAsync(d_dk, dh.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
-  TPG_LAUNCH(ctx, "inv_scale", tpg_inv_kernel, dim3(1024), dim3(256), 0, (const double*)os.dev<double>(), m, d_inv);
-  // v = Z'u / d: rows = loci (L layout), table = u (n x k)
-  TPG_TRY(run_sweep(ctx, SW_ROWSCALE, v->L, v->KG * 4, v->Q, m, n, oc.dev<double>(), d_inv, ou.dev<double>(), n, k,
-                    ov.dev<double>(), d_dk, nullptr));
+  // v = Z'u / d  (no missing values: checked by pca_counts_center_scale above)
+  TPG_TRY(pca_loadings_device(ctx, v, oc.dev<double>(), os.dev<double>(), ou.dev<double>(), d_dk, k, ov.dev<double>()));
   if (tpg_is_device_ptr(d)) TPG_HIP(hipMemcpyAsync(d, dh.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
   else memcpy(d, dh.data(), sizeof(double) * (size_t)k);
   TPG_HIP(hipStreamSynchronize(ctx->stream));
@@ -1134,6 +1217,166 @@ extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, doubl
   TPG_TRY(os.commit(ctx));
   TPG_TRY(ou.commit(ctx));
   return ov.commit(ctx);
+}
+
+// ---------------------------------------------------------------------------
+// Loadings v = Z'u/d on int8 MFMA.  With no missing values,
+//     v_jk = ( sum_i g_ij u_ik  -  c_j sum_i u_ik ) / (s_j d_k),
+// and sum_i g_ij u_ik is a contraction over individuals of the dosage plane with u.  u is rounded to
+// fixed point (FU fractional bits, relative 2^-40 of max|u|) and split into TU = 6 balanced base-128 digits;
+// column kk*TU + t of the B operand holds digit t of u[:, kk], so k = 20 components need 120 int8 columns
+// = 4 MFMA column tiles.  Exact int32 accumulation; digits are recombined in int64 and scaled once.
+#define LD_TU 6
+
+__global__ void tpg_u_digits_kernel(const double* __restrict__ U, int64_t n, int k, int FU, int64_t Q, int CT,
+                                    uint4* __restrict__ UD) {
+  const int64_t total = Q * 4 * CT * 64;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    const int64_t tq = idx >> 6;
+    const int ct = (int)(tq % CT);
+    const int64_t qs = tq / CT;
+    const int s = (int)(qs & 3);
+    const int64_t q = qs >> 2;
+    const int col = 32 * ct + (lane & 31), h = lane >> 5;
+    const int kk = col / LD_TU, t = col % LD_TU;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (kk < k)
+      for (int e = 0; e < 16; e++) {
+        const int64_t i = 128 * q + 32 * s + 16 * h + e;
+        if (i >= n) continue;
+        long long W = llrint(ldexp(U[i + (int64_t)kk * n], FU));
+        long long dig = 0;
+        for (int tt = 0; tt <= t; tt++) {
+          dig = W & 127;
+          if (dig >= 64) dig -= 128;
+          W = (W - dig) >> 7;
+        }
+        w[e >> 2] |= (uint32_t)((int)dig & 0xFF) << (8 * (e & 3));
+      }
+    UD[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// usum[kk] = sum_i round(u_ik 2^FU) 2^-FU  (the same rounded values the MFMA contraction sees)
+__global__ __launch_bounds__(256) void tpg_uq_colsum_kernel(const double* __restrict__ U, int64_t n, int FU,
+                                                            double* __restrict__ usum) {
+  __shared__ double sh[256];
+  const int kk = blockIdx.x;
+  double acc = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) acc += ldexp((double)llrint(ldexp(U[i + (int64_t)kk * n], FU)), -FU);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) usum[kk] = sh[0];
+}
+
+// out[locus][column] = sum_i g_i,locus * UD[i][column]; one wave per 32-locus tile, CTP column tiles per pass
+template <int CTP>
+__global__ __launch_bounds__(256) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
+                                                                const uint4* __restrict__ UD, int64_t n_lt,
+                                                                int64_t Q, int ct0, int CT,
+                                                                int32_t* __restrict__ out, int Cpad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (lt >= n_lt) return;
+  v16i acc[CTP];
+#pragma unroll
+  for (int c = 0; c < CTP; c++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[c][r] = 0;
+  const uint4* pa = L + (lt * Q) * 64 + lane;
+  for (int64_t q = 0; q < Q; q++) {
+    const uint4 a = pa[q * 64];
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      v4i fg;
+#pragma unroll
+      for (int k = 0; k < 4; k++) fg[k] = tpg_lut(TPG_LUT_G, tpg_codes(aw[s], k));
+#pragma unroll
+      for (int c = 0; c < CTP; c++) {
+        const uint4 b = UD[((q * 4 + s) * CT + ct0 + c) * 64 + lane];
+        v4i fb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+        acc[c] = MFMA_I8(fg, fb, acc[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CTP; c++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int64_t row = lt * 32 + tpg_cd_row(r, lane);
+      out[row * Cpad + 32 * (ct0 + c) + (lane & 31)] = acc[c][r];
+    }
+}
+
+__global__ void tpg_loadings_finalize_kernel(const int32_t* __restrict__ acc, int Cpad, int64_t m, int k, int FU,
+                                             const double* __restrict__ center, const double* __restrict__ scale,
+                                             const double* __restrict__ usum, const double* __restrict__ d,
+                                             double* __restrict__ vload) {
+  const int64_t total = m * k;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(idx % k);  // threads of a wave read one locus row of `acc` contiguously
+    const int64_t j = idx / k;
+    long long S = 0;
+#pragma unroll
+    for (int t = LD_TU - 1; t >= 0; t--) S = S * 128 + (long long)acc[j * Cpad + kk * LD_TU + t];
+    const double gu = ldexp((double)S, -FU);
+    vload[j + (int64_t)kk * m] = (gu - center[j] * usum[kk]) / (scale[j] * d[kk]);
+  }
+}
+
+// device pointers throughout; requires a view without missing values (checked by the callers' counts)
+static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_center, const double* d_scale,
+                               const double* d_U, const double* d_dk, int k, double* d_V) {
+  const int64_t n = v->n, m = v->m;
+  std::vector<double> hu((size_t)n * (size_t)k);
+  TPG_HIP(hipMemcpyAsync(hu.data(), d_U, sizeof(double) * hu.size(), hipMemcpyDeviceToHost, ctx->stream));
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  double amax = 0;
+  for (double x : hu) amax = std::max(amax, fabs(x));
+  TPG_REQUIRE(amax > 0 && amax == amax && amax < 1e300, TPG_ENUMERIC, "degenerate eigenvectors");
+  int ex = 0;
+  frexp(amax, &ex);                      // amax < 2^ex
+  const int FU = 7 * LD_TU - 2 - ex;     // |u| 2^FU < 2^(7 TU - 2), inside the balanced digit range
+  const int CT = (int)ceil_div((int64_t)k * LD_TU, 32);
+  const int Cpad = CT * 32;
+  const int64_t n_lt = v->KG * 4;
+  uint4* d_UD = nullptr;
+  int32_t* d_acc = nullptr;
+  double* d_usum = nullptr;
+  hipError_t e = tpg_pmalloc((void**)&d_UD, (size_t)v->Q * 4 * CT * 1024);
+  if (e == hipSuccess) e = tpg_pmalloc((void**)&d_acc, sizeof(int32_t) * (size_t)n_lt * 32 * (size_t)Cpad);
+  if (e == hipSuccess) e = tpg_pmalloc((void**)&d_usum, sizeof(double) * (size_t)k);
+  if (e == hipSuccess) {
+    TPG_LAUNCH(ctx, "loadings_u_digits", tpg_u_digits_kernel, dim3(1024), dim3(256), 0, d_U, n, k, FU, v->Q, CT, d_UD);
+    TPG_LAUNCH(ctx, "loadings_u_digits", tpg_uq_colsum_kernel, dim3((unsigned)k), dim3(256), 0, d_U, n, FU, d_usum);
+    const unsigned grid = (unsigned)ceil_div(n_lt, 4);
+    for (int ct0 = 0; ct0 < CT;) {
+      const int left = CT - ct0;
+#define LD_LAUNCH(C)                                                                                             \
+  TPG_LAUNCH(ctx, "loadings_mfma", tpg_loadings_mfma_kernel<C>, dim3(grid), dim3(256), 0, (const uint4*)v->L,     \
+             (const uint4*)d_UD, n_lt, v->Q, ct0, CT, d_acc, Cpad)
+      if (left >= 4) { LD_LAUNCH(4); ct0 += 4; }
+      else if (left == 3) { LD_LAUNCH(3); ct0 += 3; }
+      else if (left == 2) { LD_LAUNCH(2); ct0 += 2; }
+      else { LD_LAUNCH(1); ct0 += 1; }
+#undef LD_LAUNCH
+    }
+    TPG_LAUNCH(ctx, "loadings_finalize", tpg_loadings_finalize_kernel, dim3(2048), dim3(256), 0, (const int32_t*)d_acc,
+               Cpad, m, k, FU, d_center, d_scale, (const double*)d_usum, d_dk, d_V);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  tpg_pfree(d_UD); tpg_pfree(d_acc); tpg_pfree(d_usum);
+  if (e != hipSuccess) { tpg_set_error("loadings: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  return TPG_OK;
 }
 
 extern "C" int tpg_sym_eig_topk(tpg_ctx* ctx, const double* K, int64_t n, int k, double* lambda, double* U) {
@@ -1163,12 +1406,35 @@ extern "C" int tpg_pca_loadings(tpg_ctx* ctx, const tpg_view* v, const double* c
   TPG_TRY(id.init(ctx, d, sizeof(double) * (size_t)k));
   OutBuf ov;
   TPG_TRY(ov.init(vload, sizeof(double) * (size_t)m * (size_t)k));
-  double* d_inv = nullptr;
-  TPG_HIP(tpg_pmalloc((void**)&d_inv, sizeof(double) * (size_t)m));
-  TPG_LAUNCH(ctx, "inv_scale", tpg_inv_kernel, dim3(1024), dim3(256), 0, is.dev<double>(), m, d_inv);
-  int rc = run_sweep(ctx, SW_ROWSCALE, v->L, v->KG * 4, v->Q, m, n, ic.dev<double>(), d_inv, iu.dev<double>(), n, k,
-                     ov.dev<double>(), id.dev<double>(), nullptr);
-  tpg_pfree(d_inv);
+  // missing values? (then z = 0 there and the FP64 sweep handles it; big_SVD itself never gets here)
+  int32_t* d_counts = nullptr;
+  int* d_flag = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)m));
+  hipError_t e = tpg_pmalloc((void**)&d_flag, 2 * sizeof(int));
+  int flag[2] = {0, 1};
+  int rc = e == hipSuccess ? tpg_launch_loci_counts(ctx, v, d_counts) : TPG_EHIP;
+  if (rc == TPG_OK) {
+    e = hipMemsetAsync(d_flag, 0, 2 * sizeof(int), ctx->stream);
+    TPG_LAUNCH(ctx, "pca_center_check", tpg_center_is_mean_kernel, dim3(1024), dim3(256), 0, (const int4*)d_counts,
+               ic.dev<double>(), m, n, d_flag);
+    if (e == hipSuccess) e = hipMemcpyAsync(flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { tpg_set_error("pca_loadings: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  }
+  tpg_pfree(d_counts);
+  tpg_pfree(d_flag);
+  TPG_TRY(rc);
+  if (!flag[1]) {
+    rc = pca_loadings_device(ctx, v, ic.dev<double>(), is.dev<double>(), iu.dev<double>(), id.dev<double>(), k,
+                             ov.dev<double>());
+  } else {
+    double* d_inv = nullptr;
+    TPG_HIP(tpg_pmalloc((void**)&d_inv, sizeof(double) * (size_t)m));
+    TPG_LAUNCH(ctx, "inv_scale", tpg_inv_kernel, dim3(1024), dim3(256), 0, is.dev<double>(), m, d_inv);
+    rc = run_sweep(ctx, SW_ROWSCALE, v->L, v->KG * 4, v->Q, m, n, ic.dev<double>(), d_inv, iu.dev<double>(), n, k,
+                   ov.dev<double>(), id.dev<double>(), nullptr);
+    tpg_pfree(d_inv);
+  }
   TPG_TRY(rc);
   return ov.commit(ctx);
 }
