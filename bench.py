@@ -166,9 +166,8 @@ class Step:
             self._all_reduce_dev(pw_ptr, self.pw_tensor, self.pw_bytes, np.int32)
         for name in sums:  # ... and 2P doubles per Fst method (no-op on one rank)
             self.fst[name] = self.sharding.fst_from_sums(sums[name][0], sums[name][1])
-        chk(lib.tpg_pairwise_ibs(ctx.h, self.pw.h, C.c_int(0), C.c_int64(m * self.world), self.d_nn[0]))
-        chk(lib.tpg_pairwise_king(ctx.h, self.pw.h, self.d_nn[1]))
-        chk(lib.tpg_pairwise_grm(ctx.h, self.pw.h, self.d_nn[2]))
+        chk(lib.tpg_pairwise_epilogues(ctx.h, self.pw.h, C.c_int(0), C.c_int64(m * self.world), self.d_nn[0],
+                                       self.d_nn[1], C.c_void_p(None), self.d_nn[2]))
         v.free()
         # ---- imputed view + PCA ----
         if self.has_pca:

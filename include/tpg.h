@@ -161,6 +161,9 @@ int tpg_pairwise_ibs(tpg_ctx* ctx, const tpg_pairwise* pw, int type, int64_t m, 
 int tpg_pairwise_king(tpg_ctx* ctx, const tpg_pairwise* pw, double* out);           /* R/snp_king.R:79-101 */
 int tpg_pairwise_allele_sharing(tpg_ctx* ctx, const tpg_pairwise* pw, double* out); /* R/snp_allele_sharing.R:77-81 */
 int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* out);            /* R/pairwise_grm.R:42-50 */
+/* all four epilogues from one pass over the accumulators; any output may be NULL */
+int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int ibs_type, int64_t m, double* ibs,
+                           double* king, double* allele_sharing, double* grm);
 
 /* Literal per-block mirrors of the three increment_* entry points
  * (src/snp_ibs.cpp:22-74, src/snp_king.cpp:21-74, src/snp_as.cpp:22-67): the caller-owned

@@ -186,6 +186,13 @@ def test_pairwise_counts_bit_exact_and_epilogues(tpg, n, m, miss):
     assert np.array_equal(pw.king(), orc.snp_king(fbm), equal_nan=True)
     assert np.array_equal(pw.allele_sharing(), orc.snp_allele_sharing(fbm), equal_nan=True)
     assert np.allclose(pw.grm(), orc.pairwise_grm(orc.snp_allele_sharing(fbm)), rtol=1e-12, atol=1e-13, equal_nan=True)
+    # the fused epilogue gives the same matrices as the individual entry points
+    ep = pw.epilogues(ibs_type="adjusted_counts", m=m)
+    assert np.array_equal(ep["ibs"], pw.ibs("adjusted_counts", m), equal_nan=True)
+    assert np.array_equal(ep["king"], pw.king(), equal_nan=True)
+    assert np.array_equal(ep["allele_sharing"], pw.allele_sharing(), equal_nan=True)
+    assert np.array_equal(ep["grm"], pw.grm(), equal_nan=True)
+    assert np.array_equal(pw.epilogues(which=("grm",))["grm"], ep["grm"], equal_nan=True)
 
 
 def test_pairwise_block_invariance_and_subsets(tpg):

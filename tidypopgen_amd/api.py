@@ -247,6 +247,14 @@ class Pairwise:
         check(lib.tpg_pairwise_grm(self.ctx.h, self.h, _ptr(out)))
         return out
 
+    def epilogues(self, which=("ibs", "king", "allele_sharing", "grm"), ibs_type: str = "proportion", m: int = 0) -> dict:
+        """IBS, KING, allele sharing and GRM from one pass over the accumulators"""
+        names = ("ibs", "king", "allele_sharing", "grm")
+        outs = {k: self._mat() for k in which}
+        check(lib.tpg_pairwise_epilogues(self.ctx.h, self.h, C.c_int(0 if ibs_type == "proportion" else 1), C.c_int64(m),
+                                         *[_ptr(outs.get(k)) for k in names]))
+        return outs
+
     def free(self):
         if self.h:
             lib.tpg_pairwise_free(self.h)

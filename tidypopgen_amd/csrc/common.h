@@ -94,6 +94,16 @@ struct tpg_fbm {
   int64_t nrow, ncol;
 };
 
+// class-wise counts via MFMA: cls[n] in [0, nclass); cnt[3][Mpad][Cpad] (het, hom-alt, valid)
+struct GroupedCounts {
+  int32_t* cnt = nullptr;
+  int64_t Mpad = 0;  // 32 * n_lt
+  int Cpad = 0;      // 32 * ceil(nclass/32)
+  int nclass = 0;
+  bool borrowed = false;  // a view's cached counts handed out to a caller: not freed by the borrower
+  ~GroupedCounts();
+};
+
 struct tpg_view {
   tpg_ctx* ctx;
   int64_t n, m;    // kept individuals / loci
@@ -101,6 +111,10 @@ struct tpg_view {
   uint4* T;        // (4Q) row tiles x KG blocks
   uint4* L;        // (4KG) locus tiles x Q blocks
   size_t bytes_each;
+  // the last per-class counts computed on this view (grouped_alt_freq, grouped_summaries and the Fst
+  // methods of one analysis all use the same grouping): reused while the class vector is unchanged
+  mutable GroupedCounts gc_cache;
+  mutable std::vector<int32_t> gc_cls;
 };
 
 // tile-packed int32 accumulators of the pairwise kernel: per unit (64-row super-tile I, 32-column
@@ -164,12 +178,4 @@ int tpg_launch_synth(tpg_ctx* ctx, uint8_t* d_bytes, uint64_t seed, int64_t nrow
 
 // per-locus
 int tpg_launch_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* d_counts /* m x 4 */);
-// class-wise counts via MFMA: d_cls[n] in [0, nclass) ; out cnt[3][Mpad][Cpad] (n1, n2, nvalid)
-struct GroupedCounts {
-  int32_t* cnt = nullptr;
-  int64_t Mpad = 0;  // 32 * n_lt
-  int Cpad = 0;      // 32 * ceil(nclass/32)
-  int nclass = 0;
-  ~GroupedCounts();
-};
 int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, int nclass, GroupedCounts* out);

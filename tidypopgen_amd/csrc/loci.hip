@@ -12,6 +12,8 @@
 //    src/grouped_missingness_cpp.cpp:23-31, src/grouped_summaries_dip_pseudo_cpp.cpp:50-57).
 //    The reference's sums of x*mult and ploidy are sums of {0, 0.5, 1, 2}-multiples, exact in
 //    double in any order, so integer counts + one conversion reproduce them bit for bit.
+#include <string.h>
+
 #include "common.h"
 #include "devfrag.h"
 
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void tpg_grouped_counts_kernel(const uint4* __
 }
 
 GroupedCounts::~GroupedCounts() {
-  if (cnt) tpg_pfree(cnt);
+  if (cnt && !borrowed) tpg_pfree(cnt);
 }
 
 int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, int nclass, GroupedCounts* out) {
@@ -156,6 +158,13 @@ int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, in
                 h_cls[i], (long long)i, nclass);
   const int GT = (int)ceil_div(nclass, 32);
   const int64_t n_lt = v->KG * 4;
+  if (v->gc_cache.cnt && v->gc_cache.nclass == nclass && v->gc_cls.size() == (size_t)v->n &&
+      memcmp(v->gc_cls.data(), h_cls, sizeof(int32_t) * (size_t)v->n) == 0) {
+    *out = v->gc_cache;  // shallow copy of the cached buffer
+    out->borrowed = true;
+    return TPG_OK;
+  }
+  if (v->gc_cache.cnt) { tpg_pfree(v->gc_cache.cnt); v->gc_cache.cnt = nullptr; }
   out->Mpad = n_lt * 32;
   out->Cpad = GT * 32;
   out->nclass = nclass;
@@ -189,6 +198,12 @@ int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, in
   }
   tpg_pfree(d_cls);
   tpg_pfree(d_oh);
+  if (rc == TPG_OK) {  // the view keeps the buffer; the caller borrows it
+    v->gc_cache = *out;
+    v->gc_cache.borrowed = false;
+    v->gc_cls.assign(h_cls, h_cls + v->n);
+    out->borrowed = true;
+  }
   return rc;
 }
 
@@ -253,29 +268,57 @@ __device__ __forceinline__ GroupVals tpg_group_vals(const int32_t* __restrict__ 
 }
 
 // mode 0: grouped_alt_freq (out m x 2G; as_counts), 1: grouped_missingness (out m x G),
-// 2: grouped_summaries (o0..o3 m x G, each may be null)
-__global__ void tpg_grouped_finalize_kernel(const int32_t* __restrict__ cnt, int64_t Mpad, int Cpad, int64_t m,
-                                            int G, int has_hap, int mode, int as_counts,
-                                            const int32_t* __restrict__ group_size, double* __restrict__ o0,
-                                            double* __restrict__ o1, double* __restrict__ o2,
-                                            double* __restrict__ o3) {
-  const int64_t total = m * G;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t j = idx % m;
-    const int g = (int)(idx / m);
-    const GroupVals gv = tpg_group_vals(cnt, Mpad, Cpad, j, g, has_hap);
-    if (mode == 0) {
-      o0[j + (int64_t)g * m] = as_counts ? gv.alt : gv.alt / gv.valid;
-      o0[j + (int64_t)(G + g) * m] = gv.valid;
-    } else if (mode == 1) {
-      o0[idx] = (double)group_size[g] - gv.nvalid_ind;
-    } else {
-      const double f = gv.alt / gv.valid;
-      if (o0) o0[idx] = f;
-      if (o1) o1[idx] = 1 - f;
-      if (o2) o2[idx] = gv.valid;
-      if (o3) o3[idx] = gv.het2 / gv.valid;
+// 2: grouped_summaries (o0..o3 m x G, each may be null).
+// A workgroup owns 64 consecutive loci: the count rows are read with the class index on the lanes
+// (contiguous 4-byte loads), results are staged in LDS and written with the locus index on the lanes
+// (contiguous 8-byte stores into the column-major outputs).
+__global__ __launch_bounds__(256) void tpg_grouped_finalize_kernel(const int32_t* __restrict__ cnt, int64_t Mpad,
+                                                                   int Cpad, int64_t m, int G, int has_hap, int mode,
+                                                                   int as_counts,
+                                                                   const int32_t* __restrict__ group_size,
+                                                                   double* __restrict__ o0, double* __restrict__ o1,
+                                                                   double* __restrict__ o2, double* __restrict__ o3) {
+  __shared__ double tile[4][32][65];  // [output][group chunk][locus]
+  const int64_t j0 = (int64_t)blockIdx.x * 64;
+  for (int g0 = 0; g0 < G; g0 += 32) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+      const int gl = idx & 31, l = idx >> 5;
+      const int g = g0 + gl;
+      const int64_t j = j0 + l;
+      if (g < G && j < m) {
+        const GroupVals gv = tpg_group_vals(cnt, Mpad, Cpad, j, g, has_hap);
+        if (mode == 0) {
+          tile[0][gl][l] = as_counts ? gv.alt : gv.alt / gv.valid;
+          tile[1][gl][l] = gv.valid;
+        } else if (mode == 1) {
+          tile[0][gl][l] = (double)group_size[g] - gv.nvalid_ind;
+        } else {
+          const double f = gv.alt / gv.valid;
+          tile[0][gl][l] = f;
+          tile[1][gl][l] = 1 - f;
+          tile[2][gl][l] = gv.valid;
+          tile[3][gl][l] = gv.het2 / gv.valid;
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+      const int l = idx & 63, gl = idx >> 6;
+      const int g = g0 + gl;
+      const int64_t j = j0 + l;
+      if (g >= G || j >= m) continue;
+      if (mode == 0) {
+        o0[j + (int64_t)g * m] = tile[0][gl][l];
+        o0[j + (int64_t)(G + g) * m] = tile[1][gl][l];
+      } else if (mode == 1) {
+        o0[j + (int64_t)g * m] = tile[0][gl][l];
+      } else {
+        if (o0) o0[j + (int64_t)g * m] = tile[0][gl][l];
+        if (o1) o1[j + (int64_t)g * m] = tile[1][gl][l];
+        if (o2) o2[j + (int64_t)g * m] = tile[2][gl][l];
+        if (o3) o3[j + (int64_t)g * m] = tile[3][gl][l];
+      }
     }
   }
 }
@@ -325,8 +368,8 @@ extern "C" int tpg_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const do
   GroupedCounts gc;
   TPG_TRY(tpg_grouped_counts(ctx, v, cp.cls.data(), cp.nclass, &gc));
   // reuse the grouped finalize (mode 0 with G = 1 has the m x 2 layout wanted), then NA guard on the host side
-  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3(1024), dim3(256), 0, gc.cnt, gc.Mpad,
-             gc.Cpad, v->m, 1, cp.has_hap, 0, as_counts, (const int32_t*)nullptr, o.dev<double>(),
+  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3((unsigned)ceil_div(v->m, 64)), dim3(256), 0,
+             gc.cnt, gc.Mpad, gc.Cpad, v->m, 1, cp.has_hap, 0, as_counts, (const int32_t*)nullptr, o.dev<double>(),
              (double*)nullptr, (double*)nullptr, (double*)nullptr);
   TPG_CHECK_LAUNCH();
   TPG_HIP(hipStreamSynchronize(ctx->stream));
@@ -349,8 +392,8 @@ static int grouped_common(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupI
   if (o3) TPG_TRY(b3.init(o3, sizeof(double) * mg));
   InBuf gs;
   TPG_TRY(gs.init(ctx, cp.group_size.data(), sizeof(int32_t) * (size_t)ngroups));
-  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3(2048), dim3(256), 0, gc.cnt, gc.Mpad,
-             gc.Cpad, v->m, ngroups, cp.has_hap, mode, as_counts, gs.dev<int32_t>(), b0.dev<double>(),
+  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3((unsigned)ceil_div(v->m, 64)), dim3(256), 0,
+             gc.cnt, gc.Mpad, gc.Cpad, v->m, ngroups, cp.has_hap, mode, as_counts, gs.dev<int32_t>(), b0.dev<double>(),
              b1.dev<double>(), b2.dev<double>(), b3.dev<double>());
   TPG_CHECK_LAUNCH();
   TPG_HIP(hipStreamSynchronize(ctx->stream));

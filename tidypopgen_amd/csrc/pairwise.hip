@@ -219,7 +219,7 @@ __device__ __forceinline__ PwCounts tpg_pw_fetch(const int32_t* __restrict__ acc
 #define TPG_NAN __longlong_as_double(0x7FF8000000000000ll)
 
 // mode: 0 raw counts (six optional outputs), 1 IBS proportion / adjusted counts (scale), 2 KING,
-// 3 allele sharing
+// 3 allele sharing, 4 IBS + KING + allele sharing together
 __global__ void tpg_pairwise_epilogue_kernel(const int32_t* __restrict__ acc, int nst, int n, int mode,
                                              double scale, double* __restrict__ o0, double* __restrict__ o1,
                                              double* __restrict__ o2, double* __restrict__ o3,
@@ -227,8 +227,13 @@ __global__ void tpg_pairwise_epilogue_kernel(const int32_t* __restrict__ acc, in
   const int64_t total = (int64_t)n * n;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    const int i = (int)(idx % n), j = (int)(idx / n);
-    const PwCounts c = tpg_pw_fetch(acc, nst, i, j);
+    // idx is the output position (row r = idx % n, column cidx = idx / n).  The slab is read with the
+    // lane index on its COLUMN (contiguous 4-byte loads), so this thread fetches element (i = cidx, j = r)
+    // and emits the transposed element: every output but N_Aa is symmetric, and for N_Aa the fetch
+    // returns both A_ij and A_ji.
+    const int r = (int)(idx % n), cidx = (int)(idx / n);
+    PwCounts c = tpg_pw_fetch(acc, nst, cidx, r);
+    { const int t = c.Aij; c.Aij = c.Aji; c.Aji = t; }  // now relative to (row r, column cidx)
     if (mode == 0) {
       if (o0) o0[idx] = (double)(c.V + c.D + c.H);
       if (o1) o1[idx] = (double)(2 * c.V);
@@ -243,9 +248,21 @@ __global__ void tpg_pairwise_epilogue_kernel(const int32_t* __restrict__ acc, in
       const double K = (double)(c.D - c.V + c.Aij + c.Aji), Ni = (double)c.Aij, Nj = (double)c.Aji;
       const double mn = Ni < Nj ? Ni : Nj;
       o0[idx] = K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn;  // R/snp_king.R:86-89
-    } else {
+    } else if (mode == 3) {
       const double num = (double)c.D, den = (double)c.V;
       o0[idx] = c.V == 0 ? TPG_NAN : 0.5 * (1 + num / den);  // R/snp_allele_sharing.R:79-80
+    } else {
+      // mode 4: IBS (o0, scale), KING (o1) and allele sharing (o2) from one fetch
+      if (o0) {
+        const double prop = (double)(c.V + c.D + c.H) / (double)(2 * c.V);
+        o0[idx] = scale == 1.0 ? prop : prop * scale;
+      }
+      if (o1) {
+        const double K = (double)(c.D - c.V + c.Aij + c.Aji), Ni = (double)c.Aij, Nj = (double)c.Aji;
+        const double mn = Ni < Nj ? Ni : Nj;
+        o1[idx] = K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn;
+      }
+      if (o2) o2[idx] = c.V == 0 ? TPG_NAN : 0.5 * (1 + (double)c.D / (double)c.V);
     }
   }
 }
@@ -290,6 +307,37 @@ extern "C" int tpg_pairwise_allele_sharing(tpg_ctx* ctx, const tpg_pairwise* pw,
   return run_epilogue(ctx, pw, 3, 1.0, outs);
 }
 
+static int grm_from_as(tpg_ctx* ctx, int n, double* d_M);
+
+// IBS, KING, allele sharing and GRM in one pass over the accumulators (any output may be NULL)
+extern "C" int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int ibs_type, int64_t m, double* ibs,
+                                      double* king, double* allele_sharing, double* grm) {
+  TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(ibs_type == TPG_IBS_PROPORTION || ibs_type == TPG_IBS_ADJUSTED_COUNTS, TPG_EINVAL, "bad IBS type");
+  const int n = (int)pw->n;
+  const size_t bytes = sizeof(double) * (size_t)n * (size_t)n;
+  OutBuf bi, bk, ba, bg;
+  if (ibs) TPG_TRY(bi.init(ibs, bytes));
+  if (king) TPG_TRY(bk.init(king, bytes));
+  if (allele_sharing) TPG_TRY(ba.init(allele_sharing, bytes));
+  if (grm) TPG_TRY(bg.init(grm, bytes));
+  // GRM needs the allele-sharing matrix: write it into the GRM buffer when the caller does not want both
+  double* as_dst = allele_sharing ? ba.dev<double>() : bg.dev<double>();
+  TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(2048), dim3(256), 0,
+             (const int32_t*)pw->acc, (int)pw->nst, n, 4, ibs_type == TPG_IBS_PROPORTION ? 1.0 : (double)m,
+             bi.dev<double>(), bk.dev<double>(), as_dst, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+  TPG_CHECK_LAUNCH();
+  if (grm) {
+    if (allele_sharing) TPG_HIP(hipMemcpyAsync(bg.dev<double>(), ba.dev<double>(), bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    TPG_TRY(grm_from_as(ctx, n, bg.dev<double>()));
+  }
+  if (ibs) TPG_TRY(bi.commit(ctx));
+  if (king) TPG_TRY(bk.commit(ctx));
+  if (allele_sharing) TPG_TRY(ba.commit(ctx));
+  if (grm) TPG_TRY(bg.commit(ctx));
+  return TPG_OK;
+}
+
 // GRM (R/pairwise_grm.R:42-50): mb = mean of the off-diagonal allele-sharing values (na.rm), then
 // 2 (M - mb) / (1 - mb).  The mean is reduced per block in double and finished on the host in long
 // double (R's mean() accumulates in long double too).
@@ -323,21 +371,15 @@ __global__ void tpg_grm_kernel(double* __restrict__ M, int64_t total, double mb)
     M[idx] = (M[idx] - mb) / (1 - mb) * 2;
 }
 
-extern "C" int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
-  TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
-  const int n = (int)pw->n;
-  OutBuf o;
-  TPG_TRY(o.init(out, sizeof(double) * (size_t)n * (size_t)n));
-  double* nulls[6] = {o.dev<double>(), nullptr, nullptr, nullptr, nullptr, nullptr};
-  TPG_TRY(run_epilogue(ctx, pw, 3, 1.0, nulls));  // allele sharing straight into the device buffer
+// in place: allele-sharing matrix (device) -> GRM
+static int grm_from_as(tpg_ctx* ctx, int n, double* d_M) {
   const int NB = 512;
   double* d_sum = nullptr;
   unsigned long long* d_cnt = nullptr;
   TPG_HIP(tpg_pmalloc((void**)&d_sum, sizeof(double) * NB));
   hipError_t e = tpg_pmalloc((void**)&d_cnt, sizeof(unsigned long long) * NB);
   if (e != hipSuccess) { tpg_pfree(d_sum); tpg_set_error("hipMalloc: %s", hipGetErrorString(e)); return TPG_EHIP; }
-  TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_offdiag_sum_kernel, dim3(NB), dim3(256), 0, o.dev<double>(), n, d_sum,
-             d_cnt);
+  TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_offdiag_sum_kernel, dim3(NB), dim3(256), 0, (const double*)d_M, n, d_sum, d_cnt);
   std::vector<double> hs(NB);
   std::vector<unsigned long long> hc(NB);
   e = hipMemcpyAsync(hs.data(), d_sum, sizeof(double) * NB, hipMemcpyDeviceToHost, ctx->stream);
@@ -350,10 +392,15 @@ extern "C" int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* ou
   unsigned long long c = 0;
   for (int b = 0; b < NB; b++) { s += hs[b]; c += hc[b]; }
   const double mb = c ? (double)(s / (long double)c) : NAN;
-  TPG_LAUNCH(ctx, "grm_scale", tpg_grm_kernel, dim3(2048), dim3(256), 0, o.dev<double>(), (int64_t)n * n, mb);
+  TPG_LAUNCH(ctx, "grm_scale", tpg_grm_kernel, dim3(2048), dim3(256), 0, d_M, (int64_t)n * n, mb);
   TPG_CHECK_LAUNCH();
   TPG_HIP(hipStreamSynchronize(ctx->stream));
-  return o.commit(ctx);
+  return TPG_OK;
+}
+
+extern "C" int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
+  TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
+  return tpg_pairwise_epilogues(ctx, pw, TPG_IBS_PROPORTION, 0, nullptr, nullptr, nullptr, out);
 }
 
 // ---------------------------------------------------------------------------
