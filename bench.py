@@ -261,7 +261,8 @@ def cpu_baseline(args):
     Z = (X[:, keep] - center[keep]) / scale[keep]
     Z @ Z.T
     dt = time.time() - t0
-    return {"value": n * B / dt, "unit": "SNP-genotypes/s", "cores": os.cpu_count(), "kind": "port",
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    return {"value": n * B / dt, "unit": "SNP-genotypes/s", "cores": cores, "kind": "port",
             "sample": f"{n} x {B} loci of the same synthetic panel, IBS+KING+AS via numpy/BLAS FP64 one-hot products "
                       f"(reference's 6/4/2 products per block), per-locus + Fst (Hudson, WC84) C loops, PCA Gram via BLAS; "
                       f"{dt:.1f} s; eigen step excluded"}
@@ -300,14 +301,29 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         # dominant kernel: the int8 MFMA cross-product pass.  Algorithmic ops per launch: the fused
         # IBS+KING+AS pass needs 3 symmetric + 1 general product = 2.5 N^2 M MACs = 5 N^2 M ops.
-        cnt, ms = prof.get("pairwise_mfma", (0, 0.0))
-        roof = None
-        if cnt:
+        def mfma_roof(key, kernel, ops, note):
+            cnt, ms = prof.get(key, (0, 0.0))
+            if not cnt:
+                return None
             avg_s = ms / cnt * 1e-3
-            achieved = 5.0 * n * n * m / avg_s / 1e12
-            roof = {"bound": "mfma", "kernel": "tpg_pairwise_kernel (v_mfma_i32_32x32x32_i8)", "achieved": achieved,
-                    "peak": 5000.0, "unit": "TOP/s", "frac": achieved / 5000.0, "traffic": None,
-                    "avg_launch_ms": ms / cnt, "algorithmic_ops_per_launch": 5.0 * n * n * m}
+            achieved = ops / avg_s / 1e12
+            return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": 5000.0, "unit": "TOP/s",
+                    "frac": achieved / 5000.0, "traffic": TRAFFIC.get(key), "avg_launch_ms": ms / cnt,
+                    "algorithmic_ops_per_launch": ops, "note": note}
+
+        # HBM bytes per launch from the rocprofv3 --pmc passes committed under profiles/ (FETCH_SIZE doubled per the
+        # gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE); null when the workload is not the profiled one
+        TRAFFIC = {"pairwise_mfma": 5.44e10, "pca_gram_mfma": 7.23e10} if (n, m) == (5000, 1000000) else {}
+        m_pca = st.m_pca if st.has_pca else m
+        roofs = [
+            mfma_roof("pairwise_mfma", "tpg_pairwise_kernel (v_mfma_i32_32x32x32_i8)", 5.0 * n * n * m,
+                      "fused IBS+KING+AS/GRM: 3 symmetric + 1 general int8 product = 2.5 N^2 M MACs"),
+            mfma_roof("pca_gram_mfma", "tpg_pca_gram_kernel (v_mfma_i32_32x32x32_i8)", 4.0 * n * n * m_pca,
+                      "PCA Gram: 4 weight digits x symmetric int8 product = 4 * N^2 M / 2 MACs"),
+        ]
+        roofs = [r for r in roofs if r]
+        roofs.sort(key=lambda r: -r["avg_launch_ms"])
+        roof = roofs[0] if roofs else None
         analyses = ["pack", "loci_alt_freq", "grouped_alt_freq", "fst_hudson", "fst_wc84", "ibs", "king", "grm"]
         if st.has_pca:
             analyses.append(f"pca_partialSVD_k{args.k}")
@@ -323,6 +339,7 @@ def main():
                                    f"(imputed bytes), seed 3 [BASELINE configs 2-4]",
                        "analyses": analyses, "pca_included": bool(st.has_pca)},
             "roofline": roof,
+            "roofline_other_kernels": roofs[1:],
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
             "kernel_launches_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
         }
