@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--pops", type=int, default=51)
     ap.add_argument("--k", type=int, default=20, help="principal components")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-loci", type=int, default=4096)
+    ap.add_argument("--cpu-sample-loci", type=int, default=12288)
     ap.add_argument("--digest", default=None, help="rank 0 writes a small JSON digest of the results (tests)")
     return ap.parse_args()
 
