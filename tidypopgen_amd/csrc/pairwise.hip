@@ -23,6 +23,7 @@
 // independent) into a tile-packed buffer in MFMA register order, so each atomic wave instruction
 // is 256 contiguous bytes.  That buffer is what a multi-GPU run all-reduces.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -119,6 +120,101 @@ __global__ __launch_bounds__(256, 2) void tpg_pairwise_kernel(const uint4* __res
   }
 }
 
+// v2: the same arithmetic with the 2-bit -> byte spread of every fragment done ONCE per workgroup.
+// A workgroup of 8 waves (2 per SIMD) owns a 128 x 128 block (64-row super-tiles 2 I4, 2 I4 + 1 against
+// column tiles 4 J4 .. 4 J4 + 3); wave (ap, bt) computes exactly one (I, jt) unit of the v1 decomposition, so
+// the accumulator buffer and the epilogues are unchanged.  Per 128-locus group each wave spreads ONE of the 8
+// row tiles (28 VALU + 4 ds_write_b128) into a double-buffered LDS image of code bytes and reads the three
+// fragments it needs per 32 loci back with ds_read_b128: 4.3 decode VALU per MFMA instead of 5.7, which
+// matters because beyond ~5 VALU per MFMA the kernel is VALU-issue bound.  One barrier
+// per 128 loci.
+__global__ __launch_bounds__(512, 2) void tpg_pairwise_kernel_v2(const uint4* __restrict__ T, int64_t KG,
+                                                                 int64_t kg_begin, int64_t kg_end, int nst, int Q4,
+                                                                 int64_t nbp, int S, int32_t* __restrict__ acc_out) {
+  __shared__ __attribute__((aligned(16))) uint4 cds[2][8][4][64];  // [buffer][row tile][K step][lane]
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int ap = wv & 1, bt = wv >> 1;
+  const int64_t kgs = kg_end - kg_begin;
+  for (int64_t unit = blockIdx.x; unit < nbp * S; unit += gridDim.x) {
+    int64_t bp = unit % nbp;
+    const int ks = (int)(unit / nbp);
+    int I4 = 0;
+    while (bp >= Q4 - I4) { bp -= Q4 - I4; I4++; }
+    const int J4 = I4 + (int)bp;
+    const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
+    // the row tile this wave spreads: 0..3 = rows of the A block, 4..7 = rows of the B block
+    const int64_t my_rt = wv < 4 ? 4 * (int64_t)I4 + wv : 4 * (int64_t)J4 + (wv - 4);
+    const uint4* psrc = T + (my_rt * KG) * 64 + lane;
+    const int fa0 = 2 * ap, fa1 = 2 * ap + 1, fb = 4 + bt;
+
+    v16i cV[2], cD[2], cH[2], cHV[2], cVH[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { cV[t][r] = 0; cD[t][r] = 0; cH[t][r] = 0; cHV[t][r] = 0; cVH[t][r] = 0; }
+
+    auto spread_to = [&](const uint4& pk, int buf) {
+      const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+      for (int sidx = 0; sidx < 4; sidx++)
+        cds[buf][wv][sidx][lane] = make_uint4(tpg_codes(w[sidx], 0), tpg_codes(w[sidx], 1), tpg_codes(w[sidx], 2),
+                                              tpg_codes(w[sidx], 3));
+    };
+
+    if (k0 < k1) {
+      uint4 nxt = psrc[k0 * 64];
+      spread_to(nxt, 0);
+      nxt = psrc[((k0 + 1 < k1) ? k0 + 1 : k0) * 64];
+      __syncthreads();
+      for (int64_t kg = k0; kg < k1; kg++) {
+        const int buf = (int)((kg - k0) & 1);
+        if (kg + 1 < k1) {
+          spread_to(nxt, buf ^ 1);
+          nxt = psrc[((kg + 2 < k1) ? kg + 2 : kg + 1) * 64];
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 4; sidx++) {
+          const uint4 ca0 = cds[buf][fa0][sidx][lane], ca1 = cds[buf][fa1][sidx][lane], cb = cds[buf][fb][sidx][lane];
+          Frag3 A[2], B;
+          const uint32_t a0c[4] = {ca0.x, ca0.y, ca0.z, ca0.w}, a1c[4] = {ca1.x, ca1.y, ca1.z, ca1.w};
+          const uint32_t bc[4] = {cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            A[0].v[k] = tpg_lut(TPG_LUT_V, a0c[k]); A[0].d[k] = tpg_lut(TPG_LUT_D, a0c[k]); A[0].h[k] = tpg_lut(TPG_LUT_H, a0c[k]);
+            A[1].v[k] = tpg_lut(TPG_LUT_V, a1c[k]); A[1].d[k] = tpg_lut(TPG_LUT_D, a1c[k]); A[1].h[k] = tpg_lut(TPG_LUT_H, a1c[k]);
+            B.v[k] = tpg_lut(TPG_LUT_V, bc[k]); B.d[k] = tpg_lut(TPG_LUT_D, bc[k]); B.h[k] = tpg_lut(TPG_LUT_H, bc[k]);
+          }
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            cV[t] = MFMA_I8(A[t].v, B.v, cV[t]);
+            cD[t] = MFMA_I8(A[t].d, B.d, cD[t]);
+            cH[t] = MFMA_I8(A[t].h, B.h, cH[t]);
+            cHV[t] = MFMA_I8(A[t].h, B.v, cHV[t]);
+            cVH[t] = MFMA_I8(A[t].v, B.h, cVH[t]);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    const int I = 2 * I4 + ap, jt = 4 * J4 + bt;
+    if (I < nst && jt < 2 * nst && jt >= 2 * I) {  // inside the stored band (diagonal blocks skip their lower half)
+      int32_t* slab = acc_out + tpg_pw_unit_index(nst, I, jt) * TPG_PW_TILE_INTS + lane;
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int o = (t * 16 + r) * 64;
+          atomicAdd(slab + 0 * 2048 + o, cV[t][r]);
+          atomicAdd(slab + 1 * 2048 + o, cD[t][r]);
+          atomicAdd(slab + 2 * 2048 + o, cH[t][r]);
+          atomicAdd(slab + 3 * 2048 + o, cHV[t][r]);
+          atomicAdd(slab + 4 * 2048 + o, cVH[t][r]);
+        }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 extern "C" size_t tpg_pairwise_buffer_bytes(int64_t n) {
   const int64_t nst = ceil_div(n, 64);
@@ -171,20 +267,35 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
   if (col_begin == col_end) return TPG_OK;
   const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
   const int64_t kgs = kg1 - kg0;
-  const int64_t nwaves = (int64_t)ctx->num_cu * 8;
-  // K split: make ntp * S fill the resident waves evenly, keep >= 8 K groups (1024 loci) per unit
-  int bestS = 1;
-  double best = -1;
-  const int64_t maxS = kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1;
-  for (int64_t S = 1; S <= maxS; S++) {
-    const int64_t U = pw->ntp * S;
-    const double eff = (double)U / (double)(ceil_div(U, nwaves) * nwaves);
-    if (eff > best + 0.01) { best = eff; bestS = (int)S; }
+  static const bool use_v1 = getenv("TPG_PAIRWISE_V1") != nullptr;
+  auto pick_split = [&](int64_t units, int64_t slots) {
+    // K split: make units * S fill the resident slots evenly, keep >= 8 K groups (1024 loci) per unit
+    int bestS = 1;
+    double best = -1;
+    const int64_t maxS = kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1;
+    for (int64_t S = 1; S <= maxS; S++) {
+      const int64_t U = units * S;
+      const double eff = (double)U / (double)(ceil_div(U, slots) * slots);
+      if (eff > best + 0.01) { best = eff; bestS = (int)S; }
+    }
+    return bestS;
+  };
+  if (use_v1) {
+    const int64_t nwaves = (int64_t)ctx->num_cu * 8;
+    const int bestS = pick_split(pw->ntp, nwaves);
+    const int64_t U = pw->ntp * bestS;
+    const unsigned grid = (unsigned)(ceil_div(U, 4) < 2 * ctx->num_cu ? ceil_div(U, 4) : 2 * ctx->num_cu);
+    TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG, kg0,
+               kg1, (int)pw->nst, pw->ntp, bestS, pw->acc);
+  } else {
+    const int Q4 = (int)ceil_div(pw->nst, 2);
+    const int64_t nbp = (int64_t)Q4 * (Q4 + 1) / 2;
+    const int bestS = pick_split(nbp, ctx->num_cu);
+    const int64_t U = nbp * bestS;
+    const unsigned grid = (unsigned)(U < ctx->num_cu ? U : ctx->num_cu);
+    TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel_v2, dim3(grid), dim3(512), 0, (const uint4*)v->T, v->KG, kg0,
+               kg1, (int)pw->nst, Q4, nbp, bestS, pw->acc);
   }
-  const int64_t U = pw->ntp * bestS;
-  const unsigned grid = (unsigned)(ceil_div(U, 4) < 2 * ctx->num_cu ? ceil_div(U, 4) : 2 * ctx->num_cu);
-  TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG, kg0,
-             kg1, (int)pw->nst, pw->ntp, bestS, pw->acc);
   TPG_CHECK_LAUNCH();
   return TPG_OK;
 }
