@@ -120,6 +120,97 @@ __global__ __launch_bounds__(256, 2) void tpg_pairwise_kernel(const uint4* __res
   }
 }
 
+// v3: v1's decomposition (one wave = one (I, jt) unit, 64 x 32 tile, 10 accumulator tiles) with the fragment
+// decode SOFTWARE-PIPELINED one K step ahead.  Measured (tools/ubench_mfma_dep.hip): an MFMA whose A/B
+// operands were written by VALU instructions 0 / 1 / 2 MFMAs earlier takes 47.6 / 41.6 / 36.4 cycles instead of
+// 32, and v1 (decode placed by the compiler right before its MFMAs) ran at ~41.8.  Here the three fragments of
+// K step s+1 are decoded into a second register set while the 10 MFMAs of step s issue (one MFMA, then six
+// decode VALU, enforced with sched_group_barrier), so every operand is ~10 MFMAs old when it is read.  The
+// second register set costs 36 VGPRs -> one wave per SIMD (v1 measured the same speed with one or two waves
+// per SIMD: a single wave already saturates what the issue port allows).  Operand words are prefetched two
+// 128-locus groups ahead.  What remains is VALU issue: ~6.5 VALU-class instructions per MFMA at ~4.7 cycles.
+#define SGB_MFMA 0x008
+#define SGB_VALU 0x002
+__global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel_v3(const uint4* __restrict__ T, int64_t KG,
+                                                                 int64_t kg_begin, int64_t kg_end, int nst,
+                                                                 int64_t ntp, int S, int32_t* __restrict__ acc_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t nunits = ntp * S;
+  const int64_t kgs = kg_end - kg_begin;
+
+  for (int64_t unit = wave; unit < nunits; unit += nwaves) {
+    int64_t tp = unit % ntp;
+    const int ks = (int)(unit / ntp);
+    const int64_t tp0 = tp;
+    int I = 0;
+    while (tp >= 2 * (nst - I)) { tp -= 2 * (nst - I); I++; }
+    const int jt = 2 * I + (int)tp;
+    const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
+
+    const uint4* pa0 = T + ((int64_t)(2 * I) * KG) * 64 + lane;
+    const uint4* pa1 = T + ((int64_t)(2 * I + 1) * KG) * 64 + lane;
+    const uint4* pb0 = T + ((int64_t)jt * KG) * 64 + lane;
+
+    v16i cV[2], cD[2], cH[2], cHV[2], cVH[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { cV[t][r] = 0; cD[t][r] = 0; cH[t][r] = 0; cHV[t][r] = 0; cVH[t][r] = 0; }
+
+    if (k0 < k1) {
+      const int64_t kl = k1 - 1;
+      uint4 c0 = pa0[k0 * 64], c1 = pa1[k0 * 64], cb = pb0[k0 * 64];                      // current group
+      const int64_t i1 = k0 + 1 < k1 ? k0 + 1 : kl;
+      uint4 n0 = pa0[i1 * 64], n1 = pa1[i1 * 64], nb = pb0[i1 * 64];                      // next group
+      Frag3 P[2][3];
+      P[0][0] = tpg_decode3(c0.x); P[0][1] = tpg_decode3(c1.x); P[0][2] = tpg_decode3(cb.x);
+      for (int64_t kg = k0; kg < k1; kg++) {
+        const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
+        const uint4 m0 = pa0[i2 * 64], m1 = pa1[i2 * 64], mb = pb0[i2 * 64];              // two groups ahead
+        // words of the 4 K steps of this group, followed by step 0 of the next group
+        const uint32_t wa0[5] = {c0.x, c0.y, c0.z, c0.w, n0.x}, wa1[5] = {c1.x, c1.y, c1.z, c1.w, n1.x};
+        const uint32_t wb[5] = {cb.x, cb.y, cb.z, cb.w, nb.x};
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int cur = s & 1, nx = cur ^ 1;
+          P[nx][0] = tpg_decode3(wa0[s + 1]);
+          P[nx][1] = tpg_decode3(wa1[s + 1]);
+          P[nx][2] = tpg_decode3(wb[s + 1]);
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            cV[t] = MFMA_I8(P[cur][t].v, P[cur][2].v, cV[t]);
+            cD[t] = MFMA_I8(P[cur][t].d, P[cur][2].d, cD[t]);
+            cH[t] = MFMA_I8(P[cur][t].h, P[cur][2].h, cH[t]);
+            cHV[t] = MFMA_I8(P[cur][t].h, P[cur][2].v, cHV[t]);
+            cVH[t] = MFMA_I8(P[cur][t].v, P[cur][2].h, cVH[t]);
+          }
+#pragma unroll
+          for (int q = 0; q < 10; q++) {
+            __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SGB_VALU, 6, 0);
+          }
+        }
+        c0 = n0; c1 = n1; cb = nb;
+        n0 = m0; n1 = m1; nb = mb;
+      }
+    }
+    int32_t* slab = acc_out + tp0 * TPG_PW_TILE_INTS + lane;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int o = (t * 16 + r) * 64;
+        atomicAdd(slab + 0 * 2048 + o, cV[t][r]);
+        atomicAdd(slab + 1 * 2048 + o, cD[t][r]);
+        atomicAdd(slab + 2 * 2048 + o, cH[t][r]);
+        atomicAdd(slab + 3 * 2048 + o, cHV[t][r]);
+        atomicAdd(slab + 4 * 2048 + o, cVH[t][r]);
+      }
+  }
+}
+
 // v2: the same arithmetic with the 2-bit -> byte spread of every fragment done ONCE per workgroup.
 // A workgroup of 8 waves (2 per SIMD) owns a 128 x 128 block (64-row super-tiles 2 I4, 2 I4 + 1 against
 // column tiles 4 J4 .. 4 J4 + 3); wave (ap, bt) computes exactly one (I, jt) unit of the v1 decomposition, so
@@ -267,7 +358,9 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
   if (col_begin == col_end) return TPG_OK;
   const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
   const int64_t kgs = kg1 - kg0;
-  static const bool use_v1 = getenv("TPG_PAIRWISE_V1") != nullptr;
+  static const char* impl_env = getenv("TPG_PAIRWISE_IMPL");
+  static const int impl = impl_env ? (impl_env[1] - '0') : 3;  // "v1" | "v2" | "v3" (default)
+  const bool use_v1 = impl == 1;
   auto pick_split = [&](int64_t units, int64_t slots) {
     // K split: make units * S fill the resident slots evenly, keep >= 8 K groups (1024 loci) per unit
     int bestS = 1;
@@ -286,6 +379,13 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
     const int64_t U = pw->ntp * bestS;
     const unsigned grid = (unsigned)(ceil_div(U, 4) < 2 * ctx->num_cu ? ceil_div(U, 4) : 2 * ctx->num_cu);
     TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG, kg0,
+               kg1, (int)pw->nst, pw->ntp, bestS, pw->acc);
+  } else if (impl == 3) {
+    const int64_t nwaves = (int64_t)ctx->num_cu * 4;  // one wave per SIMD
+    const int bestS = pick_split(pw->ntp, nwaves);
+    const int64_t U = pw->ntp * bestS;
+    const unsigned grid = (unsigned)(ceil_div(U, 4) < ctx->num_cu ? ceil_div(U, 4) : ctx->num_cu);
+    TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel_v3, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG, kg0,
                kg1, (int)pw->nst, pw->ntp, bestS, pw->acc);
   } else {
     const int Q4 = (int)ceil_div(pw->nst, 2);
