@@ -366,7 +366,7 @@ __global__ void tpg_pca_digits_kernel(const double* __restrict__ scale, const do
 
 // unit (ia, jb): A row tile ia (32 individuals, weighted digit planes) x B super-tile jb (PCA_TB row tiles,
 // plain dosage), jb >= ia / PCA_TB.  Combined int64 slab per unit: [tb][reg][lane].
-#define PCA_TB 2  // B row tiles per unit: 32 x 64 wave tile, 8 accumulator tiles, 2 waves per SIMD
+#define PCA_TB 4  // B row tiles per unit: 32 x 128 wave tile, 16 accumulator tiles (256 AGPRs), 1 wave per SIMD
 #define PCA_SLAB_INTS (PCA_TB * 16 * 64)
 
 __device__ __forceinline__ int64_t tpg_gram_unit_index(int nsb, int ia, int jb) {
@@ -374,13 +374,20 @@ __device__ __forceinline__ int64_t tpg_gram_unit_index(int nsb, int ia, int jb) 
   return PCA_TB * ((int64_t)a * nsb - ((int64_t)a * (a - 1)) / 2) + (int64_t)r * (nsb - a) + (jb - a);
 }
 
+// One wave per SIMD, 16 accumulator tiles in AGPRs.  The operands of K step s+1 (one weighted A fragment per
+// digit, PCA_TB dosage fragments) are decoded into a second register set while the TD * PCA_TB MFMAs of step s
+// issue (sched_group_barrier: one MFMA, then five VALU), because an MFMA that reads registers written by VALU
+// instructions just before it stalls (tools/ubench_mfma_dep.hip: 47.6 / 41.6 / 36.4 cycles at distance 0 / 1 / 2).
+// The digit table of a 128-locus group (TD * 256 B) goes through wave-private, double-buffered LDS.
+#define SGB_MFMA 0x008
+#define SGB_VALU 0x002
+#define SGB_DSR 0x100
 template <int TD>  // digits handled by this pass (<= 4); DG holds exactly these TD digits per locus
-__global__ __launch_bounds__(256, 2) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
+__global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
                                                               int64_t kg_begin, int64_t kg_end,
                                                               const uint4* __restrict__ DG, int t0, int nrt,
                                                               int nsb, int64_t nun, int S,
                                                               long long* __restrict__ slabs) {
-  // per wave: two buffers of one K group's digit table (TD * 256 B each)
   __shared__ __attribute__((aligned(16))) uint4 dgs[4][2][TD * 16];
   constexpr int TB = PCA_TB;
   const int lane = threadIdx.x & 63;
@@ -414,59 +421,89 @@ __global__ __launch_bounds__(256, 2) void tpg_pca_gram_kernel(const uint4* __res
         for (int q = 0; q < 16; q++) acc[t][tb][q] = 0;
 
     if (k0 < k1) {
+      const int64_t kl = k1 - 1;
       const bool dlane = lane < TD * 16;  // lanes that carry a piece of the digit table
-      uint4 nA = pa[k0 * 64], nB[TB], nD = make_uint4(0, 0, 0, 0);
+      // decode of one K step: word wA of the A tile, words wB[tb] of the B tiles, digits from LDS buffer `dbuf`, step s
+      v4i PA[2][TD], PB[2][TB];
+      auto decode_step = [&](int set, uint32_t wA, const uint32_t* wB, int dbuf, int sidx) {
+        uint32_t sel[4];
 #pragma unroll
-      for (int tb = 0; tb < TB; tb++) nB[tb] = pb[tb][k0 * 64];
-      if (dlane) nD = DG[k0 * (TD * 16) + lane];
-      int buf = 0;
-      for (int64_t kg = k0; kg < k1; kg++) {
-        const uint4 A = nA;
-        uint4 B[TB];
+        for (int k = 0; k < 4; k++) {
+          const uint32_t c = tpg_codes(wA, k);
+          const uint32_t base = (uint32_t)tpg_lut(0x0C04000Cu, c);   // genotype 1 -> D (S1), 2 -> 2D (S0), else 0
+          const uint32_t mv = (uint32_t)tpg_lut(0x00FFFF00u, c);
+          sel[k] = (0x03020100u & mv) | base;
+        }
+        const uint4* dl = &dgs[wv][dbuf][((sidx * 2 + h) * TD) * 2];
 #pragma unroll
-        for (int tb = 0; tb < TB; tb++) B[tb] = nB[tb];
-        if (dlane) dgs[wv][buf][lane] = nD;
-        const int64_t kn = (kg + 1 < k1) ? kg + 1 : kg;
-        nA = pa[kn * 64];
+        for (int t = 0; t < TD; t++) {
+          const uint4 d1 = dl[t * 2], d2 = dl[t * 2 + 1];
+          PA[set][t][0] = (int)__builtin_amdgcn_perm(d2.x, d1.x, sel[0]);
+          PA[set][t][1] = (int)__builtin_amdgcn_perm(d2.y, d1.y, sel[1]);
+          PA[set][t][2] = (int)__builtin_amdgcn_perm(d2.z, d1.z, sel[2]);
+          PA[set][t][3] = (int)__builtin_amdgcn_perm(d2.w, d1.w, sel[3]);
+        }
 #pragma unroll
-        for (int tb = 0; tb < TB; tb++) nB[tb] = pb[tb][kn * 64];
-        if (dlane) nD = DG[kn * (TD * 16) + lane];
+        for (int tb = 0; tb < TB; tb++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) PB[set][tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wB[tb], k));
+      };
+      auto lds_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's MFMAs
-        const uint32_t wa[4] = {A.x, A.y, A.z, A.w};
+      };
+
+      uint4 cA = pa[k0 * 64], cB[TB], nA, nB[TB], nD = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int tb = 0; tb < TB; tb++) cB[tb] = pb[tb][k0 * 64];
+      if (dlane) dgs[wv][0][lane] = DG[k0 * (TD * 16) + lane];
+      const int64_t i1 = k0 + 1 < k1 ? k0 + 1 : kl;
+      nA = pa[i1 * 64];
+#pragma unroll
+      for (int tb = 0; tb < TB; tb++) nB[tb] = pb[tb][i1 * 64];
+      if (dlane) nD = DG[i1 * (TD * 16) + lane];
+      lds_sync();
+      {
+        const uint32_t wB0[TB] = {cB[0].x, cB[1].x, cB[2].x, cB[3].x};
+        decode_step(0, cA.x, wB0, 0, 0);
+      }
+      int buf = 0;
+      for (int64_t kg = k0; kg < k1; kg++) {
+        // digits of the next group into the other LDS buffer (its last readers were this wave's previous group)
+        if (dlane) dgs[wv][buf ^ 1][lane] = nD;
+        const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
+        const uint4 mA = pa[i2 * 64];
+        uint4 mB[TB];
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++) mB[tb] = pb[tb][i2 * 64];
+        if (dlane) nD = DG[i2 * (TD * 16) + lane];
+        lds_sync();
+        const uint32_t wA[5] = {cA.x, cA.y, cA.z, cA.w, nA.x};
+        uint32_t wB[5][TB];
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++) {
+          wB[0][tb] = cB[tb].x; wB[1][tb] = cB[tb].y; wB[2][tb] = cB[tb].z; wB[3][tb] = cB[tb].w; wB[4][tb] = nB[tb].x;
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-          // selector per register: genotype 1 -> byte b of D (S1), genotype 2 -> byte b of 2D (S0), else 0
-          uint32_t sel[4];
+          const int cur = s & 1, nx = cur ^ 1;
+          // next step's operands: steps 1..3 of this group, or step 0 of the next group (other digit buffer)
+          decode_step(nx, wA[s + 1], wB[s + 1], s < 3 ? buf : (buf ^ 1), s < 3 ? s + 1 : 0);
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const uint32_t c = tpg_codes(wa[s], k);
-            const uint32_t base = (uint32_t)tpg_lut(0x0C04000Cu, c);
-            const uint32_t mv = (uint32_t)tpg_lut(0x00FFFF00u, c);
-            sel[k] = (0x03020100u & mv) | base;
-          }
-          v4i fb[TB];
+          for (int t = 0; t < TD; t++)
 #pragma unroll
-          for (int tb = 0; tb < TB; tb++) {
-            const uint32_t wb = s == 0 ? B[tb].x : s == 1 ? B[tb].y : s == 2 ? B[tb].z : B[tb].w;
+            for (int tb = 0; tb < TB; tb++) acc[t][tb] = MFMA_I8(PA[cur][t], PB[cur][tb], acc[t][tb]);
 #pragma unroll
-            for (int k = 0; k < 4; k++) fb[tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wb, k));
-          }
-          const uint4* dl = &dgs[wv][buf][((s * 2 + h) * TD) * 2];
-#pragma unroll
-          for (int t = 0; t < TD; t++) {
-            const uint4 d1 = dl[t * 2], d2 = dl[t * 2 + 1];
-            v4i fa;
-            fa[0] = (int)__builtin_amdgcn_perm(d2.x, d1.x, sel[0]);
-            fa[1] = (int)__builtin_amdgcn_perm(d2.y, d1.y, sel[1]);
-            fa[2] = (int)__builtin_amdgcn_perm(d2.z, d1.z, sel[2]);
-            fa[3] = (int)__builtin_amdgcn_perm(d2.w, d1.w, sel[3]);
-#pragma unroll
-            for (int tb = 0; tb < TB; tb++) acc[t][tb] = MFMA_I8(fa, fb[tb], acc[t][tb]);
+          for (int q = 0; q < TD * TB; q++) {
+            __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SGB_VALU, 5, 0);
+            if ((q & 1) == 0) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 1, 0);
           }
         }
+        cA = nA; nA = mA;
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++) { cB[tb] = nB[tb]; nB[tb] = mB[tb]; }
         buf ^= 1;
       }
     }
@@ -610,8 +647,8 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   if (e == hipSuccess) {
     TPG_LAUNCH(ctx, "pca_digits", tpg_pca_digits_kernel, dim3(1024), dim3(256), 0, d_scale, d_center, m, v->KG, F, T,
                d_DG, d_what, d_wc);
-    // K-split as in the pairwise kernel: fill the resident waves (2 waves per SIMD)
-    const int64_t nwaves = (int64_t)ctx->num_cu * 8;
+    // K-split as in the pairwise kernel: fill the resident waves (1 wave per SIMD)
+    const int64_t nwaves = (int64_t)ctx->num_cu * 4;
     int bestS = 1;
     double best = -1;
     const int64_t maxS = v->KG / 8 > 0 ? (v->KG / 8 < 96 ? v->KG / 8 : 96) : 1;
@@ -621,7 +658,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
       if (eff > best + 0.01) { best = eff; bestS = (int)S; }
     }
     const int64_t U = nun * bestS;
-    const unsigned grid = (unsigned)(ceil_div(U, 4) < 2 * ctx->num_cu ? ceil_div(U, 4) : 2 * ctx->num_cu);
+    const unsigned grid = (unsigned)(ceil_div(U, 4) < ctx->num_cu ? ceil_div(U, 4) : ctx->num_cu);
     int64_t pass_base = 0;  // dwords
     for (int t0 = 0; t0 < T; t0 += 4) {
       const int td = T - t0 < 4 ? T - t0 : 4;
