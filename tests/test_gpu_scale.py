@@ -1,0 +1,123 @@
+"""GPU, BASELINE.json config sizes: properties that pin the results without an O(N^2 M) CPU oracle.
+C2 = 1 000 individuals x 650 000 SNPs (pairwise_king + pairwise_grm on one MI355X)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, M, G = 1000, 650_000, 51
+
+
+@pytest.fixture(scope="module")
+def panel():
+    import tidypopgen_amd as tpg
+
+    X = tpg.FBM.synth(2, N, M, npop=G, miss=0.02, imputed_bytes=True)
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, N)
+    pw.accumulate(v)
+    return tpg, X, v, pw
+
+
+def test_pairwise_counts_tie_to_per_locus_counts(panel):
+    tpg, X, v, pw = panel
+    c = pw.counts()
+    cnt = tpg.loci_counts(v).astype(np.int64)  # n0, n1, n2, nNA per locus
+    typed_i = np.diag(c["as_den"])             # V_ii = loci typed in i
+    assert typed_i.sum() == cnt[:, :3].sum()   # sum over individuals == sum over loci
+    assert np.diag(c["as_num"]).sum() == (cnt[:, 0] + cnt[:, 2]).sum()       # D_ii = homozygous loci of i
+    assert np.diag(c["n_Aa_i"]).sum() == cnt[:, 1].sum()                     # A_ii = heterozygous loci of i
+    assert np.array_equal(np.diag(c["ibs"]), np.diag(c["ibs_valid"]))        # a genotype is IBS 2 with itself
+    for k in ("ibs", "ibs_valid", "king_num", "as_num", "as_den"):
+        assert np.array_equal(c[k], c[k].T), k
+    assert np.all(c["ibs"] <= c["ibs_valid"]) and np.all(c["ibs"] >= 0)
+    assert np.all(c["as_den"] <= np.minimum.outer(typed_i, typed_i))
+    assert np.all(np.abs(c["as_num"]) <= c["as_den"])
+    # N_Aa_i[i, j] counts loci where i is het and j typed: bounded by row het count and column typed count
+    assert np.all(c["n_Aa_i"] <= np.diag(c["n_Aa_i"])[:, None]) and np.all(c["n_Aa_i"] <= typed_i[None, :])
+
+
+def test_block_invariance_and_idempotence_at_scale(panel):
+    tpg, X, v, pw = panel
+    whole = pw.counts(("ibs", "king_num", "n_Aa_i", "as_num"))
+    pw2 = tpg.Pairwise(X.ctx, N)
+    edges = [0, 128 * 1000, 128 * 3500, M]
+    for a, b in zip(edges, edges[1:]):
+        pw2.accumulate(v, a, b)
+    parts = pw2.counts(("ibs", "king_num", "n_Aa_i", "as_num"))
+    for k in whole:
+        assert np.array_equal(whole[k], parts[k]), k
+    pw2.zero()
+    pw2.accumulate(v)
+    again = pw2.counts(("ibs",))
+    assert np.array_equal(again["ibs"], whole["ibs"])  # integer atomics: order independent, run-to-run identical
+
+
+def test_epilogue_semantics_at_scale(panel):
+    tpg, X, v, pw = panel
+    ep = pw.epilogues()
+    c = pw.counts()
+    assert np.allclose(np.diag(ep["king"]), 0.5)  # KING diagonal = 0.5 where the individual has a het locus
+    assert np.array_equal(ep["ibs"], c["ibs"] / c["ibs_valid"])
+    as_ = 0.5 * (1 + c["as_num"] / c["as_den"])
+    assert np.array_equal(ep["allele_sharing"], as_)
+    off = as_[~np.eye(N, dtype=bool)]
+    assert np.allclose(ep["grm"], 2 * (as_ - off.mean()) / (1 - off.mean()), rtol=1e-12, atol=1e-14)
+
+
+def test_per_locus_and_fst_at_scale(panel):
+    tpg, X, v, pw = panel
+    vv = tpg.View(X)  # CODE_012: imputed bytes stay missing
+    gid = (np.arange(N) % G).astype(np.int32)
+    cnt = tpg.loci_counts(vv).astype(np.int64)
+    f = tpg.alt_freq_dip_pseudo_cpp(vv, None, as_counts=True)
+    assert np.array_equal(f[:, 0], cnt[:, 1] + 2 * cnt[:, 2]) and np.array_equal(f[:, 1], 2 * cnt[:, :3].sum(axis=1))
+    ga = tpg.grouped_alt_freq_dip_pseudo_cpp(vv, gid, G, None, as_counts=True)
+    assert np.array_equal(ga[:, :G].sum(axis=1), f[:, 0]) and np.array_equal(ga[:, G:].sum(axis=1), f[:, 1])
+    gm = tpg.grouped_missingness_cpp(vv, gid, G)
+    assert np.array_equal(gm.sum(axis=1), cnt[:, 3])
+    # Fst: whole range == ratio of the sums of two halves (the quantity SNP shards exchange); swapping the
+    # populations of a pair does not change Hudson / WC84
+    import ctypes as C
+    from tidypopgen_amd import api
+
+    pairs = np.ascontiguousarray(tpg.combn2(G).T)
+    P = pairs.shape[0]
+    ploidy = np.full(N, 2.0)
+    for method, code in (("Hudson", 0), ("WC84", 2)):
+        tot = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method)["fst_tot"]
+        sn, sd = np.zeros(P), np.zeros(P)
+        tpg._lib.check(tpg._lib.lib.tpg_pairwise_pop_fst_sums(vv.ctx.h, vv.h, api._ptr(gid), C.c_int(G), api._ptr(ploidy),
+                                                              C.c_int(code), api._ptr(pairs), C.c_int(P), api._ptr(sn),
+                                                              api._ptr(sd)))
+        assert np.allclose(sn / sd, tot, rtol=1e-13)
+        swapped = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method, pairwise_combn=tpg.combn2(G)[::-1])["fst_tot"]
+        assert np.allclose(swapped, tot, rtol=1e-12)
+        assert np.all(np.isfinite(tot)) and np.all(tot > -0.01) and np.all(tot < 1)
+
+
+def test_pca_properties_at_scale(panel):
+    tpg, X, v, pw = panel
+    vi = tpg.View(X, code256=tpg.CODE_IMPUTE_PRED)
+    cnt = tpg.loci_counts(vi).astype(np.int64)
+    alt = cnt[:, 1] + 2 * cnt[:, 2]
+    cols = (np.where((alt > 0) & (alt < 2 * N))[0] + 1).astype(np.int32)
+    k = 10
+    r = tpg.gt_pca_partialSVD(X, None, cols, k=k)
+    vv = tpg.View(X, None, cols, code256=tpg.CODE_IMPUTE_PRED)
+    K = tpg.pca_gram(vv, r["center"], r["scale"])
+    assert np.array_equal(K, K.T)
+    assert np.trace(K) == pytest.approx(r["square_frobenius"], rel=1e-9)       # trace(ZZ') = ||Z||_F^2
+    assert np.allclose(K.sum(axis=0), 0, atol=1e-6 * np.abs(K).max())          # centered columns
+    u, d = r["u"], r["d"]
+    assert np.allclose(u.T @ u, np.eye(k), atol=1e-10)
+    assert np.all(np.diff(d) <= 0) and (d ** 2).sum() < r["square_frobenius"]
+    res = K @ u - u * d ** 2
+    assert np.abs(res).max() <= 1e-9 * d[0] ** 2                                # eigenpairs of the Gram matrix
+    lam = np.linalg.eigvalsh(K)[::-1][:k]
+    assert np.allclose(d ** 2, lam, rtol=1e-9)
+    # v = Z'u/d has orthonormal columns, and X v reproduces the scores u d (projection kernel, a12)
+    assert np.allclose(r["v"].T @ r["v"], np.eye(k), atol=1e-8)
+    XV, rss = tpg.fbm256_prod_and_rowSumsSq(X, None, cols, r["center"], r["scale"], r["v"], code256=tpg.CODE_IMPUTE_PRED)
+    assert np.allclose(XV, u * d, atol=1e-7 * d[0])
+    assert np.allclose(rss, np.diag(K), rtol=1e-9)
