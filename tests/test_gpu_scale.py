@@ -107,7 +107,8 @@ def test_pca_properties_at_scale(panel):
     vv = tpg.View(X, None, cols, code256=tpg.CODE_IMPUTE_PRED)
     K = tpg.pca_gram(vv, r["center"], r["scale"])
     assert np.array_equal(K, K.T)
-    assert np.trace(K) == pytest.approx(r["square_frobenius"], rel=1e-9)       # trace(ZZ') = ||Z||_F^2
+    # trace(ZZ') = ||Z||_F^2; the Gram matrix uses per-locus weights rounded to 2^-24 relative
+    assert np.trace(K) == pytest.approx(r["square_frobenius"], rel=1e-7)
     assert np.allclose(K.sum(axis=0), 0, atol=1e-6 * np.abs(K).max())          # centered columns
     u, d = r["u"], r["d"]
     assert np.allclose(u.T @ u, np.eye(k), atol=1e-10)
@@ -120,4 +121,4 @@ def test_pca_properties_at_scale(panel):
     assert np.allclose(r["v"].T @ r["v"], np.eye(k), atol=1e-8)
     XV, rss = tpg.fbm256_prod_and_rowSumsSq(X, None, cols, r["center"], r["scale"], r["v"], code256=tpg.CODE_IMPUTE_PRED)
     assert np.allclose(XV, u * d, atol=1e-7 * d[0])
-    assert np.allclose(rss, np.diag(K), rtol=1e-9)
+    assert np.allclose(rss, np.diag(K), rtol=1e-7)
