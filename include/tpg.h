@@ -77,6 +77,12 @@ int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int64_t ncol, 
 /* deterministic synthetic panel generated on the device (csrc/synth_common.h) */
 int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0, int npop,
                   uint32_t miss_thresh, int imputed_bytes, tpg_fbm** out);
+/* a PLINK .bed file (SNP-major, 2 bits per genotype) as the genotype store, without
+ * the 1-byte-per-genotype FBM in between (R/gen_tibble_bed.R:101-125 reads it into an FBM through bigsnpr's
+ * readbina; the byte each 2-bit code would have become -- 00,01,10,11 -> 2,3,1,0 -- is what code256 is applied
+ * to).  n / m are the line counts of the .fam / .bim files.  `bytes` is the payload after the 3-byte magic. */
+int tpg_fbm_open_bed(tpg_ctx* ctx, const char* path, int64_t n, int64_t m, tpg_fbm** out);
+int tpg_fbm_from_bed_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t n, int64_t m, tpg_fbm** out);
 int tpg_fbm_to_host(tpg_ctx* ctx, const tpg_fbm* fbm, uint8_t* bytes);
 void tpg_fbm_free(tpg_fbm* fbm);
 
@@ -94,6 +100,16 @@ int tpg_view_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* codes);
 /* genotype counts per locus: out is m x 4 int32 row-major {n0,n1,n2,nNA}
  * (the counts behind a4/a6/a11; also bigstatsr::big_counts, R/loci_missingness.R:109-122) */
 int tpg_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out);
+/* genotype counts per individual over the view's loci: out is n x 4 int32 row-major {n0,n1,n2,nNA} */
+int tpg_indiv_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out);
+/* SURVEY.md §8f(2) "next" rows, same sweeps on the same counts:
+ * gt_ind_hetero (src/gt_ind_hetero.cpp:11-42): out is the 2 x n integer matrix {n_het; n_na} (column-major);
+ * gt_pi_diploid (src/gt_pi_diploid.cpp:7-38): pi[m];
+ * gt_grouped_pi_diploid (src/gt_grouped_pi_diploid.cpp:7-42): pi and n, both m x G */
+int tpg_gt_ind_hetero(tpg_ctx* ctx, const tpg_view* v, int32_t* out);
+int tpg_gt_pi_diploid(tpg_ctx* ctx, const tpg_view* v, double* pi);
+int tpg_gt_grouped_pi_diploid(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups, double* pi,
+                              double* n);
 /* replaces alt_freq_dip_pseudo_cpp (src/alt_freq_dip_pseudo_cpp.cpp:8-58) for the whole
  * colInd at once (the big_apply block loop R/loci_alt_freq.R:351-359 collapses):
  * out m x 2 = {n_alt | freq, n_valid} */

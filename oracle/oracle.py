@@ -204,6 +204,32 @@ def grouped_summaries_dip_pseudo_cpp(fbm, rowInd, colInd, groupIds, ngroups, plo
     return dict(freq_alt=outs[0], freq_ref=outs[1], n=outs[2], het_obs=outs[3])
 
 
+def gt_ind_hetero(fbm, rowInd=None, colInd=None, code256=CODE_012):
+    """src/gt_ind_hetero.cpp:11-42 -> (2, n) int matrix"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    out = np.zeros((2, len(r)), dtype=np.int32, order="F")
+    lib().orc_gt_ind_hetero(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)), _p(out, C.c_int32))
+    return out
+
+
+def gt_pi_diploid(fbm, rowInd=None, colInd=None, code256=CODE_012):
+    """src/gt_pi_diploid.cpp:7-38"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    out = np.zeros(len(c))
+    lib().orc_gt_pi_diploid(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)), _d(out))
+    return out
+
+
+def gt_grouped_pi_diploid(fbm, rowInd, colInd, groupIds, ngroups, code256=CODE_012):
+    """src/gt_grouped_pi_diploid.cpp:7-42"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    gid = np.ascontiguousarray(groupIds, dtype=np.int32)
+    pi, n = np.zeros((len(c), ngroups), order="F"), np.zeros((len(c), ngroups), order="F")
+    lib().orc_gt_grouped_pi_diploid(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)), _p(gid, C.c_int32),
+                                    C.c_int(ngroups), _d(pi), _d(n))
+    return dict(pi=pi, n=n)
+
+
 def _fst_loop(fn, pairs1, m, mats, by_locus, return_num_dem):
     pairs1 = np.ascontiguousarray(np.asarray(pairs1, dtype=np.int32).T)  # (P, 2) rows = (pop1, pop2)
     P = pairs1.shape[0]

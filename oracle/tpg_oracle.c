@@ -231,6 +231,49 @@ void orc_grouped_summaries_dip_pseudo(const uint8_t* fbm, int64_t nrow, const in
   free(mult);
 }
 
+/* src/gt_ind_hetero.cpp:11-42.  out is 2 x n column-major ints: row 0 het, row 1 na */
+void orc_gt_ind_hetero(const uint8_t* fbm, int64_t nrow, const int32_t* rowInd, int n, const int32_t* colInd,
+                       int m, const double* code256, int32_t* out) {
+  memset(out, 0, sizeof(int32_t) * 2 * (size_t)n);
+  for (int j = 0; j < m; j++)
+    for (int i = 0; i < n; i++) {
+      double x = code256[FBM(i, j)];
+      if (x > -1) { if (x == 1) out[2 * (size_t)i] += 1; }
+      else out[2 * (size_t)i + 1] += 1;
+    }
+}
+
+/* src/gt_pi_diploid.cpp:7-38 */
+void orc_gt_pi_diploid(const uint8_t* fbm, int64_t nrow, const int32_t* rowInd, int n, const int32_t* colInd,
+                       int m, const double* code256, double* pi) {
+  for (int j = 0; j < m; j++) {
+    double cnt = 0, valid = 0;
+    for (int i = 0; i < n; i++) {
+      double x = code256[FBM(i, j)];
+      if (x > -1) { cnt += x; valid += 2; }
+    }
+    pi[j] = (valid > 0) ? (cnt * (valid - cnt) / (valid * (valid - 1) / 2)) : NAN;
+  }
+}
+
+/* src/gt_grouped_pi_diploid.cpp:7-42.  pi and n are m x G column-major */
+void orc_gt_grouped_pi_diploid(const uint8_t* fbm, int64_t nrow, const int32_t* rowInd, int n,
+                               const int32_t* colInd, int m, const double* code256, const int32_t* groupIds,
+                               int ngroups, double* pi, double* valid) {
+  memset(pi, 0, sizeof(double) * (size_t)m * (size_t)ngroups);
+  memset(valid, 0, sizeof(double) * (size_t)m * (size_t)ngroups);
+  for (int j = 0; j < m; j++) {
+    for (int i = 0; i < n; i++) {
+      double x = code256[FBM(i, j)];
+      if (x > -1) { pi[(size_t)j + (size_t)groupIds[i] * m] += x; valid[(size_t)j + (size_t)groupIds[i] * m] += 2; }
+    }
+    for (int g = 0; g < ngroups; g++) {
+      size_t o = (size_t)j + (size_t)g * m;
+      pi[o] = (pi[o] * (valid[o] - pi[o]) / (valid[o] * (valid[o] - 1) / 2));
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 /* Fst pair loops.  pairs1 is 2 x P column-major, 1-based doubles in R; here
  * int32 1-based.  Inputs are m x G column-major.  fst_tot has P entries.

@@ -46,6 +46,35 @@ def test_pack_roundtrip_and_views(tpg, n, m):
     assert np.array_equal(tpg.View(Xi, code256=None).unpack(), np.where(fbi > 2, 3, fbi))
 
 
+def test_direct_bed_ingest(tpg):
+    # the .bed payload is the store; views, counts and IBS equal the FBM route
+    import os
+
+    for name, n, m in (("related/families", 12, 961), ("lobster/lobster", 176, 79)):
+        path = os.path.join(fx.GOLDEN, name + ".bed")
+        fbm = orc.read_bed(path, n, m)
+        X = tpg.FBM.open_bed(path, n, m)
+        assert np.array_equal(tpg.View(X).unpack(), fbm)
+        rows = np.arange(n, 0, -2).astype(np.int32)
+        cols = np.arange(1, m + 1, 3).astype(np.int32)
+        assert np.array_equal(tpg.View(X, rows, cols).unpack(), fbm[np.ix_(rows - 1, cols - 1)])
+        assert np.array_equal(tpg.loci_alt_freq(X, as_counts=True), orc.loci_alt_freq(fbm, as_counts=True))
+    fam = tpg.FBM.open_bed(os.path.join(fx.GOLDEN, "related/families.bed"), 12, 961)
+    assert np.array_equal(np.round(tpg.snp_ibs(fam), 6), fx.plink_mibs())  # PLINK golden straight from the .bed
+    # a larger synthetic .bed (exercises the 128-individual fast path): encode an FBM as .bed and compare
+    fbm = orc.synth_fbm(8, 300, 700, npop=3, miss=0.1)
+    enc = np.array([3, 2, 0, 1], dtype=np.uint8)[fbm]  # FBM byte 0,1,2,3 -> bed code 11,10,00,01
+    pad = np.vstack([enc, np.zeros(((-300) % 4, 700), dtype=np.uint8)])
+    bed = (pad[0::4] | (pad[1::4] << 2) | (pad[2::4] << 4) | (pad[3::4] << 6)).T.copy()  # (m, bpl)
+    tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), "tpg_test.bed")
+    with open(tmp, "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]) + bed.tobytes())
+    assert np.array_equal(tpg.View(tpg.FBM.open_bed(tmp, 300, 700)).unpack(), fbm)
+    with pytest.raises(tpg._lib.TpgError):
+        tpg.FBM.open_bed(tmp, 300, 701)  # file too small
+    os.remove(tmp)
+
+
 def test_view_errors(tpg):
     X = tpg.FBM.from_numpy(orc.synth_fbm(1, 10, 20, npop=2))
     with pytest.raises(tpg._lib.TpgError):
@@ -121,6 +150,26 @@ def test_per_locus_and_grouped_bit_exact(tpg, n, m, G, hap):
     for c in range(3):
         assert np.array_equal(cnt[:, c], (fbm == c).sum(axis=0))
     assert np.array_equal(cnt[:, 3], (fbm > 2).sum(axis=0))
+
+
+def test_next_rows_ind_hetero_and_pi(tpg):
+    # gt_ind_hetero, gt_pi_diploid, gt_grouped_pi_diploid -- bit exact
+    n, m, G = 333, 2100, 7
+    fbm = orc.synth_fbm(23, n, m, npop=G, miss=0.07)
+    fbm[:, 5] = 3  # an all-missing locus -> NA
+    X = tpg.FBM.from_numpy(fbm)
+    rows = np.random.default_rng(5).permutation(n)[:200].astype(np.int32) + 1
+    v = tpg.View(X, rows, None)
+    gid = (np.arange(200) % G).astype(np.int32)
+    assert np.array_equal(tpg.gt_ind_hetero(v), orc.gt_ind_hetero(fbm, rows, None))
+    ic = tpg.indiv_counts(v)
+    sub = fbm[rows - 1]
+    for c in range(3):
+        assert np.array_equal(ic[:, c], (sub == c).sum(axis=1))
+    assert np.array_equal(tpg.gt_pi_diploid(v), orc.gt_pi_diploid(fbm, rows, None), equal_nan=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        a, b = tpg.gt_grouped_pi_diploid(v, gid, G), orc.gt_grouped_pi_diploid(fbm, rows, None, gid, G)
+    assert np.array_equal(a["pi"], b["pi"], equal_nan=True) and np.array_equal(a["n"], b["n"])
 
 
 # ---------------------------------------------------------------- pairwise individual matrices

@@ -138,6 +138,14 @@ class FBM:
         return cls(ctx, h, nrow, ncol, code256)
 
     @classmethod
+    def open_bed(cls, path: str, n: int, m: int, ctx: Optional[Context] = None, code256=None) -> "FBM":
+        """A PLINK .bed file as the genotype store (n, m = line counts of the .fam / .bim files)"""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib.tpg_fbm_open_bed(ctx.h, path.encode(), C.c_int64(n), C.c_int64(m), C.byref(h)))
+        return cls(ctx, h, n, m, code256)
+
+    @classmethod
     def synth(cls, seed: int, nrow: int, ncol: int, j0: int = 0, npop: int = 51, miss: float = 0.02,
               imputed_bytes: bool = False, ctx: Optional[Context] = None, code256=None) -> "FBM":
         ctx = ctx or default_context()
@@ -346,6 +354,34 @@ def loci_counts(v: View) -> np.ndarray:
     out = np.zeros((v.m, 4), dtype=np.int32)
     check(lib.tpg_loci_counts(v.ctx.h, v.h, _ptr(out)))
     return out
+
+
+def indiv_counts(v: View) -> np.ndarray:
+    out = np.zeros((v.n, 4), dtype=np.int32)
+    check(lib.tpg_indiv_counts(v.ctx.h, v.h, _ptr(out)))
+    return out
+
+
+def gt_ind_hetero(v: View) -> np.ndarray:
+    """src/gt_ind_hetero.cpp:11-42 -> (2, n) integer matrix: row 0 heterozygous loci, row 1 missing loci"""
+    out = np.zeros((2, v.n), dtype=np.int32, order="F")
+    check(lib.tpg_gt_ind_hetero(v.ctx.h, v.h, _ptr(out)))
+    return out
+
+
+def gt_pi_diploid(v: View) -> np.ndarray:
+    """src/gt_pi_diploid.cpp:7-38"""
+    out = np.zeros(v.m)
+    check(lib.tpg_gt_pi_diploid(v.ctx.h, v.h, _ptr(out)))
+    return out
+
+
+def gt_grouped_pi_diploid(v: View, groupIds, ngroups: int) -> dict:
+    """src/gt_grouped_pi_diploid.cpp:7-42"""
+    pi, n = np.zeros((v.m, ngroups), order="F"), np.zeros((v.m, ngroups), order="F")
+    gid = _i32(groupIds)
+    check(lib.tpg_gt_grouped_pi_diploid(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pi), _ptr(n)))
+    return dict(pi=pi, n=n)
 
 
 def alt_freq_dip_pseudo_cpp(v: View, ploidy=None, as_counts: bool = False) -> np.ndarray:

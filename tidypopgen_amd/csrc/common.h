@@ -92,6 +92,7 @@ struct tpg_fbm {
   tpg_ctx* ctx;
   uint8_t* d_bytes;
   int64_t nrow, ncol;
+  int64_t bed_bpl = 0;  // > 0: d_bytes is a PLINK .bed payload with this many bytes per SNP (4 genotypes per byte)
 };
 
 // class-wise counts via MFMA: cls[n] in [0, nclass); cnt[3][Mpad][Cpad] (het, hom-alt, valid)

@@ -71,6 +71,70 @@ extern "C" int tpg_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out) {
   return o.commit(ctx);
 }
 
+// per-individual counts: the same kernel on the individual-tiled layout (rows = individuals, contraction over loci)
+extern "C" int tpg_indiv_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out) {
+  TPG_REQUIRE(ctx && v && out, TPG_EINVAL, "null argument");
+  OutBuf o;
+  TPG_TRY(o.init(out, sizeof(int32_t) * 4 * (size_t)v->n));
+  const int64_t n_rt = v->Q * 4;
+  TPG_LAUNCH(ctx, "indiv_counts", tpg_loci_counts_kernel, dim3((unsigned)ceil_div(n_rt, 4)), dim3(256), 0,
+             (const uint4*)v->T, n_rt, v->KG, v->m, v->n, o.dev<int4>());
+  TPG_CHECK_LAUNCH();
+  return o.commit(ctx);
+}
+
+// src/gt_ind_hetero.cpp:11-42: row 0 = heterozygous loci, row 1 = missing loci, per individual
+__global__ void tpg_ind_hetero_kernel(const int4* __restrict__ counts, int64_t n, int32_t* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    out[2 * i] = counts[i].y;
+    out[2 * i + 1] = counts[i].w;
+  }
+}
+
+extern "C" int tpg_gt_ind_hetero(tpg_ctx* ctx, const tpg_view* v, int32_t* out) {
+  TPG_REQUIRE(ctx && v && out, TPG_EINVAL, "null argument");
+  int32_t* d_counts = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->n));
+  int rc = tpg_indiv_counts(ctx, v, d_counts);
+  OutBuf o;
+  if (rc == TPG_OK) rc = o.init(out, sizeof(int32_t) * 2 * (size_t)v->n);
+  if (rc == TPG_OK) {
+    TPG_LAUNCH(ctx, "ind_hetero", tpg_ind_hetero_kernel, dim3(256), dim3(256), 0, (const int4*)d_counts, v->n,
+               o.dev<int32_t>());
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { tpg_set_error("ind_hetero: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  }
+  tpg_pfree(d_counts);
+  TPG_TRY(rc);
+  return o.commit(ctx);
+}
+
+// src/gt_pi_diploid.cpp:28-34
+__global__ void tpg_pi_kernel(const int4* __restrict__ counts, int64_t m, double* __restrict__ pi) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = counts[j];
+    const double cnt = (double)(c.y + 2 * c.z), valid = (double)(2 * (c.x + c.y + c.z));
+    pi[j] = valid > 0 ? (cnt * (valid - cnt) / (valid * (valid - 1) / 2)) : __longlong_as_double(0x7FF8000000000000ll);
+  }
+}
+
+extern "C" int tpg_gt_pi_diploid(tpg_ctx* ctx, const tpg_view* v, double* pi) {
+  TPG_REQUIRE(ctx && v && pi, TPG_EINVAL, "null argument");
+  int32_t* d_counts = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
+  int rc = tpg_launch_loci_counts(ctx, v, d_counts);
+  OutBuf o;
+  if (rc == TPG_OK) rc = o.init(pi, sizeof(double) * (size_t)v->m);
+  if (rc == TPG_OK) {
+    TPG_LAUNCH(ctx, "pi_diploid", tpg_pi_kernel, dim3(1024), dim3(256), 0, (const int4*)d_counts, v->m, o.dev<double>());
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { tpg_set_error("pi: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  }
+  tpg_pfree(d_counts);
+  TPG_TRY(rc);
+  return o.commit(ctx);
+}
+
 // ---------------------------------------------------------------------------
 // one-hot B fragments: OH[q][s][gt][lane = (c,h)][16 B], element e <-> individual
 // 128 q + 32 s + 16 h + e, byte = (cls[individual] == 32 gt + c)
@@ -321,6 +385,40 @@ __global__ __launch_bounds__(256) void tpg_grouped_finalize_kernel(const int32_t
       }
     }
   }
+}
+
+// src/gt_grouped_pi_diploid.cpp:24-38: per locus x group, pi = x (v - x) / (v (v - 1) / 2), no NA guard
+__global__ void tpg_grouped_pi_kernel(const int32_t* __restrict__ cnt, int64_t Mpad, int Cpad, int64_t m, int G,
+                                      double* __restrict__ pi, double* __restrict__ nvalid) {
+  const int64_t total = m * G;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % G);  // class index on the lanes: contiguous count reads
+    const int64_t j = idx / G;
+    const GroupVals gv = tpg_group_vals(cnt, Mpad, Cpad, j, g, 0);
+    pi[j + (int64_t)g * m] = gv.alt * (gv.valid - gv.alt) / (gv.valid * (gv.valid - 1) / 2);
+    if (nvalid) nvalid[j + (int64_t)g * m] = gv.valid;
+  }
+}
+
+extern "C" int tpg_gt_grouped_pi_diploid(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                                         double* pi, double* n) {
+  TPG_REQUIRE(ctx && v && groupIds0 && pi, TPG_EINVAL, "null argument");
+  ClassPlan cp;
+  TPG_TRY(make_class_plan(v, groupIds0, ngroups, nullptr, &cp));
+  GroupedCounts gc;
+  TPG_TRY(tpg_grouped_counts(ctx, v, cp.cls.data(), cp.nclass, &gc));
+  const size_t bytes = sizeof(double) * (size_t)v->m * (size_t)ngroups;
+  OutBuf op, on;
+  TPG_TRY(op.init(pi, bytes));
+  if (n) TPG_TRY(on.init(n, bytes));
+  TPG_LAUNCH(ctx, "grouped_pi", tpg_grouped_pi_kernel, dim3(2048), dim3(256), 0, (const int32_t*)gc.cnt, gc.Mpad, gc.Cpad,
+             v->m, ngroups, op.dev<double>(), on.dev<double>());
+  TPG_CHECK_LAUNCH();
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  TPG_TRY(op.commit(ctx));
+  if (n) TPG_TRY(on.commit(ctx));
+  return TPG_OK;
 }
 
 // ungrouped diploid: counts (m x 4) -> m x 2 doubles

@@ -14,7 +14,12 @@
 #define TILE 128
 #define LDS_STRIDE 132  // bytes per locus row in LDS (128 + 4 pad)
 
-__global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict__ fbm, int64_t nrow,
+// the FBM byte bigsnpr writes for a .bed 2-bit code (getCode(), recalled): 00,01,10,11 -> 2,3,1,0
+__device__ __forceinline__ uint8_t tpg_bed_byte(uint8_t packed, int slot) {
+  return (uint8_t)((0x00010302u >> (8 * ((packed >> (2 * slot)) & 3))) & 0xFF);
+}
+
+__global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict__ fbm, int64_t nrow, int64_t bed_bpl,
                                                        const int32_t* __restrict__ rows,
                                                        const int32_t* __restrict__ cols, uint8_t* lut_and_flag,
                                                        int64_t n, int64_t m, int64_t Q, int64_t KG,
@@ -31,9 +36,28 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
   bool bad = false;
   // fast path: identity rows, whole tile inside the FBM rows, columns 8-byte aligned -> 8-byte loads,
   // 8 independent loads per thread in flight
-  const bool fast = (rows == nullptr) && (bi * TILE + TILE <= n) && ((nrow & 7) == 0) &&
+  const bool fast = (bed_bpl == 0) && (rows == nullptr) && (bi * TILE + TILE <= n) && ((nrow & 7) == 0) &&
                     ((((uintptr_t)fbm) & 7) == 0);
-  if (fast) {
+  const bool bed_fast = (bed_bpl > 0) && (rows == nullptr) && (bi * TILE + TILE <= n);
+  if (bed_fast) {
+    // .bed: 128 individuals of one SNP = 32 contiguous bytes; 8 SNPs per pass, byte index on the lanes
+    const int b = tid & 31;
+#pragma unroll 4
+    for (int l = tid >> 5; l < TILE; l += 8) {
+      const int64_t j = bj * TILE + l;
+      uint8_t pk = 0x55;  // four "missing" codes (01)
+      if (j < m) {
+        const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
+        pk = fbm[bi * (TILE / 4) + b + src_col * bed_bpl];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        uint8_t c = j < m ? lut[tpg_bed_byte(pk, q)] : (uint8_t)3;
+        if (c == 0xFF) { bad = true; c = 3; }
+        codes[l * LDS_STRIDE + 4 * b + q] = c;
+      }
+    }
+  } else if (fast) {
     const int c8 = tid & 15;  // 8-byte chunk of the tile's 128 individuals
     uint2 v[8];
 #pragma unroll
@@ -68,7 +92,9 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
       uint8_t c = 3;
       if (src_row >= 0 && j < m) {
         const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
-        c = lut[fbm[src_row + src_col * nrow]];
+        const uint8_t raw = bed_bpl ? tpg_bed_byte(fbm[(src_row >> 2) + src_col * bed_bpl], (int)(src_row & 3))
+                                    : fbm[src_row + src_col * nrow];
+        c = lut[raw];
         if (c == 0xFF) { bad = true; c = 3; }
       }
       codes[l * LDS_STRIDE + ii] = c;
@@ -107,7 +133,7 @@ int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, con
                     const uint8_t* d_lut, tpg_view* v) {
   TPG_REQUIRE(v->KG < 2147483647ll && v->Q <= 65535, TPG_EINVAL, "view too large for the pack grid");
   dim3 grid((unsigned)v->KG, (unsigned)v->Q);
-  TPG_LAUNCH(ctx, "pack", tpg_pack_kernel, grid, dim3(256), 0, fbm->d_bytes, fbm->nrow, d_rows, d_cols,
+  TPG_LAUNCH(ctx, "pack", tpg_pack_kernel, grid, dim3(256), 0, fbm->d_bytes, fbm->nrow, fbm->bed_bpl, d_rows, d_cols,
              (uint8_t*)d_lut, v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L);
   TPG_CHECK_LAUNCH();
   return TPG_OK;

@@ -345,8 +345,53 @@ extern "C" int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t 
   return TPG_OK;
 }
 
+extern "C" int tpg_fbm_from_bed_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t n, int64_t m, tpg_fbm** out) {
+  TPG_REQUIRE(ctx && bytes && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty .bed (%lld x %lld)", (long long)n, (long long)m);
+  TPG_HIP(hipSetDevice(ctx->device));
+  const int64_t bpl = (n + 3) / 4;
+  tpg_fbm* f = new tpg_fbm{ctx, nullptr, n, m};
+  f->bed_bpl = bpl;
+  const size_t sz = (size_t)bpl * (size_t)m;
+  hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
+  if (e != hipSuccess) { delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
+  e = hipMemcpyAsync(f->d_bytes, bytes, sz, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { (void)hipFree(f->d_bytes); delete f; tpg_set_error(".bed upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  *out = f;
+  return TPG_OK;
+}
+
+extern "C" int tpg_fbm_open_bed(tpg_ctx* ctx, const char* path, int64_t n, int64_t m, tpg_fbm** out) {
+  TPG_REQUIRE(ctx && path && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty .bed (%lld x %lld)", (long long)n, (long long)m);
+  int fd = open(path, O_RDONLY);
+  TPG_REQUIRE(fd >= 0, TPG_EINVAL, "cannot open %s", path);
+  const size_t sz = 3 + (size_t)((n + 3) / 4) * (size_t)m;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < sz) {
+    close(fd);
+    tpg_set_error("%s is smaller than a %lld x %lld .bed", path, (long long)n, (long long)m);
+    return TPG_EINVAL;
+  }
+  void* p = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  TPG_REQUIRE(p != MAP_FAILED, TPG_EINVAL, "mmap of %s failed", path);
+  const uint8_t* b = (const uint8_t*)p;
+  int rc;
+  if (b[0] != 0x6C || b[1] != 0x1B || b[2] != 0x01) {
+    tpg_set_error("%s is not a SNP-major PLINK .bed (magic %02x %02x %02x)", path, b[0], b[1], b[2]);
+    rc = TPG_EINVAL;
+  } else {
+    rc = tpg_fbm_from_bed_host(ctx, b + 3, n, m, out);
+  }
+  munmap(p, sz);
+  return rc;
+}
+
 extern "C" int tpg_fbm_to_host(tpg_ctx* ctx, const tpg_fbm* fbm, uint8_t* bytes) {
   TPG_REQUIRE(ctx && fbm && bytes, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(fbm->bed_bpl == 0, TPG_EUNSUPPORTED, "a .bed store has no FBM bytes; unpack a view instead");
   TPG_HIP(hipMemcpyAsync(bytes, fbm->d_bytes, (size_t)fbm->nrow * (size_t)fbm->ncol, hipMemcpyDeviceToHost, ctx->stream));
   TPG_HIP(hipStreamSynchronize(ctx->stream));
   return TPG_OK;
