@@ -21,15 +21,33 @@
 
 #define FST_NAN __longlong_as_double(0x7FF8000000000000ll)
 
-template <int METHOD>
-__device__ __forceinline__ void fst_terms(double n1, double p1, double h1, double n2, double p2, double h2,
-                                          double& num, double& den) {
+// e1 / e2: the per-(locus, population) term staged once per locus chunk -- Hudson: p q / (n - 1), hoisted out of
+// the pair loop with its operation order unchanged (src/pairwise_fst_hudson_loop.cpp:28-29), so values stay
+// bit-identical.  FAST (only when no by-locus output is requested): WC84 with 3 divisions instead of 8
+// (reciprocals reused); the ratio of sums moves by ~1e-15 relative.
+template <int METHOD, bool FAST>
+__device__ __forceinline__ void fst_terms(double n1, double p1, double h1, double e1, double n2, double p2, double h2,
+                                          double e2, double& num, double& den) {
   if (METHOD == TPG_FST_HUDSON) {
     // src/pairwise_fst_hudson_loop.cpp:27-32
     const double q1 = 1 - p1, q2 = 1 - p2;  // freq_ref = 1 - freq_alt (grouped_summaries :53)
     const double d = p1 - p2;
-    num = d * d - (p1 * q1) / (n1 - 1) - (p2 * q2) / (n2 - 1);
+    num = d * d - e1 - e2;
     den = p1 * q2 + p2 * q1;
+  } else if (METHOD == TPG_FST_WC84 && FAST) {
+    const double ni1 = n1 * 0.5, ni2 = n2 * 0.5;
+    const double nt = ni1 + ni2, inv_nt = 1.0 / nt;
+    const double sum_sq = ni1 * ni1 + ni2 * ni2;
+    const double n_bar = nt * 0.5;
+    const double n_c = nt - sum_sq * inv_nt;
+    const double p_bar = (p1 * ni1 + p2 * ni2) * inv_nt, h_bar = (h1 * ni1 + h2 * ni2) * inv_nt;
+    const double s2 = ((p1 - p_bar) * (p1 - p_bar) * ni1 + (p2 - p_bar) * (p2 - p_bar) * ni2) * (2.0 * inv_nt);
+    const double inv_nb1 = 1.0 / (n_bar - 1.0);
+    const double core = p_bar * (1 - p_bar) - 0.5 * s2;
+    const double a = n_bar / n_c * (s2 - inv_nb1 * (core - h_bar * 0.25));
+    const double b = n_bar * inv_nb1 * (core - ((2 * n_bar - 1.0) * (0.5 * inv_nt)) * h_bar);
+    num = a;
+    den = a + b + h_bar * 0.5;
   } else if (METHOD == TPG_FST_WC84) {
     // src/pairwise_fst_wc84_loop.cpp:41-99 with r = 2
     const double r = 2.0;
@@ -92,7 +110,7 @@ struct FstSrc {
   const double* h;
 };
 
-template <int METHOD>
+template <int METHOD, bool FAST>
 __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int G, int LB,
                                                       const int32_t* __restrict__ pairs0, int P, int by_locus,
                                                       int return_num_dem, double* __restrict__ part,
@@ -101,6 +119,7 @@ __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int
   double* sh_n = sh;
   double* sh_p = sh + (size_t)LB * G;
   double* sh_h = sh + 2 * (size_t)LB * G;
+  double* sh_e = sh + 3 * (size_t)LB * G;
   const int pi = blockIdx.y * 256 + threadIdx.x;
   int g1 = 0, g2 = 0;
   if (pi < P) { g1 = pairs0[2 * pi]; g2 = pairs0[2 * pi + 1]; }
@@ -137,6 +156,7 @@ __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int
         }
       }
       sh_n[idx] = vn; sh_p[idx] = vp; sh_h[idx] = vh;
+      if (METHOD == TPG_FST_HUDSON) sh_e[idx] = (vp * (1 - vp)) / (vn - 1);  // (p q) / (n - 1), once per population
     }
     __syncthreads();
     if (pi < P) {
@@ -144,7 +164,8 @@ __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int
       for (int l = 0; l < lmax; l++) {
         const int o1 = l * G + g1, o2 = l * G + g2;
         double num, den;
-        fst_terms<METHOD>(sh_n[o1], sh_p[o1], sh_h[o1], sh_n[o2], sh_p[o2], sh_h[o2], num, den);
+        fst_terms<METHOD, FAST>(sh_n[o1], sh_p[o1], sh_h[o1], METHOD == TPG_FST_HUDSON ? sh_e[o1] : 0.0, sh_n[o2],
+                                sh_p[o2], sh_h[o2], METHOD == TPG_FST_HUDSON ? sh_e[o2] : 0.0, num, den);
         if (by_locus) {
           const int64_t o = (j0 + l) + (int64_t)pi * m;
           if (!return_num_dem) out_a[o] = num / den;
@@ -189,9 +210,10 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   InBuf pb;
   TPG_TRY(pb.init(ctx, p0.data(), sizeof(int32_t) * 2 * (size_t)P));
   int LB = 32;
-  while (LB > 1 && (size_t)LB * G * 3 * sizeof(double) > 96 * 1024) LB /= 2;
-  TPG_REQUIRE((size_t)LB * G * 3 * sizeof(double) <= 150 * 1024, TPG_EUNSUPPORTED, "too many populations (%d)", G);
-  const size_t shmem = (size_t)LB * G * 3 * sizeof(double);
+  while (LB > 1 && (size_t)LB * G * 4 * sizeof(double) > 96 * 1024) LB /= 2;
+  TPG_REQUIRE((size_t)LB * G * 4 * sizeof(double) <= 150 * 1024, TPG_EUNSUPPORTED, "too many populations (%d)", G);
+  const size_t shmem = (size_t)LB * G * 4 * sizeof(double);
+  const bool fast = !by_locus;  // exact statement order whenever per-locus values are returned
   const int64_t nchunks = ceil_div(m, LB);
   const int ypass = (int)ceil_div(P, 256);
   int nblocks = (int)(nchunks < 4 * ctx->num_cu ? nchunks : 4 * ctx->num_cu);
@@ -207,15 +229,17 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   if (rc == TPG_OK && return_num_dem) rc = ob.init(out_b, mp);
   if (rc == TPG_OK) {
     dim3 grid((unsigned)nblocks, (unsigned)ypass);
-#define FST_LAUNCH(M, NAME)                                                                                      \
+#define FST_LAUNCH(M, F, NAME)                                                                                   \
   do {                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)tpg_fst_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-    TPG_LAUNCH(ctx, NAME, tpg_fst_kernel<M>, grid, dim3(256), shmem, src, m, G, LB, pb.dev<int32_t>(), P, by_locus, \
-               return_num_dem, d_part, oa.dev<double>(), ob.dev<double>());                                      \
+    (void)hipFuncSetAttribute((const void*)tpg_fst_kernel<M, F>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                              (int)shmem);                                                                       \
+    TPG_LAUNCH(ctx, NAME, (tpg_fst_kernel<M, F>), grid, dim3(256), shmem, src, m, G, LB, pb.dev<int32_t>(), P,    \
+               by_locus, return_num_dem, d_part, oa.dev<double>(), ob.dev<double>());                            \
   } while (0)
-    if (method == TPG_FST_HUDSON) FST_LAUNCH(TPG_FST_HUDSON, "fst_hudson");
-    else if (method == TPG_FST_WC84) FST_LAUNCH(TPG_FST_WC84, "fst_wc84");
-    else FST_LAUNCH(TPG_FST_NEI87, "fst_nei87");
+    if (method == TPG_FST_HUDSON) FST_LAUNCH(TPG_FST_HUDSON, false, "fst_hudson");
+    else if (method == TPG_FST_WC84 && fast) FST_LAUNCH(TPG_FST_WC84, true, "fst_wc84");
+    else if (method == TPG_FST_WC84) FST_LAUNCH(TPG_FST_WC84, false, "fst_wc84");
+    else FST_LAUNCH(TPG_FST_NEI87, false, "fst_nei87");
 #undef FST_LAUNCH
     if (fst_tot || sum_num)
       TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, d_part,
