@@ -110,7 +110,9 @@ struct FstSrc {
   const double* h;
 };
 
-template <int METHOD, bool FAST>
+// PPT population pairs per thread (1 or 8): with P > 256 pairs the (n, p, h) staging of a locus chunk is done
+// once per workgroup instead of once per 256 pairs.
+template <int METHOD, bool FAST, int PPT>
 __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int G, int LB,
                                                       const int32_t* __restrict__ pairs0, int P, int by_locus,
                                                       int return_num_dem, double* __restrict__ part,
@@ -120,10 +122,15 @@ __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int
   double* sh_p = sh + (size_t)LB * G;
   double* sh_h = sh + 2 * (size_t)LB * G;
   double* sh_e = sh + 3 * (size_t)LB * G;
-  const int pi = blockIdx.y * 256 + threadIdx.x;
-  int g1 = 0, g2 = 0;
-  if (pi < P) { g1 = pairs0[2 * pi]; g2 = pairs0[2 * pi + 1]; }
-  double sum_num = 0.0, sum_den = 0.0;
+  int pidx[PPT], g1[PPT], g2[PPT];
+  double sum_num[PPT], sum_den[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; k++) {
+    pidx[k] = (blockIdx.y * PPT + k) * 256 + threadIdx.x;
+    g1[k] = 0; g2[k] = 0;
+    if (pidx[k] < P) { g1[k] = pairs0[2 * pidx[k]]; g2[k] = pairs0[2 * pidx[k] + 1]; }
+    sum_num[k] = 0.0; sum_den[k] = 0.0;
+  }
   const int64_t nchunks = (m + LB - 1) / LB;
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t j0 = ch * LB;
@@ -159,26 +166,30 @@ __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int
       if (METHOD == TPG_FST_HUDSON) sh_e[idx] = (vp * (1 - vp)) / (vn - 1);  // (p q) / (n - 1), once per population
     }
     __syncthreads();
-    if (pi < P) {
-      const int lmax = (int)((m - j0) < LB ? (m - j0) : LB);
+    const int lmax = (int)((m - j0) < LB ? (m - j0) : LB);
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      if (pidx[k] >= P) continue;
       for (int l = 0; l < lmax; l++) {
-        const int o1 = l * G + g1, o2 = l * G + g2;
+        const int o1 = l * G + g1[k], o2 = l * G + g2[k];
         double num, den;
         fst_terms<METHOD, FAST>(sh_n[o1], sh_p[o1], sh_h[o1], METHOD == TPG_FST_HUDSON ? sh_e[o1] : 0.0, sh_n[o2],
                                 sh_p[o2], sh_h[o2], METHOD == TPG_FST_HUDSON ? sh_e[o2] : 0.0, num, den);
         if (by_locus) {
-          const int64_t o = (j0 + l) + (int64_t)pi * m;
+          const int64_t o = (j0 + l) + (int64_t)pidx[k] * m;
           if (!return_num_dem) out_a[o] = num / den;
           else { out_a[o] = num; out_b[o] = den; }
         }
-        if (num == num && den == den) { sum_num += num; sum_den += den; }  // !is_na(num) && !is_na(den)
+        if (num == num && den == den) { sum_num[k] += num; sum_den[k] += den; }  // !is_na(num) && !is_na(den)
       }
     }
   }
-  if (pi < P) {
-    part[((int64_t)blockIdx.x * P + pi) * 2] = sum_num;
-    part[((int64_t)blockIdx.x * P + pi) * 2 + 1] = sum_den;
-  }
+#pragma unroll
+  for (int k = 0; k < PPT; k++)
+    if (pidx[k] < P) {
+      part[((int64_t)blockIdx.x * P + pidx[k]) * 2] = sum_num[k];
+      part[((int64_t)blockIdx.x * P + pidx[k]) * 2 + 1] = sum_den[k];
+    }
 }
 
 __global__ void tpg_fst_reduce_kernel(const double* __restrict__ part, int nblocks, int P, double* __restrict__ fst_tot,
@@ -215,7 +226,8 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   const size_t shmem = (size_t)LB * G * 4 * sizeof(double);
   const bool fast = !by_locus;  // exact statement order whenever per-locus values are returned
   const int64_t nchunks = ceil_div(m, LB);
-  const int ypass = (int)ceil_div(P, 256);
+  const int ppt = P > 256 ? 8 : 1;
+  const int ypass = (int)ceil_div(P, 256 * ppt);
   int nblocks = (int)(nchunks < 4 * ctx->num_cu ? nchunks : 4 * ctx->num_cu);
   if (nblocks < 1) nblocks = 1;
   double* d_part = nullptr;
@@ -229,17 +241,19 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   if (rc == TPG_OK && return_num_dem) rc = ob.init(out_b, mp);
   if (rc == TPG_OK) {
     dim3 grid((unsigned)nblocks, (unsigned)ypass);
-#define FST_LAUNCH(M, F, NAME)                                                                                   \
+#define FST_LAUNCH1(M, F, PP, NAME)                                                                              \
   do {                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)tpg_fst_kernel<M, F>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+    (void)hipFuncSetAttribute((const void*)tpg_fst_kernel<M, F, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                               (int)shmem);                                                                       \
-    TPG_LAUNCH(ctx, NAME, (tpg_fst_kernel<M, F>), grid, dim3(256), shmem, src, m, G, LB, pb.dev<int32_t>(), P,    \
+    TPG_LAUNCH(ctx, NAME, (tpg_fst_kernel<M, F, PP>), grid, dim3(256), shmem, src, m, G, LB, pb.dev<int32_t>(), P, \
                by_locus, return_num_dem, d_part, oa.dev<double>(), ob.dev<double>());                            \
   } while (0)
+#define FST_LAUNCH(M, F, NAME) do { if (ppt == 8) FST_LAUNCH1(M, F, 8, NAME); else FST_LAUNCH1(M, F, 1, NAME); } while (0)
     if (method == TPG_FST_HUDSON) FST_LAUNCH(TPG_FST_HUDSON, false, "fst_hudson");
     else if (method == TPG_FST_WC84 && fast) FST_LAUNCH(TPG_FST_WC84, true, "fst_wc84");
     else if (method == TPG_FST_WC84) FST_LAUNCH(TPG_FST_WC84, false, "fst_wc84");
     else FST_LAUNCH(TPG_FST_NEI87, false, "fst_nei87");
+#undef FST_LAUNCH1
 #undef FST_LAUNCH
     if (fst_tot || sum_num)
       TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, d_part,
