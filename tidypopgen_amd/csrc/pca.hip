@@ -425,7 +425,20 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
       const bool dlane = lane < TD * 16;  // lanes that carry a piece of the digit table
       // decode of one K step: word wA of the A tile, words wB[tb] of the B tiles, digits from LDS buffer `dbuf`, step s
       v4i PA[2][TD], PB[2][TB];
-      auto decode_step = [&](int set, uint32_t wA, const uint32_t* wB, int dbuf, int sidx) {
+      uint4 d1[TD], d2[TD];  // digits of the step being decoded
+      // first half of a decode: issue all digit reads of the step, then the B side (needs no digits: its ~44
+      // VALU instructions and the MFMAs interleaved with them cover the LDS latency)
+      auto decode_B = [&](int set, const uint32_t* wB, int dbuf, int sidx) {
+        const uint4* dl = &dgs[wv][dbuf][((sidx * 2 + h) * TD) * 2];
+#pragma unroll
+        for (int t = 0; t < TD; t++) { d1[t] = dl[t * 2]; d2[t] = dl[t * 2 + 1]; }
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) PB[set][tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wB[tb], k));
+      };
+      // second half: selectors from the A word, then one v_perm per digit and register
+      auto decode_A = [&](int set, uint32_t wA) {
         uint32_t sel[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -434,19 +447,13 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
           const uint32_t mv = (uint32_t)tpg_lut(0x00FFFF00u, c);
           sel[k] = (0x03020100u & mv) | base;
         }
-        const uint4* dl = &dgs[wv][dbuf][((sidx * 2 + h) * TD) * 2];
 #pragma unroll
         for (int t = 0; t < TD; t++) {
-          const uint4 d1 = dl[t * 2], d2 = dl[t * 2 + 1];
-          PA[set][t][0] = (int)__builtin_amdgcn_perm(d2.x, d1.x, sel[0]);
-          PA[set][t][1] = (int)__builtin_amdgcn_perm(d2.y, d1.y, sel[1]);
-          PA[set][t][2] = (int)__builtin_amdgcn_perm(d2.z, d1.z, sel[2]);
-          PA[set][t][3] = (int)__builtin_amdgcn_perm(d2.w, d1.w, sel[3]);
+          PA[set][t][0] = (int)__builtin_amdgcn_perm(d2[t].x, d1[t].x, sel[0]);
+          PA[set][t][1] = (int)__builtin_amdgcn_perm(d2[t].y, d1[t].y, sel[1]);
+          PA[set][t][2] = (int)__builtin_amdgcn_perm(d2[t].z, d1[t].z, sel[2]);
+          PA[set][t][3] = (int)__builtin_amdgcn_perm(d2[t].w, d1[t].w, sel[3]);
         }
-#pragma unroll
-        for (int tb = 0; tb < TB; tb++)
-#pragma unroll
-          for (int k = 0; k < 4; k++) PB[set][tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wB[tb], k));
       };
       auto lds_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -466,7 +473,8 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
       lds_sync();
       {
         const uint32_t wB0[TB] = {cB[0].x, cB[1].x, cB[2].x, cB[3].x};
-        decode_step(0, cA.x, wB0, 0, 0);
+        decode_B(0, wB0, 0, 0);
+        decode_A(0, cA.x);
       }
       int buf = 0;
       for (int64_t kg = k0; kg < k1; kg++) {
@@ -488,18 +496,28 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
 #pragma unroll
         for (int s = 0; s < 4; s++) {
           const int cur = s & 1, nx = cur ^ 1;
-          // next step's operands: steps 1..3 of this group, or step 0 of the next group (other digit buffer)
-          decode_step(nx, wA[s + 1], wB[s + 1], s < 3 ? buf : (buf ^ 1), s < 3 ? s + 1 : 0);
+          // next step's operands: steps 1..3 of this group, or step 0 of the next group (other digit buffer).
+          // Two scheduling regions so that the digit reads are long done when the A-side perms need them.
+          constexpr int NQ = TD * TB, Q1 = (NQ * 9) / 16 > 0 ? (NQ * 9) / 16 : 1;
+          decode_B(nx, wB[s + 1], s < 3 ? buf : (buf ^ 1), s < 3 ? s + 1 : 0);
 #pragma unroll
-          for (int t = 0; t < TD; t++)
+          for (int q = 0; q < Q1; q++) acc[q / TB][q % TB] = MFMA_I8(PA[cur][q / TB], PB[cur][q % TB], acc[q / TB][q % TB]);
+          __builtin_amdgcn_sched_group_barrier(SGB_DSR, 2 * TD, 0);
 #pragma unroll
-            for (int tb = 0; tb < TB; tb++) acc[t][tb] = MFMA_I8(PA[cur][t], PB[cur][tb], acc[t][tb]);
-#pragma unroll
-          for (int q = 0; q < TD * TB; q++) {
+          for (int q = 0; q < Q1; q++) {
             __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
             __builtin_amdgcn_sched_group_barrier(SGB_VALU, 5, 0);
-            if ((q & 1) == 0) __builtin_amdgcn_sched_group_barrier(SGB_DSR, 1, 0);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          decode_A(nx, wA[s + 1]);
+#pragma unroll
+          for (int q = Q1; q < NQ; q++) acc[q / TB][q % TB] = MFMA_I8(PA[cur][q / TB], PB[cur][q % TB], acc[q / TB][q % TB]);
+#pragma unroll
+          for (int q = Q1; q < NQ; q++) {
+            __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SGB_VALU, 5, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
         cA = nA; nA = mA;
 #pragma unroll
