@@ -33,6 +33,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include <type_traits>
 #include "devfrag.h"
 
 #define MFMA_I8(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8((a), (b), (c), 0, 0, 0)
@@ -461,37 +462,45 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       };
 
-      uint4 cA = pa[k0 * 64], cB[TB], nA, nB[TB], nD = make_uint4(0, 0, 0, 0);
+      // three rotating register slots (current group, next, the one being loaded): the K loop is unrolled by
+      // three so that no slot is ever copied -- a copy at the end of a group would wait for loads issued at its
+      // start, i.e. cut the prefetch distance from two groups to one
+      uint4 RA[3], RB[3][TB], RD[3];
+      RD[0] = RD[1] = RD[2] = make_uint4(0, 0, 0, 0);
+      RA[0] = pa[k0 * 64];
 #pragma unroll
-      for (int tb = 0; tb < TB; tb++) cB[tb] = pb[tb][k0 * 64];
+      for (int tb = 0; tb < TB; tb++) RB[0][tb] = pb[tb][k0 * 64];
       if (dlane) dgs[wv][0][lane] = DG[k0 * (TD * 16) + lane];
       const int64_t i1 = k0 + 1 < k1 ? k0 + 1 : kl;
-      nA = pa[i1 * 64];
+      if (dlane) RD[1] = DG[i1 * (TD * 16) + lane];
+      RA[1] = pa[i1 * 64];
+      if (k0 + 1 >= k1) RA[1] = make_uint4(~0u, ~0u, ~0u, ~0u);
 #pragma unroll
-      for (int tb = 0; tb < TB; tb++) nB[tb] = pb[tb][i1 * 64];
-      if (dlane) nD = DG[i1 * (TD * 16) + lane];
+      for (int tb = 0; tb < TB; tb++) RB[1][tb] = pb[tb][i1 * 64];
       lds_sync();
       {
-        const uint32_t wB0[TB] = {cB[0].x, cB[1].x, cB[2].x, cB[3].x};
+        const uint32_t wB0[TB] = {RB[0][0].x, RB[0][1].x, RB[0][2].x, RB[0][3].x};
         decode_B(0, wB0, 0, 0);
-        decode_A(0, cA.x);
+        decode_A(0, RA[0].x);
       }
       int buf = 0;
-      for (int64_t kg = k0; kg < k1; kg++) {
+      auto group = [&](auto Cc, auto Nn, auto Mm, int64_t kg) {
+        constexpr int C = decltype(Cc)::value, N = decltype(Nn)::value, M = decltype(Mm)::value;
         // digits of the next group into the other LDS buffer (its last readers were this wave's previous group)
-        if (dlane) dgs[wv][buf ^ 1][lane] = nD;
+        if (dlane) dgs[wv][buf ^ 1][lane] = RD[N];
         const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
-        const uint4 mA = pa[i2 * 64];
-        uint4 mB[TB];
+        if (dlane) RD[M] = DG[i2 * (TD * 16) + lane];
+        RA[M] = pa[i2 * 64];
+        if (kg + 2 >= k1) RA[M] = make_uint4(~0u, ~0u, ~0u, ~0u);
 #pragma unroll
-        for (int tb = 0; tb < TB; tb++) mB[tb] = pb[tb][i2 * 64];
-        if (dlane) nD = DG[i2 * (TD * 16) + lane];
+        for (int tb = 0; tb < TB; tb++) RB[M][tb] = pb[tb][i2 * 64];
         lds_sync();
-        const uint32_t wA[5] = {cA.x, cA.y, cA.z, cA.w, nA.x};
+        const uint32_t wA[5] = {RA[C].x, RA[C].y, RA[C].z, RA[C].w, RA[N].x};
         uint32_t wB[5][TB];
 #pragma unroll
         for (int tb = 0; tb < TB; tb++) {
-          wB[0][tb] = cB[tb].x; wB[1][tb] = cB[tb].y; wB[2][tb] = cB[tb].z; wB[3][tb] = cB[tb].w; wB[4][tb] = nB[tb].x;
+          wB[0][tb] = RB[C][tb].x; wB[1][tb] = RB[C][tb].y; wB[2][tb] = RB[C][tb].z; wB[3][tb] = RB[C][tb].w;
+          wB[4][tb] = RB[N][tb].x;
         }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -519,10 +528,16 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        cA = nA; nA = mA;
-#pragma unroll
-        for (int tb = 0; tb < TB; tb++) { cB[tb] = nB[tb]; nB[tb] = mB[tb]; }
         buf ^= 1;
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      // single-exit loop over triples: groups past k1 run with an all-missing A word (zero planes, adds nothing)
+      for (int64_t kg = k0; kg < k1; kg += 3) {
+        group(I0{}, I1{}, I2{}, kg);
+        group(I1{}, I2{}, I0{}, kg + 1);
+        group(I2{}, I0{}, I1{}, kg + 2);
       }
     }
     long long* slab = slabs + u0 * PCA_SLAB_INTS + lane;
