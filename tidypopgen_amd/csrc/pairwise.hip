@@ -27,6 +27,7 @@
 #include <string.h>
 
 #include "common.h"
+#include <type_traits>
 #include "devfrag.h"
 
 #define MFMA_I8(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8((a), (b), (c), 0, 0, 0)
@@ -161,23 +162,37 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel_v3(const uint4* __
 
     if (k0 < k1) {
       const int64_t kl = k1 - 1;
-      uint4 c0 = pa0[k0 * 64], c1 = pa1[k0 * 64], cb = pb0[k0 * 64];                      // current group
+      // three rotating load slots (current group, next, two ahead): the K loop is unrolled by three so that no
+      // slot is copied -- a copy at the end of a group waits for the loads issued at its start, which cuts the
+      // prefetch distance to one group.  Groups past k1 run with all-missing A words (zero planes).
+      // native vectors, not HIP's uint4 struct: with the struct the register allocator splits the loaded tuple right
+      // after the load (v_mov behind an s_waitcnt vmcnt: a full memory latency at the top of every group)
+      typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+      v4u R0[3], R1[3], RB[3];
+      auto LD = [&](const uint4* p) { return *(const v4u*)p; };
+      R0[0] = LD(pa0 + k0 * 64); R1[0] = LD(pa1 + k0 * 64); RB[0] = LD(pb0 + k0 * 64);
       const int64_t i1 = k0 + 1 < k1 ? k0 + 1 : kl;
-      uint4 n0 = pa0[i1 * 64], n1 = pa1[i1 * 64], nb = pb0[i1 * 64];                      // next group
+      R0[1] = LD(pa0 + i1 * 64); R1[1] = LD(pa1 + i1 * 64); RB[1] = LD(pb0 + i1 * 64);
       Frag3 P[2][3];
-      P[0][0] = tpg_decode3(c0.x); P[0][1] = tpg_decode3(c1.x); P[0][2] = tpg_decode3(cb.x);
-      for (int64_t kg = k0; kg < k1; kg++) {
+      P[0][0] = tpg_decode3(R0[0].x); P[0][1] = tpg_decode3(R1[0].x); P[0][2] = tpg_decode3(RB[0].x);
+      auto group = [&](auto Cc, auto Nn, auto Mm, int64_t kg) {
+        constexpr int C = decltype(Cc)::value, N = decltype(Nn)::value, M = decltype(Mm)::value;
         const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
-        const uint4 m0 = pa0[i2 * 64], m1 = pa1[i2 * 64], mb = pb0[i2 * 64];              // two groups ahead
-        // words of the 4 K steps of this group, followed by step 0 of the next group
-        const uint32_t wa0[5] = {c0.x, c0.y, c0.z, c0.w, n0.x}, wa1[5] = {c1.x, c1.y, c1.z, c1.w, n1.x};
-        const uint32_t wb[5] = {cb.x, cb.y, cb.z, cb.w, nb.x};
+        R0[M] = LD(pa0 + i2 * 64); R1[M] = LD(pa1 + i2 * 64); RB[M] = LD(pb0 + i2 * 64);
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler otherwise sinks them to their use
+        // words of the 4 K steps of this group, followed by step 0 of the next group; past k1: all missing
+        const uint32_t dead = kg < k1 ? 0u : ~0u, dead1 = kg + 1 < k1 ? 0u : ~0u;
+        const uint32_t wa0[4] = {R0[C].x | dead, R0[C].y | dead, R0[C].z | dead, R0[C].w | dead};
+        const uint32_t wa1[4] = {R1[C].x | dead, R1[C].y | dead, R1[C].z | dead, R1[C].w | dead};
+        const uint32_t wb[4] = {RB[C].x, RB[C].y, RB[C].z, RB[C].w};
 #pragma unroll
         for (int s = 0; s < 4; s++) {
           const int cur = s & 1, nx = cur ^ 1;
-          P[nx][0] = tpg_decode3(wa0[s + 1]);
-          P[nx][1] = tpg_decode3(wa1[s + 1]);
-          P[nx][2] = tpg_decode3(wb[s + 1]);
+          // the next group's slot is first touched in the last step's region (one barrier per step), so the wait
+          // for its loads comes as late as possible
+          P[nx][0] = tpg_decode3(s < 3 ? wa0[s < 3 ? s + 1 : 0] : (R0[N].x | dead1));
+          P[nx][1] = tpg_decode3(s < 3 ? wa1[s < 3 ? s + 1 : 0] : (R1[N].x | dead1));
+          P[nx][2] = tpg_decode3(s < 3 ? wb[s < 3 ? s + 1 : 0] : RB[N].x);
 #pragma unroll
           for (int t = 0; t < 2; t++) {
             cV[t] = MFMA_I8(P[cur][t].v, P[cur][2].v, cV[t]);
@@ -191,9 +206,16 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel_v3(const uint4* __
             __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
             __builtin_amdgcn_sched_group_barrier(SGB_VALU, 6, 0);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        c0 = n0; c1 = n1; cb = nb;
-        n0 = m0; n1 = m1; nb = mb;
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      for (int64_t kg = k0; kg < k1; kg += 3) {
+        group(I0{}, I1{}, I2{}, kg);
+        group(I1{}, I2{}, I0{}, kg + 1);
+        group(I2{}, I0{}, I1{}, kg + 2);
       }
     }
     int32_t* slab = acc_out + tp0 * TPG_PW_TILE_INTS + lane;

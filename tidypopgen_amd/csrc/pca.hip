@@ -474,7 +474,6 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
       const int64_t i1 = k0 + 1 < k1 ? k0 + 1 : kl;
       if (dlane) RD[1] = DG[i1 * (TD * 16) + lane];
       RA[1] = pa[i1 * 64];
-      if (k0 + 1 >= k1) RA[1] = make_uint4(~0u, ~0u, ~0u, ~0u);
 #pragma unroll
       for (int tb = 0; tb < TB; tb++) RB[1][tb] = pb[tb][i1 * 64];
       lds_sync();
@@ -491,11 +490,12 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
         const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
         if (dlane) RD[M] = DG[i2 * (TD * 16) + lane];
         RA[M] = pa[i2 * 64];
-        if (kg + 2 >= k1) RA[M] = make_uint4(~0u, ~0u, ~0u, ~0u);
 #pragma unroll
         for (int tb = 0; tb < TB; tb++) RB[M][tb] = pb[tb][i2 * 64];
         lds_sync();
-        const uint32_t wA[5] = {RA[C].x, RA[C].y, RA[C].z, RA[C].w, RA[N].x};
+        // groups past k1 (the loop runs in triples): all-missing A words, i.e. zero planes
+        const uint32_t dead = kg < k1 ? 0u : ~0u, dead1 = kg + 1 < k1 ? 0u : ~0u;
+        const uint32_t wA[5] = {RA[C].x | dead, RA[C].y | dead, RA[C].z | dead, RA[C].w | dead, RA[N].x | dead1};
         uint32_t wB[5][TB];
 #pragma unroll
         for (int tb = 0; tb < TB; tb++) {
