@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel_v3(const uint4* __
       auto group = [&](auto Cc, auto Nn, auto Mm, int64_t kg) {
         constexpr int C = decltype(Cc)::value, N = decltype(Nn)::value, M = decltype(Mm)::value;
         const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
-        R0[M] = LD(pa0 + i2 * 64); R1[M] = LD(pa1 + i2 * 64); RB[M] = LD(pb0 + i2 * 64);
-        __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler otherwise sinks them to their use
+        // the three loads of the group after next go out one per step (behind a step barrier, so the scheduler
+        // cannot sink them to their use): back-to-back loads hold this wave's issue while the MFMA pipe drains
         // words of the 4 K steps of this group, followed by step 0 of the next group; past k1: all missing
         const uint32_t dead = kg < k1 ? 0u : ~0u, dead1 = kg + 1 < k1 ? 0u : ~0u;
         const uint32_t wa0[4] = {R0[C].x | dead, R0[C].y | dead, R0[C].z | dead, R0[C].w | dead};
@@ -188,6 +188,9 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel_v3(const uint4* __
 #pragma unroll
         for (int s = 0; s < 4; s++) {
           const int cur = s & 1, nx = cur ^ 1;
+          if (s == 0) R0[M] = LD(pa0 + i2 * 64);
+          if (s == 1) R1[M] = LD(pa1 + i2 * 64);
+          if (s == 2) RB[M] = LD(pb0 + i2 * 64);
           // the next group's slot is first touched in the last step's region (one barrier per step), so the wait
           // for its loads comes as late as possible
           P[nx][0] = tpg_decode3(s < 3 ? wa0[s < 3 ? s + 1 : 0] : (R0[N].x | dead1));
