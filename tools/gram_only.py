@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Time the PCA Gram kernel alone (HIP events inside the library).  TPG_GRAM_DBG selects timing experiments."""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import tidypopgen_amd as tpg
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+m = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+ctx = tpg.default_context()
+ctx.prof_enable(True)
+X = tpg.FBM.synth(3, n, m, npop=51, imputed_bytes=True)
+v = tpg.View(X, None, None, code256=np.ascontiguousarray(tpg.CODE_IMPUTE_PRED))
+center, scale = tpg.pca_center_scale(v)
+for rep in range(3):
+    ctx.prof_reset()
+    K = tpg.pca_gram(v, center, scale)
+    ctx.sync()
+    for name, (cnt, ms) in sorted(ctx.prof_dump().items()):
+        if "gram_mfma" in name:
+            print(f"rep{rep} {name}: {cnt} launches {ms:.3f} ms")
