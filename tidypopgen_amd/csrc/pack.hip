@@ -129,10 +129,113 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
   }
 }
 
+// Fast path of the pack: FBM bytes (not .bed), all rows in file order, columns 8-byte aligned.
+//   phase 1  thread = (locus, 16 individuals): two 8-byte loads, byte -> code through v_perm_b32 with the first
+//            eight table entries as the 8-byte pool (one instruction per four genotypes; a dword holding a byte
+//            >= 8 takes the LDS table instead), the L word is the four code dwords shifted and OR-ed together
+//            (that is what the element order of the layout is for) and goes straight to HBM; the code bytes go to
+//            LDS as one 16-byte write;
+//   phase 2  thread = (16 loci, 4 individuals): 16 dword reads, four 4x4 byte transposes (8 v_perm each), four T
+//            words.  Rows are rotated by 32 bytes per 16 loci so that both phases are free of bank conflicts.
+// ~20 VALU and ~6 LDS instructions per output word pair instead of ~100 and ~50: the kernel sits on the HBM
+// roofline (reads n*m bytes, writes n*m/2).
+__global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __restrict__ fbm, int64_t nrow,
+                                                            const int32_t* __restrict__ cols, uint8_t* lut_and_flag,
+                                                            int64_t n, int64_t m, int64_t Q, int64_t KG,
+                                                            uint32_t* __restrict__ T, uint32_t* __restrict__ L) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[256 + TILE * TILE];
+  uint8_t* lut = smem;
+  uint8_t* codes = smem + 256;  // codes[locus][(individual + 32 * (locus >> 4)) & 127]
+  const int tid = threadIdx.x;
+  // 1-D grid, individual chunk fastest: neighbouring workgroups read neighbouring 128-byte pieces of the same
+  // 128 columns (columns are only 8-byte aligned, so the pieces share cache lines and DRAM pages)
+  const int64_t bj = blockIdx.x / Q;  // locus group (kg)
+  const int64_t bi = blockIdx.x % Q;  // individual chunk (q)
+  lut[tid] = lut_and_flag[tid];
+  __syncthreads();
+  const uint32_t lo = *reinterpret_cast<const uint32_t*>(lut), hi = *reinterpret_cast<const uint32_t*>(lut + 4);
+  bool bad = false;
+  auto conv = [&](uint32_t w) -> uint32_t {
+    uint32_t c;
+    if ((w & 0xF8F8F8F8u) == 0) c = __builtin_amdgcn_perm(hi, lo, w);
+    else
+      c = (uint32_t)lut[w & 0xFF] | ((uint32_t)lut[(w >> 8) & 0xFF] << 8) | ((uint32_t)lut[(w >> 16) & 0xFF] << 16) |
+          ((uint32_t)lut[w >> 24] << 24);
+    if (c & 0x80808080u) {  // 0xFF = value the code table does not map: flag it, treat as missing
+      bad = true;
+      const uint32_t msk = ((c & 0x80808080u) >> 7) * 0xFFu;
+      c = (c & ~msk) | (0x03030303u & msk);
+    }
+    return c;
+  };
+  {
+    const int c16 = tid & 7;
+    const int64_t i0 = bi * TILE + 16 * c16;
+    uint2 va[4], vb[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int64_t j = bj * TILE + (tid >> 3) + 32 * it;
+      va[it] = make_uint2(0, 0);
+      vb[it] = make_uint2(0, 0);
+      if (j < m) {
+        const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
+        const uint8_t* p = fbm + i0 + src_col * nrow;
+        if (i0 + 8 <= n) va[it] = *reinterpret_cast<const uint2*>(p);
+        if (i0 + 16 <= n) vb[it] = *reinterpret_cast<const uint2*>(p + 8);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int l = (tid >> 3) + 32 * it;
+      const bool inside = bj * TILE + l < m;
+      uint32_t c[4] = {0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u};
+      if (inside && i0 + 8 <= n) { c[0] = conv(va[it].x); c[1] = conv(va[it].y); }
+      if (inside && i0 + 16 <= n) { c[2] = conv(vb[it].x); c[3] = conv(vb[it].y); }
+      *reinterpret_cast<uint4*>(codes + l * TILE + ((16 * c16 + 32 * (l >> 4)) & 127)) = make_uint4(c[0], c[1], c[2], c[3]);
+      const int64_t lt = bj * 4 + (l >> 5);
+      const int lane = (l & 31) + 32 * (c16 & 1);
+      L[((lt * Q + bi) * 64 + lane) * 4 + (c16 >> 1)] = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
+    }
+  }
+  if (bad) atomicOr((unsigned int*)(lut_and_flag + 256), 1u);
+  __syncthreads();
+  {
+    const int wv = tid >> 6, t = tid & 63;
+    const int g = t >> 3, iqq = t & 7;  // loci 16 g .. 16 g + 15, individuals 32 wv + 4 iqq .. + 3
+    uint32_t d[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+      d[e] = *reinterpret_cast<const uint32_t*>(codes + (16 * g + e) * TILE + ((32 * wv + 4 * iqq + 32 * g) & 127));
+    uint32_t W[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t x0 = d[4 * k], x1 = d[4 * k + 1], x2 = d[4 * k + 2], x3 = d[4 * k + 3];
+      const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+      const uint32_t t2 = __builtin_amdgcn_perm(x3, x2, 0x05010400u), t3 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+      W[0] |= __builtin_amdgcn_perm(t2, t0, 0x05040100u) << (2 * k);
+      W[1] |= __builtin_amdgcn_perm(t2, t0, 0x07060302u) << (2 * k);
+      W[2] |= __builtin_amdgcn_perm(t3, t1, 0x05040100u) << (2 * k);
+      W[3] |= __builtin_amdgcn_perm(t3, t1, 0x07060302u) << (2 * k);
+    }
+    const int64_t rt = bi * 4 + wv;
+    uint32_t* dst = T + ((rt * KG + bj) * 64 + 4 * iqq + 32 * (g & 1)) * 4 + (g >> 1);
+#pragma unroll
+    for (int b = 0; b < 4; b++) dst[b * 4] = W[b];
+  }
+}
+
 int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,
                     const uint8_t* d_lut, tpg_view* v) {
   TPG_REQUIRE(v->KG < 2147483647ll && v->Q <= 65535, TPG_EINVAL, "view too large for the pack grid");
   dim3 grid((unsigned)v->KG, (unsigned)v->Q);
+  if (fbm->bed_bpl == 0 && d_rows == nullptr && (fbm->nrow & 7) == 0 && (((uintptr_t)fbm->d_bytes) & 7) == 0 &&
+      !getenv("TPG_PACK_GENERIC")) {
+    TPG_REQUIRE(v->KG * v->Q < 2147483647ll, TPG_EINVAL, "view too large for the pack grid");
+    TPG_LAUNCH(ctx, "pack", tpg_pack_fast_kernel, dim3((unsigned)(v->KG * v->Q)), dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
+               v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L);
+    TPG_CHECK_LAUNCH();
+    return TPG_OK;
+  }
   TPG_LAUNCH(ctx, "pack", tpg_pack_kernel, grid, dim3(256), 0, fbm->d_bytes, fbm->nrow, fbm->bed_bpl, d_rows, d_cols,
              (uint8_t*)d_lut, v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L);
   TPG_CHECK_LAUNCH();
