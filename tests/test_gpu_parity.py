@@ -316,6 +316,9 @@ def test_fst_vs_oracle(tpg, n, m, G, method):
     t = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method, by_locus=True)
     assert np.allclose(t["fst_tot"], o_tot, rtol=1e-12, atol=0, equal_nan=True)
     assert np.array_equal(t["fst_locus"], o_loc, equal_nan=True)  # same statements, contraction off -> same bits
+    # sums-only call: WC84 takes the hand-reduced two-population form (fast reciprocals), rounding differs
+    t_fast = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method)["fst_tot"]
+    assert np.allclose(t_fast, o_tot, rtol=1e-11, atol=1e-15, equal_nan=True)
     nd = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method, return_num_dem=True)
     assert np.array_equal(nd["Fst_by_locus_num"], o_nd["Fst_by_locus_num"], equal_nan=True)
     assert np.array_equal(nd["Fst_by_locus_den"], o_nd["Fst_by_locus_den"], equal_nan=True)

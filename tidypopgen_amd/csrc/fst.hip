@@ -25,6 +25,15 @@
 // the pair loop with its operation order unchanged (src/pairwise_fst_hudson_loop.cpp:28-29), so values stay
 // bit-identical.  FAST (only when no by-locus output is requested): WC84 with 3 divisions instead of 8
 // (reciprocals reused); the ratio of sums moves by ~1e-15 relative.
+// 1 / x to ~1 ulp: v_rcp_f64 (about 2^-23 relative) and two Newton steps.  x = 0 or inf gives NaN, callers guard.
+__device__ __forceinline__ double fst_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(e, r, r);
+  e = fma(-x, r, 1.0);
+  return fma(e, r, r);
+}
+
 template <int METHOD, bool FAST>
 __device__ __forceinline__ void fst_terms(double n1, double p1, double h1, double e1, double n2, double p2, double h2,
                                           double e2, double& num, double& den) {
@@ -35,19 +44,26 @@ __device__ __forceinline__ void fst_terms(double n1, double p1, double h1, doubl
     num = d * d - e1 - e2;
     den = p1 * q2 + p2 * q1;
   } else if (METHOD == TPG_FST_WC84 && FAST) {
-    const double ni1 = n1 * 0.5, ni2 = n2 * 0.5;
-    const double nt = ni1 + ni2, inv_nt = 1.0 / nt;
-    const double sum_sq = ni1 * ni1 + ni2 * ni2;
-    const double n_bar = nt * 0.5;
-    const double n_c = nt - sum_sq * inv_nt;
-    const double p_bar = (p1 * ni1 + p2 * ni2) * inv_nt, h_bar = (h1 * ni1 + h2 * ni2) * inv_nt;
-    const double s2 = ((p1 - p_bar) * (p1 - p_bar) * ni1 + (p2 - p_bar) * (p2 - p_bar) * ni2) * (2.0 * inv_nt);
-    const double inv_nb1 = 1.0 / (n_bar - 1.0);
-    const double core = p_bar * (1 - p_bar) - 0.5 * s2;
-    const double a = n_bar / n_c * (s2 - inv_nb1 * (core - h_bar * 0.25));
-    const double b = n_bar * inv_nb1 * (core - ((2 * n_bar - 1.0) * (0.5 * inv_nt)) * h_bar);
+    // Sums only (no per-locus output): the same estimator with the two-population algebra done by hand.
+    // Staged per (locus, population): n1 = individuals (allele count / 2), h1 = het_obs * individuals, e1 = 1 /
+    // individuals.  With r = 2:  n_c = 2 n1 n2 / nt,  s2 = 2 d^2 n1 n2 / nt^2  (d = p1 - p2), so
+    // n_bar / n_c * s2 = d^2 / 2 and n_bar / n_c = nt^2 / (4 n1 n2): two reciprocals per pair and locus (by
+    // v_rcp_f64 + two Newton steps) instead of three IEEE divisions, ~50 FP64 instructions instead of ~100.
+    // Differs from the statement-order path by rounding only (tests: <= 1e-12 relative on the sums).
+    const double nt = n1 + n2;
+    const double inv_nt = fst_rcp(nt);
+    const double nb1 = 0.5 * nt - 1.0;
+    double inv_nb1 = fst_rcp(nb1);
+    if (nb1 == 0.0) inv_nb1 = HUGE_VAL;  // one individual per population (nb1 = +0): the reference's 1 / 0 = +inf
+    const double p_bar = (p1 * n1 + p2 * n2) * inv_nt, h_bar = (h1 + h2) * inv_nt;
+    const double d = p1 - p2, hd2 = 0.5 * (d * d);
+    const double half_s2 = (2.0 * hd2) * (n1 * n2) * (inv_nt * inv_nt);
+    const double core = p_bar * (1.0 - p_bar) - half_s2;
+    const double X = (0.25 * (nt * nt)) * (e1 * e2) * inv_nb1;
+    const double a = hd2 - X * (core - 0.25 * h_bar);
+    const double b = (0.5 * nt) * inv_nb1 * (core - (0.5 * (nt - 1.0)) * inv_nt * h_bar);
     num = a;
-    den = a + b + h_bar * 0.5;
+    den = a + b + 0.5 * h_bar;
   } else if (METHOD == TPG_FST_WC84) {
     // src/pairwise_fst_wc84_loop.cpp:41-99 with r = 2
     const double r = 2.0;
@@ -164,18 +180,24 @@ __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int
       }
       sh_n[idx] = vn; sh_p[idx] = vp; sh_h[idx] = vh;
       if (METHOD == TPG_FST_HUDSON) sh_e[idx] = (vp * (1 - vp)) / (vn - 1);  // (p q) / (n - 1), once per population
+      if (METHOD == TPG_FST_WC84 && FAST) {  // individuals, het_obs * individuals, 1 / individuals
+        const double ni = 0.5 * vn;
+        sh_n[idx] = ni; sh_h[idx] = vh * ni; sh_e[idx] = 1.0 / ni;
+      }
     }
     __syncthreads();
     const int lmax = (int)((m - j0) < LB ? (m - j0) : LB);
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
       if (pidx[k] >= P) continue;
+#pragma unroll 2
       for (int l = 0; l < lmax; l++) {
         const int o1 = l * G + g1[k], o2 = l * G + g2[k];
         double num, den;
-        fst_terms<METHOD, FAST>(sh_n[o1], sh_p[o1], sh_h[o1], METHOD == TPG_FST_HUDSON ? sh_e[o1] : 0.0, sh_n[o2],
-                                sh_p[o2], sh_h[o2], METHOD == TPG_FST_HUDSON ? sh_e[o2] : 0.0, num, den);
-        if (by_locus) {
+        constexpr bool use_e = METHOD == TPG_FST_HUDSON || (METHOD == TPG_FST_WC84 && FAST);
+        fst_terms<METHOD, FAST>(sh_n[o1], sh_p[o1], sh_h[o1], use_e ? sh_e[o1] : 0.0, sh_n[o2], sh_p[o2], sh_h[o2],
+                                use_e ? sh_e[o2] : 0.0, num, den);
+        if (!FAST && by_locus) {  // FAST instantiations are launched for sums only
           const int64_t o = (j0 + l) + (int64_t)pidx[k] * m;
           if (!return_num_dem) out_a[o] = num / den;
           else { out_a[o] = num; out_b[o] = den; }
@@ -249,7 +271,8 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
                by_locus, return_num_dem, d_part, oa.dev<double>(), ob.dev<double>());                            \
   } while (0)
 #define FST_LAUNCH(M, F, NAME) do { if (ppt == 8) FST_LAUNCH1(M, F, 8, NAME); else FST_LAUNCH1(M, F, 1, NAME); } while (0)
-    if (method == TPG_FST_HUDSON) FST_LAUNCH(TPG_FST_HUDSON, false, "fst_hudson");
+    if (method == TPG_FST_HUDSON && fast) FST_LAUNCH(TPG_FST_HUDSON, true, "fst_hudson");  // same arithmetic, no per-locus stores
+    else if (method == TPG_FST_HUDSON) FST_LAUNCH(TPG_FST_HUDSON, false, "fst_hudson");
     else if (method == TPG_FST_WC84 && fast) FST_LAUNCH(TPG_FST_WC84, true, "fst_wc84");
     else if (method == TPG_FST_WC84) FST_LAUNCH(TPG_FST_WC84, false, "fst_wc84");
     else FST_LAUNCH(TPG_FST_NEI87, false, "fst_nei87");
