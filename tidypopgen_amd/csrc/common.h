@@ -129,6 +129,7 @@ struct tpg_pairwise {
   int64_t ntp;  // number of (I, jt) units = nst*(nst+1)
   int32_t* acc;
   bool owns;
+  void* order;  // device int2[ntp]: the units (I, jt) in XCD patch order (pairwise.hip)
 };
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -26,6 +26,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 #include <type_traits>
 #include "devfrag.h"
@@ -54,100 +57,39 @@ __device__ __forceinline__ int64_t tpg_pw_unit_index(int nst, int I, int jt) {
   return 2 * ((int64_t)I * nst - ((int64_t)I * (I - 1)) / 2) + (jt - 2 * I);
 }
 
-__global__ __launch_bounds__(256, 2) void tpg_pairwise_kernel(const uint4* __restrict__ T, int64_t KG,
-                                                              int64_t kg_begin, int64_t kg_end, int nst,
-                                                              int64_t ntp, int S, int32_t* __restrict__ acc_out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  const int64_t nunits = ntp * S;
-  const int64_t kgs = kg_end - kg_begin;
-
-  for (int64_t unit = wave; unit < nunits; unit += nwaves) {
-    int64_t tp = unit % ntp;
-    const int ks = (int)(unit / ntp);
-    const int64_t tp0 = tp;
-    int I = 0;
-    while (tp >= 2 * (nst - I)) { tp -= 2 * (nst - I); I++; }
-    const int jt = 2 * I + (int)tp;
-    const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
-
-    const uint4* pa0 = T + ((int64_t)(2 * I) * KG) * 64 + lane;
-    const uint4* pa1 = T + ((int64_t)(2 * I + 1) * KG) * 64 + lane;
-    const uint4* pb0 = T + ((int64_t)jt * KG) * 64 + lane;
-
-    v16i cV[2], cD[2], cH[2], cHV[2], cVH[2];
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) { cV[t][r] = 0; cD[t][r] = 0; cH[t][r] = 0; cHV[t][r] = 0; cVH[t][r] = 0; }
-
-    if (k0 < k1) {
-      uint4 na0 = pa0[k0 * 64], na1 = pa1[k0 * 64], nb0 = pb0[k0 * 64];
-      for (int64_t kg = k0; kg < k1; kg++) {
-        const uint4 a0 = na0, a1 = na1, b0 = nb0;
-        const int64_t kn = (kg + 1 < k1) ? kg + 1 : kg;
-        na0 = pa0[kn * 64]; na1 = pa1[kn * 64]; nb0 = pb0[kn * 64];
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this K group's MFMAs
-        const uint32_t wa0[4] = {a0.x, a0.y, a0.z, a0.w}, wa1[4] = {a1.x, a1.y, a1.z, a1.w};
-        const uint32_t wb0[4] = {b0.x, b0.y, b0.z, b0.w};
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const Frag3 A[2] = {tpg_decode3(wa0[s]), tpg_decode3(wa1[s])};
-          const Frag3 B = tpg_decode3(wb0[s]);
-#pragma unroll
-          for (int t = 0; t < 2; t++) {
-            cV[t] = MFMA_I8(A[t].v, B.v, cV[t]);
-            cD[t] = MFMA_I8(A[t].d, B.d, cD[t]);
-            cH[t] = MFMA_I8(A[t].h, B.h, cH[t]);
-            cHV[t] = MFMA_I8(A[t].h, B.v, cHV[t]);
-            cVH[t] = MFMA_I8(A[t].v, B.h, cVH[t]);
-          }
-        }
-      }
-    }
-    int32_t* slab = acc_out + tp0 * TPG_PW_TILE_INTS + lane;
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int o = (t * 16 + r) * 64;
-        atomicAdd(slab + 0 * 2048 + o, cV[t][r]);
-        atomicAdd(slab + 1 * 2048 + o, cD[t][r]);
-        atomicAdd(slab + 2 * 2048 + o, cH[t][r]);
-        atomicAdd(slab + 3 * 2048 + o, cHV[t][r]);
-        atomicAdd(slab + 4 * 2048 + o, cVH[t][r]);
-      }
-  }
-}
-
-// v3: v1's decomposition (one wave = one (I, jt) unit, 64 x 32 tile, 10 accumulator tiles) with the fragment
-// decode SOFTWARE-PIPELINED one K step ahead.  Measured (tools/ubench_mfma_dep.hip): an MFMA whose A/B
-// operands were written by VALU instructions 0 / 1 / 2 MFMAs earlier takes 47.6 / 41.6 / 36.4 cycles instead of
-// 32, and v1 (decode placed by the compiler right before its MFMAs) ran at ~41.8.  Here the three fragments of
-// K step s+1 are decoded into a second register set while the 10 MFMAs of step s issue (one MFMA, then six
-// decode VALU, enforced with sched_group_barrier), so every operand is ~10 MFMAs old when it is read.  The
-// second register set costs 36 VGPRs -> one wave per SIMD (v1 measured the same speed with one or two waves
-// per SIMD: a single wave already saturates what the issue port allows).  Operand words are prefetched two
-// 128-locus groups ahead.  What remains is VALU issue: ~6.5 VALU-class instructions per MFMA at ~4.7 cycles.
+// The pairwise kernel.  One wave = one (I, jt) unit: a 64 x 32 tile of pairs, five products, ten accumulator
+// tiles (160 AGPRs), one wave per SIMD.  The fragment decode is SOFTWARE-PIPELINED one K step ahead: an MFMA
+// whose A/B operands were written by VALU instructions 0 / 1 / 2 MFMAs earlier takes 47.6 / 41.6 / 36.4 cycles
+// instead of 32 (tools/ubench_mfma_dep.hip), so the three fragments of K step s+1 are decoded into a second
+// register set while the 10 MFMAs of step s issue (one MFMA, then six decode VALU, enforced with
+// sched_group_barrier) and every operand is ~10 MFMAs old when it is read.  Operand words are prefetched two
+// 128-locus groups ahead through three rotating register slots.  Earlier forms of this kernel (decode placed by
+// the compiler; 2 waves per SIMD; a workgroup-shared 2-bit -> byte spread through LDS) measured 10-20% slower
+// and are gone; DESIGN.md 3.4 keeps the numbers.
 #define SGB_MFMA 0x008
 #define SGB_VALU 0x002
-__global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel_v3(const uint4* __restrict__ T, int64_t KG,
+__global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __restrict__ T, int64_t KG,
                                                                  int64_t kg_begin, int64_t kg_end, int nst,
-                                                                 int64_t ntp, int S, int32_t* __restrict__ acc_out) {
+                                                                 const int2* __restrict__ order, int64_t ntp, int S,
+                                                                 int32_t* __restrict__ acc_out) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  const int64_t nunits = ntp * S;
+  const int wv = threadIdx.x >> 6;
   const int64_t kgs = kg_end - kg_begin;
-
-  for (int64_t unit = wave; unit < nunits; unit += nwaves) {
-    int64_t tp = unit % ntp;
-    const int ks = (int)(unit / ntp);
-    const int64_t tp0 = tp;
-    int I = 0;
-    while (tp >= 2 * (nst - I)) { tp -= 2 * (nst - I); I++; }
-    const int jt = 2 * I + (int)tp;
+  // Work distribution.  `order` (host-built, tpg_pairwise_create) lists the (I, jt) units of the triangle in
+  // PATCH order: blocks of 16 column tiles, inside a block row after row, so four consecutive entries nearly
+  // always share the 64-row super-tile I (the four waves of a workgroup then fetch the A stream into the CU
+  // once) and a run of 128 consecutive entries is ~8 rows x 16 columns.  Workgroups are dispatched round-robin
+  // over the 8 XCDs (blockIdx % 8); in every round XCD x takes such a run for its 128 waves (same K range):
+  // ~16 A and ~16 B tiles per 128 loci instead of ~100 distinct ones with a plain strided assignment, so the
+  // re-reads hit that XCD's own L2.
+  const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+  for (int64_t round = 0;; round++) {
+    const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
+    if (un >= ntp * S) break;
+    const int ks = (int)(un / ntp);
+    const int2 ijt = order[un % ntp];
+    const int I = ijt.x, jt = ijt.y;
+    const int64_t tp0 = tpg_pw_unit_index(nst, I, jt);
     const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
 
     const uint4* pa0 = T + ((int64_t)(2 * I) * KG) * 64 + lane;
@@ -236,101 +178,6 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel_v3(const uint4* __
   }
 }
 
-// v2: the same arithmetic with the 2-bit -> byte spread of every fragment done ONCE per workgroup.
-// A workgroup of 8 waves (2 per SIMD) owns a 128 x 128 block (64-row super-tiles 2 I4, 2 I4 + 1 against
-// column tiles 4 J4 .. 4 J4 + 3); wave (ap, bt) computes exactly one (I, jt) unit of the v1 decomposition, so
-// the accumulator buffer and the epilogues are unchanged.  Per 128-locus group each wave spreads ONE of the 8
-// row tiles (28 VALU + 4 ds_write_b128) into a double-buffered LDS image of code bytes and reads the three
-// fragments it needs per 32 loci back with ds_read_b128: 4.3 decode VALU per MFMA instead of 5.7, which
-// matters because beyond ~5 VALU per MFMA the kernel is VALU-issue bound.  One barrier
-// per 128 loci.
-__global__ __launch_bounds__(512, 2) void tpg_pairwise_kernel_v2(const uint4* __restrict__ T, int64_t KG,
-                                                                 int64_t kg_begin, int64_t kg_end, int nst, int Q4,
-                                                                 int64_t nbp, int S, int32_t* __restrict__ acc_out) {
-  __shared__ __attribute__((aligned(16))) uint4 cds[2][8][4][64];  // [buffer][row tile][K step][lane]
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const int ap = wv & 1, bt = wv >> 1;
-  const int64_t kgs = kg_end - kg_begin;
-  for (int64_t unit = blockIdx.x; unit < nbp * S; unit += gridDim.x) {
-    int64_t bp = unit % nbp;
-    const int ks = (int)(unit / nbp);
-    int I4 = 0;
-    while (bp >= Q4 - I4) { bp -= Q4 - I4; I4++; }
-    const int J4 = I4 + (int)bp;
-    const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
-    // the row tile this wave spreads: 0..3 = rows of the A block, 4..7 = rows of the B block
-    const int64_t my_rt = wv < 4 ? 4 * (int64_t)I4 + wv : 4 * (int64_t)J4 + (wv - 4);
-    const uint4* psrc = T + (my_rt * KG) * 64 + lane;
-    const int fa0 = 2 * ap, fa1 = 2 * ap + 1, fb = 4 + bt;
-
-    v16i cV[2], cD[2], cH[2], cHV[2], cVH[2];
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) { cV[t][r] = 0; cD[t][r] = 0; cH[t][r] = 0; cHV[t][r] = 0; cVH[t][r] = 0; }
-
-    auto spread_to = [&](const uint4& pk, int buf) {
-      const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
-#pragma unroll
-      for (int sidx = 0; sidx < 4; sidx++)
-        cds[buf][wv][sidx][lane] = make_uint4(tpg_codes(w[sidx], 0), tpg_codes(w[sidx], 1), tpg_codes(w[sidx], 2),
-                                              tpg_codes(w[sidx], 3));
-    };
-
-    if (k0 < k1) {
-      uint4 nxt = psrc[k0 * 64];
-      spread_to(nxt, 0);
-      nxt = psrc[((k0 + 1 < k1) ? k0 + 1 : k0) * 64];
-      __syncthreads();
-      for (int64_t kg = k0; kg < k1; kg++) {
-        const int buf = (int)((kg - k0) & 1);
-        if (kg + 1 < k1) {
-          spread_to(nxt, buf ^ 1);
-          nxt = psrc[((kg + 2 < k1) ? kg + 2 : kg + 1) * 64];
-        }
-#pragma unroll
-        for (int sidx = 0; sidx < 4; sidx++) {
-          const uint4 ca0 = cds[buf][fa0][sidx][lane], ca1 = cds[buf][fa1][sidx][lane], cb = cds[buf][fb][sidx][lane];
-          Frag3 A[2], B;
-          const uint32_t a0c[4] = {ca0.x, ca0.y, ca0.z, ca0.w}, a1c[4] = {ca1.x, ca1.y, ca1.z, ca1.w};
-          const uint32_t bc[4] = {cb.x, cb.y, cb.z, cb.w};
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            A[0].v[k] = tpg_lut(TPG_LUT_V, a0c[k]); A[0].d[k] = tpg_lut(TPG_LUT_D, a0c[k]); A[0].h[k] = tpg_lut(TPG_LUT_H, a0c[k]);
-            A[1].v[k] = tpg_lut(TPG_LUT_V, a1c[k]); A[1].d[k] = tpg_lut(TPG_LUT_D, a1c[k]); A[1].h[k] = tpg_lut(TPG_LUT_H, a1c[k]);
-            B.v[k] = tpg_lut(TPG_LUT_V, bc[k]); B.d[k] = tpg_lut(TPG_LUT_D, bc[k]); B.h[k] = tpg_lut(TPG_LUT_H, bc[k]);
-          }
-#pragma unroll
-          for (int t = 0; t < 2; t++) {
-            cV[t] = MFMA_I8(A[t].v, B.v, cV[t]);
-            cD[t] = MFMA_I8(A[t].d, B.d, cD[t]);
-            cH[t] = MFMA_I8(A[t].h, B.h, cH[t]);
-            cHV[t] = MFMA_I8(A[t].h, B.v, cHV[t]);
-            cVH[t] = MFMA_I8(A[t].v, B.h, cVH[t]);
-          }
-        }
-        __syncthreads();
-      }
-    }
-    const int I = 2 * I4 + ap, jt = 4 * J4 + bt;
-    if (I < nst && jt < 2 * nst && jt >= 2 * I) {  // inside the stored band (diagonal blocks skip their lower half)
-      int32_t* slab = acc_out + tpg_pw_unit_index(nst, I, jt) * TPG_PW_TILE_INTS + lane;
-#pragma unroll
-      for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int o = (t * 16 + r) * 64;
-          atomicAdd(slab + 0 * 2048 + o, cV[t][r]);
-          atomicAdd(slab + 1 * 2048 + o, cD[t][r]);
-          atomicAdd(slab + 2 * 2048 + o, cH[t][r]);
-          atomicAdd(slab + 3 * 2048 + o, cHV[t][r]);
-          atomicAdd(slab + 4 * 2048 + o, cVH[t][r]);
-        }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 extern "C" size_t tpg_pairwise_buffer_bytes(int64_t n) {
   const int64_t nst = ceil_div(n, 64);
@@ -341,8 +188,23 @@ extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tp
   TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && n < (1 << 22), TPG_EINVAL, "bad n = %lld", (long long)n);
   TPG_HIP(hipSetDevice(ctx->device));
-  tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 64), 0, nullptr, false};
+  tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 64), 0, nullptr, false, nullptr};
   pw->ntp = pw->nst * (pw->nst + 1);
+  {
+    // units (I, jt), jt >= 2 I, in patch order: blocks of 16 column tiles, inside a block row after row
+    const int nst = (int)pw->nst, nct = 2 * nst;
+    std::vector<int2> order;
+    order.reserve((size_t)pw->ntp);
+    for (int pc = 0; pc * 16 < nct; pc++) {
+      const int c1 = std::min(nct, pc * 16 + 16);
+      for (int I = 0; I < nst && 2 * I < c1; I++)
+        for (int jt = std::max(pc * 16, 2 * I); jt < c1; jt++) order.push_back(make_int2(I, jt));
+    }
+    if ((int64_t)order.size() != pw->ntp) { tpg_pairwise_free(pw); tpg_set_error("pairwise order table size"); return TPG_EINVAL; }
+    hipError_t e = tpg_pmalloc(&pw->order, sizeof(int2) * order.size());
+    if (e == hipSuccess) e = hipMemcpy(pw->order, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { tpg_pairwise_free(pw); tpg_set_error("pairwise order table: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  }
   if (ext_buffer) {
     if (!tpg_is_device_ptr(ext_buffer)) { delete pw; tpg_set_error("ext_buffer is not device memory"); return TPG_EINVAL; }
     pw->acc = (int32_t*)ext_buffer;
@@ -360,6 +222,7 @@ extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tp
 extern "C" void tpg_pairwise_free(tpg_pairwise* pw) {
   if (!pw) return;
   if (pw->owns && pw->acc) tpg_pfree(pw->acc);
+  tpg_pfree(pw->order);
   delete pw;
 }
 
@@ -383,44 +246,20 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
   if (col_begin == col_end) return TPG_OK;
   const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
   const int64_t kgs = kg1 - kg0;
-  static const char* impl_env = getenv("TPG_PAIRWISE_IMPL");
-  static const int impl = impl_env ? (impl_env[1] - '0') : 3;  // "v1" | "v2" | "v3" (default)
-  const bool use_v1 = impl == 1;
-  auto pick_split = [&](int64_t units, int64_t slots) {
-    // K split: make units * S fill the resident slots evenly, keep >= 8 K groups (1024 loci) per unit
-    int bestS = 1;
-    double best = -1;
-    const int64_t maxS = kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1;
-    for (int64_t S = 1; S <= maxS; S++) {
-      const int64_t U = units * S;
-      const double eff = (double)U / (double)(ceil_div(U, slots) * slots);
-      if (eff > best + 0.01) { best = eff; bestS = (int)S; }
-    }
-    return bestS;
-  };
-  if (use_v1) {
-    const int64_t nwaves = (int64_t)ctx->num_cu * 8;
-    const int bestS = pick_split(pw->ntp, nwaves);
-    const int64_t U = pw->ntp * bestS;
-    const unsigned grid = (unsigned)(ceil_div(U, 4) < 2 * ctx->num_cu ? ceil_div(U, 4) : 2 * ctx->num_cu);
-    TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG, kg0,
-               kg1, (int)pw->nst, pw->ntp, bestS, pw->acc);
-  } else if (impl == 3) {
-    const int64_t nwaves = (int64_t)ctx->num_cu * 4;  // one wave per SIMD
-    const int bestS = pick_split(pw->ntp, nwaves);
-    const int64_t U = pw->ntp * bestS;
-    const unsigned grid = (unsigned)(ceil_div(U, 4) < ctx->num_cu ? ceil_div(U, 4) : ctx->num_cu);
-    TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel_v3, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG, kg0,
-               kg1, (int)pw->nst, pw->ntp, bestS, pw->acc);
-  } else {
-    const int Q4 = (int)ceil_div(pw->nst, 2);
-    const int64_t nbp = (int64_t)Q4 * (Q4 + 1) / 2;
-    const int bestS = pick_split(nbp, ctx->num_cu);
-    const int64_t U = nbp * bestS;
-    const unsigned grid = (unsigned)(U < ctx->num_cu ? U : ctx->num_cu);
-    TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel_v2, dim3(grid), dim3(512), 0, (const uint4*)v->T, v->KG, kg0,
-               kg1, (int)pw->nst, Q4, nbp, bestS, pw->acc);
+  // K split: make units * S fill the resident waves evenly, keep >= 8 K groups (1024 loci) per unit
+  int nblk = ctx->num_cu / 8 * 8;  // one workgroup per CU (one wave per SIMD), a multiple of the 8 XCDs
+  if (nblk < 8) nblk = 8;
+  const int64_t nwaves = 4 * (int64_t)nblk;
+  int bestS = 1;
+  double best = -1;
+  const int64_t maxS = kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1;
+  for (int64_t S = 1; S <= maxS; S++) {
+    const int64_t U = pw->ntp * S;
+    const double eff = (double)U / (double)(ceil_div(U, nwaves) * nwaves);
+    if (eff > best + 0.01) { best = eff; bestS = (int)S; }
   }
+  TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T, v->KG,
+             kg0, kg1, (int)pw->nst, (const int2*)pw->order, pw->ntp, bestS, pw->acc);
   TPG_CHECK_LAUNCH();
   return TPG_OK;
 }

@@ -389,25 +389,28 @@ template <int TD, int DBG = 0>  // digits handled by this pass (<= 4); DG holds 
 __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
                                                               int64_t kg_begin, int64_t kg_end,
                                                               const uint4* __restrict__ DG, int t0, int nrt,
-                                                              int nsb, int64_t nun, int S,
+                                                              int nsb, const int2* __restrict__ order, int nsu, int S,
                                                               long long* __restrict__ slabs) {
   __shared__ __attribute__((aligned(16))) uint4 dgs[4][2][TD * 16];
   constexpr int TB = PCA_TB;
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int h = lane >> 5;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int64_t kgs = kg_end - kg_begin;
-  for (int64_t unit = wave; unit < nun * S; unit += nwaves) {
-    int64_t u = unit % nun;
-    const int ks = (int)(unit / nun);
-    const int64_t u0 = u;
-    int a = 0;
-    while (u >= TB * (int64_t)(nsb - a)) { u -= TB * (int64_t)(nsb - a); a++; }
-    const int r = (int)(u / (nsb - a));
-    const int jb = a + (int)(u % (nsb - a));
-    const int ia = TB * a + r;
+  // Work distribution.  A workgroup (4 waves) takes one SUPER-unit (a, jb): its waves are the four A row tiles
+  // 4a .. 4a+3 against the same B super-tile, so the B stream is fetched into the CU once.  Workgroups are
+  // dispatched round-robin over the 8 XCDs (blockIdx % 8), each XCD with its own L2: in every round XCD x takes a
+  // run of gridDim/8 CONSECUTIVE super-units of `order` (host-built: patches of 4 super-rows x 8 super-columns of
+  // the triangle, same K range), i.e. ~16 A tiles and ~32 B tiles per 128 loci for its 128 waves instead of up
+  // to ~190 distinct ones with a plain strided assignment -- the re-reads then hit that XCD's L2.
+  const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+  for (int64_t round = 0;; round++) {
+    const int64_t su = (round * 8 + xcd) * cpx + cidx;
+    if (su >= (int64_t)nsu * S) break;
+    const int ks = (int)(su / nsu);
+    const int2 ajb = order[su % nsu];
+    const int jb = ajb.y, ia = TB * ajb.x + wv;
+    const int64_t u0 = tpg_gram_unit_index(nsb, ia, jb);
     const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
 
     const uint4* pa = Tl + ((int64_t)ia * KG) * 64 + lane;
@@ -713,6 +716,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   uint32_t* d_DG = nullptr;
   double *d_what = nullptr, *d_wc = nullptr, *d_r = nullptr, *d_part = nullptr;
   long long* d_slabs = nullptr;
+  int2* d_order = nullptr;
   int rc = TPG_OK;
   hipError_t e = hipSuccess;
 #define GHIP(call) do { if (e == hipSuccess) { e = (call); if (e != hipSuccess) tpg_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e)); } } while (0)
@@ -726,30 +730,41 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   if (e == hipSuccess) {
     TPG_LAUNCH(ctx, "pca_digits", tpg_pca_digits_kernel, dim3(1024), dim3(256), 0, d_scale, d_center, m, v->KG, F, T,
                d_DG, d_what, d_wc);
-    // K-split as in the pairwise kernel: fill the resident waves (1 wave per SIMD)
-    const int64_t nwaves = (int64_t)ctx->num_cu * 4;
+    // super-units (a, jb >= a) in patch order: super-column blocks of 8, inside them super-rows in runs of 4
+    const int nsu = nsb * (nsb + 1) / 2;
+    std::vector<int2> order;
+    order.reserve((size_t)nsu);
+    for (int pj = 0; pj * 8 < nsb; pj++) {
+      const int j1 = std::min(nsb, pj * 8 + 8);
+      for (int a = 0; a < j1; a++)
+        for (int jb = std::max(pj * 8, a); jb < j1; jb++) order.push_back(make_int2(a, jb));
+    }
+    GHIP(tpg_pmalloc((void**)&d_order, sizeof(int2) * (size_t)nsu));
+    GHIP(hipMemcpyAsync(d_order, order.data(), sizeof(int2) * (size_t)nsu, hipMemcpyHostToDevice, ctx->stream));
+    // K-split: fill the resident workgroups (one per CU, 1 wave per SIMD); grid a multiple of the 8 XCDs
+    int nblk = ctx->num_cu / 8 * 8;
+    if (nblk < 8) nblk = 8;
     int bestS = 1;
     double best = -1;
     const int64_t maxS = v->KG / 8 > 0 ? (v->KG / 8 < 96 ? v->KG / 8 : 96) : 1;
     for (int64_t S = 1; S <= maxS; S++) {
-      const int64_t U = nun * S;
-      const double eff = (double)U / (double)(ceil_div(U, nwaves) * nwaves);
-      if (eff > best + 0.01) { best = eff; bestS = (int)S; }
+      const int64_t U = (int64_t)nsu * S;
+      const double eff = (double)U / (double)(ceil_div(U, nblk) * nblk);
+      if (eff > best + 0.003) { best = eff; bestS = (int)S; }
     }
-    const int64_t U = nun * bestS;
-    const unsigned grid = (unsigned)(ceil_div(U, 4) < ctx->num_cu ? ceil_div(U, 4) : ctx->num_cu);
+    const unsigned grid = (unsigned)nblk;
     int64_t pass_base = 0;  // dwords
     for (int t0 = 0; t0 < T; t0 += 4) {
       const int td = T - t0 < 4 ? T - t0 : 4;
       const uint4* dgp = (const uint4*)(d_DG + pass_base);
 #define GRAM_LAUNCH(TD)                                                                                              \
   TPG_LAUNCH(ctx, "pca_gram_mfma", tpg_pca_gram_kernel<TD>, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG,      \
-             (int64_t)0, v->KG, dgp, t0, nrt, nsb, nun, bestS, d_slabs)
+             (int64_t)0, v->KG, dgp, t0, nrt, nsb, (const int2*)d_order, nsu, bestS, d_slabs)
       static const int dbg = getenv("TPG_GRAM_DBG") ? atoi(getenv("TPG_GRAM_DBG")) : 0;
       if (td == 4 && dbg) {
 #define GRAM_DBG(D)                                                                                                  \
   TPG_LAUNCH(ctx, "pca_gram_mfma", (tpg_pca_gram_kernel<4, D>), dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG,   \
-             (int64_t)0, v->KG, dgp, t0, nrt, nsb, nun, bestS, d_slabs)
+             (int64_t)0, v->KG, dgp, t0, nrt, nsb, (const int2*)d_order, nsu, bestS, d_slabs)
         if (dbg == 1) GRAM_DBG(1); else if (dbg == 2) GRAM_DBG(2); else if (dbg == 3) GRAM_DBG(3); else if (dbg == 4) GRAM_DBG(4); else if (dbg == 5) GRAM_DBG(5); else GRAM_DBG(6);
 #undef GRAM_DBG
       } else
@@ -795,6 +810,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
 #undef GHIP
   tpg_pfree(d_DG); tpg_pfree(d_what); tpg_pfree(d_wc); tpg_pfree(d_r); tpg_pfree(d_part);
   tpg_pfree(d_slabs);
+  tpg_pfree(d_order);
   if (e != hipSuccess) return TPG_EHIP;
   return rc;
 }
