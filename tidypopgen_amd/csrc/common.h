@@ -129,7 +129,8 @@ struct tpg_pairwise {
   int64_t ntp;  // number of (I, jt) units = nst*(nst+1)
   int32_t* acc;
   bool owns;
-  void* order;  // device int2[ntp]: the units (I, jt) in XCD patch order (pairwise.hip)
+  void* order;  // device int2[nun]: the units (I, jt) that hold data, in XCD patch order (pairwise.hip)
+  int64_t nun;
 };
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

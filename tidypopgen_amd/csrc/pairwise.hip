@@ -70,7 +70,7 @@ __device__ __forceinline__ int64_t tpg_pw_unit_index(int nst, int I, int jt) {
 #define SGB_VALU 0x002
 __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __restrict__ T, int64_t KG,
                                                                  int64_t kg_begin, int64_t kg_end, int nst,
-                                                                 const int2* __restrict__ order, int64_t ntp, int S,
+                                                                 const int2* __restrict__ order, int64_t nun, int S,
                                                                  int32_t* __restrict__ acc_out) {
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
   const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
   for (int64_t round = 0;; round++) {
     const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
-    if (un >= ntp * S) break;
-    const int ks = (int)(un / ntp);
-    const int2 ijt = order[un % ntp];
+    if (un >= nun * S) break;
+    const int ks = (int)(un / nun);
+    const int2 ijt = order[un % nun];
     const int I = ijt.x, jt = ijt.y;
     const int64_t tp0 = tpg_pw_unit_index(nst, I, jt);
     const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
@@ -188,11 +188,13 @@ extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tp
   TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && n < (1 << 22), TPG_EINVAL, "bad n = %lld", (long long)n);
   TPG_HIP(hipSetDevice(ctx->device));
-  tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 64), 0, nullptr, false, nullptr};
+  tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 64), 0, nullptr, false, nullptr, 0};
   pw->ntp = pw->nst * (pw->nst + 1);
   {
-    // units (I, jt), jt >= 2 I, in patch order: blocks of 16 column tiles, inside a block row after row
-    const int nst = (int)pw->nst, nct = 2 * nst;
+    // units (I, jt), jt >= 2 I, in patch order: blocks of 16 column tiles, inside a block row after row.  Column
+    // tiles that hold only padding (32 jt >= n: all-missing codes, zero products) are left out -- their slabs stay
+    // zero and no epilogue reads them.
+    const int nst = (int)pw->nst, nct = (int)ceil_div(n, 32);
     std::vector<int2> order;
     order.reserve((size_t)pw->ntp);
     for (int pc = 0; pc * 16 < nct; pc++) {
@@ -200,7 +202,7 @@ extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tp
       for (int I = 0; I < nst && 2 * I < c1; I++)
         for (int jt = std::max(pc * 16, 2 * I); jt < c1; jt++) order.push_back(make_int2(I, jt));
     }
-    if ((int64_t)order.size() != pw->ntp) { tpg_pairwise_free(pw); tpg_set_error("pairwise order table size"); return TPG_EINVAL; }
+    pw->nun = (int64_t)order.size();
     hipError_t e = tpg_pmalloc(&pw->order, sizeof(int2) * order.size());
     if (e == hipSuccess) e = hipMemcpy(pw->order, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { tpg_pairwise_free(pw); tpg_set_error("pairwise order table: %s", hipGetErrorString(e)); return TPG_EHIP; }
@@ -254,12 +256,12 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
   double best = -1;
   const int64_t maxS = kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1;
   for (int64_t S = 1; S <= maxS; S++) {
-    const int64_t U = pw->ntp * S;
+    const int64_t U = pw->nun * S;
     const double eff = (double)U / (double)(ceil_div(U, nwaves) * nwaves);
     if (eff > best + 0.01) { best = eff; bestS = (int)S; }
   }
   TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T, v->KG,
-             kg0, kg1, (int)pw->nst, (const int2*)pw->order, pw->ntp, bestS, pw->acc);
+             kg0, kg1, (int)pw->nst, (const int2*)pw->order, pw->nun, bestS, pw->acc);
   TPG_CHECK_LAUNCH();
   return TPG_OK;
 }
