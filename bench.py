@@ -313,7 +313,13 @@ def main():
 
         # HBM bytes per launch from the rocprofv3 --pmc passes committed under profiles/ (FETCH_SIZE doubled per the
         # gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE); null when the workload is not the profiled one
-        TRAFFIC = {"pairwise_mfma": 5.44e10, "pca_gram_mfma": 7.23e10} if (n, m) == (5000, 1000000) else {}
+        TRAFFIC = {}
+        if (n, m, args.pops, args.k) == (5000, 1000000, 51, 20):
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
+                    TRAFFIC = json.load(f)["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                TRAFFIC = {}
         m_pca = st.m_pca if st.has_pca else m
         roofs = [
             mfma_roof("pairwise_mfma", "tpg_pairwise_kernel (v_mfma_i32_32x32x32_i8)", 5.0 * n * n * m,
@@ -333,7 +339,7 @@ def main():
             "unit": "SNP-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8 MFMA / int32 accumulate for counts and cross-products, f64 for statistics",
+            "dtype": "int8 (int32 accumulate) for counts and cross-products, f64 for statistics",
             "data": "synthetic",
             "config": {"workload": f"{n} individuals x {m} SNPs per GPU ({world} GPU), 51 populations, 2% missing "
                                    f"(imputed bytes), seed 3 [BASELINE configs 2-4]",

@@ -385,7 +385,7 @@ __device__ __forceinline__ int64_t tpg_gram_unit_index(int nsb, int ia, int jb) 
 #define SGB_VALU 0x002
 #define SGB_DSR 0x100
 #define SGB_VMEMR 0x020
-template <int TD, int DBG = 0>  // digits handled by this pass (<= 4); DG holds exactly these TD digits per locus.  DBG != 0: timing experiments only (wrong results)
+template <int TD>  // digits handled by this pass (<= 4); DG holds exactly these TD digits per locus
 __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
                                                               int64_t kg_begin, int64_t kg_end,
                                                               const uint4* __restrict__ DG, int t0, int nrt,
@@ -432,28 +432,19 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
       // decode of one K step: word wA of the A tile, words wB[tb] of the B tiles, digits from LDS buffer `dbuf`, step s
       v4i PA[2][TD], PB[2][TB];
       uint4 d1[TD], d2[TD];  // digits of the step being decoded
-      if (DBG == 1 || DBG == 6) {
-#pragma unroll
-        for (int t = 0; t < TD; t++) { d1[t] = DG[lane + t]; d2[t] = DG[lane + 7 + t]; }
-      }
       // first half of a decode: issue all digit reads of the step, then the B side (needs no digits: its ~44
       // VALU instructions and the MFMAs interleaved with them cover the LDS latency)
       auto decode_B = [&](int set, const uint32_t* wB, int dbuf, int sidx) {
         const uint4* dl = &dgs[wv][dbuf][((sidx * 2 + h) * TD) * 2];
-        if (DBG != 1 && DBG != 6) {
 #pragma unroll
-          for (int t = 0; t < TD; t++) { d1[t] = dl[t * 2]; d2[t] = dl[t * 2 + 1]; }
-        }
-        if (DBG != 4 && DBG != 6) {
+        for (int t = 0; t < TD; t++) { d1[t] = dl[t * 2]; d2[t] = dl[t * 2 + 1]; }
 #pragma unroll
-          for (int tb = 0; tb < TB; tb++)
+        for (int tb = 0; tb < TB; tb++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) PB[set][tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wB[tb], k));
-        }
+          for (int k = 0; k < 4; k++) PB[set][tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wB[tb], k));
       };
       // second half: selectors from the A word, then one v_perm per digit and register
       auto decode_A = [&](int set, uint32_t wA) {
-        if (DBG == 3 || DBG == 6) return;
         uint32_t sel[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -500,8 +491,8 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
       auto group = [&](auto Cc, auto Nn, auto Mm, int64_t kg) {
         constexpr int C = decltype(Cc)::value, N = decltype(Nn)::value, M = decltype(Mm)::value;
         // digits of the next group into the other LDS buffer (its last readers were this wave's previous group)
-        if (DBG != 2 && DBG != 6 && dlane) dgs[wv][buf ^ 1][lane] = RD[N];
-        if (DBG != 2 && DBG != 6) lds_sync();
+        if (dlane) dgs[wv][buf ^ 1][lane] = RD[N];
+        lds_sync();
         // the loads of the group after next are spread over steps 0..2 (at most two back to back): six in a row
         // hold this wave's instruction issue long enough for the MFMA pipe to drain (one wave per SIMD)
         const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
@@ -520,14 +511,12 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
           // next step's operands: steps 1..3 of this group, or step 0 of the next group (other digit buffer).
           // Two scheduling regions so that the digit reads are long done when the A-side perms need them.
           constexpr int NQ = TD * TB, Q1 = (NQ * 9) / 16 > 0 ? (NQ * 9) / 16 : 1;
-          if (DBG < 5) {
-            if (s == 0) {
-              if (DBG != 2 && dlane) RD[M] = DG[i2 * (TD * 16) + lane];
-              RA[M] = pa[i2 * 64];
-            } else if (s <= (TB + 1) / 2) {
+          if (s == 0) {
+            if (dlane) RD[M] = DG[i2 * (TD * 16) + lane];
+            RA[M] = pa[i2 * 64];
+          } else if (s <= (TB + 1) / 2) {
 #pragma unroll
-              for (int tb = 2 * (s - 1); tb < 2 * s && tb < TB; tb++) RB[M][tb] = pb[tb][i2 * 64];
-            }
+            for (int tb = 2 * (s - 1); tb < 2 * s && tb < TB; tb++) RB[M][tb] = pb[tb][i2 * 64];
           }
           decode_B(nx, wB[s + 1], s < 3 ? buf : (buf ^ 1), s < 3 ? s + 1 : 0);
 #pragma unroll
@@ -760,14 +749,6 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
 #define GRAM_LAUNCH(TD)                                                                                              \
   TPG_LAUNCH(ctx, "pca_gram_mfma", tpg_pca_gram_kernel<TD>, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG,      \
              (int64_t)0, v->KG, dgp, t0, nrt, nsb, (const int2*)d_order, nsu, bestS, d_slabs)
-      static const int dbg = getenv("TPG_GRAM_DBG") ? atoi(getenv("TPG_GRAM_DBG")) : 0;
-      if (td == 4 && dbg) {
-#define GRAM_DBG(D)                                                                                                  \
-  TPG_LAUNCH(ctx, "pca_gram_mfma", (tpg_pca_gram_kernel<4, D>), dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG,   \
-             (int64_t)0, v->KG, dgp, t0, nrt, nsb, (const int2*)d_order, nsu, bestS, d_slabs)
-        if (dbg == 1) GRAM_DBG(1); else if (dbg == 2) GRAM_DBG(2); else if (dbg == 3) GRAM_DBG(3); else if (dbg == 4) GRAM_DBG(4); else if (dbg == 5) GRAM_DBG(5); else GRAM_DBG(6);
-#undef GRAM_DBG
-      } else
       if (td == 4) GRAM_LAUNCH(4);
       else if (td == 3) GRAM_LAUNCH(3);
       else if (td == 2) GRAM_LAUNCH(2);

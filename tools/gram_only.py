@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the PCA Gram kernel alone (HIP events inside the library).  TPG_GRAM_DBG selects timing experiments."""
+"""Time the PCA Gram kernel alone (HIP events inside the library)."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
