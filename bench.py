@@ -270,6 +270,11 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: libraries that print to fd 1 (RCCL's version banner on communicator
+    # creation, for one) are sent to stderr for the whole run, the result goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -351,7 +356,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist_on:
         st.dist.destroy_process_group()
 

@@ -110,6 +110,16 @@ int tpg_gt_ind_hetero(tpg_ctx* ctx, const tpg_view* v, int32_t* out);
 int tpg_gt_pi_diploid(tpg_ctx* ctx, const tpg_view* v, double* pi);
 int tpg_gt_grouped_pi_diploid(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups, double* pi,
                               double* n);
+/* genotype counts per locus x group, the 3 x ngroups table gt_grouped_hwe fills before each exact test
+ * (src/hwe.cpp:238-250; the test itself, PLINK's SNPHWE2, is out of scope): out = three m x G int32 matrices
+ * (column-major), k = 0, 1, 2 alternate alleles */
+int tpg_grouped_genotype_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                                int32_t* out);
+/* pop_global_stats (R/pop_global_stats.R:113-212, with compute_np_mn, src/compute_np_mn.cpp:8-34): by_locus =
+ * m x 10 column-major {Ho, Hs, Ht, Dst, Htp, Dstp, Fst, Fstp, Fis, Dest} (may be NULL), overall = the 10
+ * by_locus = FALSE values (may be NULL).  ploidy (may be NULL) must be all 2: the reference stops otherwise. */
+int tpg_pop_global_stats(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                         const double* ploidy, double* by_locus, double* overall);
 /* replaces alt_freq_dip_pseudo_cpp (src/alt_freq_dip_pseudo_cpp.cpp:8-58) for the whole
  * colInd at once (the big_apply block loop R/loci_alt_freq.R:351-359 collapses):
  * out m x 2 = {n_alt | freq, n_valid} */

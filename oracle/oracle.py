@@ -22,6 +22,8 @@ import math
 import os
 import subprocess
 
+import warnings
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -228,6 +230,68 @@ def gt_grouped_pi_diploid(fbm, rowInd, colInd, groupIds, ngroups, code256=CODE_0
     lib().orc_gt_grouped_pi_diploid(*_args(fbm, r, c), _d(np.ascontiguousarray(code256)), _p(gid, C.c_int32),
                                     C.c_int(ngroups), _d(pi), _d(n))
     return dict(pi=pi, n=n)
+
+
+def grouped_genotype_counts(fbm, rowInd, colInd, groupIds, ngroups, code256=CODE_012):
+    """the 3 x ngroups genotype table gt_grouped_hwe fills per locus (src/hwe.cpp:238-250) -> (3, m, G) int32"""
+    fbm, r, c = _view(fbm, rowInd, colInd)
+    g = np.asarray(code256)[fbm[np.ix_(r - 1, c - 1)]]  # (n, m) decoded, NaN = missing (indices are 1-based)
+    gid = np.asarray(groupIds)
+    out = np.zeros((3, len(c), ngroups), dtype=np.int32)
+    for k in range(3):
+        hit = (g == k)
+        for grp in range(ngroups):
+            out[k, :, grp] = hit[gid == grp].sum(axis=0)
+    return out
+
+
+def compute_np_mn(n):
+    """src/compute_np_mn.cpp:8-34"""
+    n = np.asarray(n, dtype=float)
+    ok = ~np.isnan(n)
+    np_ = ok.sum(axis=1).astype(float)
+    with np.errstate(divide="ignore"):
+        denom = np.where(ok, 1.0 / n, 0.0).sum(axis=1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mn = np.where(denom > 0.0, np_ / denom, np.nan)
+    return np_, mn
+
+
+def pop_global_stats(fbm, rowInd, colInd, groupIds, ngroups, ploidy=None, by_locus=False, code256=CODE_012):
+    """R/pop_global_stats.R:113-212, statement by statement (hierfstat::basic.stats arithmetic)"""
+    fbm_, r, c = _view(fbm, rowInd, colInd)
+    ploidy = np.full(len(r), 2.0) if ploidy is None else np.asarray(ploidy, dtype=float)
+    if not np.all(ploidy == 2.0):
+        raise ValueError("pop_global_stats only works on diploid data")  # stopifnot_diploid, :117
+    with np.errstate(invalid="ignore", divide="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        pf = grouped_summaries_dip_pseudo_cpp(fbm, rowInd, colInd, groupIds, ngroups, ploidy, code256)
+        n = pf["n"] / 2                                   # :146
+        sHo = pf["het_obs"]                               # :148
+        mHo = np.nanmean(sHo, axis=1)                     # :149
+        sp2 = pf["freq_alt"] ** 2 + pf["freq_ref"] ** 2   # :151
+        np_, mn = compute_np_mn(n)                        # :166-168
+        msp2 = np.nanmean(sp2, axis=1)                    # :170
+        mp2 = pf["freq_alt"].mean(axis=1) ** 2 + pf["freq_ref"].mean(axis=1) ** 2  # :171
+        mHs = mn / (mn - 1) * (1 - msp2 - mHo / 2 / mn)   # :172
+        Ht = 1 - mp2 + mHs / mn / np_ - mHo / 2 / mn / np_  # :173
+        mFis = 1 - mHo / mHs                              # :174
+        Dst = Ht - mHs
+        Dstp = np_ / (np_ - 1) * Dst
+        Htp = mHs + Dstp
+        Fst = Dst / Ht
+        Fstp = Dstp / Htp
+        Dest = Dstp / (1 - mHs)
+        res = np.column_stack([mHo, mHs, Ht, Dst, Htp, Dstp, Fst, Fstp, mFis, Dest])
+        if by_locus:
+            return res
+        res = np.where(np.isinf(res), np.nan, res)        # :203
+        overall = np.nanmean(res, axis=0)                 # :204
+        overall[6] = overall[3] / overall[2]
+        overall[7] = overall[5] / overall[4]
+        overall[8] = 1 - overall[0] / overall[1]
+        overall[9] = overall[5] / (1 - overall[1])
+    return overall
 
 
 def _fst_loop(fn, pairs1, m, mats, by_locus, return_num_dem):

@@ -423,3 +423,45 @@ def test_pca_errors_like_big_svd(tpg):
     with pytest.raises(tpg._lib.TpgError) as e:  # zero scale
         tpg.gt_pca_partialSVD(tpg.FBM.from_numpy(mono), k=3)
     assert e.value.code == 4
+
+
+# ---------------------------------------------------------------- more §8f(2) rows
+@pytest.mark.parametrize("n,m,G,miss", [(7, 6, 3, None), (60, 200, 4, 0.1), (300, 2500, 6, 0.05), (500, 1500, 51, 0.3)])
+def test_grouped_genotype_counts_and_global_stats(tpg, n, m, G, miss):
+    if miss is None:
+        fbm, gid = orc.fbm_from_genotypes(fx.FST_7x6), fx.FST_GROUPS_3
+    else:
+        fbm = orc.synth_fbm(71, n, m, npop=G, miss=miss)
+        gid = (np.arange(n) % G).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    v = tpg.View(X)
+    # the genotype table gt_grouped_hwe builds per locus (src/hwe.cpp:238-250): exact
+    assert np.array_equal(tpg.grouped_genotype_counts(v, gid, G), orc.grouped_genotype_counts(fbm, None, None, gid, G))
+    # pop_global_stats (R/pop_global_stats.R:113-212): same statements in FP64, contraction off
+    o_loc = orc.pop_global_stats(fbm, None, None, gid, G, by_locus=True)
+    t_loc = tpg.pop_global_stats(X, None, None, gid, G, by_locus=True)
+    assert np.array_equal(np.isnan(t_loc), np.isnan(o_loc))
+    assert np.array_equal(np.isinf(t_loc), np.isinf(o_loc))
+    fin = np.isfinite(o_loc)
+    assert np.allclose(t_loc[fin], o_loc[fin], rtol=1e-12, atol=1e-13)
+    o_all = orc.pop_global_stats(fbm, None, None, gid, G)
+    t_all = tpg.pop_global_stats(X, None, None, gid, G)
+    assert np.allclose(t_all, o_all, rtol=1e-11, atol=1e-13, equal_nan=True)
+    # subsets of rows / loci go through the same view machinery
+    rows = np.arange(1, n + 1, 2, dtype=np.int32)
+    cols = np.arange(m, 0, -3, dtype=np.int32)
+    o_sub = orc.pop_global_stats(fbm, rows, cols, gid[rows - 1], G, by_locus=True)
+    t_sub = tpg.pop_global_stats(X, rows, cols, gid[rows - 1], G, by_locus=True)
+    fin = np.isfinite(o_sub)
+    assert np.array_equal(np.isfinite(t_sub), fin) and np.allclose(t_sub[fin], o_sub[fin], rtol=1e-12, atol=1e-13)
+
+
+def test_global_stats_single_population_and_ploidy(tpg):
+    # tests/testthat/test_pop_basic_stats.R:160-176: Fstp is not defined for a single population
+    fbm = orc.fbm_from_genotypes(fx.FST_7x6)
+    X = tpg.FBM.from_numpy(fbm)
+    gid = np.zeros(7, dtype=np.int32)
+    loc = tpg.pop_global_stats(X, None, None, gid, 1, by_locus=True)
+    assert np.all(np.isnan(loc[:, 7]))
+    with pytest.raises(tpg._lib.TpgError):  # stopifnot_diploid
+        tpg.pop_global_stats(X, None, None, gid, 1, ploidy=np.array([2, 2, 1, 2, 2, 2, 2.0]))

@@ -384,6 +384,29 @@ def gt_grouped_pi_diploid(v: View, groupIds, ngroups: int) -> dict:
     return dict(pi=pi, n=n)
 
 
+def grouped_genotype_counts(v: View, groupIds, ngroups: int) -> np.ndarray:
+    """the genotype table of gt_grouped_hwe (src/hwe.cpp:238-250) -> (3, m, G) int32: [k] = individuals with k alternate alleles"""
+    out = np.zeros((3, ngroups, v.m), dtype=np.int32)  # three column-major m x G matrices
+    gid = _i32(groupIds)
+    check(lib.tpg_grouped_genotype_counts(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(out)))
+    return np.ascontiguousarray(out.transpose(0, 2, 1))
+
+
+GLOBAL_STATS_COLUMNS = ("Ho", "Hs", "Ht", "Dst", "Htp", "Dstp", "Fst", "Fstp", "Fis", "Dest")
+
+
+def pop_global_stats(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=None, by_locus: bool = False):
+    """R/pop_global_stats.R:113-212 -> (m, 10) array (by_locus) or the 10 overall values; columns GLOBAL_STATS_COLUMNS"""
+    v = View(X, ind_row, ind_col)
+    gid = _i32(groupIds)
+    pl = _ploidy(v, ploidy)
+    loc = np.zeros((v.m, 10), order="F") if by_locus else None
+    ov = np.zeros(10)
+    check(lib.tpg_pop_global_stats(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pl),
+                                   _ptr(loc) if by_locus else None, _ptr(ov)))
+    return loc if by_locus else ov
+
+
 def alt_freq_dip_pseudo_cpp(v: View, ploidy=None, as_counts: bool = False) -> np.ndarray:
     """src/alt_freq_dip_pseudo_cpp.cpp:8-58 -> (m, 2)"""
     out = np.zeros((v.m, 2), order="F")

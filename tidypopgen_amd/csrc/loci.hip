@@ -421,6 +421,149 @@ extern "C" int tpg_gt_grouped_pi_diploid(tpg_ctx* ctx, const tpg_view* v, const 
   return TPG_OK;
 }
 
+// genotype counts per locus x group, the table gt_grouped_hwe fills before each exact test
+// (src/hwe.cpp:238-250): out[k][j + g m] = individuals of group g with k alternate alleles at locus j
+__global__ void tpg_grouped_genotype_counts_kernel(const int32_t* __restrict__ cnt, int64_t Mpad, int Cpad, int64_t m,
+                                                   int G, int32_t* __restrict__ out) {
+  const int64_t total = m * G, plane = Mpad * Cpad;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % G);
+    const int64_t j = idx / G;
+    const int64_t o = j * Cpad + g;
+    const int n1 = cnt[o], n2 = cnt[plane + o], nv = cnt[2 * plane + o];
+    out[j + (int64_t)g * m] = nv - n1 - n2;
+    out[total + j + (int64_t)g * m] = n1;
+    out[2 * total + j + (int64_t)g * m] = n2;
+  }
+}
+
+extern "C" int tpg_grouped_genotype_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                                           int32_t* out) {
+  TPG_REQUIRE(ctx && v && groupIds0 && out, TPG_EINVAL, "null argument");
+  ClassPlan cp;
+  TPG_TRY(make_class_plan(v, groupIds0, ngroups, nullptr, &cp));
+  GroupedCounts gc;
+  TPG_TRY(tpg_grouped_counts(ctx, v, cp.cls.data(), cp.nclass, &gc));
+  OutBuf o;
+  TPG_TRY(o.init(out, sizeof(int32_t) * 3 * (size_t)v->m * (size_t)ngroups));
+  TPG_LAUNCH(ctx, "grouped_genotype_counts", tpg_grouped_genotype_counts_kernel, dim3(2048), dim3(256), 0,
+             (const int32_t*)gc.cnt, gc.Mpad, gc.Cpad, v->m, ngroups, o.dev<int32_t>());
+  TPG_CHECK_LAUNCH();
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return o.commit(ctx);
+}
+
+// R/pop_global_stats.R:129-197 (hierfstat::basic.stats arithmetic), one thread per locus; out = m x 10,
+// column-major, columns Ho Hs Ht Dst Htp Dstp Fst Fstp Fis Dest.  np / mn as src/compute_np_mn.cpp:8-34 (n is
+// never NA there: a group with no typed individual has n = 0, counts in np and makes mn = 0).
+#define TPG_GS_NAN __longlong_as_double(0x7FF8000000000000ll)
+__global__ void tpg_global_stats_kernel(const int32_t* __restrict__ cnt, int64_t Mpad, int Cpad, int64_t m, int G,
+                                        double* __restrict__ out) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    double np = 0, denom = 0, sho = 0, ssp2 = 0, sfa = 0, sfr = 0;
+    int nho = 0, nsp2 = 0;
+    for (int g = 0; g < G; g++) {
+      const GroupVals gv = tpg_group_vals(cnt, Mpad, Cpad, j, g, 0);
+      const double n = gv.valid / 2;
+      const double fa = gv.alt / gv.valid, fr = 1 - fa, ho = gv.het2 / gv.valid;
+      np += 1.0;
+      denom += 1.0 / n;
+      if (ho == ho) { sho += ho; nho++; }             // rowMeans(sHo, na.rm = TRUE)
+      const double sp2 = fa * fa + fr * fr;
+      if (sp2 == sp2) { ssp2 += sp2; nsp2++; }        // rowMeans(sp2, na.rm = TRUE)
+      sfa += fa;                                      // rowMeans(freq) without na.rm: NaN propagates
+      sfr += fr;
+    }
+    const double mn = denom > 0.0 ? np / denom : TPG_GS_NAN;
+    const double mHo = sho / nho, msp2 = ssp2 / nsp2;  // 0 / 0 = NaN, as mean(numeric(0))
+    const double mfa = sfa / G, mfr = sfr / G;
+    const double mp2 = mfa * mfa + mfr * mfr;
+    const double mHs = mn / (mn - 1) * (1 - msp2 - mHo / 2 / mn);
+    const double Ht = 1 - mp2 + mHs / mn / np - mHo / 2 / mn / np;
+    const double mFis = 1 - mHo / mHs;
+    const double Dst = Ht - mHs;
+    const double Dstp = np / (np - 1) * Dst;
+    const double Htp = mHs + Dstp;
+    const double Fst = Dst / Ht, Fstp = Dstp / Htp, Dest = Dstp / (1 - mHs);
+    out[j] = mHo; out[m + j] = mHs; out[2 * m + j] = Ht; out[3 * m + j] = Dst; out[4 * m + j] = Htp;
+    out[5 * m + j] = Dstp; out[6 * m + j] = Fst; out[7 * m + j] = Fstp; out[8 * m + j] = mFis; out[9 * m + j] = Dest;
+  }
+}
+
+// per column: sum and count of the finite entries, in a fixed order (block partials, then one thread)
+__global__ __launch_bounds__(256) void tpg_finite_colsum_kernel(const double* __restrict__ x, int64_t m,
+                                                                double* __restrict__ part) {
+  __shared__ double ssum[256], scnt[256];
+  const int c = blockIdx.y;
+  const int64_t chunk = (m + gridDim.x - 1) / gridDim.x;
+  const int64_t a = blockIdx.x * chunk, b = a + chunk < m ? a + chunk : m;
+  double s = 0, k = 0;
+  for (int64_t j = a + threadIdx.x; j < b; j += 256) {
+    const double v = x[(int64_t)c * m + j];
+    if (v == v && fabs(v) != HUGE_VAL) { s += v; k += 1; }
+  }
+  ssum[threadIdx.x] = s; scnt[threadIdx.x] = k;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[((int64_t)c * gridDim.x + blockIdx.x) * 2] = ssum[0];
+    part[((int64_t)c * gridDim.x + blockIdx.x) * 2 + 1] = scnt[0];
+  }
+}
+
+extern "C" int tpg_pop_global_stats(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                                    const double* ploidy, double* by_locus, double* overall) {
+  TPG_REQUIRE(ctx && v && groupIds0 && (by_locus || overall), TPG_EINVAL, "null argument");
+  if (ploidy)
+    for (int64_t i = 0; i < v->n; i++)  // stopifnot_diploid(.x), R/pop_global_stats.R:117
+      TPG_REQUIRE(ploidy[i] == 2.0, TPG_EINVAL, "pop_global_stats only works on diploid data");
+  ClassPlan cp;
+  TPG_TRY(make_class_plan(v, groupIds0, ngroups, nullptr, &cp));
+  GroupedCounts gc;
+  TPG_TRY(tpg_grouped_counts(ctx, v, cp.cls.data(), cp.nclass, &gc));
+  const int64_t m = v->m;
+  OutBuf ob;
+  double* d_tmp = nullptr;
+  if (by_locus) TPG_TRY(ob.init(by_locus, sizeof(double) * 10 * (size_t)m));
+  else TPG_HIP(tpg_pmalloc((void**)&d_tmp, sizeof(double) * 10 * (size_t)m));
+  double* d_loc = by_locus ? ob.dev<double>() : d_tmp;
+  const int NB = 64;
+  double* d_part = nullptr;
+  hipError_t e = tpg_pmalloc((void**)&d_part, sizeof(double) * 2 * 10 * NB);
+  std::vector<double> part((size_t)2 * 10 * NB);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(tpg_global_stats_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const int32_t*)gc.cnt, gc.Mpad,
+                       gc.Cpad, m, ngroups, d_loc);
+    if (overall) {
+      hipLaunchKernelGGL(tpg_finite_colsum_kernel, dim3(NB, 10), dim3(256), 0, ctx->stream, (const double*)d_loc, m, d_part);
+      e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  tpg_pfree(d_part);
+  tpg_pfree(d_tmp);
+  if (e != hipSuccess) { tpg_set_error("pop_global_stats: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  if (overall) {
+    // is.na(res) <- is.infinite(res); colMeans(res, na.rm = TRUE); then the ratios of means (:203-210)
+    for (int c = 0; c < 10; c++) {
+      double s = 0, k = 0;
+      for (int b = 0; b < NB; b++) { s += part[((size_t)c * NB + b) * 2]; k += part[((size_t)c * NB + b) * 2 + 1]; }
+      overall[c] = s / k;
+    }
+    overall[6] = overall[3] / overall[2];
+    overall[7] = overall[5] / overall[4];
+    overall[8] = 1 - overall[0] / overall[1];
+    overall[9] = overall[5] / (1 - overall[1]);
+  }
+  if (by_locus) TPG_TRY(ob.commit(ctx));
+  return TPG_OK;
+}
+
 // ungrouped diploid: counts (m x 4) -> m x 2 doubles
 __global__ void tpg_alt_freq_finalize_kernel(const int4* __restrict__ counts, int64_t m, int as_counts,
                                              double* __restrict__ out) {
