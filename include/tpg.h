@@ -190,6 +190,12 @@ int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* out);        
 /* all four epilogues from one pass over the accumulators; any output may be NULL */
 int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int ibs_type, int64_t m, double* ibs,
                            double* king, double* allele_sharing, double* grm);
+/* the reduction pop_fst / pop_fis(method = "WG17") make of the N x N allele-sharing matrix
+ * (R/pop_fst.R:40-63, R/pop_fis.R:151-173): mean[g1 + g2 G] = mean(A[rows of g1, columns of g2], na.rm = TRUE),
+ * with the diagonal of A left out when skip_diag != 0; count (may be NULL) = number of entries averaged.
+ * A is n x n column-major, host or device. */
+int tpg_block_means(tpg_ctx* ctx, const double* A, int64_t n, const int32_t* groupIds0, int ngroups, int skip_diag,
+                    double* mean, double* count);
 
 /* Literal per-block mirrors of the three increment_* entry points
  * (src/snp_ibs.cpp:22-74, src/snp_king.cpp:21-74, src/snp_as.cpp:22-67): the caller-owned

@@ -294,6 +294,47 @@ def pop_global_stats(fbm, rowInd, colInd, groupIds, ngroups, ploidy=None, by_loc
     return overall
 
 
+def _as_blocks(Mij, groupIds, ngroups):
+    """the block part shared by pop_fst and pop_fis_wg17: R/pop_fst.R:40-63"""
+    Mij = np.array(Mij, dtype=float)
+    np.fill_diagonal(Mij, np.nan)
+    gid = np.asarray(groupIds)
+    wil = [np.where(gid == z)[0] for z in range(ngroups)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        Fsts = np.array([np.nanmean(Mij[np.ix_(w, w)]) if len(w) else np.nan for w in wil])
+        Mb = 0.0
+        for i in range(1, ngroups):
+            for j in range(i):
+                Mb = Mb + np.nanmean(Mij[np.ix_(wil[i], wil[j])])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            Mb = Mb * 2 / (ngroups * (ngroups - 1))
+    return wil, Fsts, Mb
+
+
+def pop_fst(allele_sharing_mat, groupIds, ngroups, include_global=False):
+    """R/pop_fst.R:31-76"""
+    _, Fsts, Mb = _as_blocks(allele_sharing_mat, groupIds, ngroups)
+    with np.errstate(invalid="ignore", divide="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        fst = (Fsts - Mb) / (1 - Mb)
+        if include_global:
+            fst = np.append(fst, np.nanmean(fst))
+    return fst
+
+
+def pop_fis_wg17(allele_sharing_mat, groupIds, ngroups, include_global=False):
+    """R/pop_fis.R:136-197"""
+    Mii = np.diag(np.asarray(allele_sharing_mat, dtype=float)) * 2 - 1
+    wil, Fsts, _ = _as_blocks(allele_sharing_mat, groupIds, ngroups)
+    with np.errstate(invalid="ignore", divide="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        fis = np.array([np.nanmean((Mii[w] - Fsts[g]) / (1 - Fsts[g])) if len(w) else np.nan for g, w in enumerate(wil)])
+        if include_global:
+            fis = np.append(fis, np.nanmean(fis))
+    return fis
+
+
 def _fst_loop(fn, pairs1, m, mats, by_locus, return_num_dem):
     pairs1 = np.ascontiguousarray(np.asarray(pairs1, dtype=np.int32).T)  # (P, 2) rows = (pop1, pop2)
     P = pairs1.shape[0]

@@ -465,3 +465,37 @@ def test_global_stats_single_population_and_ploidy(tpg):
     assert np.all(np.isnan(loc[:, 7]))
     with pytest.raises(tpg._lib.TpgError):  # stopifnot_diploid
         tpg.pop_global_stats(X, None, None, gid, 1, ploidy=np.array([2, 2, 1, 2, 2, 2, 2.0]))
+
+
+@pytest.mark.parametrize("n,m,G", [(7, 6, 3), (300, 2500, 6), (500, 1500, 51)])
+def test_pop_fst_and_fis_wg17_from_allele_sharing(tpg, n, m, G):
+    if n == 7:
+        fbm, gid = orc.fbm_from_genotypes(fx.FST_7x6), fx.FST_GROUPS_3
+    else:
+        fbm = orc.synth_fbm(81, n, m, npop=G, miss=0.05)
+        gid = (np.arange(n) % G).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    A_o = orc.snp_allele_sharing(fbm)
+    A_t = tpg.snp_allele_sharing(X)
+    # block means of an arbitrary matrix (NaN entries and the diagonal are skipped)
+    B = A_o.copy()
+    B[1, 0] = np.nan
+    mean, cnt = tpg.block_means(B, gid, G, skip_diag=True)
+    Bn = B.copy()
+    np.fill_diagonal(Bn, np.nan)
+    for g1 in range(G):
+        for g2 in range(G):
+            blk = Bn[np.ix_(np.where(gid == g1)[0], np.where(gid == g2)[0])]
+            assert cnt[g1, g2] == np.sum(~np.isnan(blk))
+            if cnt[g1, g2]:
+                assert mean[g1, g2] == pytest.approx(np.nanmean(blk), rel=1e-12, abs=1e-15)
+            else:
+                assert np.isnan(mean[g1, g2])
+    for glob in (False, True):
+        assert np.allclose(tpg.pop_fst(X, None, None, gid, G, include_global=glob), orc.pop_fst(A_o, gid, G, glob),
+                           rtol=1e-9, atol=1e-12, equal_nan=True)
+        assert np.allclose(tpg.pop_fis_wg17(X, None, None, gid, G, include_global=glob),
+                           orc.pop_fis_wg17(A_o, gid, G, glob), rtol=1e-9, atol=1e-12, equal_nan=True)
+    # a pre-computed matrix gives the same answer (R/pop_fst.R:36-38)
+    assert np.allclose(tpg.pop_fst(X, None, None, gid, G, allele_sharing_mat=A_t), tpg.pop_fst(X, None, None, gid, G),
+                       rtol=0, atol=0, equal_nan=True)

@@ -67,7 +67,7 @@ SYMBOLS = [
     "tpg_grouped_alt_freq_dip_pseudo", "tpg_grouped_missingness", "tpg_grouped_summaries_dip_pseudo",
     "tpg_pairwise_pop_fst", "tpg_pairwise_fst_loop", "tpg_pairwise_buffer_bytes", "tpg_pairwise_create",
     "tpg_pairwise_free", "tpg_pairwise_zero", "tpg_pairwise_accumulate", "tpg_pairwise_counts", "tpg_pairwise_ibs",
-    "tpg_pairwise_king", "tpg_pairwise_allele_sharing", "tpg_pairwise_grm", "tpg_pairwise_epilogues", "tpg_increment_ibs_counts",
+    "tpg_pairwise_king", "tpg_pairwise_allele_sharing", "tpg_pairwise_grm", "tpg_pairwise_epilogues", "tpg_block_means", "tpg_increment_ibs_counts",
     "tpg_increment_king_numerator", "tpg_increment_as_counts", "tpg_pca_center_scale", "tpg_pca_gram",
     "tpg_pca_partial_svd", "tpg_fbm256_prod_and_rowSumsSq", "tpg_square_frobenius",
 ]

@@ -321,6 +321,60 @@ def pairwise_grm(X: FBM, ind_row=None, ind_col=None, block_size=None):
     return pw.grm()
 
 
+def block_means(A, groupIds, ngroups: int, skip_diag: bool = True, ctx: Optional[Context] = None):
+    """mean(A[p1, p2], na.rm = TRUE) for every pair of groups (R/pop_fst.R:47-62) -> (G, G) means, (G, G) counts"""
+    ctx = ctx or default_context()
+    A = np.asfortranarray(A, dtype=np.float64)
+    gid = _i32(groupIds)
+    mean, cnt = np.zeros((ngroups, ngroups), order="F"), np.zeros((ngroups, ngroups), order="F")
+    check(lib.tpg_block_means(ctx.h, _ptr(A), C.c_int64(A.shape[0]), _ptr(gid), C.c_int(ngroups),
+                              C.c_int(int(skip_diag)), _ptr(mean), _ptr(cnt)))
+    return mean, cnt
+
+
+def _as_block_stats(X, ind_row, ind_col, groupIds, ngroups, allele_sharing_mat):
+    if ngroups < 1:
+        raise ValueError(".x should be a grouped gen_tibble")
+    if allele_sharing_mat is None:
+        allele_sharing_mat = snp_allele_sharing(X, ind_row, ind_col)
+    mMij, _ = block_means(allele_sharing_mat, groupIds, ngroups, skip_diag=True, ctx=X.ctx if X is not None else None)
+    Fsts = np.diag(mMij).copy()
+    # Mb: sum of the strictly lower triangle in the reference's loop order (i = 2..n_pop, j = 1..i-1), :53-63
+    Mb = 0.0
+    for i in range(1, ngroups):
+        for j in range(i):
+            Mb = Mb + mMij[i, j]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        Mb = Mb * 2 / (ngroups * (ngroups - 1))
+    return allele_sharing_mat, Fsts, Mb
+
+
+def pop_fst(X: FBM, ind_row, ind_col, groupIds, ngroups: int, include_global: bool = False, allele_sharing_mat=None):
+    """R/pop_fst.R:31-76 (Weir & Goudet 2017 population-specific Fst from the allele-sharing matrix)"""
+    _, Fsts, Mb = _as_block_stats(X, ind_row, ind_col, groupIds, ngroups, allele_sharing_mat)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        fst = (Fsts - Mb) / (1 - Mb)
+        if include_global:
+            fst = np.append(fst, np.nanmean(fst) if np.any(~np.isnan(fst)) else np.nan)
+    return fst
+
+
+def pop_fis_wg17(X: FBM, ind_row, ind_col, groupIds, ngroups: int, include_global: bool = False, allele_sharing_mat=None):
+    """R/pop_fis.R:136-197 (method = "WG17")"""
+    A, Fsts, _ = _as_block_stats(X, ind_row, ind_col, groupIds, ngroups, allele_sharing_mat)
+    Mii = np.diag(np.asarray(A)) * 2 - 1
+    gid = np.asarray(groupIds)
+    out = np.full(ngroups, np.nan)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for g in range(ngroups):
+            Fi = (Mii[gid == g] - Fsts[g]) / (1 - Fsts[g])
+            if np.any(~np.isnan(Fi)):
+                out[g] = np.nanmean(Fi)
+        if include_global:
+            out = np.append(out, np.nanmean(out) if np.any(~np.isnan(out)) else np.nan)
+    return out
+
+
 def increment_ibs_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] = None):
     """Literal mirror of src/snp_ibs.cpp:22-74 (k, k2 are incremented in place; X_bytes is the host FBM)."""
     return _increment(lib.tpg_increment_ibs_counts, k, k2, X_bytes, rowInd, colInd, ctx)

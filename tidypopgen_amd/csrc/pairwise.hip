@@ -481,6 +481,93 @@ extern "C" int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* ou
 }
 
 // ---------------------------------------------------------------------------
+// Block means of an N x N matrix by groups of individuals: the reduction pop_fst / pop_fis (WG17) make of the
+// allele-sharing matrix, mean(Mij[p1, p2], na.rm = TRUE) for every pair of populations with the diagonal set
+// to NA (R/pop_fst.R:40-63, R/pop_fis.R:151-173).  Deterministic: kernel A sums, for one column j and one
+// group g, the rows of g in index order; kernel B sums those per-column results over the columns of a group in
+// index order -- the column-major order R's mean() walks the sub-matrix in.
+__global__ __launch_bounds__(64) void tpg_block_colsum_kernel(const double* __restrict__ A, int64_t n, int G,
+                                                              const int32_t* __restrict__ perm,
+                                                              const int32_t* __restrict__ goff, int skip_diag,
+                                                              double* __restrict__ colsum, double* __restrict__ colcnt) {
+  const int64_t j = blockIdx.x;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    double s = 0, k = 0;
+    for (int t = goff[g]; t < goff[g + 1]; t++) {
+      const int64_t i = perm[t];
+      const double v = A[i + j * n];
+      if (v == v && !(skip_diag && i == j)) { s += v; k += 1; }
+    }
+    colsum[j * G + g] = s;
+    colcnt[j * G + g] = k;
+  }
+}
+
+__global__ void tpg_block_combine_kernel(const double* __restrict__ colsum, const double* __restrict__ colcnt, int G,
+                                         const int32_t* __restrict__ perm, const int32_t* __restrict__ goff,
+                                         double* __restrict__ mean, double* __restrict__ count) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G * G) return;
+  const int g1 = idx % G, g2 = idx / G;  // rows of g1, columns of g2
+  double s = 0, k = 0;
+  for (int t = goff[g2]; t < goff[g2 + 1]; t++) {
+    const int64_t j = perm[t];
+    s += colsum[j * G + g1];
+    k += colcnt[j * G + g1];
+  }
+  mean[idx] = s / k;  // 0 / 0 = NaN = mean(numeric(0))
+  if (count) count[idx] = k;
+}
+
+extern "C" int tpg_block_means(tpg_ctx* ctx, const double* A, int64_t n, const int32_t* groupIds0, int ngroups,
+                               int skip_diag, double* mean, double* count) {
+  TPG_REQUIRE(ctx && A && groupIds0 && mean, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(n > 0 && ngroups > 0, TPG_EINVAL, "bad n = %lld or ngroups = %d", (long long)n, ngroups);
+  std::vector<int32_t> goff((size_t)ngroups + 1, 0), perm((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    TPG_REQUIRE(groupIds0[i] >= 0 && groupIds0[i] < ngroups, TPG_EINVAL, "groupIds[%lld] = %d out of [0,%d)",
+                (long long)i, groupIds0[i], ngroups);
+    goff[(size_t)groupIds0[i] + 1]++;
+  }
+  for (int g = 0; g < ngroups; g++) goff[(size_t)g + 1] += goff[(size_t)g];
+  {
+    std::vector<int32_t> fill(goff.begin(), goff.end() - 1);
+    for (int64_t i = 0; i < n; i++) perm[(size_t)fill[(size_t)groupIds0[i]]++] = (int32_t)i;  // index order inside a group
+  }
+  InBuf ia, ip, ig;
+  TPG_TRY(ia.init(ctx, A, sizeof(double) * (size_t)n * (size_t)n));
+  TPG_TRY(ip.init(ctx, perm.data(), sizeof(int32_t) * (size_t)n));
+  TPG_TRY(ig.init(ctx, goff.data(), sizeof(int32_t) * ((size_t)ngroups + 1)));
+  const size_t gg = (size_t)ngroups * (size_t)ngroups;
+  OutBuf om, oc;
+  TPG_TRY(om.init(mean, sizeof(double) * gg));
+  if (count) TPG_TRY(oc.init(count, sizeof(double) * gg));
+  double *d_cs = nullptr, *d_cc = nullptr;
+  hipError_t e = tpg_pmalloc((void**)&d_cs, sizeof(double) * (size_t)n * (size_t)ngroups);
+  if (e == hipSuccess) e = tpg_pmalloc((void**)&d_cc, sizeof(double) * (size_t)n * (size_t)ngroups);
+  int rc = TPG_OK;
+  if (e == hipSuccess) {
+    [&]() -> int {
+      TPG_LAUNCH(ctx, "block_colsum", tpg_block_colsum_kernel, dim3((unsigned)n), dim3(64), 0, ia.dev<double>(), n,
+                 ngroups, ip.dev<int32_t>(), ig.dev<int32_t>(), skip_diag, d_cs, d_cc);
+      TPG_LAUNCH(ctx, "block_combine", tpg_block_combine_kernel, dim3((unsigned)ceil_div((int64_t)gg, 256)), dim3(256), 0,
+                 (const double*)d_cs, (const double*)d_cc, ngroups, ip.dev<int32_t>(), ig.dev<int32_t>(),
+                 om.dev<double>(), oc.dev<double>());
+      return TPG_OK;
+    }();
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  tpg_pfree(d_cs);
+  tpg_pfree(d_cc);
+  if (e != hipSuccess) { tpg_set_error("block means: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  TPG_TRY(rc);
+  TPG_TRY(om.commit(ctx));
+  if (count) TPG_TRY(oc.commit(ctx));
+  return TPG_OK;
+}
+
+// ---------------------------------------------------------------------------
 // literal per-block mirrors of increment_{ibs,king,as}_counts
 static int increment_common(tpg_ctx* ctx, int which, double* A, double* B, const uint8_t* fbm_bytes, int64_t nrow,
                             int64_t ncol, const int32_t* rowInd1, int64_t n, const int32_t* colInd1, int64_t m) {
