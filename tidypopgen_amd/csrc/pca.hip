@@ -371,10 +371,6 @@ __global__ void tpg_pca_digits_kernel(const double* __restrict__ scale, const do
 #define PCA_TB 4  // B row tiles per unit: 32 x 128 wave tile, 16 accumulator tiles (256 AGPRs), 1 wave per SIMD
 #define PCA_SLAB_INTS (PCA_TB * 16 * 64)
 
-__device__ __forceinline__ int64_t tpg_gram_unit_index(int nsb, int ia, int jb) {
-  const int a = ia / PCA_TB, r = ia % PCA_TB;
-  return PCA_TB * ((int64_t)a * nsb - ((int64_t)a * (a - 1)) / 2) + (int64_t)r * (nsb - a) + (jb - a);
-}
 
 // One wave per SIMD, 16 accumulator tiles in AGPRs.  The operands of K step s+1 (one weighted A fragment per
 // digit, PCA_TB dosage fragments) are decoded into a second register set while the TD * PCA_TB MFMAs of step s
@@ -389,7 +385,7 @@ template <int TD>  // digits handled by this pass (<= 4); DG holds exactly these
 __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
                                                               int64_t kg_begin, int64_t kg_end,
                                                               const uint4* __restrict__ DG, int t0, int nrt,
-                                                              int nsb, const int2* __restrict__ order, int nsu, int S,
+                                                              int nsb, const int2* __restrict__ order, int nun, int S,
                                                               long long* __restrict__ slabs) {
   __shared__ __attribute__((aligned(16))) uint4 dgs[4][2][TD * 16];
   constexpr int TB = PCA_TB;
@@ -397,20 +393,21 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
   const int wv = threadIdx.x >> 6;
   const int h = lane >> 5;
   const int64_t kgs = kg_end - kg_begin;
-  // Work distribution.  A workgroup (4 waves) takes one SUPER-unit (a, jb): its waves are the four A row tiles
-  // 4a .. 4a+3 against the same B super-tile, so the B stream is fetched into the CU once.  Workgroups are
-  // dispatched round-robin over the 8 XCDs (blockIdx % 8), each XCD with its own L2: in every round XCD x takes a
-  // run of gridDim/8 CONSECUTIVE super-units of `order` (host-built: patches of 4 super-rows x 8 super-columns of
-  // the triangle, same K range), i.e. ~16 A tiles and ~32 B tiles per 128 loci for its 128 waves instead of up
-  // to ~190 distinct ones with a plain strided assignment -- the re-reads then hit that XCD's L2.
+  // Work distribution.  `order` (host-built, pca_gram_device) lists the units (ia, jb) -- A row tile ia against the
+  // B super-tile jb -- in PATCH order: four consecutive entries are the A row tiles 4a .. 4a+3 against the same B
+  // super-tile (the four waves of a workgroup fetch the B stream into the CU once), and a run of 128 consecutive
+  // entries is ~16 A tiles x 8 B super-tiles.  Workgroups are dispatched round-robin over the 8 XCDs
+  // (blockIdx % 8), each XCD with its own L2: in every round XCD x takes such a run for its 128 waves (same K
+  // range), ~16 A and ~32 B tiles per 128 loci instead of up to ~190 distinct ones with a plain strided
+  // assignment -- the re-reads then hit that XCD's L2.  The slab of a unit is its position in the table.
   const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
   for (int64_t round = 0;; round++) {
-    const int64_t su = (round * 8 + xcd) * cpx + cidx;
-    if (su >= (int64_t)nsu * S) break;
-    const int ks = (int)(su / nsu);
-    const int2 ajb = order[su % nsu];
-    const int jb = ajb.y, ia = TB * ajb.x + wv;
-    const int64_t u0 = tpg_gram_unit_index(nsb, ia, jb);
+    const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
+    if (un >= (int64_t)nun * S) break;
+    const int ks = (int)(un / nun);
+    const int64_t u0 = un % nun;
+    const int2 ijb = order[u0];
+    const int ia = ijb.x, jb = ijb.y;
     const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
 
     const uint4* pa = Tl + ((int64_t)ia * KG) * 64 + lane;
@@ -564,20 +561,41 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
   }
 }
 
-// K[i + k n] = 2^-F S[i][k] - r_i - r_k + C  (both triangles)
-__global__ void tpg_pca_assemble_kernel(const long long* __restrict__ slabs, int nsb, int n, int F,
-                                        const double* __restrict__ rvec, double Cc, double* __restrict__ K) {
+// Which unit holds element (i, k) of S = G W G', and where in its slab.  Full super-tiles (4 row tiles with data)
+// are the columns of the regular units (ia, jb >= ia / 4); the 1..3 row tiles left over past the last full
+// super-tile ("remainder" tiles, first one F4 = 4 nsbf) are kept as A ROW tiles against every full super-tile --
+// element (i, k) with k in the remainder is read from the transposed unit -- plus one unit against the partial
+// super-tile nsbf for the remainder x remainder corner.  (Treating the partial super-tile as a column of every
+// row tile instead would spend 4 MFMAs per step on it for every row tile with 1..3 of them useful: 3.7 % of the
+// kernel at N = 5 000.)
+__device__ __forceinline__ void tpg_gram_locate(int nsbf, int i, int k, int& ia, int& jb, int& tb, int& row, int& col) {
+  const int F4 = 4 * nsbf;
+  int ti = i >> 5, tk = k >> 5;
+  if (ti < F4 && tk < F4) {
+    if ((tk >> 2) < (ti >> 2)) { int t = i; i = k; k = t; ti = i >> 5; tk = k >> 5; }
+    ia = ti; jb = tk >> 2; tb = tk & 3;
+  } else if (ti >= F4 && tk >= F4) {
+    ia = ti; jb = nsbf; tb = tk - F4;
+  } else {
+    if (ti < F4) { int t = i; i = k; k = t; ti = i >> 5; tk = k >> 5; }  // i in the remainder, k in the full part
+    ia = ti; jb = tk >> 2; tb = tk & 3;
+  }
+  row = i & 31; col = k & 31;
+}
+
+// K[i + k n] = 2^-F S[i][k] - r_i - r_k + C  (both triangles); lut[ia (nsbf + 1) + jb] = slab of unit (ia, jb)
+__global__ void tpg_pca_assemble_kernel(const long long* __restrict__ slabs, const int32_t* __restrict__ lut, int nsbf,
+                                        int n, int F, const double* __restrict__ rvec, double Cc,
+                                        double* __restrict__ K) {
   const int64_t total = (int64_t)n * n;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    int i = (int)(idx % n), k = (int)(idx / n);
-    const int oi = i, ok = k;
-    if ((k / (32 * PCA_TB)) < (i / (32 * PCA_TB))) { int t = i; i = k; k = t; }
-    const int ia = i >> 5, jb = k / (32 * PCA_TB);
-    const int tb = (k % (32 * PCA_TB)) >> 5, row = i & 31, col = k & 31;
+    const int oi = (int)(idx % n), ok = (int)(idx / n);
+    int ia, jb, tb, row, col;
+    tpg_gram_locate(nsbf, oi, ok, ia, jb, tb, row, col);
     const int lane = col + 32 * ((row >> 2) & 1);
     const int reg = (row & 3) + 4 * (row >> 3);
-    const long long s = slabs[tpg_gram_unit_index(nsb, ia, jb) * PCA_SLAB_INTS + (tb * 16 + reg) * 64 + lane];
+    const long long s = slabs[(int64_t)lut[ia * (nsbf + 1) + jb] * PCA_SLAB_INTS + (tb * 16 + reg) * 64 + lane];
     double val = ldexp((double)s, -F);
     if (rvec) val = val - rvec[oi] - rvec[ok] + Cc;
     K[idx] = val;
@@ -700,12 +718,26 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   TPG_REQUIRE(T <= 8, TPG_ENUMERIC, "per-locus weight range too wide (max 1/scale^2 = %g)", wmax);
   const int F = 7 * T - 1 - wbits;
 
+  // units: see tpg_gram_locate.  nrtv row tiles hold data, nsbf full super-tiles, rem remainder tiles
   const int nrt = (int)(v->Q * 4), nsb = nrt / PCA_TB;
-  const int64_t nun = PCA_TB * ((int64_t)nsb * (nsb + 1) / 2);
+  const int nrtv = (int)ceil_div(n, 32), nsbf = nrtv / PCA_TB, rem = nrtv - PCA_TB * nsbf;
+  std::vector<int2> order;
+  for (int pj = 0; pj * 8 < nsbf; pj++) {  // patch order: super-column blocks of 8, inside them the super-rows
+    const int j1 = std::min(nsbf, pj * 8 + 8);
+    for (int a = 0; a < j1; a++)
+      for (int jb = std::max(pj * 8, a); jb < j1; jb++)
+        for (int r = 0; r < PCA_TB; r++) order.push_back(make_int2(PCA_TB * a + r, jb));
+  }
+  for (int jb = 0; jb <= nsbf && rem > 0; jb++)
+    for (int r = 0; r < rem; r++) order.push_back(make_int2(PCA_TB * nsbf + r, jb));
+  const int64_t nun = (int64_t)order.size();
+  std::vector<int32_t> lut((size_t)nrt * (size_t)(nsbf + 1), -1);
+  for (int64_t u = 0; u < nun; u++) lut[(size_t)order[(size_t)u].x * (size_t)(nsbf + 1) + (size_t)order[(size_t)u].y] = (int32_t)u;
   uint32_t* d_DG = nullptr;
   double *d_what = nullptr, *d_wc = nullptr, *d_r = nullptr, *d_part = nullptr;
   long long* d_slabs = nullptr;
   int2* d_order = nullptr;
+  int32_t* d_lut = nullptr;
   int rc = TPG_OK;
   hipError_t e = hipSuccess;
 #define GHIP(call) do { if (e == hipSuccess) { e = (call); if (e != hipSuccess) tpg_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e)); } } while (0)
@@ -719,17 +751,10 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   if (e == hipSuccess) {
     TPG_LAUNCH(ctx, "pca_digits", tpg_pca_digits_kernel, dim3(1024), dim3(256), 0, d_scale, d_center, m, v->KG, F, T,
                d_DG, d_what, d_wc);
-    // super-units (a, jb >= a) in patch order: super-column blocks of 8, inside them super-rows in runs of 4
-    const int nsu = nsb * (nsb + 1) / 2;
-    std::vector<int2> order;
-    order.reserve((size_t)nsu);
-    for (int pj = 0; pj * 8 < nsb; pj++) {
-      const int j1 = std::min(nsb, pj * 8 + 8);
-      for (int a = 0; a < j1; a++)
-        for (int jb = std::max(pj * 8, a); jb < j1; jb++) order.push_back(make_int2(a, jb));
-    }
-    GHIP(tpg_pmalloc((void**)&d_order, sizeof(int2) * (size_t)nsu));
-    GHIP(hipMemcpyAsync(d_order, order.data(), sizeof(int2) * (size_t)nsu, hipMemcpyHostToDevice, ctx->stream));
+    GHIP(tpg_pmalloc((void**)&d_order, sizeof(int2) * (size_t)nun));
+    GHIP(hipMemcpyAsync(d_order, order.data(), sizeof(int2) * (size_t)nun, hipMemcpyHostToDevice, ctx->stream));
+    GHIP(tpg_pmalloc((void**)&d_lut, sizeof(int32_t) * lut.size()));
+    GHIP(hipMemcpyAsync(d_lut, lut.data(), sizeof(int32_t) * lut.size(), hipMemcpyHostToDevice, ctx->stream));
     // K-split: fill the resident workgroups (one per CU, 1 wave per SIMD); grid a multiple of the 8 XCDs
     int nblk = ctx->num_cu / 8 * 8;
     if (nblk < 8) nblk = 8;
@@ -737,8 +762,8 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     double best = -1;
     const int64_t maxS = v->KG / 8 > 0 ? (v->KG / 8 < 96 ? v->KG / 8 : 96) : 1;
     for (int64_t S = 1; S <= maxS; S++) {
-      const int64_t U = (int64_t)nsu * S;
-      const double eff = (double)U / (double)(ceil_div(U, nblk) * nblk);
+      const int64_t U = nun * S;
+      const double eff = (double)U / (double)(ceil_div(U, 4 * (int64_t)nblk) * 4 * nblk);
       if (eff > best + 0.003) { best = eff; bestS = (int)S; }
     }
     const unsigned grid = (unsigned)nblk;
@@ -748,7 +773,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
       const uint4* dgp = (const uint4*)(d_DG + pass_base);
 #define GRAM_LAUNCH(TD)                                                                                              \
   TPG_LAUNCH(ctx, "pca_gram_mfma", tpg_pca_gram_kernel<TD>, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG,      \
-             (int64_t)0, v->KG, dgp, t0, nrt, nsb, (const int2*)d_order, nsu, bestS, d_slabs)
+             (int64_t)0, v->KG, dgp, t0, nrt, nsb, (const int2*)d_order, (int)nun, bestS, d_slabs)
       if (td == 4) GRAM_LAUNCH(4);
       else if (td == 3) GRAM_LAUNCH(3);
       else if (td == 2) GRAM_LAUNCH(2);
@@ -759,8 +784,8 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     GHIP(hipGetLastError());
   }
   if (e == hipSuccess && own_center) {
-    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, nsb, (int)n, F,
-               (const double*)nullptr, 0.0, d_K);
+    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, (const int32_t*)d_lut, nsbf,
+               (int)n, F, (const double*)nullptr, 0.0, d_K);
     TPG_LAUNCH(ctx, "pca_colmean", tpg_colmean_kernel, dim3((unsigned)n), dim3(256), 0, (const double*)d_K, (int)n, d_r);
     TPG_LAUNCH(ctx, "pca_colmean", tpg_mean_kernel, dim3(1), dim3(256), 0, (const double*)d_r, (int)n, d_part);
     TPG_LAUNCH(ctx, "pca_double_center", tpg_double_center_kernel, dim3(2048), dim3(256), 0, d_K, (int)n,
@@ -783,8 +808,8 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     Cc = (double)s;
   }
   if (e == hipSuccess && rc == TPG_OK && !own_center) {
-    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, nsb, (int)n, F,
-               (const double*)d_r, Cc, d_K);
+    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, (const int32_t*)d_lut, nsbf,
+               (int)n, F, (const double*)d_r, Cc, d_K);
     GHIP(hipGetLastError());
     GHIP(hipStreamSynchronize(ctx->stream));
   }
@@ -792,6 +817,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   tpg_pfree(d_DG); tpg_pfree(d_what); tpg_pfree(d_wc); tpg_pfree(d_r); tpg_pfree(d_part);
   tpg_pfree(d_slabs);
   tpg_pfree(d_order);
+  tpg_pfree(d_lut);
   if (e != hipSuccess) return TPG_EHIP;
   return rc;
 }
