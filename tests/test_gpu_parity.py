@@ -380,7 +380,7 @@ def test_pca_families_against_prcomp_definition(tpg):
     assert np.allclose(res["d"], o["d"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("n,m,G,k", [(60, 500, 3, 5), (300, 4000, 6, 10), (500, 6000, 12, 20)])
+@pytest.mark.parametrize("n,m,G,k", [(60, 500, 3, 5), (210, 1500, 4, 6), (300, 4000, 6, 10), (500, 6000, 12, 20)])
 def test_pca_vs_oracle(tpg, n, m, G, k):
     fbm = orc.synth_fbm(71, n, m, npop=G, miss=0.03, imputed_bytes=True)
     # drop monomorphic loci (big_SVD stops on a zero scale)
