@@ -438,7 +438,9 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
 #pragma unroll
         for (int tb = 0; tb < TB; tb++)
 #pragma unroll
-          for (int k = 0; k < 4; k++) PB[set][tb][k] = tpg_lut(TPG_LUT_G, tpg_codes(wB[tb], k));
+          // the view has no missing value (both callers check): codes 0 / 1 / 2 ARE the dosage bytes.  Code 3 only
+          // pads rows past n (their columns of K are never read) and loci past m (zero digits on the A side).
+          for (int k = 0; k < 4; k++) PB[set][tb][k] = (int)tpg_codes(wB[tb], k);
       };
       // second half: selectors from the A word, then one v_perm per digit and register
       auto decode_A = [&](int set, uint32_t wA) {
