@@ -120,6 +120,14 @@ int tpg_grouped_genotype_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* 
  * by_locus = FALSE values (may be NULL).  ploidy (may be NULL) must be all 2: the reference stops otherwise. */
 int tpg_pop_global_stats(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                          const double* ploidy, double* by_locus, double* overall);
+/* the numeric core of windows_stats_generic (R/windows_stats_generic.R:113-176: runner::mean_run /
+ * sum_run with na_rm = TRUE) for every column of the per-locus matrix x (m x ncol, column-major, host or device):
+ * window w covers the loci lo[w] .. hi[w]-1 (0-based; the host side derives them from chromosome / position /
+ * window_size / step_size); pad_na[w] != 0 marks a window the reference returns as NA under complete = TRUE (may be
+ * NULL).  op 0 = mean, 1 = sum.  stat (nw x ncol) is NaN where the window holds no value or fewer than min_loci;
+ * n_loci (nw x ncol int32, may be NULL) = values present, -1 for a pad_na window. */
+int tpg_window_stats(tpg_ctx* ctx, const double* x, int64_t m, int ncol, const int64_t* lo, const int64_t* hi,
+                     const uint8_t* pad_na, int64_t nw, int op, int min_loci, double* stat, int32_t* n_loci);
 /* replaces alt_freq_dip_pseudo_cpp (src/alt_freq_dip_pseudo_cpp.cpp:8-58) for the whole
  * colInd at once (the big_apply block loop R/loci_alt_freq.R:351-359 collapses):
  * out m x 2 = {n_alt | freq, n_valid} */

@@ -499,3 +499,58 @@ def test_pop_fst_and_fis_wg17_from_allele_sharing(tpg, n, m, G):
     # a pre-computed matrix gives the same answer (R/pop_fst.R:36-38)
     assert np.allclose(tpg.pop_fst(X, None, None, gid, G, allele_sharing_mat=A_t), tpg.pop_fst(X, None, None, gid, G),
                        rtol=0, atol=0, equal_nan=True)
+
+
+# ---------------------------------------------------------------- §8f(3): windows
+def test_windows_stats_generic_reference_expectations(tpg):
+    # tests/testthat/test_window_stats_generic.R:1-86
+    x = np.array([1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16], dtype=float)
+    chrom = np.array(["chr1"] * 6 + ["chr2"] * 7)
+    pos = np.array([50, 120, 150, 180, 230, 390, 110, 120, 150, 180, 230, 280, 350])
+    for kw in (dict(operator="sum", window_size=4, step_size=3, size_unit="snp", min_loci=1),
+               dict(operator="sum", window_size=4, step_size=3, size_unit="snp", min_loci=1, complete=True),
+               dict(operator="sum", window_size=100, step_size=50, size_unit="bp", min_loci=1),
+               dict(operator="mean", window_size=100, step_size=50, size_unit="bp", min_loci=2),
+               dict(operator="mean", window_size=5, step_size=1, size_unit="snp", min_loci=3, complete=True)):
+        t = tpg.windows_stats_generic(x, chrom, pos, **kw)
+        o = orc.windows_stats_generic(x, chrom, pos, **kw)
+        for key in ("start", "end"):
+            assert np.array_equal(t[key], o[key])
+        assert list(t["chromosome"]) == list(o["chromosome"])
+        assert np.array_equal(t["n_loci"], o["n_loci"], equal_nan=True)
+        assert np.allclose(t["stat"], o["stat"], rtol=1e-15, atol=0, equal_nan=True)
+    w = tpg.windows_stats_generic(x, chrom, pos, operator="sum", window_size=4, step_size=3, size_unit="snp", min_loci=1)
+    assert list(w["n_loci"]) == [4, 3, 4, 4] and w["stat"][0] == 10 and w["stat"][3] == 58
+    for bad in (dict(window_size=-1, step_size=1), dict(window_size=4, step_size=-1),
+                dict(window_size=4, step_size=1, min_loci=-1), dict(window_size=4, step_size=1, min_loci=9),
+                dict(window_size=4, step_size=1, complete="blah"), dict(window_size=4, step_size=1, operator="nope")):
+        with pytest.raises(ValueError):
+            tpg.windows_stats_generic(x, chrom, pos, **{"operator": "sum", "min_loci": 1, **bad})
+
+
+@pytest.mark.parametrize("n,m,G", [(10, 8, 3), (300, 2500, 6)])
+def test_windows_pairwise_pop_fst(tpg, n, m, G):
+    fbm = orc.synth_fbm(91, n, m, npop=G, miss=0.1)
+    gid = (np.arange(n) % G).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    chrom = np.array(["chr1"] * (m // 3) + ["chr2"] * (m - m // 3))
+    rng = np.random.default_rng(5)
+    pos = np.concatenate([np.sort(rng.integers(1, 50 * m, m // 3)), np.sort(rng.integers(1, 50 * m, m - m // 3))])
+    for kw in (dict(window_size=3, step_size=2, size_unit="snp", min_loci=2),
+               dict(window_size=40, step_size=40, size_unit="snp", min_loci=1, complete=True),
+               dict(window_size=5000, step_size=2500, size_unit="bp", min_loci=2)):
+        t = tpg.windows_pairwise_pop_fst(X, None, None, gid, G, chrom, pos, **kw)
+        o = orc.windows_pairwise_pop_fst(fbm, None, None, gid, G, chrom, pos, **kw)
+        assert np.array_equal(t["start"], o["start"]) and np.array_equal(t["end"], o["end"])
+        assert np.array_equal(np.isnan(t["fst"]), np.isnan(o["fst"]))
+        assert np.allclose(t["fst"], o["fst"], rtol=1e-11, atol=1e-14, equal_nan=True)
+    # tests/testthat/test_window_pairwise_pop_fst.R:113-160: the first SNP window of a chromosome equals the
+    # pairwise Fst of those loci on their own
+    t = tpg.windows_pairwise_pop_fst(X, None, None, gid, G, chrom, pos, window_size=3, step_size=2, size_unit="snp", min_loci=2)
+    wr = tpg.window_index_ranges(chrom, pos, 3, 2, "snp")
+    for w in (0, len(wr["lo"]) - 1):
+        loci = np.arange(wr["lo"][w] + 1, wr["hi"][w] + 1, dtype=np.int32)
+        if len(loci) < 2:
+            continue
+        alone = tpg.pairwise_pop_fst(X, None, loci, gid, G, method="Hudson")["fst_tot"]
+        assert np.allclose(t["fst"][w], alone, rtol=1e-11, atol=1e-14, equal_nan=True)

@@ -221,3 +221,22 @@ def test_synth_is_deterministic_and_shardable():
     c = orc.synth_fbm(3, 50, 200, npop=7, imputed_bytes=True)
     assert set(np.unique(c)) <= {0, 1, 2, 4, 5, 6}
     assert np.array_equal(np.where(a == 3, 9, a), np.where(c > 3, 9, c))
+
+
+def test_windows_stats_generic_reference_expectations():
+    # tests/testthat/test_window_stats_generic.R:1-86: the values the reference asserts (runner's window rule)
+    x = np.array([1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16], dtype=float)
+    chrom = np.array(["chr1"] * 6 + ["chr2"] * 7)
+    pos = np.array([50, 120, 150, 180, 230, 390, 110, 120, 150, 180, 230, 280, 350])
+    w = orc.windows_stats_generic(x, chrom, pos, "sum", 4, 3, "snp", 1)
+    assert list(w["n_loci"]) == [4, 3, 4, 4]
+    assert w["stat"][0] == x[0:4].sum() and w["stat"][3] == x[9:13].sum()
+    wc = orc.windows_stats_generic(x, chrom, pos, "sum", 4, 3, "snp", 1, complete=True)
+    assert np.isnan(wc["stat"][1])
+    wb = orc.windows_stats_generic(x, chrom, pos, "sum", 100, 50, "bp", 1)
+    c2 = wb["chromosome"] == "chr2"
+    assert wb["start"][c2].min() == 101
+    assert wb["n_loci"][c2 & (wb["start"] == 101)][0] == 4
+    assert wb["stat"][c2 & (wb["start"] == 251)][0] == 31
+    c1 = wb["chromosome"] == "chr1"
+    assert np.isnan(wb["stat"][c1 & (wb["start"] == 251)][0])  # chr1 window 251-350 is empty

@@ -66,6 +66,15 @@ class Context:
     def set_stream(self, hip_stream: Optional[int]):
         check(lib.tpg_ctx_set_stream(self.h, C.c_void_p(hip_stream)))
 
+    def dev_alloc(self, nbytes: int) -> "C.c_void_p":
+        """raw device memory for outputs that stay in HBM between two library calls; release with dev_free"""
+        p = C.c_void_p()
+        check(lib.tpg_dev_alloc(self.h, C.c_size_t(int(nbytes)), C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        lib.tpg_dev_free(p)
+
     def sync(self):
         check(lib.tpg_ctx_sync(self.h))
 
@@ -547,6 +556,111 @@ def pairwise_pop_fst(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=No
                                    C.c_int(FST_METHODS[method]), _ptr(pairs_c), C.c_int(P), C.c_int(int(by_locus)),
                                    C.c_int(int(return_num_dem)), _ptr(tot), _ptr(a), _ptr(b)))
     return _fst_result(tot, a, b, by_locus, return_num_dem)
+
+
+def window_index_ranges(chromosome, position, window_size, step_size, size_unit="snp", complete=False):
+    """Host part of windows_stats_generic (R/windows_stats_generic.R:113-141 and runner's window rule, recalled:
+    the window ending at `at` holds the indices in (at - k, at]; with na_pad = TRUE a window that reaches outside
+    the index range is NA).  Loci must be ordered by position inside a chromosome, chromosomes in blocks, as in a
+    gen_tibble.  -> dict(chromosome, start, end, lo, hi, pad_na) with lo/hi 0-based half-open locus ranges."""
+    if size_unit not in ("snp", "bp"):
+        raise ValueError("'arg' should be one of 'snp', 'bp'")
+    if not isinstance(complete, (bool, np.bool_)):
+        raise ValueError("complete must be a boolean (logical).")
+    if window_size <= 0:
+        raise ValueError("window_size must be positive.")
+    if step_size <= 0:
+        raise ValueError("step_size must be positive.")
+    chromosome = np.asarray(chromosome)
+    if size_unit == "bp":
+        if position is None:
+            raise ValueError("loci_table must contain columns 'chromosome' and 'position' when size_unit is 'bp'.")
+        position = np.asarray(position, dtype=np.float64)
+    chroms, starts_, ends_, lo, hi, pad = [], [], [], [], [], []
+    seen = []
+    for ch in chromosome:  # unique(), order of first appearance
+        if ch not in seen:
+            seen.append(ch)
+    for ch in seen:
+        idx = np.where(chromosome == ch)[0]
+        first = int(idx[0])
+        if not np.array_equal(idx, np.arange(first, first + len(idx))):
+            raise ValueError("the loci of a chromosome must be contiguous")
+        pos = position[idx] if size_unit == "bp" else np.arange(1, len(idx) + 1, dtype=np.float64)
+        if np.any(np.diff(pos) < 0):
+            raise ValueError("positions must be sorted inside a chromosome")
+        r0, r1 = math.ceil(pos.min() / window_size), math.ceil(pos.max() / window_size)
+        at = np.arange(r0 * window_size, r1 * window_size + 1e-9 * step_size, step_size, dtype=np.float64)
+        for a in at:
+            w_lo = int(np.searchsorted(pos, a - window_size, side="right"))  # first index with pos > at - k
+            w_hi = int(np.searchsorted(pos, a, side="right"))                # one past the last with pos <= at
+            chroms.append(ch); starts_.append(a - window_size + 1); ends_.append(a)
+            lo.append(first + w_lo); hi.append(first + w_hi)
+            pad.append(bool(complete) and (a - window_size + 1 < pos[0] or a > pos[-1]))
+    return dict(chromosome=np.array(chroms), start=np.array(starts_), end=np.array(ends_),
+                lo=np.array(lo, dtype=np.int64), hi=np.array(hi, dtype=np.int64), pad_na=np.array(pad, dtype=np.uint8))
+
+
+def _window_stats(ctx, x_ptr, m, ncol, wr, op, min_loci):
+    nw = len(wr["lo"])
+    stat = np.zeros((nw, ncol), order="F")
+    nl = np.zeros((nw, ncol), dtype=np.int32, order="F")
+    lo, hi, pad = wr["lo"], wr["hi"], wr["pad_na"]
+    check(lib.tpg_window_stats(ctx.h, x_ptr, C.c_int64(m), C.c_int(ncol), _ptr(lo), _ptr(hi), _ptr(pad), C.c_int64(nw),
+                               C.c_int(op), C.c_int(int(min_loci)), _ptr(stat), _ptr(nl)))
+    return stat, nl
+
+
+def windows_stats_generic(x, chromosome, position=None, operator="mean", window_size=None, step_size=None,
+                          size_unit="snp", min_loci=1, complete=False, ctx: Optional[Context] = None):
+    """R/windows_stats_generic.R:47-184 for operator "mean" / "sum" -> dict(chromosome, start, end, stat, n_loci)"""
+    if operator not in ("mean", "sum"):
+        raise ValueError("'arg' should be one of 'mean', 'sum' (custom functions run on the host in the reference)")
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if len(chromosome) != len(x):
+        raise ValueError("loci_table must have the same number of rows as x.")
+    if min_loci is not None and min_loci <= 0:
+        raise ValueError("min_loci must be positive.")
+    wr = window_index_ranges(chromosome, position, window_size, step_size, size_unit, complete)
+    if min_loci > window_size:
+        raise ValueError("min_loci must be less than window_size.")
+    ctx = ctx or default_context()
+    stat, nl = _window_stats(ctx, _ptr(x), len(x), 1, wr, 0 if operator == "mean" else 1, min_loci)
+    n_loci = nl[:, 0].astype(float)
+    n_loci[nl[:, 0] < 0] = np.nan
+    return dict(chromosome=wr["chromosome"], start=wr["start"], end=wr["end"], stat=stat[:, 0], n_loci=n_loci)
+
+
+def windows_pairwise_pop_fst(X: FBM, ind_row, ind_col, groupIds, ngroups: int, chromosome, position=None, ploidy=None,
+                             window_size=None, step_size=None, size_unit="snp", min_loci=1, complete=False):
+    """R/windows_pairwise_pop_fst.R:49-118 (type = "matrix"): window means of the by-locus Hudson numerators and
+    denominators, then their ratio (the reference always takes Hudson here, whatever `method` says, :62-65).  The two
+    m x P matrices stay in HBM.  -> dict(chromosome, start, end, fst (nw, P))"""
+    v = View(X, ind_row, ind_col)
+    if len(chromosome) != v.m:
+        raise ValueError("loci_table must have the same number of rows as x.")
+    wr = window_index_ranges(chromosome, position, window_size, step_size, size_unit, complete)
+    if min_loci <= 0:
+        raise ValueError("min_loci must be positive.")
+    if min_loci > window_size:
+        raise ValueError("min_loci must be less than window_size.")
+    pairs_c = np.ascontiguousarray(combn2(ngroups).T)
+    P = pairs_c.shape[0]
+    gid, pl = _i32(groupIds), _ploidy(v, ploidy)
+    ctx = v.ctx
+    nbytes = 8 * v.m * P
+    d_num, d_den = ctx.dev_alloc(nbytes), ctx.dev_alloc(nbytes)
+    try:
+        check(lib.tpg_pairwise_pop_fst(ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pl), C.c_int(FST_METHODS["Hudson"]),
+                                       _ptr(pairs_c), C.c_int(P), C.c_int(1), C.c_int(1), None, d_num, d_den))
+        num, _ = _window_stats(ctx, d_num, v.m, P, wr, 0, min_loci)
+        den, _ = _window_stats(ctx, d_den, v.m, P, wr, 0, min_loci)
+    finally:
+        ctx.dev_free(d_num)
+        ctx.dev_free(d_den)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        fst = num / den
+    return dict(chromosome=wr["chromosome"], start=wr["start"], end=wr["end"], fst=fst)
 
 
 def _fst_loop(method, pairwise_combn, n, freq_alt, freq_ref, het_obs, by_locus, return_num_dem, ctx):

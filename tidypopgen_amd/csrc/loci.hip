@@ -564,6 +564,64 @@ extern "C" int tpg_pop_global_stats(tpg_ctx* ctx, const tpg_view* v, const int32
   return TPG_OK;
 }
 
+// Window statistics of per-locus values: the core of windows_stats_generic (R/windows_stats_generic.R:113-176),
+// i.e. runner::sum_run / mean_run with na_rm = TRUE over the loci lo[w] .. hi[w]-1 of each window, for every column
+// of x (m x ncol, column-major).  One wave per (window, column); lanes stride the window, fixed-order reduction.
+// stat = NaN where no value is present (the reference's NA) or where fewer than min_loci are.
+__global__ __launch_bounds__(64) void tpg_window_stats_kernel(const double* __restrict__ x, int64_t m,
+                                                              const int64_t* __restrict__ lo,
+                                                              const int64_t* __restrict__ hi,
+                                                              const uint8_t* __restrict__ pad_na, int64_t nw, int op,
+                                                              int min_loci, double* __restrict__ stat,
+                                                              int32_t* __restrict__ n_loci) {
+  const int64_t w = blockIdx.x;
+  const int c = blockIdx.y;
+  const int lane = threadIdx.x;
+  double s = 0;
+  int k = 0;
+  const bool pad = pad_na && pad_na[w];
+  if (!pad)
+    for (int64_t j = lo[w] + lane; j < hi[w]; j += 64) {
+      const double v = x[j + (int64_t)c * m];
+      if (v == v) { s += v; k++; }
+    }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); k += __shfl_xor(k, o); }
+  if (lane == 0) {
+    double r = TPG_GS_NAN;
+    if (!pad && k > 0 && k >= min_loci) r = op == 0 ? s / k : s;
+    stat[w + (int64_t)c * nw] = r;
+    if (n_loci) n_loci[w + (int64_t)c * nw] = pad ? -1 : k;  // -1 = NA (incomplete window with complete = TRUE)
+  }
+}
+
+extern "C" int tpg_window_stats(tpg_ctx* ctx, const double* x, int64_t m, int ncol, const int64_t* lo,
+                                const int64_t* hi, const uint8_t* pad_na, int64_t nw, int op, int min_loci,
+                                double* stat, int32_t* n_loci) {
+  TPG_REQUIRE(ctx && x && lo && hi && stat, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(op == 0 || op == 1, TPG_EINVAL, "operator must be 0 (mean) or 1 (sum)");
+  TPG_REQUIRE(m >= 0 && ncol >= 1 && ncol <= 65535 && nw >= 0 && nw < 2147483647ll, TPG_EINVAL, "bad sizes");
+  if (nw == 0) return TPG_OK;
+  for (int64_t w = 0; w < nw; w++)
+    TPG_REQUIRE(lo[w] >= 0 && lo[w] <= hi[w] && hi[w] <= m, TPG_EINVAL, "window %lld = [%lld, %lld) outside [0, %lld]",
+                (long long)w, (long long)lo[w], (long long)hi[w], (long long)m);
+  InBuf ix, il, ih, ip;
+  TPG_TRY(ix.init(ctx, x, sizeof(double) * (size_t)m * (size_t)ncol));
+  TPG_TRY(il.init(ctx, lo, sizeof(int64_t) * (size_t)nw));
+  TPG_TRY(ih.init(ctx, hi, sizeof(int64_t) * (size_t)nw));
+  if (pad_na) TPG_TRY(ip.init(ctx, pad_na, (size_t)nw));
+  OutBuf os, on;
+  TPG_TRY(os.init(stat, sizeof(double) * (size_t)nw * (size_t)ncol));
+  if (n_loci) TPG_TRY(on.init(n_loci, sizeof(int32_t) * (size_t)nw * (size_t)ncol));
+  TPG_LAUNCH(ctx, "window_stats", tpg_window_stats_kernel, dim3((unsigned)nw, (unsigned)ncol), dim3(64), 0,
+             ix.dev<double>(), m, il.dev<int64_t>(), ih.dev<int64_t>(), pad_na ? ip.dev<uint8_t>() : (const uint8_t*)nullptr,
+             nw, op, min_loci, os.dev<double>(), on.dev<int32_t>());
+  TPG_CHECK_LAUNCH();
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  TPG_TRY(os.commit(ctx));
+  if (n_loci) TPG_TRY(on.commit(ctx));
+  return TPG_OK;
+}
+
 // ungrouped diploid: counts (m x 4) -> m x 2 doubles
 __global__ void tpg_alt_freq_finalize_kernel(const int4* __restrict__ counts, int64_t m, int as_counts,
                                              double* __restrict__ out) {
