@@ -214,14 +214,25 @@ __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int
     }
 }
 
-__global__ void tpg_fst_reduce_kernel(const double* __restrict__ part, int nblocks, int P, double* __restrict__ fst_tot,
-                                      double* __restrict__ sum_num, double* __restrict__ sum_den) {
-  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= P) return;
+// sum the per-workgroup partials of every pair: 16 pairs x 16 slices of the partial list per workgroup (the
+// slices are summed in a fixed order: deterministic), so ~P/16 workgroups share the read instead of P/256
+__global__ __launch_bounds__(256) void tpg_fst_reduce_kernel(const double* __restrict__ part, int nblocks, int P,
+                                                             double* __restrict__ fst_tot, double* __restrict__ sum_num,
+                                                             double* __restrict__ sum_den) {
+  __shared__ double shn[16][17], shd[16][17];
+  const int px = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int pi = blockIdx.x * 16 + px;
   double sn = 0.0, sd = 0.0;
-  for (int b = 0; b < nblocks; b++) { sn += part[((int64_t)b * P + pi) * 2]; sd += part[((int64_t)b * P + pi) * 2 + 1]; }
-  if (fst_tot) fst_tot[pi] = sn / sd;
-  if (sum_num) { sum_num[pi] = sn; sum_den[pi] = sd; }
+  if (pi < P)
+    for (int b = sl; b < nblocks; b += 16) { sn += part[((int64_t)b * P + pi) * 2]; sd += part[((int64_t)b * P + pi) * 2 + 1]; }
+  shn[sl][px] = sn; shd[sl][px] = sd;
+  __syncthreads();
+  if (sl == 0 && pi < P) {
+    sn = 0.0; sd = 0.0;
+    for (int t = 0; t < 16; t++) { sn += shn[t][px]; sd += shd[t][px]; }
+    if (fst_tot) fst_tot[pi] = sn / sd;
+    if (sum_num) { sum_num[pi] = sn; sum_den[pi] = sd; }
+  }
 }
 
 static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const int32_t* pairs1, int P, int by_locus,
@@ -279,7 +290,7 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
 #undef FST_LAUNCH1
 #undef FST_LAUNCH
     if (fst_tot || sum_num)
-      TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, d_part,
+      TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 16)), dim3(256), 0, d_part,
                  nblocks, P, ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

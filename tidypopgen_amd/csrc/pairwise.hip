@@ -270,76 +270,88 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
 // epilogues.  FP64 arithmetic follows the R drivers' operation order (file compiled with
 // -ffp-contract=off).
 struct PwCounts {
-  int V, D, H, Aij, Aji;
+  int V, D, H, Aij, Aji;  // relative to the OUTPUT element (row i, column j): Aij = loci where i is het and j typed
 };
-
-__device__ __forceinline__ PwCounts tpg_pw_fetch(const int32_t* __restrict__ acc, int nst, int i, int j) {
-  bool sw = (j >> 5) < 2 * (i >> 6);  // below the stored band: read the mirrored element
-  if (sw) { int t = i; i = j; j = t; }
-  const int I = i >> 6, jt = j >> 5;
-  const int64_t u = tpg_pw_unit_index(nst, I, jt);
-  const int ta = (i >> 5) & 1;
-  const int row = i & 31, col = j & 31;
-  const int lane = col + 32 * ((row >> 2) & 1);
-  const int reg = (row & 3) + 4 * (row >> 3);
-  const int32_t* p = acc + u * TPG_PW_TILE_INTS + (ta * 16 + reg) * 64 + lane;
-  PwCounts c;
-  c.V = p[0];
-  c.D = p[2048];
-  c.H = p[2 * 2048];
-  const int hv = p[3 * 2048], vh = p[4 * 2048];
-  c.Aij = sw ? vh : hv;
-  c.Aji = sw ? hv : vh;
-  return c;
-}
 
 #define TPG_NAN __longlong_as_double(0x7FF8000000000000ll)
 
 // mode: 0 raw counts (six optional outputs), 1 IBS proportion / adjusted counts (scale), 2 KING,
 // 3 allele sharing, 4 IBS + KING + allele sharing together
-__global__ void tpg_pairwise_epilogue_kernel(const int32_t* __restrict__ acc, int nst, int n, int mode,
-                                             double scale, double* __restrict__ o0, double* __restrict__ o1,
-                                             double* __restrict__ o2, double* __restrict__ o3,
-                                             double* __restrict__ o4, double* __restrict__ o5) {
-  const int64_t total = (int64_t)n * n;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    // idx is the output position (row r = idx % n, column cidx = idx / n).  The slab is read with the
-    // lane index on its COLUMN (contiguous 4-byte loads), so this thread fetches element (i = cidx, j = r)
-    // and emits the transposed element: every output but N_Aa is symmetric, and for N_Aa the fetch
-    // returns both A_ij and A_ji.
-    const int r = (int)(idx % n), cidx = (int)(idx / n);
-    PwCounts c = tpg_pw_fetch(acc, nst, cidx, r);
-    { const int t = c.Aij; c.Aij = c.Aji; c.Aji = t; }  // now relative to (row r, column cidx)
-    if (mode == 0) {
-      if (o0) o0[idx] = (double)(c.V + c.D + c.H);
-      if (o1) o1[idx] = (double)(2 * c.V);
-      if (o2) o2[idx] = (double)(c.D - c.V + c.Aij + c.Aji);
-      if (o3) o3[idx] = (double)c.Aij;
-      if (o4) o4[idx] = (double)c.D;
-      if (o5) o5[idx] = (double)c.V;
-    } else if (mode == 1) {
-      const double prop = (double)(c.V + c.D + c.H) / (double)(2 * c.V);  // R/snp_ibs.R:88-95
-      o0[idx] = scale == 1.0 ? prop : prop * scale;                        // :100
-    } else if (mode == 2) {
+__device__ __forceinline__ void tpg_pw_emit(const PwCounts c, int mode, double scale, int64_t idx, double* __restrict__ o0,
+                                            double* __restrict__ o1, double* __restrict__ o2, double* __restrict__ o3,
+                                            double* __restrict__ o4, double* __restrict__ o5) {
+  if (mode == 0) {
+    if (o0) o0[idx] = (double)(c.V + c.D + c.H);
+    if (o1) o1[idx] = (double)(2 * c.V);
+    if (o2) o2[idx] = (double)(c.D - c.V + c.Aij + c.Aji);
+    if (o3) o3[idx] = (double)c.Aij;
+    if (o4) o4[idx] = (double)c.D;
+    if (o5) o5[idx] = (double)c.V;
+  } else if (mode == 1) {
+    const double prop = (double)(c.V + c.D + c.H) / (double)(2 * c.V);  // R/snp_ibs.R:88-95
+    o0[idx] = scale == 1.0 ? prop : prop * scale;                        // :100
+  } else if (mode == 2) {
+    const double K = (double)(c.D - c.V + c.Aij + c.Aji), Ni = (double)c.Aij, Nj = (double)c.Aji;
+    const double mn = Ni < Nj ? Ni : Nj;
+    o0[idx] = K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn;  // R/snp_king.R:86-89
+  } else if (mode == 3) {
+    const double num = (double)c.D, den = (double)c.V;
+    o0[idx] = c.V == 0 ? TPG_NAN : 0.5 * (1 + num / den);  // R/snp_allele_sharing.R:79-80
+  } else {
+    // mode 4: IBS (o0, scale), KING (o1) and allele sharing (o2) from one fetch
+    if (o0) {
+      const double prop = (double)(c.V + c.D + c.H) / (double)(2 * c.V);
+      o0[idx] = scale == 1.0 ? prop : prop * scale;
+    }
+    if (o1) {
       const double K = (double)(c.D - c.V + c.Aij + c.Aji), Ni = (double)c.Aij, Nj = (double)c.Aji;
       const double mn = Ni < Nj ? Ni : Nj;
-      o0[idx] = K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn;  // R/snp_king.R:86-89
-    } else if (mode == 3) {
-      const double num = (double)c.D, den = (double)c.V;
-      o0[idx] = c.V == 0 ? TPG_NAN : 0.5 * (1 + num / den);  // R/snp_allele_sharing.R:79-80
-    } else {
-      // mode 4: IBS (o0, scale), KING (o1) and allele sharing (o2) from one fetch
-      if (o0) {
-        const double prop = (double)(c.V + c.D + c.H) / (double)(2 * c.V);
-        o0[idx] = scale == 1.0 ? prop : prop * scale;
+      o1[idx] = K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn;
+    }
+    if (o2) o2[idx] = c.V == 0 ? TPG_NAN : 0.5 * (1 + (double)c.D / (double)c.V);
+  }
+}
+
+// One workgroup per 32 x 32 tile (ti <= tj) of the stored band.  The five count planes of the tile are read once,
+// lane index on the slab's lane (contiguous 4-byte loads), into LDS; the tile is then written twice -- as it stands,
+// threads running down a column of the column-major outputs, and mirrored for the lower triangle, threads running
+// along the slab's column index -- so that every store instruction writes 32 contiguous doubles and no slab element
+// is fetched more than once.
+__global__ __launch_bounds__(256) void tpg_pairwise_epilogue_kernel(const int32_t* __restrict__ acc, int nst, int n,
+                                                                    int mode, double scale, double* __restrict__ o0,
+                                                                    double* __restrict__ o1, double* __restrict__ o2,
+                                                                    double* __restrict__ o3, double* __restrict__ o4,
+                                                                    double* __restrict__ o5) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (ti > tj) return;
+  __shared__ int sp[5][32][33];
+  const int32_t* p = acc + tpg_pw_unit_index(nst, ti >> 1, tj) * TPG_PW_TILE_INTS + ((ti & 1) * 16) * 64;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int idx = threadIdx.x + 256 * e, reg = idx >> 6, lane = idx & 63;
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 5; q++) sp[q][row][col] = p[q * 2048 + reg * 64 + lane];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int idx = threadIdx.x + 256 * e;
+    {  // as stored: output row = 32 ti + row (contiguous), column = 32 tj + col
+      const int row = idx & 31, col = idx >> 5;
+      const int gi = 32 * ti + row, gj = 32 * tj + col;
+      if (gi < n && gj < n) {
+        const PwCounts c = {sp[0][row][col], sp[1][row][col], sp[2][row][col], sp[3][row][col], sp[4][row][col]};
+        tpg_pw_emit(c, mode, scale, gi + (int64_t)gj * n, o0, o1, o2, o3, o4, o5);
       }
-      if (o1) {
-        const double K = (double)(c.D - c.V + c.Aij + c.Aji), Ni = (double)c.Aij, Nj = (double)c.Aji;
-        const double mn = Ni < Nj ? Ni : Nj;
-        o1[idx] = K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn;
+    }
+    if (ti != tj) {  // mirrored: output row = 32 tj + col (contiguous), column = 32 ti + row
+      const int col = idx & 31, row = idx >> 5;
+      const int gi = 32 * ti + row, gj = 32 * tj + col;
+      if (gi < n && gj < n) {
+        const PwCounts c = {sp[0][row][col], sp[1][row][col], sp[2][row][col], sp[4][row][col], sp[3][row][col]};
+        tpg_pw_emit(c, mode, scale, gj + (int64_t)gi * n, o0, o1, o2, o3, o4, o5);
       }
-      if (o2) o2[idx] = c.V == 0 ? TPG_NAN : 0.5 * (1 + (double)c.D / (double)c.V);
     }
   }
 }
@@ -349,7 +361,8 @@ static int run_epilogue(tpg_ctx* ctx, const tpg_pairwise* pw, int mode, double s
   OutBuf b[6];
   for (int k = 0; k < 6; k++)
     if (outs[k]) TPG_TRY(b[k].init(outs[k], bytes));
-  TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(2048), dim3(256), 0,
+  const unsigned nt = (unsigned)ceil_div(pw->n, 32);
+  TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(nt, nt), dim3(256), 0,
              (const int32_t*)pw->acc, (int)pw->nst, (int)pw->n, mode, scale, b[0].dev<double>(), b[1].dev<double>(),
              b[2].dev<double>(), b[3].dev<double>(), b[4].dev<double>(), b[5].dev<double>());
   TPG_CHECK_LAUNCH();
@@ -400,7 +413,8 @@ extern "C" int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int 
   if (grm) TPG_TRY(bg.init(grm, bytes));
   // GRM needs the allele-sharing matrix: write it into the GRM buffer when the caller does not want both
   double* as_dst = allele_sharing ? ba.dev<double>() : bg.dev<double>();
-  TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(2048), dim3(256), 0,
+  const unsigned nt = (unsigned)ceil_div(pw->n, 32);
+  TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(nt, nt), dim3(256), 0,
              (const int32_t*)pw->acc, (int)pw->nst, n, 4, ibs_type == TPG_IBS_PROPORTION ? 1.0 : (double)m,
              bi.dev<double>(), bk.dev<double>(), as_dst, (double*)nullptr, (double*)nullptr, (double*)nullptr);
   TPG_CHECK_LAUNCH();
