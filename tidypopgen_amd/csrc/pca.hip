@@ -1220,6 +1220,11 @@ struct EigWork {
   const double* L = nullptr;
   int nl = 0;
   double *lam_dev = nullptr, *cdev = nullptr, *dtmp = nullptr;
+  // small host matrices go to the device through a ring of pinned staging slots, so rmult() needs no host
+  // synchronisation (a slot is reused only after a stream synchronisation at wrap-around)
+  static constexpr int XSLOTS = 16;
+  double *xpin = nullptr, *xdev = nullptr;
+  int xslot = 0;
   int init() {
     S = 1;
     const int row_blocks = (n + 63) / 64;
@@ -1232,6 +1237,10 @@ struct EigWork {
     TPG_HIP(tpg_pmalloc((void**)&lam_dev, sizeof(double) * 64));
     TPG_HIP(tpg_pmalloc((void**)&cdev, sizeof(double) * 64 * 64));
     TPG_HIP(tpg_pmalloc((void**)&dtmp, sizeof(double) * (size_t)b * (size_t)n));
+    static double* pinned = nullptr;  // 512 KB, allocated once per process (pinning costs ~1 ms)
+    if (!pinned) TPG_HIP(hipHostMalloc((void**)&pinned, sizeof(double) * 64 * 64 * XSLOTS, hipHostMallocDefault));
+    xpin = pinned;
+    TPG_HIP(tpg_pmalloc((void**)&xdev, sizeof(double) * 64 * 64 * XSLOTS));
     return TPG_OK;
   }
   ~EigWork() {
@@ -1241,6 +1250,8 @@ struct EigWork {
     if (lam_dev) tpg_pfree(lam_dev);
     if (cdev) tpg_pfree(cdev);
     if (dtmp) tpg_pfree(dtmp);
+    if (xdev) tpg_pfree(xdev);
+    if (xpin) (void)hipStreamSynchronize(ctx->stream);  // pending copies out of the (process-wide) staging slots
   }
   int set_locked(const double* Lptr, int count, const double* lam_host) {
     L = Lptr;
@@ -1283,11 +1294,15 @@ struct EigWork {
   }
   // Y = A X  (X host p x b2)
   int rmult(const double* A, int p, const std::vector<double>& X, int b2, double* Y) {
-    TPG_HIP(hipMemcpyAsync(xsmall, X.data(), sizeof(double) * (size_t)p * b2, hipMemcpyHostToDevice, ctx->stream));
+    if (xslot == XSLOTS) { TPG_HIP(hipStreamSynchronize(ctx->stream)); xslot = 0; }
+    double* hx = xpin + (size_t)xslot * 64 * 64;
+    double* dx = xdev + (size_t)xslot * 64 * 64;
+    xslot++;
+    memcpy(hx, X.data(), sizeof(double) * (size_t)p * b2);
+    TPG_HIP(hipMemcpyAsync(dx, hx, sizeof(double) * (size_t)p * b2, hipMemcpyHostToDevice, ctx->stream));
     TPG_LAUNCH(ctx, "eig_right_mult", tpg_right_mult_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, A, n, p,
-               (const double*)xsmall, b2, Y);
+               (const double*)dx, b2, Y);
     TPG_CHECK_LAUNCH();
-    TPG_HIP(hipStreamSynchronize(ctx->stream));  // X may go out of scope on the host
     return TPG_OK;
   }
 };
