@@ -147,10 +147,13 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
   uint8_t* lut = smem;
   uint8_t* codes = smem + 256;  // codes[locus][(individual + 32 * (locus >> 4)) & 127]
   const int tid = threadIdx.x;
-  // 1-D grid, individual chunk fastest: neighbouring workgroups read neighbouring 128-byte pieces of the same
-  // 128 columns (columns are only 8-byte aligned, so the pieces share cache lines and DRAM pages)
-  const int64_t bj = blockIdx.x / Q;  // locus group (kg)
-  const int64_t bi = blockIdx.x % Q;  // individual chunk (q)
+  // 1-D grid, individual chunk fastest: neighbouring workgroups read neighbouring pieces of the same 128 columns
+  // (columns are only 8-byte aligned, so the pieces share cache lines and DRAM pages).  A workgroup does NSUB
+  // individual chunks one after the other with all their loads issued up front (16 x 8 B in flight per thread).
+  constexpr int NSUB = 2;
+  const int64_t QB = (Q + NSUB - 1) / NSUB;
+  const int64_t bj = blockIdx.x / QB;          // locus group (kg)
+  const int64_t bi0 = (blockIdx.x % QB) * NSUB;  // first individual chunk (q)
   lut[tid] = lut_and_flag[tid];
   __syncthreads();
   const uint32_t lo = *reinterpret_cast<const uint32_t*>(lut), hi = *reinterpret_cast<const uint32_t*>(lut + 4);
@@ -168,36 +171,44 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
     }
     return c;
   };
-  {
-    const int c16 = tid & 7;
-    const int64_t i0 = bi * TILE + 16 * c16;
-    uint2 va[4], vb[4];
+  const int c16 = tid & 7;
+  uint2 va[NSUB][4], vb[NSUB][4];
+#pragma unroll
+  for (int sub = 0; sub < NSUB; sub++) {
+    const int64_t i0 = (bi0 + sub) * TILE + 16 * c16;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
       const int64_t j = bj * TILE + (tid >> 3) + 32 * it;
-      va[it] = make_uint2(0, 0);
-      vb[it] = make_uint2(0, 0);
-      if (j < m) {
+      va[sub][it] = make_uint2(0, 0);
+      vb[sub][it] = make_uint2(0, 0);
+      if (j < m && bi0 + sub < Q) {
         const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
         const uint8_t* p = fbm + i0 + src_col * nrow;
-        if (i0 + 8 <= n) va[it] = *reinterpret_cast<const uint2*>(p);
-        if (i0 + 16 <= n) vb[it] = *reinterpret_cast<const uint2*>(p + 8);
+        if (i0 + 8 <= n) va[sub][it] = *reinterpret_cast<const uint2*>(p);
+        if (i0 + 16 <= n) vb[sub][it] = *reinterpret_cast<const uint2*>(p + 8);
       }
     }
+  }
+#pragma unroll
+  for (int sub = 0; sub < NSUB; sub++) {
+  const int64_t bi = bi0 + sub;
+  if (bi >= Q) break;
+  if (sub) __syncthreads();  // the previous chunk's readers are done with `codes`
+  {
+    const int64_t i0 = bi * TILE + 16 * c16;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
       const int l = (tid >> 3) + 32 * it;
       const bool inside = bj * TILE + l < m;
       uint32_t c[4] = {0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u};
-      if (inside && i0 + 8 <= n) { c[0] = conv(va[it].x); c[1] = conv(va[it].y); }
-      if (inside && i0 + 16 <= n) { c[2] = conv(vb[it].x); c[3] = conv(vb[it].y); }
+      if (inside && i0 + 8 <= n) { c[0] = conv(va[sub][it].x); c[1] = conv(va[sub][it].y); }
+      if (inside && i0 + 16 <= n) { c[2] = conv(vb[sub][it].x); c[3] = conv(vb[sub][it].y); }
       *reinterpret_cast<uint4*>(codes + l * TILE + ((16 * c16 + 32 * (l >> 4)) & 127)) = make_uint4(c[0], c[1], c[2], c[3]);
       const int64_t lt = bj * 4 + (l >> 5);
       const int lane = (l & 31) + 32 * (c16 & 1);
       L[((lt * Q + bi) * 64 + lane) * 4 + (c16 >> 1)] = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
     }
   }
-  if (bad) atomicOr((unsigned int*)(lut_and_flag + 256), 1u);
   __syncthreads();
   {
     const int wv = tid >> 6, t = tid & 63;
@@ -222,6 +233,8 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
 #pragma unroll
     for (int b = 0; b < 4; b++) dst[b * 4] = W[b];
   }
+  }  // sub
+  if (bad) atomicOr((unsigned int*)(lut_and_flag + 256), 1u);
 }
 
 int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,
@@ -231,7 +244,7 @@ int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, con
   if (fbm->bed_bpl == 0 && d_rows == nullptr && (fbm->nrow & 7) == 0 && (((uintptr_t)fbm->d_bytes) & 7) == 0 &&
       !getenv("TPG_PACK_GENERIC")) {
     TPG_REQUIRE(v->KG * v->Q < 2147483647ll, TPG_EINVAL, "view too large for the pack grid");
-    TPG_LAUNCH(ctx, "pack", tpg_pack_fast_kernel, dim3((unsigned)(v->KG * v->Q)), dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
+    TPG_LAUNCH(ctx, "pack", tpg_pack_fast_kernel, dim3((unsigned)(v->KG * ((v->Q + 1) / 2))), dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
                v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L);
     TPG_CHECK_LAUNCH();
     return TPG_OK;
