@@ -122,3 +122,35 @@ def test_pca_properties_at_scale(panel):
     XV, rss = tpg.fbm256_prod_and_rowSumsSq(X, None, cols, r["center"], r["scale"], r["v"], code256=tpg.CODE_IMPUTE_PRED)
     assert np.allclose(XV, u * d, atol=1e-7 * d[0])
     assert np.allclose(rss, np.diag(K), rtol=1e-7)
+
+
+def test_many_individuals_indexing():
+    """N = 12 000 (375 row tiles, 35 000 pairwise units, 1.4 GB of int32 accumulators, 1.2 GB Gram matrix): the tables,
+    slabs and epilogues index correctly far from the bench shape.  The full results must contain, as a sub-matrix, the
+    results of the same analysis run on a subset of the individuals alone."""
+    import tidypopgen_amd as tpg
+
+    n, m, G = 12_000, 2_048, 40
+    X = tpg.FBM.synth(11, n, m, npop=G, miss=0.03, imputed_bytes=True)
+    rows = np.arange(1, n + 1, 7, dtype=np.int32)
+    full = tpg.Pairwise(X.ctx, n)
+    full.accumulate(tpg.View(X, code256=None))
+    sub = tpg.Pairwise(X.ctx, len(rows))
+    sub.accumulate(tpg.View(X, rows, None, code256=None))
+    ix = np.ix_(rows - 1, rows - 1)
+    for names in (("ibs", "ibs_valid", "king_num"), ("n_Aa_i", "as_num", "as_den")):
+        cf, cs = full.counts(names), sub.counts(names)
+        for k in cs:
+            assert np.array_equal(cf[k][ix], cs[k]), k
+        del cf, cs
+    which = ("ibs", "king", "allele_sharing")
+    ef, es = full.epilogues(which, m=m), sub.epilogues(which, m=m)
+    for k in which:
+        assert np.array_equal(ef[k][ix], es[k], equal_nan=True), k
+    del ef, es, full, sub
+    # PCA at this N: orthonormal scores, descending singular values, and orthonormal loadings (v = Z'u / d, so
+    # V'V = U'KU / d^2 is the identity only if (u, d^2) are eigenpairs of K = ZZ')
+    r = tpg.gt_pca_partialSVD(X, k=5)
+    assert np.all(np.diff(r["d"]) < 0) and np.all(r["d"] > 0)
+    assert np.allclose(r["u"].T @ r["u"], np.eye(5), atol=1e-9)
+    assert np.allclose(r["v"].T @ r["v"], np.eye(5), atol=1e-7)
