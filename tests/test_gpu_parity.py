@@ -554,3 +554,16 @@ def test_windows_pairwise_pop_fst(tpg, n, m, G):
             continue
         alone = tpg.pairwise_pop_fst(X, None, loci, gid, G, method="Hudson")["fst_tot"]
         assert np.allclose(t["fst"][w], alone, rtol=1e-11, atol=1e-14, equal_nan=True)
+
+
+def test_open_bk_chunked_upload(tpg, tmp_path):
+    # backing files go up in 32-MiB pieces through pinned slots (runtime.hip: tpg_upload): 2.x chunks + a ragged tail
+    n, m = 1001, 80_123
+    rng = np.random.default_rng(3)
+    a = np.asfortranarray(rng.integers(0, 4, size=(n, m), dtype=np.uint8))
+    path = tmp_path / "panel.bk"
+    a.T.tofile(path)  # column-major bytes, as bigstatsr writes them
+    X = tpg.FBM.open_bk(str(path), n, m)
+    assert np.array_equal(X.to_numpy(), a)
+    cnt = tpg.loci_counts(tpg.View(X, code256=None))
+    assert np.array_equal(cnt, np.stack([(a == c).sum(axis=0) for c in range(4)], axis=1))

@@ -51,6 +51,7 @@ struct tpg_ctx {
   std::map<std::string, std::pair<double, int64_t>> prof_acc;  // name -> (ms, launches)
   std::vector<hipEvent_t> event_pool;
   int num_cu = 256;
+  bool upload_from_mapped_file = false;  // set by tpg_fbm_open_bk / open_bed around the upload (runtime.hip: tpg_upload)
 };
 
 struct ProfScope {
