@@ -1,12 +1,12 @@
 // pack.hip -- FBM bytes -> 2-bit fragment layouts T and L (common.h), unpack, synthetic panel.
 //
-// pack: one workgroup per 128 individuals x 128 loci tile.  The tile's bytes are gathered
-// through (rowInd, colInd), decoded by the 256-entry byte -> 2-bit table held in LDS, kept as
-// one code byte per genotype in LDS, then emitted twice: four 1-KiB T blocks (contraction over
-// loci) and four 1-KiB L blocks (contraction over individuals).  HBM-bound: reads n*m bytes,
-// writes n*m/2 bytes.  Replaces the per-block byte decode loops of the reference
-// (src/snp_ibs.cpp:45-55, src/snp_king.cpp:45-58, src/snp_as.cpp:44-53 and the
-// SubBMCode256Acc accessor in src/alt_freq_dip_pseudo_cpp.cpp:15-16).
+// pack: one workgroup per 128 individuals x 128 loci tile.  Generic kernel (row subsets, .bed sources, unaligned
+// columns): the tile's bytes are gathered through (rowInd, colInd), decoded by the 256-entry byte -> 2-bit table
+// held in LDS, kept as one code byte per genotype in LDS, then emitted twice: four 1-KiB T blocks (contraction
+// over loci) and four 1-KiB L blocks (contraction over individuals).  The common case (all rows of a byte FBM)
+// takes tpg_pack_fast_kernel below.  HBM-bound: reads n*m bytes, writes n*m/2 bytes.  Replaces the per-block
+// byte decode loops of the reference (src/snp_ibs.cpp:45-55, src/snp_king.cpp:45-58, src/snp_as.cpp:44-53 and
+// the SubBMCode256Acc accessor in src/alt_freq_dip_pseudo_cpp.cpp:15-16).
 #include "common.h"
 #include "devfrag.h"
 #include "synth_common.h"
@@ -34,10 +34,6 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
   __syncthreads();
 
   bool bad = false;
-  // fast path: identity rows, whole tile inside the FBM rows, columns 8-byte aligned -> 8-byte loads,
-  // 8 independent loads per thread in flight
-  const bool fast = (bed_bpl == 0) && (rows == nullptr) && (bi * TILE + TILE <= n) && ((nrow & 7) == 0) &&
-                    ((((uintptr_t)fbm) & 7) == 0);
   const bool bed_fast = (bed_bpl > 0) && (rows == nullptr) && (bi * TILE + TILE <= n);
   if (bed_fast) {
     // .bed: 128 individuals of one SNP = 32 contiguous bytes; 8 SNPs per pass, byte index on the lanes
@@ -55,31 +51,6 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
         uint8_t c = j < m ? lut[tpg_bed_byte(pk, q)] : (uint8_t)3;
         if (c == 0xFF) { bad = true; c = 3; }
         codes[l * LDS_STRIDE + 4 * b + q] = c;
-      }
-    }
-  } else if (fast) {
-    const int c8 = tid & 15;  // 8-byte chunk of the tile's 128 individuals
-    uint2 v[8];
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int64_t j = bj * TILE + (tid >> 4) + 16 * it;
-      v[it] = make_uint2(0, 0);
-      if (j < m) {
-        const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
-        v[it] = *reinterpret_cast<const uint2*>(fbm + bi * TILE + 8 * c8 + src_col * nrow);
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int l = (tid >> 4) + 16 * it;
-      const bool inside = bj * TILE + l < m;
-      uint8_t* dst = codes + l * LDS_STRIDE + 8 * c8;
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const uint32_t word = q < 4 ? v[it].x : v[it].y;
-        uint8_t c = inside ? lut[(word >> (8 * (q & 3))) & 0xFFu] : (uint8_t)3;
-        if (c == 0xFF) { bad = true; c = 3; }
-        dst[q] = c;
       }
     }
   } else {
