@@ -128,6 +128,12 @@ int tpg_pop_global_stats(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupId
  * n_loci (nw x ncol int32, may be NULL) = values present, -1 for a pad_na window. */
 int tpg_window_stats(tpg_ctx* ctx, const double* x, int64_t m, int ncol, const int64_t* lo, const int64_t* hi,
                      const uint8_t* pad_na, int64_t nw, int op, int min_loci, double* stat, int32_t* n_loci);
+/* population branch statistic from a by-locus (or by-window) pairwise Fst matrix: pbs_one_triplet of
+ * R/nwise_pop_pbs.R:118-156.  fst is m x P (column-major, host or device); triplet t names the columns of
+ * (pop1.pop2, pop1.pop3, pop2.pop3) in trip_cols0[3t..3t+2] (0-based); out is m x 6 ntrip, six columns per triplet:
+ * pbs_1, pbs_2, pbs_3, pbsn1_1, pbsn1_2, pbsn1_3 */
+int tpg_pbs_from_fst(tpg_ctx* ctx, const double* fst, int64_t m, int P, const int32_t* trip_cols0, int ntrip,
+                     double* out);
 /* replaces alt_freq_dip_pseudo_cpp (src/alt_freq_dip_pseudo_cpp.cpp:8-58) for the whole
  * colInd at once (the big_apply block loop R/loci_alt_freq.R:351-359 collapses):
  * out m x 2 = {n_alt | freq, n_valid} */

@@ -392,6 +392,28 @@ def windows_pairwise_pop_fst(fbm, rowInd, colInd, groupIds, ngroups, chromosome,
     return dict(chromosome=first["chromosome"], start=first["start"], end=first["end"], fst=np.column_stack(cols))
 
 
+def nwise_pop_pbs(fbm, rowInd, colInd, groupIds, ngroups, ploidy=None, fst_method="Hudson", code256=CODE_012):
+    """R/nwise_pop_pbs.R:36-156 (type = "matrix"): columns per triplet in combn(levels, 3) order:
+    pbs_1, pbs_2, pbs_3, pbsn1_1, pbsn1_2, pbsn1_3"""
+    fst = pairwise_pop_fst(fbm, rowInd, colInd, groupIds, ngroups, ploidy, method=fst_method, by_locus=True,
+                           code256=code256)["fst_locus"]
+    pairs = combn2(ngroups)
+    col = {(int(a), int(b)): k for k, (a, b) in enumerate(pairs.T)}
+    cols = []
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for a in range(1, ngroups + 1):
+            for b in range(a + 1, ngroups + 1):
+                for c in range(b + 1, ngroups + 1):
+                    fst12, fst13, fst23 = fst[:, col[(a, b)]], fst[:, col[(a, c)]], fst[:, col[(b, c)]]
+                    t12, t13, t23 = -np.log(1 - fst12), -np.log(1 - fst13), -np.log(1 - fst23)   # :138-140
+                    pbs_1 = (t12 + t13 - t23) / 2
+                    pbs_2 = (t12 + t23 - t13) / 2
+                    pbs_3 = (t13 + t23 - t12) / 2
+                    cols += [pbs_1, pbs_2, pbs_3, pbs_1 / (1 + pbs_1 + pbs_2 + pbs_3), pbs_2 / (1 + pbs_1 + pbs_2 + pbs_3),
+                             pbs_3 / (1 + pbs_1 + pbs_2 + pbs_3)]
+    return np.column_stack(cols)
+
+
 def _fst_loop(fn, pairs1, m, mats, by_locus, return_num_dem):
     pairs1 = np.ascontiguousarray(np.asarray(pairs1, dtype=np.int32).T)  # (P, 2) rows = (pop1, pop2)
     P = pairs1.shape[0]

@@ -567,3 +567,22 @@ def test_open_bk_chunked_upload(tpg, tmp_path):
     assert np.array_equal(X.to_numpy(), a)
     cnt = tpg.loci_counts(tpg.View(X, code256=None))
     assert np.array_equal(cnt, np.stack([(a == c).sum(axis=0) for c in range(4)], axis=1))
+
+
+@pytest.mark.parametrize("n,m,G,method", [(10, 6, 4, "Hudson"), (300, 2500, 5, "Hudson"), (300, 2500, 5, "WC84")])
+def test_nwise_pop_pbs(tpg, n, m, G, method):
+    # R/nwise_pop_pbs.R; tests/testthat/test_nwise_pop_pbs.R:55-62 expects 6 columns per triplet (24 for 4 populations)
+    fbm = orc.synth_fbm(101, n, m, npop=G, miss=0.1)
+    gid = (np.arange(n) % G).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    t = tpg.nwise_pop_pbs(X, None, None, gid, G, fst_method=method, return_fst=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        o = orc.nwise_pop_pbs(fbm, None, None, gid, G, fst_method=method)
+        o_fst = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method, by_locus=True)["fst_locus"]
+    ntrip = G * (G - 1) * (G - 2) // 6
+    assert t["pbs"].shape == (m, 6 * ntrip) == o.shape and len(t["names"]) == 6 * ntrip
+    assert np.array_equal(t["fst"], o_fst, equal_nan=True)
+    assert np.array_equal(np.isnan(t["pbs"]), np.isnan(o))
+    assert np.allclose(t["pbs"], o, rtol=1e-12, atol=1e-14, equal_nan=True)
+    with pytest.raises(ValueError):
+        tpg.nwise_pop_pbs(X, None, None, gid % 2, 2)

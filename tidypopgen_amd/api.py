@@ -663,6 +663,57 @@ def windows_pairwise_pop_fst(X: FBM, ind_row, ind_col, groupIds, ngroups: int, c
     return dict(chromosome=wr["chromosome"], start=wr["start"], end=wr["end"], fst=fst)
 
 
+def _pbs_triplets(ngroups):
+    """utils::combn(levels, 3) order, with the Fst columns of (p1.p2, p1.p3, p2.p3) in combn(levels, 2) order"""
+    pairs = combn2(ngroups)  # (2, P), 1-based
+    col = {(int(a), int(b)): k for k, (a, b) in enumerate(pairs.T)}
+    trips, cols = [], []
+    for a in range(1, ngroups + 1):
+        for b in range(a + 1, ngroups + 1):
+            for c in range(b + 1, ngroups + 1):
+                trips.append((a, b, c))
+                cols.append((col[(a, b)], col[(a, c)], col[(b, c)]))
+    return trips, np.ascontiguousarray(cols, dtype=np.int32)
+
+
+def nwise_pop_pbs(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=None, fst_method: str = "Hudson",
+                  return_fst: bool = False):
+    """R/nwise_pop_pbs.R:36-156, type = "matrix": by-locus PBS and normalised PBS for every triplet of populations.
+    -> dict(pbs (m, 6 * n_triplets), names, [fst (m, P)]); the by-locus Fst matrix stays in HBM in between."""
+    if ngroups < 3:
+        raise ValueError("At least 3 populations are required to compute PBS.")
+    if not isinstance(return_fst, (bool, np.bool_)):
+        raise ValueError("return_fst must be a logical value (TRUE or FALSE)")
+    if fst_method not in FST_METHODS:
+        raise ValueError("'arg' should be one of 'Hudson', 'Nei87', 'WC84'")
+    v = View(X, ind_row, ind_col)
+    pairs_c = np.ascontiguousarray(combn2(ngroups).T)
+    P = pairs_c.shape[0]
+    trips, tcols = _pbs_triplets(ngroups)
+    gid, pl = _i32(groupIds), _ploidy(v, ploidy)
+    ctx = v.ctx
+    tot = np.zeros(P)
+    d_fst = ctx.dev_alloc(8 * v.m * P)
+    try:
+        check(lib.tpg_pairwise_pop_fst(ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pl), C.c_int(FST_METHODS[fst_method]),
+                                       _ptr(pairs_c), C.c_int(P), C.c_int(1), C.c_int(0), _ptr(tot), d_fst, None))
+        out = np.zeros((v.m, 6 * len(trips)), order="F")
+        check(lib.tpg_pbs_from_fst(ctx.h, d_fst, C.c_int64(v.m), C.c_int(P), _ptr(tcols), C.c_int(len(trips)), _ptr(out)))
+        res = dict(pbs=out)
+        if return_fst:
+            f = np.zeros((v.m, P), order="F")
+            check(lib.tpg_dev_to_host(ctx.h, _ptr(f), d_fst, C.c_size_t(f.nbytes)))
+            res["fst"] = f
+    finally:
+        ctx.dev_free(d_fst)
+    names = []
+    for (a, b, c) in trips:
+        for stat in ("pbs", "pbsn1"):
+            names += [f"{stat}_{a}.{b}.{c}", f"{stat}_{b}.{a}.{c}", f"{stat}_{c}.{a}.{b}"]
+    res["names"] = names
+    return res
+
+
 def _fst_loop(method, pairwise_combn, n, freq_alt, freq_ref, het_obs, by_locus, return_num_dem, ctx):
     ctx = ctx or default_context()
     pairs_c = np.ascontiguousarray(np.asarray(pairwise_combn, dtype=np.int32).T)

@@ -366,3 +366,44 @@ extern "C" int tpg_pairwise_pop_fst_sums(tpg_ctx* ctx, const tpg_view* v, const 
   return fused_fst(ctx, v, groupIds0, ngroups, ploidy, method, pairs1, P, 0, 0, nullptr, nullptr, nullptr, sum_num,
                    sum_den);
 }
+
+// ---------------------------------------------------------------------------
+// Population branch statistic from by-locus (or by-window) pairwise Fst: pbs_one_triplet of R/nwise_pop_pbs.R:118-156.
+// For triplet t with Fst columns (c12, c13, c23): six output columns {pbs_1, pbs_2, pbs_3, pbsn1_1, pbsn1_2, pbsn1_3}.
+__global__ void tpg_pbs_kernel(const double* __restrict__ fst, int64_t m, const int32_t* __restrict__ trip, int ntrip,
+                               double* __restrict__ out) {
+  const int64_t total = m * ntrip;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = idx % m;
+    const int t = (int)(idx / m);
+    const double f12 = fst[j + (int64_t)trip[3 * t] * m], f13 = fst[j + (int64_t)trip[3 * t + 1] * m],
+                 f23 = fst[j + (int64_t)trip[3 * t + 2] * m];
+    const double t12 = -log(1 - f12), t13 = -log(1 - f13), t23 = -log(1 - f23);  // :138-140
+    const double p1 = (t12 + t13 - t23) / 2, p2 = (t12 + t23 - t13) / 2, p3 = (t13 + t23 - t12) / 2;
+    double* o = out + (int64_t)t * 6 * m + j;
+    o[0] = p1; o[m] = p2; o[2 * m] = p3;
+    o[3 * m] = p1 / (1 + p1 + p2 + p3);  // :147-149
+    o[4 * m] = p2 / (1 + p1 + p2 + p3);
+    o[5 * m] = p3 / (1 + p1 + p2 + p3);
+  }
+}
+
+extern "C" int tpg_pbs_from_fst(tpg_ctx* ctx, const double* fst, int64_t m, int P, const int32_t* trip_cols0, int ntrip,
+                                double* out) {
+  TPG_REQUIRE(ctx && fst && trip_cols0 && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(m > 0 && P > 0 && ntrip > 0, TPG_EINVAL, "bad sizes");
+  for (int k = 0; k < 3 * ntrip; k++)
+    TPG_REQUIRE(trip_cols0[k] >= 0 && trip_cols0[k] < P, TPG_EINVAL, "triplet column %d out of [0,%d)", trip_cols0[k], P);
+  InBuf ifst, itr;
+  TPG_TRY(ifst.init(ctx, fst, sizeof(double) * (size_t)m * (size_t)P));
+  TPG_TRY(itr.init(ctx, trip_cols0, sizeof(int32_t) * 3 * (size_t)ntrip));
+  OutBuf o;
+  TPG_TRY(o.init(out, sizeof(double) * (size_t)m * 6 * (size_t)ntrip));
+  TPG_LAUNCH(ctx, "pbs", tpg_pbs_kernel, dim3(2048), dim3(256), 0, ifst.dev<double>(), m, itr.dev<int32_t>(), ntrip,
+             o.dev<double>());
+  TPG_CHECK_LAUNCH();
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return o.commit(ctx);
+}
+
