@@ -120,6 +120,11 @@ int tpg_grouped_genotype_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* 
  * by_locus = FALSE values (may be NULL).  ploidy (may be NULL) must be all 2: the reference stops otherwise. */
 int tpg_pop_global_stats(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                          const double* ploidy, double* by_locus, double* overall);
+/* pop_het_obs (which = 0, R/pop_het_obs.R:78-91), pop_het_exp / pop_gene_div (1, R/pop_het_exp.R:85-103) and
+ * pop_fis(method = "Nei87") (2, R/pop_fis.R:108-130): by_locus = m x G (may be NULL), colmeans = colMeans(na.rm = TRUE)
+ * over the loci, G values (may be NULL).  ploidy as in tpg_pop_global_stats. */
+int tpg_pop_basic_stats(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups, const double* ploidy,
+                        int which, double* by_locus, double* colmeans);
 /* the numeric core of windows_stats_generic (R/windows_stats_generic.R:113-176: runner::mean_run /
  * sum_run with na_rm = TRUE) for every column of the per-locus matrix x (m x ncol, column-major, host or device):
  * window w covers the loci lo[w] .. hi[w]-1 (0-based; the host side derives them from chromosome / position /

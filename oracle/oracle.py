@@ -414,6 +414,27 @@ def nwise_pop_pbs(fbm, rowInd, colInd, groupIds, ngroups, ploidy=None, fst_metho
     return np.column_stack(cols)
 
 
+def pop_basic_stat(fbm, rowInd, colInd, groupIds, ngroups, which, by_locus=False, include_global=False, code256=CODE_012):
+    """pop_het_obs (which="Ho", R/pop_het_obs.R:78-92), pop_het_exp ("Hs", R/pop_het_exp.R:85-103) and
+    pop_fis(method = "Nei87") ("Fis", R/pop_fis.R:108-133)"""
+    _, r, _c = _view(fbm, rowInd, colInd)
+    with np.errstate(invalid="ignore", divide="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        pf = grouped_summaries_dip_pseudo_cpp(fbm, rowInd, colInd, groupIds, ngroups, np.full(len(r), 2.0), code256)
+        sHo = pf["het_obs"]
+        n = pf["n"] / 2
+        sp2 = pf["freq_alt"] ** 2 + pf["freq_ref"] ** 2
+        Hs = (1 - sp2 - sHo / 2 / n)
+        Hs = n / (n - 1) * Hs
+        x = {"Ho": sHo, "Hs": Hs, "Fis": 1 - sHo / Hs}[which]
+        col = {"Ho": 0, "Hs": 1, "Fis": 8}[which]
+        if which == "Fis" and include_global and not by_locus:
+            return np.append(np.nanmean(x, axis=0), pop_global_stats(fbm, rowInd, colInd, groupIds, ngroups)[col])
+        if include_global:
+            x = np.column_stack([x, pop_global_stats(fbm, rowInd, colInd, groupIds, ngroups, by_locus=True)[:, col]])
+        return x if by_locus else np.nanmean(x, axis=0)
+
+
 def _fst_loop(fn, pairs1, m, mats, by_locus, return_num_dem):
     pairs1 = np.ascontiguousarray(np.asarray(pairs1, dtype=np.int32).T)  # (P, 2) rows = (pop1, pop2)
     P = pairs1.shape[0]

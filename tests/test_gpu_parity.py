@@ -586,3 +586,30 @@ def test_nwise_pop_pbs(tpg, n, m, G, method):
     assert np.allclose(t["pbs"], o, rtol=1e-12, atol=1e-14, equal_nan=True)
     with pytest.raises(ValueError):
         tpg.nwise_pop_pbs(X, None, None, gid % 2, 2)
+
+
+@pytest.mark.parametrize("n,m,G", [(7, 6, 3), (300, 2500, 6), (500, 1500, 51)])
+def test_pop_basic_stats(tpg, n, m, G):
+    # pop_het_obs / pop_het_exp / pop_fis (Nei87): R/pop_het_obs.R, R/pop_het_exp.R, R/pop_fis.R:81-133
+    if n == 7:
+        fbm, gid = orc.fbm_from_genotypes(fx.FST_7x6), fx.FST_GROUPS_3
+    else:
+        fbm = orc.synth_fbm(111, n, m, npop=G, miss=0.1)
+        gid = (np.arange(n) % G).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    fns = {"Ho": tpg.pop_het_obs, "Hs": tpg.pop_het_exp, "Fis": lambda *a, **k: tpg.pop_fis(*a, method="Nei87", **k)}
+    for which, fn in fns.items():
+        for by_locus in (True, False):
+            for glob in (False, True):
+                t = fn(X, None, None, gid, G, by_locus=by_locus, include_global=glob)
+                o = orc.pop_basic_stat(fbm, None, None, gid, G, which, by_locus, glob)
+                assert t.shape == o.shape
+                assert np.array_equal(np.isnan(t), np.isnan(o)), (which, by_locus, glob)
+                fin = np.isfinite(o)
+                assert np.array_equal(np.isfinite(t), fin)
+                assert np.allclose(t[fin], o[fin], rtol=1e-11, atol=1e-13), (which, by_locus, glob)
+    assert tpg.pop_gene_div is tpg.pop_het_exp
+    with pytest.raises(ValueError):
+        tpg.pop_fis(X, None, None, gid, G, method="Nei87", allele_sharing_mat=np.ones((n, n)))
+    with pytest.raises(ValueError):
+        tpg.pop_fis(X, None, None, gid, G, method="WG17", by_locus=True)

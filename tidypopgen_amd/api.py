@@ -470,6 +470,53 @@ def pop_global_stats(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=No
     return loc if by_locus else ov
 
 
+def _pop_basic(X, ind_row, ind_col, groupIds, ngroups, ploidy, which, by_locus, include_global, global_col):
+    v = View(X, ind_row, ind_col)
+    gid, pl = _i32(groupIds), _ploidy(v, ploidy)
+    loc = np.zeros((v.m, ngroups), order="F") if by_locus else None
+    cm = np.zeros(ngroups)
+    check(lib.tpg_pop_basic_stats(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pl), C.c_int(which),
+                                  _ptr(loc) if by_locus else None, _ptr(cm)))
+    if not include_global:
+        return loc if by_locus else cm
+    g_loc = pop_global_stats(X, ind_row, ind_col, groupIds, ngroups, ploidy, by_locus=True)[:, global_col]
+    if by_locus:
+        return np.column_stack([loc, g_loc])
+    with np.errstate(invalid="ignore"):
+        return np.append(cm, np.nanmean(g_loc) if np.any(~np.isnan(g_loc)) else np.nan)
+
+
+def pop_het_obs(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=None, by_locus=False, include_global=False):
+    """R/pop_het_obs.R:52-92"""
+    return _pop_basic(X, ind_row, ind_col, groupIds, ngroups, ploidy, 0, by_locus, include_global, 0)
+
+
+def pop_het_exp(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=None, by_locus=False, include_global=False):
+    """R/pop_het_exp.R:53-104 (alias pop_gene_div)"""
+    return _pop_basic(X, ind_row, ind_col, groupIds, ngroups, ploidy, 1, by_locus, include_global, 1)
+
+
+pop_gene_div = pop_het_exp
+
+
+def pop_fis(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=None, method: str = "Nei87", by_locus=False,
+            include_global=False, allele_sharing_mat=None):
+    """R/pop_fis.R:56-133"""
+    if method not in ("Nei87", "WG17"):
+        raise ValueError("'arg' should be one of 'Nei87', 'WG17'")
+    if method == "WG17":
+        if by_locus:
+            raise ValueError("by_locus not implemented for WG17")
+        return pop_fis_wg17(X, ind_row, ind_col, groupIds, ngroups, include_global, allele_sharing_mat)
+    if allele_sharing_mat is not None:
+        raise ValueError("allele_sharing_mat not relevant for Nei87")
+    if by_locus or not include_global:
+        return _pop_basic(X, ind_row, ind_col, groupIds, ngroups, ploidy, 2, by_locus, include_global, 8)
+    # by_locus = FALSE with the global value: the reference takes pop_global_stats(by_locus = FALSE)["Fis"], :126-130
+    cm = _pop_basic(X, ind_row, ind_col, groupIds, ngroups, ploidy, 2, False, False, 8)
+    return np.append(cm, pop_global_stats(X, ind_row, ind_col, groupIds, ngroups, ploidy, by_locus=False)[8])
+
+
 def alt_freq_dip_pseudo_cpp(v: View, ploidy=None, as_counts: bool = False) -> np.ndarray:
     """src/alt_freq_dip_pseudo_cpp.cpp:8-58 -> (m, 2)"""
     out = np.zeros((v.m, 2), order="F")

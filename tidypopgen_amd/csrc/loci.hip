@@ -491,8 +491,8 @@ __global__ void tpg_global_stats_kernel(const int32_t* __restrict__ cnt, int64_t
   }
 }
 
-// per column: sum and count of the finite entries, in a fixed order (block partials, then one thread)
-__global__ __launch_bounds__(256) void tpg_finite_colsum_kernel(const double* __restrict__ x, int64_t m,
+// per column: sum and count of the non-NaN (drop_inf: finite) entries, in a fixed order (block partials, then the host)
+__global__ __launch_bounds__(256) void tpg_finite_colsum_kernel(const double* __restrict__ x, int64_t m, int drop_inf,
                                                                 double* __restrict__ part) {
   __shared__ double ssum[256], scnt[256];
   const int c = blockIdx.y;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void tpg_finite_colsum_kernel(const double* __
   double s = 0, k = 0;
   for (int64_t j = a + threadIdx.x; j < b; j += 256) {
     const double v = x[(int64_t)c * m + j];
-    if (v == v && fabs(v) != HUGE_VAL) { s += v; k += 1; }
+    if (v == v && !(drop_inf && fabs(v) == HUGE_VAL)) { s += v; k += 1; }
   }
   ssum[threadIdx.x] = s; scnt[threadIdx.x] = k;
   __syncthreads();
@@ -539,7 +539,7 @@ extern "C" int tpg_pop_global_stats(tpg_ctx* ctx, const tpg_view* v, const int32
     hipLaunchKernelGGL(tpg_global_stats_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const int32_t*)gc.cnt, gc.Mpad,
                        gc.Cpad, m, ngroups, d_loc);
     if (overall) {
-      hipLaunchKernelGGL(tpg_finite_colsum_kernel, dim3(NB, 10), dim3(256), 0, ctx->stream, (const double*)d_loc, m, d_part);
+      hipLaunchKernelGGL(tpg_finite_colsum_kernel, dim3(NB, 10), dim3(256), 0, ctx->stream, (const double*)d_loc, m, 1, d_part);
       e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipGetLastError();
@@ -619,6 +619,75 @@ extern "C" int tpg_window_stats(tpg_ctx* ctx, const double* x, int64_t m, int nc
   TPG_HIP(hipStreamSynchronize(ctx->stream));
   TPG_TRY(os.commit(ctx));
   if (n_loci) TPG_TRY(on.commit(ctx));
+  return TPG_OK;
+}
+
+// pop_het_obs / pop_het_exp / pop_fis(method = "Nei87") by locus x population (R/pop_het_obs.R:78-91,
+// R/pop_het_exp.R:85-103, R/pop_fis.R:108-115): which 0 = Ho, 1 = Hs, 2 = Fis
+__global__ void tpg_pop_basic_kernel(const int32_t* __restrict__ cnt, int64_t Mpad, int Cpad, int64_t m, int G, int which,
+                                     double* __restrict__ out) {
+  const int64_t total = m * G;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % G);
+    const int64_t j = idx / G;
+    const GroupVals gv = tpg_group_vals(cnt, Mpad, Cpad, j, g, 0);
+    const double sHo = gv.het2 / gv.valid;
+    double r = sHo;
+    if (which != 0) {
+      const double n = gv.valid / 2, fa = gv.alt / gv.valid, fr = 1 - fa;
+      const double sp2 = fa * fa + fr * fr;
+      double Hs = (1 - sp2 - sHo / 2 / n);
+      Hs = n / (n - 1) * Hs;
+      r = which == 1 ? Hs : 1 - sHo / Hs;
+    }
+    out[j + (int64_t)g * m] = r;
+  }
+}
+
+extern "C" int tpg_pop_basic_stats(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
+                                   const double* ploidy, int which, double* by_locus, double* colmeans) {
+  TPG_REQUIRE(ctx && v && groupIds0 && (by_locus || colmeans), TPG_EINVAL, "null argument");
+  TPG_REQUIRE(which >= 0 && which <= 2, TPG_EINVAL, "which must be 0 (Ho), 1 (Hs) or 2 (Fis)");
+  if (ploidy)
+    for (int64_t i = 0; i < v->n; i++)  // stopifnot_diploid(.x)
+      TPG_REQUIRE(ploidy[i] == 2.0, TPG_EINVAL, "this statistic only works on diploid data");
+  ClassPlan cp;
+  TPG_TRY(make_class_plan(v, groupIds0, ngroups, nullptr, &cp));
+  GroupedCounts gc;
+  TPG_TRY(tpg_grouped_counts(ctx, v, cp.cls.data(), cp.nclass, &gc));
+  const int64_t m = v->m;
+  const size_t bytes = sizeof(double) * (size_t)m * (size_t)ngroups;
+  OutBuf ob;
+  double* d_tmp = nullptr;
+  if (by_locus) TPG_TRY(ob.init(by_locus, bytes));
+  else TPG_HIP(tpg_pmalloc((void**)&d_tmp, bytes));
+  double* d_loc = by_locus ? ob.dev<double>() : d_tmp;
+  const int NB = 64;
+  double* d_part = nullptr;
+  hipError_t e = tpg_pmalloc((void**)&d_part, sizeof(double) * 2 * (size_t)ngroups * NB);
+  std::vector<double> part((size_t)2 * ngroups * NB);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(tpg_pop_basic_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const int32_t*)gc.cnt, gc.Mpad, gc.Cpad,
+                       m, ngroups, which, d_loc);
+    if (colmeans) {
+      hipLaunchKernelGGL(tpg_finite_colsum_kernel, dim3(NB, (unsigned)ngroups), dim3(256), 0, ctx->stream,
+                         (const double*)d_loc, m, 0, d_part);
+      e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  tpg_pfree(d_part);
+  tpg_pfree(d_tmp);
+  if (e != hipSuccess) { tpg_set_error("pop_basic_stats: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  if (colmeans)
+    for (int g = 0; g < ngroups; g++) {  // colMeans(x, na.rm = TRUE)
+      double sm = 0, k = 0;
+      for (int b = 0; b < NB; b++) { sm += part[((size_t)g * NB + b) * 2]; k += part[((size_t)g * NB + b) * 2 + 1]; }
+      colmeans[g] = sm / k;
+    }
+  if (by_locus) TPG_TRY(ob.commit(ctx));
   return TPG_OK;
 }
 
