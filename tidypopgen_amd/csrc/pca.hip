@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __res
           const int cur = s & 1, nx = cur ^ 1;
           // next step's operands: steps 1..3 of this group, or step 0 of the next group (other digit buffer).
           // Two scheduling regions so that the digit reads are long done when the A-side perms need them.
-          constexpr int NQ = TD * TB, Q1 = (NQ * 9) / 16 > 0 ? (NQ * 9) / 16 : 1;
+          constexpr int NQ = TD * TB, Q1 = NQ / 2 > 0 ? NQ / 2 : 1;  // half the MFMAs per region: ~3.5 and ~4.4 VALU per MFMA
           if (s == 0) {
             if (dlane) RD[M] = DG[i2 * (TD * 16) + lane];
             RA[M] = pa[i2 * 64];
