@@ -139,13 +139,15 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
           P[nx][1] = tpg_decode3(s < 3 ? wa1[s < 3 ? s + 1 : 0] : (R1[N].x | dead1));
           P[nx][2] = tpg_decode3(s < 3 ? wb[s < 3 ? s + 1 : 0] : RB[N].x);
 #pragma unroll
-          for (int t = 0; t < 2; t++) {
-            cV[t] = MFMA_I8(P[cur][t].v, P[cur][2].v, cV[t]);
-            cD[t] = MFMA_I8(P[cur][t].d, P[cur][2].d, cD[t]);
-            cH[t] = MFMA_I8(P[cur][t].h, P[cur][2].h, cH[t]);
-            cHV[t] = MFMA_I8(P[cur][t].h, P[cur][2].v, cHV[t]);
-            cVH[t] = MFMA_I8(P[cur][t].v, P[cur][2].h, cVH[t]);
-          }
+          for (int t = 0; t < 2; t++) cV[t] = MFMA_I8(P[cur][t].v, P[cur][2].v, cV[t]);  // product-major order: ~1 % faster
+#pragma unroll
+          for (int t = 0; t < 2; t++) cD[t] = MFMA_I8(P[cur][t].d, P[cur][2].d, cD[t]);  // than tile-major (measured)
+#pragma unroll
+          for (int t = 0; t < 2; t++) cH[t] = MFMA_I8(P[cur][t].h, P[cur][2].h, cH[t]);
+#pragma unroll
+          for (int t = 0; t < 2; t++) cHV[t] = MFMA_I8(P[cur][t].h, P[cur][2].v, cHV[t]);
+#pragma unroll
+          for (int t = 0; t < 2; t++) cVH[t] = MFMA_I8(P[cur][t].v, P[cur][2].h, cVH[t]);
 #pragma unroll
           for (int q = 0; q < 10; q++) {
             __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
