@@ -1593,44 +1593,68 @@ __global__ __launch_bounds__(256) void tpg_uq_colsum_kernel(const double* __rest
   if (threadIdx.x == 0) usum[kk] = sh[0];
 }
 
-// out[locus][column] = sum_i g_i,locus * UD[i][column]; one wave per 32-locus tile, CTP column tiles per pass
+// out[locus][column] = sum_i g_i,locus * UD[i][column].  One wave owns LD_NLT consecutive 32-locus tiles and CTP
+// column tiles (LD_NLT * CTP accumulator tiles, up to 256 AGPRs, one wave per SIMD): every 1-KiB fragment of the
+// digit table UD fetched from L2 feeds LD_NLT MFMAs.  With one locus tile per wave the kernel moved 1 KiB per MFMA,
+// 20 GB per launch at C5, and was bound by that (1.6 ms); the A side is the code bytes themselves (no missing
+// values here, see the Gram kernel).
+#define LD_NLT 4
 template <int CTP>
-__global__ __launch_bounds__(256) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
-                                                                const uint4* __restrict__ UD, int64_t n_lt,
-                                                                int64_t Q, int ct0, int CT,
-                                                                int32_t* __restrict__ out, int Cpad) {
+__global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
+                                                                   const uint4* __restrict__ UD, int64_t n_lt,
+                                                                   int64_t Q, int ct0, int CT,
+                                                                   int32_t* __restrict__ out, int Cpad) {
   const int lane = threadIdx.x & 63;
-  const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (lt >= n_lt) return;
-  v16i acc[CTP];
+  const int64_t lt0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LD_NLT;
+  if (lt0 >= n_lt) return;
+  v16i acc[LD_NLT][CTP];
 #pragma unroll
-  for (int c = 0; c < CTP; c++)
+  for (int t = 0; t < LD_NLT; t++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[c][r] = 0;
-  const uint4* pa = L + (lt * Q) * 64 + lane;
+    for (int c = 0; c < CTP; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[t][c][r] = 0;
+  const uint4* pa[LD_NLT];
+#pragma unroll
+  for (int t = 0; t < LD_NLT; t++) pa[t] = L + ((lt0 + t < n_lt ? lt0 + t : lt0) * Q) * 64 + lane;  // past the end: a copy
+  uint4 a[LD_NLT], an[LD_NLT];
+#pragma unroll
+  for (int t = 0; t < LD_NLT; t++) a[t] = pa[t][0];
   for (int64_t q = 0; q < Q; q++) {
-    const uint4 a = pa[q * 64];
-    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+    const int64_t qn = q + 1 < Q ? q + 1 : q;
+#pragma unroll
+    for (int t = 0; t < LD_NLT; t++) an[t] = pa[t][qn * 64];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-      v4i fg;
+      v4i fg[LD_NLT];
 #pragma unroll
-      for (int k = 0; k < 4; k++) fg[k] = tpg_lut(TPG_LUT_G, tpg_codes(aw[s], k));
+      for (int t = 0; t < LD_NLT; t++) {
+        const uint32_t w = s == 0 ? a[t].x : s == 1 ? a[t].y : s == 2 ? a[t].z : a[t].w;
+#pragma unroll
+        for (int k = 0; k < 4; k++) fg[t][k] = (int)tpg_codes(w, k);
+      }
 #pragma unroll
       for (int c = 0; c < CTP; c++) {
         const uint4 b = UD[((q * 4 + s) * CT + ct0 + c) * 64 + lane];
         v4i fb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
-        acc[c] = MFMA_I8(fg, fb, acc[c]);
+#pragma unroll
+        for (int t = 0; t < LD_NLT; t++) acc[t][c] = MFMA_I8(fg[t], fb, acc[t][c]);
       }
     }
+#pragma unroll
+    for (int t = 0; t < LD_NLT; t++) a[t] = an[t];
   }
 #pragma unroll
-  for (int c = 0; c < CTP; c++)
+  for (int t = 0; t < LD_NLT; t++) {
+    if (lt0 + t >= n_lt) break;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int64_t row = lt * 32 + tpg_cd_row(r, lane);
-      out[row * Cpad + 32 * (ct0 + c) + (lane & 31)] = acc[c][r];
-    }
+    for (int c = 0; c < CTP; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int64_t row = (lt0 + t) * 32 + tpg_cd_row(r, lane);
+        out[row * Cpad + 32 * (ct0 + c) + (lane & 31)] = acc[t][c][r];
+      }
+  }
 }
 
 __global__ void tpg_loadings_finalize_kernel(const int32_t* __restrict__ acc, int Cpad, int64_t m, int k, int FU,
@@ -1675,7 +1699,7 @@ static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_
   if (e == hipSuccess) {
     TPG_LAUNCH(ctx, "loadings_u_digits", tpg_u_digits_kernel, dim3(1024), dim3(256), 0, d_U, n, k, FU, v->Q, CT, d_UD);
     TPG_LAUNCH(ctx, "loadings_u_digits", tpg_uq_colsum_kernel, dim3((unsigned)k), dim3(256), 0, d_U, n, FU, d_usum);
-    const unsigned grid = (unsigned)ceil_div(n_lt, 4);
+    const unsigned grid = (unsigned)ceil_div(n_lt, 4 * LD_NLT);
     for (int ct0 = 0; ct0 < CT;) {
       const int left = CT - ct0;
 #define LD_LAUNCH(C)                                                                                             \
