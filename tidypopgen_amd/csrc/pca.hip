@@ -1594,19 +1594,21 @@ __global__ __launch_bounds__(256) void tpg_uq_colsum_kernel(const double* __rest
 }
 
 // out[locus][column] = sum_i g_i,locus * UD[i][column].  One wave owns LD_NLT consecutive 32-locus tiles and CTP
-// column tiles (LD_NLT * CTP accumulator tiles, up to 256 AGPRs, one wave per SIMD): every 1-KiB fragment of the
-// digit table UD fetched from L2 feeds LD_NLT MFMAs.  With one locus tile per wave the kernel moved 1 KiB per MFMA,
-// 20 GB per launch at C5, and was bound by that (1.6 ms); the A side is the code bytes themselves (no missing
-// values here, see the Gram kernel).
+// column tiles (LD_NLT * CTP accumulator tiles, up to 256 AGPRs, one wave per SIMD), and the four waves of a
+// workgroup share the digit fragments of a 128-individual group through double-buffered LDS (each wave fetches a
+// quarter, one barrier per group): a 1-KiB fragment of UD fetched from L2 feeds 4 * LD_NLT MFMAs.  With one locus
+// tile per wave and a fragment per MFMA straight from L2 the kernel moved 20 GB per launch at C5 through the L1s
+// and was bound by that (1.6 ms).  The A side is the code bytes themselves (no missing values here, see the Gram
+// kernel).
 #define LD_NLT 4
 template <int CTP>
 __global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
                                                                    const uint4* __restrict__ UD, int64_t n_lt,
                                                                    int64_t Q, int ct0, int CT,
                                                                    int32_t* __restrict__ out, int Cpad) {
-  const int lane = threadIdx.x & 63;
-  const int64_t lt0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LD_NLT;
-  if (lt0 >= n_lt) return;
+  __shared__ __attribute__((aligned(16))) uint4 ubuf[2][4 * CTP][64];  // [buffer][K step * CTP + column tile][lane]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t lt0 = ((int64_t)blockIdx.x * 4 + wv) * LD_NLT;  // may lie past n_lt: the wave still serves the LDS
   v16i acc[LD_NLT][CTP];
 #pragma unroll
   for (int t = 0; t < LD_NLT; t++)
@@ -1616,14 +1618,29 @@ __global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* 
       for (int r = 0; r < 16; r++) acc[t][c][r] = 0;
   const uint4* pa[LD_NLT];
 #pragma unroll
-  for (int t = 0; t < LD_NLT; t++) pa[t] = L + ((lt0 + t < n_lt ? lt0 + t : lt0) * Q) * 64 + lane;  // past the end: a copy
+  for (int t = 0; t < LD_NLT; t++) pa[t] = L + ((lt0 + t < n_lt ? lt0 + t : 0) * Q) * 64 + lane;  // past the end: a copy
   uint4 a[LD_NLT], an[LD_NLT];
 #pragma unroll
   for (int t = 0; t < LD_NLT; t++) a[t] = pa[t][0];
+  // this wave's share of a group's fragments: items wv, wv + 4, ... of the 4 * CTP (K step, column tile) pairs
+  const uint4* pu = UD + ct0 * 64 + lane;  // fragment (ks, c) = pu[(ks * CT + c) * 64]
+  uint4 un[CTP];
+#pragma unroll
+  for (int j = 0; j < CTP; j++) {
+    const int it = wv + 4 * j;
+    ubuf[0][it][lane] = pu[((int64_t)(it / CTP) * CT + it % CTP) * 64];
+  }
+  __syncthreads();
   for (int64_t q = 0; q < Q; q++) {
     const int64_t qn = q + 1 < Q ? q + 1 : q;
+    const int cur = (int)(q & 1);
 #pragma unroll
     for (int t = 0; t < LD_NLT; t++) an[t] = pa[t][qn * 64];
+#pragma unroll
+    for (int j = 0; j < CTP; j++) {
+      const int it = wv + 4 * j;
+      un[j] = pu[((qn * 4 + it / CTP) * CT + it % CTP) * 64];
+    }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       v4i fg[LD_NLT];
@@ -1635,7 +1652,7 @@ __global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* 
       }
 #pragma unroll
       for (int c = 0; c < CTP; c++) {
-        const uint4 b = UD[((q * 4 + s) * CT + ct0 + c) * 64 + lane];
+        const uint4 b = ubuf[cur][s * CTP + c][lane];
         v4i fb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
 #pragma unroll
         for (int t = 0; t < LD_NLT; t++) acc[t][c] = MFMA_I8(fg[t], fb, acc[t][c]);
@@ -1643,6 +1660,10 @@ __global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* 
     }
 #pragma unroll
     for (int t = 0; t < LD_NLT; t++) a[t] = an[t];
+    // the other buffer was last read in group q - 1, which every wave left through the barrier below
+#pragma unroll
+    for (int j = 0; j < CTP; j++) ubuf[cur ^ 1][wv + 4 * j][lane] = un[j];
+    __syncthreads();
   }
 #pragma unroll
   for (int t = 0; t < LD_NLT; t++) {
