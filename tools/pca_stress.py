@@ -13,7 +13,7 @@ for n, m in ((40, 300), (128, 1000), (333, 2500), (1000, 4000)):
         X = tpg.FBM.from_numpy(fbm)
         alt = orc.CODE_012[fbm].sum(axis=0)
         keep = np.where((alt > 0) & (alt < 2 * n))[0] + 1
-        for k in (1, 2, 5, 10, 30, 52):
+        for k in (1, 2, 5, 14, 30, 52):
             if k >= min(n, len(keep)):
                 continue
             t0 = time.time()
@@ -33,8 +33,12 @@ for n, m in ((40, 300), (128, 1000), (333, 2500), (1000, 4000)):
             for j in range(k):
                 if sep[j] and (j == 0 or sep[j - 1]):
                     eu = max(eu, min(np.max(np.abs(r["u"][:, j] - o["u"][:, j])), np.max(np.abs(r["u"][:, j] + o["u"][:, j]))))
-            flag = "" if (ed < 1e-6 and eu < 1e-5) else "  <-- CHECK"
+            ev = 0.0
+            for j in range(k):
+                if sep[j] and (j == 0 or sep[j - 1]):
+                    ev = max(ev, min(np.max(np.abs(r["v"][:, j] - o["v"][:, j])), np.max(np.abs(r["v"][:, j] + o["v"][:, j]))))
+            flag = "" if (ed < 1e-6 and eu < 1e-5 and ev < 1e-5) else "  <-- CHECK"
             if flag:
                 bad += 1
-            print(f"n={n} m={m} G={G} k={k}: d err {ed:.2e}  u err {eu:.2e}  {dt*1e3:.0f} ms{flag}")
+            print(f"n={n} m={m} G={G} k={k}: d err {ed:.2e}  u err {eu:.2e}  v err {ev:.2e}  {dt*1e3:.0f} ms{flag}")
 print("bad:", bad)
