@@ -384,8 +384,8 @@ __global__ void tpg_pca_digits_kernel(const double* __restrict__ scale, const do
 template <int TD>  // digits handled by this pass (<= 4); DG holds exactly these TD digits per locus
 __global__ __launch_bounds__(256, 1) void tpg_pca_gram_kernel(const uint4* __restrict__ Tl, int64_t KG,
                                                               int64_t kg_begin, int64_t kg_end,
-                                                              const uint4* __restrict__ DG, int t0, int nrt,
-                                                              int nsb, const int2* __restrict__ order, int nun, int S,
+                                                              const uint4* __restrict__ DG, int t0,
+                                                              const int2* __restrict__ order, int nun, int S,
                                                               long long* __restrict__ slabs) {
   __shared__ __attribute__((aligned(16))) uint4 dgs[4][2][TD * 16];
   constexpr int TB = PCA_TB;
@@ -721,7 +721,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   const int F = 7 * T - 1 - wbits;
 
   // units: see tpg_gram_locate.  nrtv row tiles hold data, nsbf full super-tiles, rem remainder tiles
-  const int nrt = (int)(v->Q * 4), nsb = nrt / PCA_TB;
+  const int nrt = (int)(v->Q * 4);
   const int nrtv = (int)ceil_div(n, 32), nsbf = nrtv / PCA_TB, rem = nrtv - PCA_TB * nsbf;
   std::vector<int2> order;
   for (int pj = 0; pj * 8 < nsbf; pj++) {  // patch order: super-column blocks of 8, inside them the super-rows
@@ -775,7 +775,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
       const uint4* dgp = (const uint4*)(d_DG + pass_base);
 #define GRAM_LAUNCH(TD)                                                                                              \
   TPG_LAUNCH(ctx, "pca_gram_mfma", tpg_pca_gram_kernel<TD>, dim3(grid), dim3(256), 0, (const uint4*)v->T, v->KG,      \
-             (int64_t)0, v->KG, dgp, t0, nrt, nsb, (const int2*)d_order, (int)nun, bestS, d_slabs)
+             (int64_t)0, v->KG, dgp, t0, (const int2*)d_order, (int)nun, bestS, d_slabs)
       if (td == 4) GRAM_LAUNCH(4);
       else if (td == 3) GRAM_LAUNCH(3);
       else if (td == 2) GRAM_LAUNCH(2);
@@ -1214,7 +1214,7 @@ struct EigWork {
   tpg_ctx* ctx;
   const double* K;
   int n, b, S;
-  double *part = nullptr, *gpart = nullptr, *xsmall = nullptr;
+  double *part = nullptr, *gpart = nullptr;
   int nchunks, rows_per_chunk;
   // deflation: K' = K - L diag(lam) L' for the nl locked eigenpairs (L = first nl columns of the block)
   const double* L = nullptr;
@@ -1233,7 +1233,6 @@ struct EigWork {
     nchunks = (n + rows_per_chunk - 1) / rows_per_chunk;
     TPG_HIP(tpg_pmalloc((void**)&part, sizeof(double) * (size_t)S * (size_t)b * (size_t)n));
     TPG_HIP(tpg_pmalloc((void**)&gpart, sizeof(double) * (size_t)nchunks * 64 * 64));  // nchunks = n/32
-    TPG_HIP(tpg_pmalloc((void**)&xsmall, sizeof(double) * 64 * 64));
     TPG_HIP(tpg_pmalloc((void**)&lam_dev, sizeof(double) * 64));
     TPG_HIP(tpg_pmalloc((void**)&cdev, sizeof(double) * 64 * 64));
     TPG_HIP(tpg_pmalloc((void**)&dtmp, sizeof(double) * (size_t)b * (size_t)n));
@@ -1246,7 +1245,6 @@ struct EigWork {
   ~EigWork() {
     if (part) tpg_pfree(part);
     if (gpart) tpg_pfree(gpart);
-    if (xsmall) tpg_pfree(xsmall);
     if (lam_dev) tpg_pfree(lam_dev);
     if (cdev) tpg_pfree(cdev);
     if (dtmp) tpg_pfree(dtmp);
