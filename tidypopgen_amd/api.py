@@ -845,6 +845,17 @@ def gt_pca_partialSVD(X: FBM, ind_row=None, ind_col=None, k: int = 10, total_var
     return out
 
 
+def gt_pca_randomSVD(X: FBM, ind_row=None, ind_col=None, k: int = 10, tol: float = 1e-4, total_var: bool = True,
+                     code256=CODE_IMPUTE_PRED) -> dict:
+    """R/gt_pca_randomSVD.R:77-135.  The reference reaches the same truncated SVD of the scaled matrix through
+    bigstatsr::big_randomSVD (implicitly restarted Lanczos on Z x / Z'x, stopped at `tol`); here it is the same
+    device computation as gt_pca_partialSVD (Gram matrix + eigen step, residual 1e-12), which meets any `tol`.
+    Only the method label differs."""
+    out = gt_pca_partialSVD(X, ind_row, ind_col, k=k, total_var=total_var, code256=code256)
+    out["method"] = "randomSVD"
+    return out
+
+
 def fbm256_prod_and_rowSumsSq(X: FBM, ind_row, ind_col, center, scale, V, code256="fbm"):
     """src/fbm_prod_and_rowSumSq.cpp:10-47 -> (XV (n, K), rowSumsSq (n,))"""
     v = View(X, ind_row, ind_col, code256=code256)
