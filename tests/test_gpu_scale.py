@@ -154,3 +154,47 @@ def test_many_individuals_indexing():
     assert np.all(np.diff(r["d"]) < 0) and np.all(r["d"] > 0)
     assert np.allclose(r["u"].T @ r["u"], np.eye(5), atol=1e-9)
     assert np.allclose(r["v"].T @ r["v"], np.eye(5), atol=1e-7)
+
+
+def test_bench_size_properties():
+    """BASELINE configs 3-5 (5 000 x 1 000 000, 51 populations): results pinned by properties that need no CPU pass
+    over the panel -- additivity over locus blocks (bit-exact for counts, 1e-12 for Fst sums), and the SVD identity
+    Z v_j = d_j u_j checked with the independent FP64 sweep kernel (fbm256_prod_and_rowSumsSq)."""
+    import tidypopgen_amd as tpg
+
+    n, m, G, k = 5_000, 1_000_000, 51, 20
+    X = tpg.FBM.synth(3, n, m, npop=G, miss=0.02, imputed_bytes=True)
+    gid = (np.arange(n) % G).astype(np.int32)
+    v = tpg.View(X, code256=None)
+    # pairwise: one pass == three unequal blocks, and the diagonal ties to the per-locus counts
+    whole, parts = tpg.Pairwise(X.ctx, n), tpg.Pairwise(X.ctx, n)
+    whole.accumulate(v)
+    edges = [0, 128 * 1111, 128 * 5000, m]
+    for a, b in zip(edges, edges[1:]):
+        parts.accumulate(v, a, b)
+    cw, cp = whole.counts(("ibs", "king_num", "n_Aa_i")), parts.counts(("ibs", "king_num", "n_Aa_i"))
+    for key in cw:
+        assert np.array_equal(cw[key], cp[key]), key
+    cnt = tpg.loci_counts(v).astype(np.int64)
+    assert np.diag(cw["n_Aa_i"]).sum() == cnt[:, 1].sum()
+    assert np.diag(cw["ibs"]).sum() == 2 * cnt[:, :3].sum()
+    del cw, cp, whole, parts
+    # Fst: the sums over two halves of the loci add up to the sums over all of them
+    half = 128 * 3906
+    for method in ("Hudson", "WC84"):
+        r_all = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method, sums=True)
+        r_a = tpg.pairwise_pop_fst(X, None, np.arange(1, half + 1, dtype=np.int32), gid, G, method=method, sums=True)
+        r_b = tpg.pairwise_pop_fst(X, None, np.arange(half + 1, m + 1, dtype=np.int32), gid, G, method=method, sums=True)
+        for key in ("sum_num", "sum_den"):
+            assert np.allclose(r_a[key] + r_b[key], r_all[key], rtol=1e-11, atol=0), (method, key)
+        assert np.all(np.isfinite(r_all["fst_tot"])) and np.all(np.abs(r_all["fst_tot"]) < 1)
+    # PCA: orthonormal factors and Z v = u d through a different kernel
+    alt = cnt[:, 1] + 2 * cnt[:, 2]  # (raw view: imputed bytes read as missing, fine for a polymorphism filter)
+    cols = (np.where((alt > 0) & (alt < 2 * cnt[:, :3].sum(axis=1)))[0] + 1).astype(np.int32)
+    r = tpg.gt_pca_partialSVD(X, None, cols, k=k)
+    assert np.all(np.diff(r["d"]) < 0) and np.all(r["d"] > 0)
+    assert np.allclose(r["u"].T @ r["u"], np.eye(k), atol=1e-9)
+    assert np.allclose(r["v"].T @ r["v"], np.eye(k), atol=1e-7)
+    XV, rss = tpg.fbm256_prod_and_rowSumsSq(X, None, cols, r["center"], r["scale"], r["v"], code256=tpg.CODE_IMPUTE_PRED)
+    assert np.allclose(XV, r["u"] * r["d"], rtol=0, atol=1e-6 * r["d"][0])
+    assert rss.sum() == pytest.approx(r["square_frobenius"], rel=1e-9)

@@ -585,8 +585,10 @@ def _fst_result(tot, a, b, by_locus, return_num_dem):
 
 
 def pairwise_pop_fst(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=None, method: str = "Hudson",
-                     by_locus: bool = False, return_num_dem: bool = False, pairwise_combn=None):
-    """R/pairwise_pop_fst.R:71-161 (numeric part; the tidy / matrix formatting is out of scope)"""
+                     by_locus: bool = False, return_num_dem: bool = False, pairwise_combn=None, sums: bool = False):
+    """R/pairwise_pop_fst.R:71-161 (numeric part; the tidy / matrix formatting is out of scope).  sums = True
+    (not in the reference): also return the sums of numerators and denominators over the loci, the additive
+    quantities a run sharded by loci exchanges."""
     if method not in FST_METHODS:
         raise ValueError("'arg' should be one of 'Hudson', 'Nei87', 'WC84'")
     if not isinstance(return_num_dem, (bool, np.bool_)):
@@ -597,8 +599,16 @@ def pairwise_pop_fst(X: FBM, ind_row, ind_col, groupIds, ngroups: int, ploidy=No
     pairs = combn2(ngroups) if pairwise_combn is None else np.asarray(pairwise_combn, dtype=np.int32)
     pairs_c = np.ascontiguousarray(pairs.T)  # (P, 2) row-major == 2 x P column-major
     P = pairs_c.shape[0]
-    tot, a, b = _fst_outputs(v.m, P, by_locus, return_num_dem)
     gid, pl = _i32(groupIds), _ploidy(v, ploidy)
+    if sums:
+        if by_locus:
+            raise ValueError("sums = True returns totals only")
+        sn, sd = np.zeros(P), np.zeros(P)
+        check(lib.tpg_pairwise_pop_fst_sums(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pl),
+                                            C.c_int(FST_METHODS[method]), _ptr(pairs_c), C.c_int(P), _ptr(sn), _ptr(sd)))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return dict(fst_tot=sn / sd, sum_num=sn, sum_den=sd)
+    tot, a, b = _fst_outputs(v.m, P, by_locus, return_num_dem)
     check(lib.tpg_pairwise_pop_fst(v.ctx.h, v.h, _ptr(gid), C.c_int(ngroups), _ptr(pl),
                                    C.c_int(FST_METHODS[method]), _ptr(pairs_c), C.c_int(P), C.c_int(int(by_locus)),
                                    C.c_int(int(return_num_dem)), _ptr(tot), _ptr(a), _ptr(b)))
