@@ -335,6 +335,22 @@ def main():
         roofs = [r for r in roofs if r]
         roofs.sort(key=lambda r: -r["avg_launch_ms"])
         roof = roofs[0] if roofs else None
+
+        # the HBM-bound kernels of the path, priced on their algorithmic bytes
+        def hbm_roof(key, kernel, nbytes, note):
+            cnt, ms = prof.get(key, (0, 0.0))
+            if not cnt:
+                return None
+            achieved = nbytes / (ms / cnt * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": ms / cnt,
+                    "algorithmic_bytes_per_launch": nbytes, "note": note}
+
+        hbm_roofs = [
+            hbm_roof("pack", "tpg_pack_fast_kernel", 1.5 * n * m, "FBM bytes -> two 2-bit layouts: N M read + N M / 2 written"),
+            hbm_roof("loci_counts", "tpg_loci_counts_kernel", 0.25 * n * m + 16.0 * m,
+                     "per-locus genotype counts: N M / 4 read + 16 B per locus written"),
+        ]
         analyses = ["pack", "loci_alt_freq", "grouped_alt_freq", "fst_hudson", "fst_wc84", "ibs", "king", "grm"]
         if st.has_pca:
             analyses.append(f"pca_partialSVD_k{args.k}")
@@ -350,7 +366,7 @@ def main():
                                    f"(imputed bytes), seed 3 [BASELINE configs 2-4]",
                        "analyses": analyses, "pca_included": bool(st.has_pca)},
             "roofline": roof,
-            "roofline_other_kernels": roofs[1:],
+            "roofline_other_kernels": roofs[1:] + [r for r in hbm_roofs if r],
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
             "kernel_launches_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
         }
