@@ -262,9 +262,17 @@ def cpu_baseline(args):
     Z @ Z.T
     dt = time.time() - t0
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    try:  # the threads the BLAS products actually ran on (OpenBLAS caps them at its build maximum)
+        from threadpoolctl import threadpool_info
+
+        blas = [int(t["num_threads"]) for t in threadpool_info() if t.get("user_api") == "blas"]
+        if blas:
+            cores = min(cores, max(blas))
+    except ImportError:
+        pass
     return {"value": n * B / dt, "unit": "SNP-genotypes/s", "cores": cores, "kind": "port",
             "sample": f"{n} x {B} loci of the same synthetic panel, IBS+KING+AS via numpy/BLAS FP64 one-hot products "
-                      f"(reference's 6/4/2 products per block), per-locus + Fst (Hudson, WC84) C loops, PCA Gram via BLAS; "
+                      f"(reference's 6/4/2 products per block, multi-threaded), per-locus + Fst (Hudson, WC84) C loops (one thread), PCA Gram via BLAS; "
                       f"{dt:.1f} s; eigen step excluded"}
 
 
