@@ -195,6 +195,14 @@ int tpg_pairwise_zero(tpg_ctx* ctx, tpg_pairwise* pw);
 /* add loci [col_begin, col_end) of the view (0-based, end exclusive; -1 = m) */
 int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
                             int64_t col_end);
+/* Reference quirk Q1, opt-in.  increment_as_counts adds +1 to EVERY element of the allele-sharing
+ * numerator for every block of the R driver that is one column narrower than the widest (src/snp_as.cpp:57-63 with
+ * the scratch matrices of R/snp_allele_sharing.R:55-56).  The default (0 blocks) is the mathematically intended
+ * value, which is what the reference's own test asserts; to reproduce a real R run bit for bit pass the number of
+ * narrower blocks of that run: as_num, allele sharing and GRM then come out as R's.  tpg_as_pad_quirk_blocks gives
+ * that number for m loci cut by CutBySize(m, block_size) (R/local_reimplementations.R:13-15). */
+int tpg_pairwise_set_as_pad_quirk(tpg_pairwise* pw, int64_t narrow_blocks);
+int64_t tpg_as_pad_quirk_blocks(int64_t m, int64_t block_size);
 /* raw count matrices, n x n column-major doubles, any may be NULL:
  * ibs / ibs_valid (snp_ibs raw_counts), king_num / n_Aa_i (snp_king), as_num / as_den */
 int tpg_pairwise_counts(tpg_ctx* ctx, const tpg_pairwise* pw, double* ibs, double* ibs_valid,
@@ -217,9 +225,13 @@ int tpg_block_means(tpg_ctx* ctx, const double* A, int64_t n, const int32_t* gro
                     double* mean, double* count);
 
 /* Literal per-block mirrors of the three increment_* entry points
- * (src/snp_ibs.cpp:22-74, src/snp_king.cpp:21-74, src/snp_as.cpp:22-67): the caller-owned
- * n x n doubles are incremented in place; the scratch matrices of the reference are not needed.
- * fbm_bytes is the host (mmapped) FBM. */
+ * (src/snp_ibs.cpp:22-74, src/snp_king.cpp:21-74, src/snp_as.cpp:22-67); the scratch matrices of the reference
+ * are not needed.  fbm_bytes is the host (mmapped) FBM.  RESIDENT and DEFERRED: the FBM is uploaded the first time
+ * its address is seen and stays in HBM (tpg_resident_drop forgets it -- call that if the FBM's bytes change); every
+ * (K, K2) pair gets device accumulators that live across the calls of the R block loop (R/snp_ibs.R:69-82), so a
+ * block moves nothing over PCIe.  The caller's n x n doubles are incremented when tpg_increment_flush is called (once,
+ * after the loop: one line added to the R driver) -- not at every block, which would cost two
+ * N x N downloads per block.  All blocks that accumulate into the same (K, K2) must pass the same rowInd. */
 int tpg_increment_ibs_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes,
                              int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
                              const int32_t* colInd1, int64_t m);
@@ -229,6 +241,14 @@ int tpg_increment_king_numerator(tpg_ctx* ctx, double* K, double* N_Aa_i, const 
 int tpg_increment_as_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes,
                             int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
                             const int32_t* colInd1, int64_t m);
+
+/* K += accumulated sums for every pending (K, K2) pair; the device accumulators are released */
+int tpg_increment_flush(tpg_ctx* ctx);
+/* forget the FBMs uploaded by the increment_* mirrors (an error while increments are pending) */
+int tpg_resident_drop(tpg_ctx* ctx);
+/* quirk Q1 through the literal mirror (opt-in): note that the block just passed to tpg_increment_as_counts for
+ * matrix K was one column narrower than the R driver's scratch matrices */
+int tpg_increment_as_note_narrow_block(tpg_ctx* ctx, const double* K);
 
 /* ---- PCA (gt_pca_partialSVD) ---------------------------------------------- */
 /* center / scale of bigsnpr::snp_scaleBinom; TPG_ENUMERIC on a missing value or zero scale */

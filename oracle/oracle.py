@@ -695,3 +695,14 @@ def synth_fbm(seed: int, n: int, m: int, j0: int = 0, npop: int = 51, miss: floa
     lib().orc_synth_fbm(C.c_uint64(seed), C.c_int64(n), C.c_int64(m), C.c_int64(j0), C.c_int(npop),
                         C.c_uint32(thr), C.c_int(int(imputed_bytes)), _p(out, C.c_uint8))
     return out
+
+
+def synth_rows(seed: int, rows0, m: int, j0: int = 0, npop: int = 51, miss: float = 0.02,
+               imputed_bytes: bool = False) -> np.ndarray:
+    """rows `rows0` (0-based) of the panel synth_fbm(seed, n, m, ...) would give, without generating the rest"""
+    rows0 = np.ascontiguousarray(rows0, dtype=np.int64)
+    out = np.zeros((len(rows0), m), dtype=np.uint8, order="F")
+    thr = min(int(round(miss * 2 ** 32)), 2 ** 32 - 1)
+    lib().orc_synth_rows(C.c_uint64(seed), _p(rows0, C.c_int64), C.c_int64(len(rows0)), C.c_int64(m), C.c_int64(j0),
+                         C.c_int(npop), C.c_uint32(thr), C.c_int(int(imputed_bytes)), _p(out, C.c_uint8))
+    return out

@@ -65,6 +65,7 @@ void orc_increment_ibs_counts(const uint8_t* fbm, int64_t nrow, const int32_t* r
   uint8_t* g = (uint8_t*)malloc((size_t)n * (size_t)m);
   for (int j = 0; j < m; j++)
     for (int i = 0; i < n; i++) g[(size_t)i * m + j] = FBM(i, j);
+#pragma omp parallel for schedule(dynamic, 1)
   for (int a = 0; a < n; a++) {
     const uint8_t* ga = g + (size_t)a * m;
     for (int b = 0; b < n; b++) {
@@ -93,6 +94,7 @@ void orc_increment_king_numerator(const uint8_t* fbm, int64_t nrow, const int32_
   uint8_t* g = (uint8_t*)malloc((size_t)n * (size_t)m);
   for (int j = 0; j < m; j++)
     for (int i = 0; i < n; i++) g[(size_t)i * m + j] = FBM(i, j);
+#pragma omp parallel for schedule(dynamic, 1)
   for (int a = 0; a < n; a++) {
     const uint8_t* ga = g + (size_t)a * m;
     for (int b = 0; b < n; b++) {
@@ -129,6 +131,7 @@ void orc_increment_as_counts(const uint8_t* fbm, int64_t nrow, const int32_t* ro
       if (value < 3) { d[(size_t)i * m + j] = (int8_t)(value - 1); v[(size_t)i * m + j] = 1; }
       else           { d[(size_t)i * m + j] = 0;                   v[(size_t)i * m + j] = 0; }
     }
+#pragma omp parallel for schedule(dynamic, 1)
   for (int a = 0; a < n; a++)
     for (int b = 0; b < n; b++) {
       int64_t k = 0, k2 = 0;
@@ -483,4 +486,27 @@ void orc_synth_fbm(uint64_t seed, int64_t n, int64_t m, int64_t j0, int npop, ui
           tpg_synth_geno(seed, (uint64_t)i, (uint64_t)(j0 + j), pjg[i % npop], miss_thresh, imputed_bytes);
   }
   free(pjg);
+}
+
+/* The same panel for a SUBSET of the individuals (rows0: 0-based indices into the full panel) over m loci from j0:
+ * lets a test check a 5 000 x 1 000 000 device result against this oracle on a few dozen individuals over ALL loci
+ * without generating 5 GB on the host.  out is nrows x m column-major. */
+void orc_synth_rows(uint64_t seed, const int64_t* rows0, int64_t nrows, int64_t m, int64_t j0, int npop,
+                    uint32_t miss_thresh, int imputed_bytes, uint8_t* out) {
+#pragma omp parallel
+  {
+    uint32_t* pjg = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)npop);
+    uint8_t* need = (uint8_t*)calloc((size_t)npop, 1);
+    for (int64_t r = 0; r < nrows; r++) need[rows0[r] % npop] = 1;
+#pragma omp for schedule(static)
+    for (int64_t j = 0; j < m; j++) {
+      for (int g = 0; g < npop; g++)
+        if (need[g]) pjg[g] = tpg_synth_pjg(seed, (uint64_t)(j0 + j), (uint32_t)g, (uint32_t)npop);
+      for (int64_t r = 0; r < nrows; r++)
+        out[(size_t)r + (size_t)j * (size_t)nrows] = tpg_synth_geno(seed, (uint64_t)rows0[r], (uint64_t)(j0 + j),
+                                                                    pjg[rows0[r] % npop], miss_thresh, imputed_bytes);
+    }
+    free(pjg);
+    free(need);
+  }
 }

@@ -1,0 +1,180 @@
+"""GPU vs the CPU oracle AT the BASELINE.json sizes (configs 2 and 3-5), on samples the oracle finishes in seconds.
+
+The panels are the bench panels (synthetic, seed 2: 1 000 x 650 000; seed 3: 5 000 x 1 000 000; 51 populations, 2 %
+missing stored as imputed bytes).  The synthetic generator is a pure function of (seed, individual, locus), so the
+oracle regenerates on the host exactly the rows / loci it needs (oracle.synth_rows / synth_fbm -- bit-identical to
+the device generator, tests/test_gpu_parity.py::test_synth_matches_host) and restates the reference on them:
+
+  * pairwise: 64 individuals spread over the first, middle and last (partial) row tiles x ALL loci.  The 64 x 64
+    sub-blocks of all six count matrices of increment_{ibs,king,as}_counts must be bit-exact (this is where K-split
+    > 1, multi-round unit tables and the 10^6-deep int32 accumulation of the full-size launch would show), and IBS /
+    KING / allele sharing identical to the oracle's R-order epilogues;
+  * Hudson / WC84 by locus for 5 population pairs x ALL loci bit-identical, totals <= 1e-12;
+  * alt_freq, missingness and grouped_alt_freq (all 51 groups) on 30 000 sampled loci bit-exact, read out of the
+    whole-panel device result;
+  * PCA: numpy.linalg.eigvalsh of the device Gram matrix vs d^2 (<= 1e-9), the Gram sub-block of the 64 individuals
+    vs an FP64 numpy Gram over all loci (<= 1e-6 of its scale), center / scale vs the counts.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = 51
+
+
+def _sample_rows(n):
+    """64 individuals: both ends of the first 64-row super-tile, a run across a tile edge in the middle, scattered
+    ones (stride coprime with the 51 populations), and the last rows (the partial last tile)."""
+    mid = (n // 2) // 32 * 32
+    rows = [0, 1, 30, 31, 32, 33, 62, 63, 64, 65, mid - 2, mid - 1, mid, mid + 1, mid + 31, mid + 32]
+    rows += list(range(n - 12, n))
+    rng = np.random.default_rng(n)
+    extra = [int(x) for x in rng.permutation(n) if x not in rows][: 64 - len(rows)]
+    return np.array(sorted(rows + extra), dtype=np.int64)
+
+
+def _check_pairwise_sample(tpg, orc, X, seed, n, m):
+    rows = _sample_rows(n)
+    assert len(set(rows.tolist())) == 64
+    sub = orc.synth_rows(seed, rows, m, npop=G, miss=0.02, imputed_bytes=True)  # 64 x m FBM bytes of those rows
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, n)
+    pw.accumulate(v)
+    ix = np.ix_(rows, rows)
+    o = {k: np.zeros((64, 64), order="F") for k in ("ibs", "ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den")}
+    orc.increment_ibs_counts(o["ibs"], o["ibs_valid"], sub, None, None)        # src/snp_ibs.cpp:45-72
+    orc.increment_king_numerator(o["king_num"], o["n_Aa_i"], sub, None, None)  # src/snp_king.cpp:45-72
+    orc.increment_as_counts(o["as_num"], o["as_den"], sub, None, None)         # src/snp_as.cpp:44-65
+    for names in (("ibs", "ibs_valid", "king_num"), ("n_Aa_i", "as_num", "as_den")):
+        c = pw.counts(names)
+        for k in names:
+            assert np.array_equal(c[k][ix], o[k]), k
+        del c
+    ep = pw.epilogues(("ibs", "king", "allele_sharing", "grm"), m=m)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert np.array_equal(ep["ibs"][ix], o["ibs"] / o["ibs_valid"], equal_nan=True)       # R/snp_ibs.R:88-95
+    assert np.array_equal(ep["king"][ix], orc.king_epilogue(o["king_num"], o["n_Aa_i"]), equal_nan=True)
+    assert np.array_equal(ep["allele_sharing"][ix], orc.as_epilogue(o["as_num"], o["as_den"]), equal_nan=True)
+    # GRM = the reference's formula on the (sample-verified) allele-sharing matrix: the mean is over all N (N - 1) pairs
+    assert np.allclose(ep["grm"], orc.pairwise_grm(ep["allele_sharing"]), rtol=1e-12, atol=1e-14)
+    return v
+
+
+def _check_loci_sample(tpg, orc, X, v012, seed, n, m, nblocks=30, width=1000):
+    gid = (np.arange(n) % G).astype(np.int32)
+    ploidy = np.full(n, 2.0)
+    cnt = tpg.loci_counts(v012)
+    f = tpg.alt_freq_dip_pseudo_cpp(v012, None, as_counts=False)
+    ga = tpg.grouped_alt_freq_dip_pseudo_cpp(v012, gid, G, None, as_counts=False)
+    gm = tpg.grouped_missingness_cpp(v012, gid, G)
+    starts = np.linspace(0, m - width, nblocks).astype(np.int64)
+    starts[1:-1] += 37  # off the 128-locus group grid, but keep the very first and very last loci
+    for j0 in starts:
+        blk = orc.synth_fbm(seed, n, width, j0=int(j0), npop=G, miss=0.02, imputed_bytes=True)
+        sl = slice(int(j0), int(j0) + width)
+        of = orc.alt_freq_dip_pseudo_cpp(blk, None, None, ploidy)                     # src/alt_freq_dip_pseudo_cpp.cpp:21-57
+        assert np.array_equal(f[sl], of, equal_nan=True)
+        og = orc.grouped_alt_freq_dip_pseudo_cpp(blk, None, None, gid, G, ploidy)     # src/grouped_alt_freq_dip_pseudo_cpp.cpp:24-57
+        assert np.array_equal(ga[sl], og, equal_nan=True)
+        om = orc.grouped_missingness_cpp(blk, None, None, gid, G)                     # src/grouped_missingness_cpp.cpp:21-32
+        assert np.array_equal(gm[sl], om)
+        codes = np.minimum(blk, 3)
+        for k in range(4):
+            assert np.array_equal(cnt[sl, k], (codes == k).sum(axis=0))
+    return cnt
+
+
+def _check_fst_sample(tpg, orc, X, seed, n, m):
+    gid = (np.arange(n) % G).astype(np.int32)
+    pairs_full = np.array([[1, 2], [1, 51], [26, 27], [50, 51], [11, 41]], dtype=np.int32).T  # 2 x 5, 1-based
+    pops = sorted(set(pairs_full.ravel().tolist()))
+    remap = {p: k + 1 for k, p in enumerate(pops)}
+    pairs_sub = np.vectorize(remap.get)(pairs_full).astype(np.int32)
+    rows = np.array([i for i in range(n) if (i % G) + 1 in pops], dtype=np.int64)
+    gid_sub = np.array([remap[(i % G) + 1] - 1 for i in rows], dtype=np.int32)
+    sub = orc.synth_rows(seed, rows, m, npop=G, miss=0.02, imputed_bytes=True)
+    pf = orc.grouped_summaries_dip_pseudo_cpp(sub, None, None, gid_sub, len(pops), np.full(len(rows), 2.0))
+    del sub
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for method in ("Hudson", "WC84"):
+            if method == "Hudson":  # src/pairwise_fst_hudson_loop.cpp:23-62
+                o = orc.pairwise_fst_hudson_loop(pairs_sub, pf["n"], pf["freq_alt"], pf["freq_ref"], by_locus=True)
+                ond = orc.pairwise_fst_hudson_loop(pairs_sub, pf["n"], pf["freq_alt"], pf["freq_ref"], by_locus=True,
+                                                   return_num_dem=True)
+            else:                   # src/pairwise_fst_wc84_loop.cpp:22-120
+                o = orc.pairwise_fst_wc84_loop(pairs_sub, pf["n"], pf["freq_alt"], pf["het_obs"], by_locus=True)
+                ond = orc.pairwise_fst_wc84_loop(pairs_sub, pf["n"], pf["freq_alt"], pf["het_obs"], by_locus=True,
+                                                 return_num_dem=True)
+            d = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method, by_locus=True, pairwise_combn=pairs_full)
+            assert np.array_equal(d["fst_locus"], o["fst_locus"], equal_nan=True), method
+            assert np.allclose(d["fst_tot"], o["fst_tot"], rtol=1e-12, atol=0), method
+            dnd = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method, return_num_dem=True,
+                                       pairwise_combn=pairs_full)
+            for key in ("Fst_by_locus_num", "Fst_by_locus_den"):
+                assert np.array_equal(dnd[key], ond[key], equal_nan=True), (method, key)
+            # the fused totals-only path (what bench.py times) against the oracle's totals, all 1 275 pairs' code path
+            s = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method, pairwise_combn=pairs_full, sums=True)
+            assert np.allclose(s["fst_tot"], o["fst_tot"], rtol=1e-10, atol=0), method
+
+
+def _check_pca_sample(tpg, orc, X, seed, n, m, k):
+    rows = _sample_rows(n)
+    vi = tpg.View(X, code256=tpg.CODE_IMPUTE_PRED)
+    cnt = tpg.loci_counts(vi).astype(np.int64)
+    assert cnt[:, 3].sum() == 0
+    alt = cnt[:, 1] + 2 * cnt[:, 2]
+    keep = (alt > 0) & (alt < 2 * n)
+    cols = (np.where(keep)[0] + 1).astype(np.int32)
+    r = tpg.gt_pca_partialSVD(X, None, cols, k=k)
+    # center / scale of bigsnpr::snp_scaleBinom from the (oracle-checked) counts
+    center = alt[keep] / n
+    p = center / 2
+    scale = np.sqrt(2 * p * (1 - p))
+    assert np.array_equal(r["center"], center)
+    assert np.allclose(r["scale"], scale, rtol=1e-15, atol=0)
+    vv = tpg.View(X, None, cols, code256=tpg.CODE_IMPUTE_PRED)
+    K = tpg.pca_gram(vv, r["center"], r["scale"])
+    lam = np.linalg.eigvalsh(K)[::-1][:k]
+    assert np.allclose(r["d"] ** 2, lam, rtol=1e-9, atol=0)
+    # FP64 Gram of the 64 sampled individuals over all kept loci
+    sub = orc.CODE_IMPUTE_PRED[orc.synth_rows(seed, rows, m, npop=G, miss=0.02, imputed_bytes=True)][:, keep]
+    Ks = np.zeros((64, 64))
+    for a in range(0, sub.shape[1], 65536):
+        Z = (sub[:, a:a + 65536] - center[a:a + 65536]) / scale[a:a + 65536]
+        Ks += Z @ Z.T
+    Kd = K[np.ix_(rows, rows)]
+    assert np.abs(Kd - Ks).max() <= 1e-6 * np.abs(Ks).max()
+    assert np.allclose(np.diag(Kd), np.diag(Ks), rtol=1e-6)
+    # scores: u d = Z v through the independent FP64 sweep, and u spans eigenvectors of K
+    assert np.abs(K @ r["u"] - r["u"] * r["d"] ** 2).max() <= 1e-9 * r["d"][0] ** 2
+    return r
+
+
+def test_config2_hgdp_shape_against_oracle():
+    """BASELINE config 2: 1 000 x 650 000, pairwise_king + pairwise_grm (+ the per-locus sweeps and PCA)"""
+    import tidypopgen_amd as tpg
+    from oracle import oracle as orc
+
+    n, m, seed = 1000, 650_000, 2
+    X = tpg.FBM.synth(seed, n, m, npop=G, miss=0.02, imputed_bytes=True)
+    _check_pairwise_sample(tpg, orc, X, seed, n, m)
+    v012 = tpg.View(X)
+    _check_loci_sample(tpg, orc, X, v012, seed, n, m, nblocks=12)
+    _check_fst_sample(tpg, orc, X, seed, n, m)
+    _check_pca_sample(tpg, orc, X, seed, n, m, k=10)
+
+
+def test_config3_to_5_bench_panel_against_oracle():
+    """BASELINE configs 3-5: 5 000 x 1 000 000, 51 populations, k = 20 -- the bench.py panel (seed 3)"""
+    import tidypopgen_amd as tpg
+    from oracle import oracle as orc
+
+    n, m, seed = 5000, 1_000_000, 3
+    X = tpg.FBM.synth(seed, n, m, npop=G, miss=0.02, imputed_bytes=True)
+    _check_pairwise_sample(tpg, orc, X, seed, n, m)
+    v012 = tpg.View(X)
+    _check_loci_sample(tpg, orc, X, v012, seed, n, m, nblocks=30)
+    del v012
+    _check_fst_sample(tpg, orc, X, seed, n, m)
+    _check_pca_sample(tpg, orc, X, seed, n, m, k=20)

@@ -280,9 +280,110 @@ def test_increment_mirrors(tpg):
         A = np.zeros((n, n), order="F"); B = np.zeros((n, n), order="F")
         Ao = np.zeros((n, n), order="F"); Bo = np.zeros((n, n), order="F")
         for a, b in zip(lo, up):  # unequal blocks 240,240,241,240 as R/snp_ibs.R:59-82 would cut them
-            inc_t(A, B, fbm, rows, cols[a - 1:b])
+            inc_t(A, B, fbm, rows, cols[a - 1:b])  # flush = True: incremented when the call returns, as the reference
             inc_o(Ao, Bo, fbm, rows, cols[a - 1:b])
-        assert np.array_equal(A, Ao) and np.array_equal(B, Bo)
+            assert np.array_equal(A, Ao) and np.array_equal(B, Bo)
+    tpg.resident_drop()
+
+
+def test_increment_mirrors_resident_block_loop(tpg):
+    """The R block loop unchanged (R/snp_ibs.R:69-82): FBM uploaded once, accumulators resident, one flush at the end.
+    Accumulators that already hold values (a second pass over more loci) are incremented, not overwritten."""
+    n, m = 70, 3000
+    fbm = orc.synth_fbm(21, n, m, npop=4, miss=0.05)
+    rows = (np.random.default_rng(2).permutation(n)[:50] + 1).astype(np.int32)
+    cols = np.arange(1, m + 1, dtype=np.int32)
+    lo, up = orc.cut_by_size(m, 700)
+    mats = {}
+    for name, inc_t, inc_o in (("ibs", tpg.increment_ibs_counts, orc.increment_ibs_counts),
+                               ("king", tpg.increment_king_numerator, orc.increment_king_numerator),
+                               ("as", tpg.increment_as_counts, orc.increment_as_counts)):
+        A = np.full((50, 50), 7.0, order="F"); B = np.full((50, 50), -3.0, order="F")  # not zero: += semantics
+        Ao = A.copy(order="F"); Bo = B.copy(order="F")
+        mats[name] = (A, B, Ao, Bo)
+        for a, b in zip(lo, up):
+            inc_t(A, B, fbm, rows, cols[a - 1:b], flush=False)
+            inc_o(Ao, Bo, fbm, rows, cols[a - 1:b])
+        assert np.all(A == 7.0) and np.all(B == -3.0)  # deferred: nothing written before the flush
+    tpg.increment_flush()  # all three pending pairs at once
+    for name, (A, B, Ao, Bo) in mats.items():
+        assert np.array_equal(A, Ao) and np.array_equal(B, Bo), name
+    tpg.increment_flush()  # nothing pending: a no-op
+    for name, (A, B, Ao, Bo) in mats.items():
+        assert np.array_equal(A, Ao), name
+    # changing rowInd between blocks of the same accumulators is refused
+    A, B = np.zeros((50, 50), order="F"), np.zeros((50, 50), order="F")
+    tpg.increment_ibs_counts(A, B, fbm, rows, cols[:100], flush=False)
+    with pytest.raises(tpg._lib.TpgError):
+        tpg.increment_ibs_counts(A, B, fbm, rows[::-1].copy(), cols[100:200], flush=False)
+    with pytest.raises(tpg._lib.TpgError):
+        tpg.resident_drop()  # pending increments
+    tpg.increment_flush()
+    tpg.resident_drop()
+
+
+def test_allele_sharing_pad_quirk_opt_in(tpg):
+    """Reference quirk Q1 (src/snp_as.cpp:57-63): off by default, reproducible on request -- through the whole-range
+    driver (block count from CutBySize), through the accumulator object, and through the literal per-block mirror."""
+    fbm = fx.families_fbm()
+    X = tpg.FBM.from_numpy(fbm)
+    lo, up = orc.cut_by_size(961, 300)  # 240, 240, 241, 240: three narrower blocks
+    assert tpg.as_pad_quirk_blocks(961, 300) == 3 and tpg.as_pad_quirk_blocks(960, 300) == 0
+    assert tpg.as_pad_quirk_blocks(6, 3) == 0 and tpg.as_pad_quirk_blocks(7, 3) == 2  # 2, 3, 2
+    for bs in (300, 100, 961, 37):
+        sizes = np.diff(np.concatenate([[0], orc.cut_by_size(961, bs)[1]]))
+        assert tpg.as_pad_quirk_blocks(961, bs) == int((sizes < sizes.max()).sum())
+    intended = orc.snp_allele_sharing(fbm, block_size=300)
+    quirk = orc.snp_allele_sharing(fbm, block_size=300, emulate_as_pad_quirk=True)
+    assert not np.array_equal(intended, quirk)
+    assert np.array_equal(tpg.snp_allele_sharing(X, block_size=300), intended, equal_nan=True)
+    assert np.array_equal(tpg.snp_allele_sharing(X, block_size=300, emulate_as_pad_quirk=True), quirk, equal_nan=True)
+    assert np.allclose(tpg.pairwise_grm(X, block_size=300, emulate_as_pad_quirk=True), orc.pairwise_grm(quirk),
+                       rtol=1e-12, atol=1e-14)
+    # raw numerators through the accumulator object
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, 12)
+    pw.accumulate(v)
+    base = pw.counts(("as_num", "as_den"))
+    pw.set_as_pad_quirk(3)
+    q = pw.counts(("as_num", "as_den"))
+    assert np.array_equal(q["as_num"], base["as_num"] + 3) and np.array_equal(q["as_den"], base["as_den"])
+    # literal mirror: the shim passes the width of the R driver's scratch matrices (the widest block)
+    cols = np.arange(1, 962, dtype=np.int32)
+    rows = np.arange(1, 13, dtype=np.int32)
+    A = np.zeros((12, 12), order="F"); B = np.zeros((12, 12), order="F")
+    Ao = np.zeros((12, 12), order="F"); Bo = np.zeros((12, 12), order="F")
+    for a, b in zip(lo, up):
+        tpg.increment_as_counts(A, B, fbm, rows, cols[a - 1:b], flush=False, scratch_cols=241, emulate_as_pad_quirk=True)
+        orc.increment_as_counts(Ao, Bo, fbm, rows, cols[a - 1:b], pad_quirk=(b - a + 1) < 241)
+    tpg.increment_flush()
+    assert np.array_equal(A, Ao) and np.array_equal(B, Bo)
+    tpg.resident_drop()
+
+
+def test_two_contexts_keep_their_own_memory(tpg):
+    """Two contexts (two streams) on one device, used alternately: each has its own device-memory pool, so scratch
+    blocks freed by one are never handed to the other while its kernels may still be running."""
+    n, m = 300, 20000
+    fa, fb = orc.synth_fbm(31, n, m, npop=5, miss=0.03), orc.synth_fbm(32, n, m, npop=5, miss=0.03)
+    ca, cb = tpg.Context(0), tpg.Context(0)
+    Xa, Xb = tpg.FBM.from_numpy(fa, ctx=ca), tpg.FBM.from_numpy(fb, ctx=cb)
+    gid = (np.arange(n) % 5).astype(np.int32)
+    ea = orc.snp_ibs(fa, type="raw_counts")["ibs"]
+    eb = orc.snp_ibs(fb, type="raw_counts")["ibs"]
+    ga = orc.grouped_alt_freq_dip_pseudo_cpp(fa, None, None, gid, 5, np.full(n, 2.0))
+    gb = orc.grouped_alt_freq_dip_pseudo_cpp(fb, None, None, gid, 5, np.full(n, 2.0))
+    for _ in range(3):
+        ra = tpg.snp_ibs(Xa, type="raw_counts")["ibs"]
+        rb = tpg.snp_ibs(Xb, type="raw_counts")["ibs"]
+        assert np.array_equal(ra, ea) and np.array_equal(rb, eb)
+        va, vb = tpg.View(Xa), tpg.View(Xb)
+        assert np.array_equal(tpg.grouped_alt_freq_dip_pseudo_cpp(va, gid, 5), ga, equal_nan=True)
+        assert np.array_equal(tpg.grouped_alt_freq_dip_pseudo_cpp(vb, gid, 5), gb, equal_nan=True)
+        va.free(); vb.free()
+    Xa.free(); ca.close()          # destroying one context leaves the other's blocks alone
+    assert np.array_equal(tpg.snp_ibs(Xb, type="raw_counts")["ibs"], eb)
+    Xb.free(); cb.close()
 
 
 # ---------------------------------------------------------------- Fst
@@ -333,6 +434,16 @@ def test_fst_vs_oracle(tpg, n, m, G, method):
     else:
         lm = tpg.pairwise_fst_nei87_loop(pairs, pf["n"], pf["het_obs"], pf["freq_alt"], pf["freq_ref"])
     assert np.allclose(lm["fst_tot"], o_tot, rtol=1e-12, atol=0, equal_nan=True)
+    if method != "WC84":
+        # the reference's Hudson / Nei87 loops read the caller's freq_ref; the device recomputes 1 - freq_alt, so a
+        # matrix that is anything else is refused rather than silently ignored
+        bad = pf["freq_ref"].copy()
+        bad[3, 1] += 1e-9
+        with pytest.raises(tpg._lib.TpgError):
+            if method == "Hudson":
+                tpg.pairwise_fst_hudson_loop(pairs, pf["n"], pf["freq_alt"], bad)
+            else:
+                tpg.pairwise_fst_nei87_loop(pairs, pf["n"], pf["het_obs"], pf["freq_alt"], bad)
 
 
 def test_fst_pseudohaploid_hudson_only(tpg):

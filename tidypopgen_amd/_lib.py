@@ -52,6 +52,9 @@ lib.tpg_view_n.restype = C.c_int64
 lib.tpg_view_m.restype = C.c_int64
 lib.tpg_view_n.argtypes = [vp]
 lib.tpg_view_m.argtypes = [vp]
+lib.tpg_as_pad_quirk_blocks.restype = C.c_int64
+lib.tpg_as_pad_quirk_blocks.argtypes = [C.c_int64, C.c_int64]
+lib.tpg_pairwise_set_as_pad_quirk.argtypes = [vp, C.c_int64]
 for _name in ("tpg_ctx_destroy", "tpg_fbm_free", "tpg_view_free", "tpg_pairwise_free", "tpg_dev_free"):
     getattr(lib, _name).restype = None
     getattr(lib, _name).argtypes = [vp]
@@ -70,6 +73,8 @@ SYMBOLS = [
     "tpg_pairwise_king", "tpg_pairwise_allele_sharing", "tpg_pairwise_grm", "tpg_pairwise_epilogues", "tpg_block_means", "tpg_increment_ibs_counts",
     "tpg_increment_king_numerator", "tpg_increment_as_counts", "tpg_pca_center_scale", "tpg_pca_gram",
     "tpg_pca_partial_svd", "tpg_fbm256_prod_and_rowSumsSq", "tpg_square_frobenius",
+    "tpg_pairwise_set_as_pad_quirk", "tpg_as_pad_quirk_blocks", "tpg_increment_flush", "tpg_resident_drop",
+    "tpg_increment_as_note_narrow_block",
 ]
 
 

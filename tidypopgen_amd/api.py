@@ -235,6 +235,10 @@ class Pairwise:
     def accumulate(self, view: View, col_begin: int = 0, col_end: int = -1):
         check(lib.tpg_pairwise_accumulate(self.ctx.h, self.h, view.h, C.c_int64(col_begin), C.c_int64(col_end)))
 
+    def set_as_pad_quirk(self, narrow_blocks: int):
+        """opt-in emulation of reference quirk Q1 (include/tpg.h): +narrow_blocks on every allele-sharing numerator"""
+        check(lib.tpg_pairwise_set_as_pad_quirk(self.h, C.c_int64(int(narrow_blocks))))
+
     def _mat(self):
         return np.zeros((self.n, self.n), order="F")
 
@@ -317,17 +321,29 @@ def snp_king(X: FBM, ind_row=None, ind_col=None, block_size=None):
     return pw.king()
 
 
-def snp_allele_sharing(X: FBM, ind_row=None, ind_col=None, block_size=None):
-    """R/snp_allele_sharing.R:33-82 (the mathematically intended value; reference quirk Q1 of
-    SURVEY.md §8a is NOT reproduced)."""
-    _, pw = _pairwise_pass(X, ind_row, ind_col)
-    return pw.allele_sharing()
+def as_pad_quirk_blocks(m: int, block_size: int) -> int:
+    """blocks narrower than the widest when CutBySize(m, block_size) cuts m loci (R/local_reimplementations.R:13-15)"""
+    return int(lib.tpg_as_pad_quirk_blocks(C.c_int64(int(m)), C.c_int64(int(block_size))))
 
 
-def pairwise_grm(X: FBM, ind_row=None, ind_col=None, block_size=None):
+def _as_pass(X, ind_row, ind_col, block_size, emulate_as_pad_quirk):
+    v, pw = _pairwise_pass(X, ind_row, ind_col)
+    if emulate_as_pad_quirk:
+        # what the reference BINARY returns: +1 on every numerator per narrower block (src/snp_as.cpp:57-63)
+        pw.set_as_pad_quirk(as_pad_quirk_blocks(v.m, block_size or block_size_default(X.nrow)))
+    return pw
+
+
+def snp_allele_sharing(X: FBM, ind_row=None, ind_col=None, block_size=None, emulate_as_pad_quirk: bool = False):
+    """R/snp_allele_sharing.R:33-82.  Default: the mathematically intended value (what the reference's test asserts
+    through hierfstat::matching).  emulate_as_pad_quirk = True reproduces what the reference binary computes when
+    its blocks are unequal (quirk Q1 of SURVEY.md 8a) for the given block_size (default bigstatsr::block_size)."""
+    return _as_pass(X, ind_row, ind_col, block_size, emulate_as_pad_quirk).allele_sharing()
+
+
+def pairwise_grm(X: FBM, ind_row=None, ind_col=None, block_size=None, emulate_as_pad_quirk: bool = False):
     """R/pairwise_grm.R:30-51 on top of snp_allele_sharing"""
-    _, pw = _pairwise_pass(X, ind_row, ind_col)
-    return pw.grm()
+    return _as_pass(X, ind_row, ind_col, block_size, emulate_as_pad_quirk).grm()
 
 
 def block_means(A, groupIds, ngroups: int, skip_diag: bool = True, ctx: Optional[Context] = None):
@@ -384,22 +400,43 @@ def pop_fis_wg17(X: FBM, ind_row, ind_col, groupIds, ngroups: int, include_globa
     return out
 
 
-def increment_ibs_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] = None):
-    """Literal mirror of src/snp_ibs.cpp:22-74 (k, k2 are incremented in place; X_bytes is the host FBM)."""
-    return _increment(lib.tpg_increment_ibs_counts, k, k2, X_bytes, rowInd, colInd, ctx)
+def increment_ibs_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] = None, flush: bool = True):
+    """Literal mirror of src/snp_ibs.cpp:22-74 (X_bytes is the host FBM).  The FBM and the accumulators stay resident
+    on the device between calls; with flush = True (default) k, k2 are incremented when the call returns, as in the
+    reference; a block loop passes flush = False and calls increment_flush() once after the loop."""
+    return _increment(lib.tpg_increment_ibs_counts, k, k2, X_bytes, rowInd, colInd, ctx, flush)
 
 
-def increment_king_numerator(k, n_Aa_i, X_bytes, rowInd, colInd, ctx: Optional[Context] = None):
+def increment_king_numerator(k, n_Aa_i, X_bytes, rowInd, colInd, ctx: Optional[Context] = None, flush: bool = True):
     """Literal mirror of src/snp_king.cpp:21-74"""
-    return _increment(lib.tpg_increment_king_numerator, k, n_Aa_i, X_bytes, rowInd, colInd, ctx)
+    return _increment(lib.tpg_increment_king_numerator, k, n_Aa_i, X_bytes, rowInd, colInd, ctx, flush)
 
 
-def increment_as_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] = None):
-    """Literal mirror of src/snp_as.cpp:22-67"""
-    return _increment(lib.tpg_increment_as_counts, k, k2, X_bytes, rowInd, colInd, ctx)
+def increment_as_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] = None, flush: bool = True,
+                        scratch_cols: Optional[int] = None, emulate_as_pad_quirk: bool = False):
+    """Literal mirror of src/snp_as.cpp:22-67.  scratch_cols = number of columns of the scratch matrices the R driver
+    passes; with emulate_as_pad_quirk a block one column narrower than that adds +1 to every numerator (quirk Q1)."""
+    ctx = ctx or default_context()
+    _increment(lib.tpg_increment_as_counts, k, k2, X_bytes, rowInd, colInd, ctx, False)
+    if emulate_as_pad_quirk and scratch_cols is not None and scratch_cols == len(colInd) + 1:
+        check(lib.tpg_increment_as_note_narrow_block(ctx.h, _ptr(k)))
+    if flush:
+        increment_flush(ctx)
 
 
-def _increment(fn, a, b, X_bytes, rowInd, colInd, ctx):
+def increment_flush(ctx: Optional[Context] = None):
+    """add the sums the increment_* mirrors hold on the device to their host matrices"""
+    ctx = ctx or default_context()
+    check(lib.tpg_increment_flush(ctx.h))
+
+
+def resident_drop(ctx: Optional[Context] = None):
+    """forget the FBMs the increment_* mirrors uploaded (needed if the host bytes change)"""
+    ctx = ctx or default_context()
+    check(lib.tpg_resident_drop(ctx.h))
+
+
+def _increment(fn, a, b, X_bytes, rowInd, colInd, ctx, flush):
     ctx = ctx or default_context()
     X_bytes = np.asarray(X_bytes)
     assert X_bytes.dtype == np.uint8 and X_bytes.flags.f_contiguous
@@ -407,6 +444,8 @@ def _increment(fn, a, b, X_bytes, rowInd, colInd, ctx):
     r, c = _i32(rowInd), _i32(colInd)
     check(fn(ctx.h, _ptr(a), _ptr(b), _ptr(X_bytes), C.c_int64(X_bytes.shape[0]), C.c_int64(X_bytes.shape[1]),
              _ptr(r), C.c_int64(len(r)), _ptr(c), C.c_int64(len(c))))
+    if flush:
+        increment_flush(ctx)
 
 
 def _ploidy(v: View, ploidy):
@@ -894,3 +933,6 @@ def square_frobenius(X: FBM, ind_row, ind_col, center, scale, code256=CODE_IMPUT
 def block_size(n: int, ncores: int = 1) -> int:
     """bigstatsr::block_size (recalled)"""
     return max(1, int(math.floor(1024.0 ** 3 / (8.0 * n * ncores))))
+
+
+block_size_default = block_size

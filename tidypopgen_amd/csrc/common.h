@@ -51,6 +51,8 @@ struct tpg_ctx {
   std::map<std::string, std::pair<double, int64_t>> prof_acc;  // name -> (ms, launches)
   std::vector<hipEvent_t> event_pool;
   int num_cu = 256;
+  int pool_id = 0;  // this context's device-memory pool (runtime.hip): blocks are reused in the order of ITS stream
+  void* resident = nullptr;  // pairwise.hip: FBM uploads and accumulators kept across increment_* calls
   bool upload_from_mapped_file = false;  // set by tpg_fbm_open_bk / open_bed around the upload (runtime.hip: tpg_upload)
 };
 
@@ -132,17 +134,29 @@ struct tpg_pairwise {
   bool owns;
   void* order;  // device int2[nun]: the units (I, jt) that hold data, in XCD patch order (pairwise.hip)
   int64_t nun;
+  int64_t loci;          // loci accumulated since the last zero (all ranks' loci after a reduction): overflow guard
+  int64_t as_pad_quirk;  // reference quirk Q1: added to every allele-sharing numerator (tpg_pairwise_set_as_pad_quirk)
 };
+#define TPG_PW_MAX_LOCI 2147483647ll
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Size-bucketed cache of device allocations (hipMalloc / hipFree cost milliseconds and synchronise
-// the device; a step of the hot path needs ~40 scratch buffers).  Blocks are reused in stream order:
-// the library issues all work of a context on one stream, and a process is expected to drive one
-// context per device.  tpg_pfree() of a pointer the pool does not know falls back to hipFree().
+// the device; a step of the hot path needs ~40 scratch buffers).  One pool PER CONTEXT: a context issues
+// all its work on one stream, so a block that goes back to its pool and out again is reused in stream
+// order; a block never crosses to another context (another device, or another stream of the same device).
+// tpg_pmalloc() serves the context the calling thread entered last (TpgEnter, first statement of every C-ABI
+// entry point, which also makes that context's device current); tpg_pfree() returns a block to the pool it
+// came from, or to hipFree() when that context is gone or the pointer is not the pool's.
 hipError_t tpg_pmalloc(void** p, size_t bytes);
 void tpg_pfree(void* p);
-void tpg_pool_trim(void);
+void tpg_pool_trim(int pool_id);  // release the cached (free) blocks of one pool
+struct TpgEnter {
+  tpg_ctx* prev;
+  explicit TpgEnter(tpg_ctx* ctx);
+  ~TpgEnter();
+};
+tpg_ctx* tpg_current_ctx();
 
 // device allocation helpers
 template <typename T>
@@ -172,6 +186,8 @@ struct InBuf {
   ~InBuf();
   template <typename T> const T* dev() { return (const T*)d; }
 };
+
+void tpg_resident_release(tpg_ctx* ctx);
 
 // ---- cross-TU entry points (one per .hip file) -----------------------------
 int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,

@@ -235,6 +235,15 @@ __global__ __launch_bounds__(256) void tpg_fst_reduce_kernel(const double* __res
   }
 }
 
+// flag[0] = 1 if some freq_ref entry is not exactly 1 - freq_alt (NaN matches NaN)
+__global__ void tpg_freq_ref_check_kernel(const double* __restrict__ p, const double* __restrict__ q, int64_t total,
+                                          int* __restrict__ flag) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const double want = 1 - p[idx], got = q[idx];
+    if (!(want == got || (want != want && got != got))) flag[0] = 1;
+  }
+}
+
 static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const int32_t* pairs1, int P, int by_locus,
                    int return_num_dem, double* fst_tot, double* out_a, double* out_b, double* sum_num = nullptr,
                    double* sum_den = nullptr) {
@@ -309,17 +318,36 @@ extern "C" int tpg_pairwise_fst_loop(tpg_ctx* ctx, int method, const int32_t* pa
                                      const double* n, const double* freq_alt, const double* freq_ref,
                                      const double* het_obs, int by_locus, int return_num_dem, double* fst_tot,
                                      double* out_a, double* out_b) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && n && freq_alt, TPG_EINVAL, "null argument");
   TPG_REQUIRE(m > 0 && G > 0, TPG_EINVAL, "empty input");
   TPG_REQUIRE(method == TPG_FST_HUDSON || het_obs, TPG_EINVAL, "het_obs is required for WC84 / Nei87");
-  // freq_ref is 1 - freq_alt by construction (src/grouped_summaries_dip_pseudo_cpp.cpp:53); the device
-  // code recomputes it, so a caller-supplied freq_ref is accepted but not read.
-  (void)freq_ref;
   const size_t bytes = sizeof(double) * (size_t)m * (size_t)G;
   InBuf bn, bp, bh;
   TPG_TRY(bn.init(ctx, n, bytes));
   TPG_TRY(bp.init(ctx, freq_alt, bytes));
   if (het_obs) TPG_TRY(bh.init(ctx, het_obs, bytes));
+  // freq_ref is 1 - freq_alt by construction (src/grouped_summaries_dip_pseudo_cpp.cpp:53) and the device code
+  // recomputes it.  The reference's Hudson and Nei87 loops READ the caller's matrix
+  // (src/pairwise_fst_hudson_loop.cpp:28-32, src/pairwise_fst_nei87_loop.cpp:66-72), so a matrix that is anything
+  // else would silently give other numbers there: refuse it instead.
+  if (freq_ref && method != TPG_FST_WC84) {
+    InBuf bq;
+    TPG_TRY(bq.init(ctx, freq_ref, bytes));
+    int* d_bad = nullptr;
+    TPG_HIP(tpg_pmalloc((void**)&d_bad, sizeof(int)));
+    int bad = 0;
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(tpg_freq_ref_check_kernel, dim3(1024), dim3(256), 0, ctx->stream, bp.dev<double>(),
+                         bq.dev<double>(), (int64_t)m * G, d_bad);
+      e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    tpg_pfree(d_bad);
+    TPG_HIP(e);
+    TPG_REQUIRE(!bad, TPG_EINVAL, "freq_ref is not 1 - freq_alt: the device path recomputes it and would not match the reference");
+  }
   FstSrc src{nullptr, 0, 0, 0, bn.dev<double>(), bp.dev<double>(), nullptr, het_obs ? bh.dev<double>() : nullptr};
   return run_fst(ctx, method, src, m, G, pairs1, P, by_locus, return_num_dem, fst_tot, out_a, out_b);
 }
@@ -355,6 +383,7 @@ static int fused_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, 
 extern "C" int tpg_pairwise_pop_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                                     const double* ploidy, int method, const int32_t* pairs1, int P, int by_locus,
                                     int return_num_dem, double* fst_tot, double* out_a, double* out_b) {
+  TpgEnter _enter(ctx);
   return fused_fst(ctx, v, groupIds0, ngroups, ploidy, method, pairs1, P, by_locus, return_num_dem, fst_tot, out_a,
                    out_b, nullptr, nullptr);
 }
@@ -362,6 +391,7 @@ extern "C" int tpg_pairwise_pop_fst(tpg_ctx* ctx, const tpg_view* v, const int32
 extern "C" int tpg_pairwise_pop_fst_sums(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                                          const double* ploidy, int method, const int32_t* pairs1, int P,
                                          double* sum_num, double* sum_den) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(sum_num && sum_den, TPG_EINVAL, "null output");
   return fused_fst(ctx, v, groupIds0, ngroups, ploidy, method, pairs1, P, 0, 0, nullptr, nullptr, nullptr, sum_num,
                    sum_den);
@@ -391,6 +421,7 @@ __global__ void tpg_pbs_kernel(const double* __restrict__ fst, int64_t m, const 
 
 extern "C" int tpg_pbs_from_fst(tpg_ctx* ctx, const double* fst, int64_t m, int P, const int32_t* trip_cols0, int ntrip,
                                 double* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && fst && trip_cols0 && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(m > 0 && P > 0 && ntrip > 0, TPG_EINVAL, "bad sizes");
   for (int k = 0; k < 3 * ntrip; k++)

@@ -64,6 +64,7 @@ int tpg_launch_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* d_counts) {
 }
 
 extern "C" int tpg_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && out, TPG_EINVAL, "null argument");
   OutBuf o;
   TPG_TRY(o.init(out, sizeof(int32_t) * 4 * (size_t)v->m));
@@ -73,6 +74,7 @@ extern "C" int tpg_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out) {
 
 // per-individual counts: the same kernel on the individual-tiled layout (rows = individuals, contraction over loci)
 extern "C" int tpg_indiv_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && out, TPG_EINVAL, "null argument");
   OutBuf o;
   TPG_TRY(o.init(out, sizeof(int32_t) * 4 * (size_t)v->n));
@@ -92,6 +94,7 @@ __global__ void tpg_ind_hetero_kernel(const int4* __restrict__ counts, int64_t n
 }
 
 extern "C" int tpg_gt_ind_hetero(tpg_ctx* ctx, const tpg_view* v, int32_t* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && out, TPG_EINVAL, "null argument");
   int32_t* d_counts = nullptr;
   TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->n));
@@ -119,6 +122,7 @@ __global__ void tpg_pi_kernel(const int4* __restrict__ counts, int64_t m, double
 }
 
 extern "C" int tpg_gt_pi_diploid(tpg_ctx* ctx, const tpg_view* v, double* pi) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && pi, TPG_EINVAL, "null argument");
   int32_t* d_counts = nullptr;
   TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)v->m));
@@ -403,6 +407,7 @@ __global__ void tpg_grouped_pi_kernel(const int32_t* __restrict__ cnt, int64_t M
 
 extern "C" int tpg_gt_grouped_pi_diploid(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                                          double* pi, double* n) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && groupIds0 && pi, TPG_EINVAL, "null argument");
   ClassPlan cp;
   TPG_TRY(make_class_plan(v, groupIds0, ngroups, nullptr, &cp));
@@ -440,6 +445,7 @@ __global__ void tpg_grouped_genotype_counts_kernel(const int32_t* __restrict__ c
 
 extern "C" int tpg_grouped_genotype_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                                            int32_t* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && groupIds0 && out, TPG_EINVAL, "null argument");
   ClassPlan cp;
   TPG_TRY(make_class_plan(v, groupIds0, ngroups, nullptr, &cp));
@@ -517,6 +523,7 @@ __global__ __launch_bounds__(256) void tpg_finite_colsum_kernel(const double* __
 
 extern "C" int tpg_pop_global_stats(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                                     const double* ploidy, double* by_locus, double* overall) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && groupIds0 && (by_locus || overall), TPG_EINVAL, "null argument");
   if (ploidy)
     for (int64_t i = 0; i < v->n; i++)  // stopifnot_diploid(.x), R/pop_global_stats.R:117
@@ -597,6 +604,7 @@ __global__ __launch_bounds__(64) void tpg_window_stats_kernel(const double* __re
 extern "C" int tpg_window_stats(tpg_ctx* ctx, const double* x, int64_t m, int ncol, const int64_t* lo,
                                 const int64_t* hi, const uint8_t* pad_na, int64_t nw, int op, int min_loci,
                                 double* stat, int32_t* n_loci) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && x && lo && hi && stat, TPG_EINVAL, "null argument");
   TPG_REQUIRE(op == 0 || op == 1, TPG_EINVAL, "operator must be 0 (mean) or 1 (sum)");
   TPG_REQUIRE(m >= 0 && ncol >= 1 && ncol <= 65535 && nw >= 0 && nw < 2147483647ll, TPG_EINVAL, "bad sizes");
@@ -647,6 +655,7 @@ __global__ void tpg_pop_basic_kernel(const int32_t* __restrict__ cnt, int64_t Mp
 
 extern "C" int tpg_pop_basic_stats(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                                    const double* ploidy, int which, double* by_locus, double* colmeans) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && groupIds0 && (by_locus || colmeans), TPG_EINVAL, "null argument");
   TPG_REQUIRE(which >= 0 && which <= 2, TPG_EINVAL, "which must be 0 (Ho), 1 (Hs) or 2 (Fis)");
   if (ploidy)
@@ -706,6 +715,7 @@ __global__ void tpg_alt_freq_finalize_kernel(const int4* __restrict__ counts, in
 
 extern "C" int tpg_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const double* ploidy, int as_counts,
                                        double* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && out, TPG_EINVAL, "null argument");
   bool all_dip = true;
   if (ploidy)
@@ -774,6 +784,7 @@ static int grouped_common(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupI
 
 extern "C" int tpg_grouped_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0,
                                                int ngroups, const double* ploidy, int as_counts, double* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && groupIds0 && out, TPG_EINVAL, "null argument");
   return grouped_common(ctx, v, groupIds0, ngroups, ploidy, 0, as_counts, out, (size_t)v->m * 2 * (size_t)ngroups,
                         nullptr, nullptr, nullptr);
@@ -781,6 +792,7 @@ extern "C" int tpg_grouped_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, 
 
 extern "C" int tpg_grouped_missingness(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
                                        double* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && groupIds0 && out, TPG_EINVAL, "null argument");
   return grouped_common(ctx, v, groupIds0, ngroups, nullptr, 1, 0, out, (size_t)v->m * (size_t)ngroups, nullptr,
                         nullptr, nullptr);
@@ -789,6 +801,7 @@ extern "C" int tpg_grouped_missingness(tpg_ctx* ctx, const tpg_view* v, const in
 extern "C" int tpg_grouped_summaries_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0,
                                                 int ngroups, const double* ploidy, double* freq_alt,
                                                 double* freq_ref, double* n, double* het_obs) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && groupIds0, TPG_EINVAL, "null argument");
   return grouped_common(ctx, v, groupIds0, ngroups, ploidy, 2, 0, freq_alt, (size_t)v->m * (size_t)ngroups,
                         freq_ref, n, het_obs);

@@ -14,19 +14,20 @@
 // so the fused pass needs 3 symmetric + 1 general product = 2.5 N^2 M MACs instead of the
 // reference's 12 N^2 M FP64 flops for IBS+KING+AS.
 //
-// Kernel: one wave owns a 64 x 64 output tile (2 x 2 MFMA 32x32 tiles) of a super-tile pair
-// (I <= J) and a K range; it keeps 5 products x 4 sub-tiles = 20 int32 accumulator tiles (320
-// registers, one wave per SIMD), streams its four operand row tiles from T with 16-B coalesced
-// loads (1 KiB per wave instruction, next K group prefetched), decodes each 16-locus slice with
-// 7 bit ops + 12 v_perm_b32 per fragment, and issues 20 v_mfma_i32_32x32x32_i8 per 32 loci.
-// No LDS, no barriers.  Partial tiles are added to HBM with integer atomics (exact, order
-// independent) into a tile-packed buffer in MFMA register order, so each atomic wave instruction
-// is 256 contiguous bytes.  That buffer is what a multi-GPU run all-reduces.
+// Kernel (tpg_pairwise_kernel below): one wave owns a 64 x 32 tile of pairs -- super-tile I (row tiles 2I, 2I+1)
+// against column tile jt >= 2I -- and a K range; 5 products x 2 sub-tiles = 10 int32 accumulator tiles (160 AGPRs),
+// one wave per SIMD.  It streams its three operand row tiles from T with 16-B coalesced loads (1 KiB per wave
+// instruction, prefetched two 128-locus groups ahead through rotating register slots), decodes each 16-locus slice
+// with 7 bit ops + 12 v_perm_b32 per fragment one K step ahead of its use, and issues 10 v_mfma_i32_32x32x32_i8 per
+// 32 loci.  No LDS, no barriers.  Units are taken from a host-built table in XCD patch order.  Partial tiles are
+// added to HBM with integer atomics (exact, order independent) into a tile-packed buffer in MFMA register order, so
+// each atomic wave instruction is 256 contiguous bytes.  That buffer is what a multi-GPU run reduces.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -187,10 +188,11 @@ extern "C" size_t tpg_pairwise_buffer_bytes(int64_t n) {
 }
 
 extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tpg_pairwise** out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && n < (1 << 22), TPG_EINVAL, "bad n = %lld", (long long)n);
   TPG_HIP(hipSetDevice(ctx->device));
-  tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 64), 0, nullptr, false, nullptr, 0};
+  tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 64), 0, nullptr, false, nullptr, 0, 0, 0};
   pw->ntp = pw->nst * (pw->nst + 1);
   {
     // units (I, jt), jt >= 2 I, in patch order: blocks of 16 column tiles, inside a block row after row.  Column
@@ -210,11 +212,11 @@ extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tp
     if (e != hipSuccess) { tpg_pairwise_free(pw); tpg_set_error("pairwise order table: %s", hipGetErrorString(e)); return TPG_EHIP; }
   }
   if (ext_buffer) {
-    if (!tpg_is_device_ptr(ext_buffer)) { delete pw; tpg_set_error("ext_buffer is not device memory"); return TPG_EINVAL; }
+    if (!tpg_is_device_ptr(ext_buffer)) { tpg_pairwise_free(pw); tpg_set_error("ext_buffer is not device memory"); return TPG_EINVAL; }
     pw->acc = (int32_t*)ext_buffer;
   } else {
     hipError_t e = tpg_pmalloc((void**)&pw->acc, tpg_pairwise_buffer_bytes(n));
-    if (e != hipSuccess) { delete pw; tpg_set_error("hipMalloc pairwise buffer: %s", hipGetErrorString(e)); return TPG_EHIP; }
+    if (e != hipSuccess) { tpg_pairwise_free(pw); tpg_set_error("hipMalloc pairwise buffer: %s", hipGetErrorString(e)); return TPG_EHIP; }
     pw->owns = true;
   }
   int rc = tpg_pairwise_zero(ctx, pw);
@@ -231,14 +233,48 @@ extern "C" void tpg_pairwise_free(tpg_pairwise* pw) {
 }
 
 extern "C" int tpg_pairwise_zero(tpg_ctx* ctx, tpg_pairwise* pw) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
   ProfScope ps(ctx, "pairwise_zero");
   TPG_HIP(hipMemsetAsync(pw->acc, 0, tpg_pairwise_buffer_bytes(pw->n), ctx->stream));
+  pw->loci = 0;
   return TPG_OK;
+}
+
+// Reference quirk Q1 (src/snp_as.cpp:57-63 with R/snp_allele_sharing.R:55-56): every block of the R
+// driver that is one column narrower than the widest adds +1 to EVERY element of the allele-sharing numerator.
+// The default (0) is the intended value; a caller who must reproduce a real R run bit for bit passes the number of
+// narrower blocks of that run (tpg_as_pad_quirk_blocks) and as_num / allele sharing / GRM come out as R's.
+extern "C" int tpg_pairwise_set_as_pad_quirk(tpg_pairwise* pw, int64_t narrow_blocks) {
+  TPG_REQUIRE(pw, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(narrow_blocks >= 0 && narrow_blocks < (1ll << 31), TPG_EINVAL, "bad block count %lld", (long long)narrow_blocks);
+  pw->as_pad_quirk = narrow_blocks;
+  return TPG_OK;
+}
+
+// blocks narrower than the widest when m loci are cut as the R drivers cut them: CutBySize(m, block.size)
+// (R/local_reimplementations.R:13-15) = bigparallelr::split_len(m, nb = ceiling(m / block.size)) (third-party,
+// recalled: upper_b = round(b m / nb), R's round-half-even)
+extern "C" int64_t tpg_as_pad_quirk_blocks(int64_t m, int64_t block_size) {
+  if (m <= 0 || block_size <= 0) return 0;
+  const int64_t nb = (m + block_size - 1) / block_size;
+  const double step = (double)m / (double)nb;
+  int64_t prev = 0, widest = 0;
+  std::vector<int64_t> size((size_t)nb);
+  for (int64_t b = 0; b < nb; b++) {
+    const int64_t up = (int64_t)rint((double)(b + 1) * step);
+    size[(size_t)b] = up - prev;
+    prev = up;
+    widest = std::max(widest, size[(size_t)b]);
+  }
+  int64_t narrow = 0;
+  for (int64_t b = 0; b < nb; b++) narrow += size[(size_t)b] < widest;
+  return narrow;
 }
 
 extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
                                        int64_t col_end) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && v, TPG_EINVAL, "null argument");
   TPG_REQUIRE(pw->n == v->n, TPG_EINVAL, "pairwise n = %lld but view n = %lld", (long long)pw->n, (long long)v->n);
   if (col_end < 0) col_end = v->m;
@@ -248,6 +284,12 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
   TPG_REQUIRE(col_begin % 128 == 0 && (col_end % 128 == 0 || col_end == v->m), TPG_EINVAL,
               "locus range must start on a multiple of 128 and end on one (or at m)");
   if (col_begin == col_end) return TPG_OK;
+  // int32 accumulators: every product is bounded by the number of loci accumulated (the epilogues form their sums
+  // in 64 bits), so the total must stay below 2^31
+  TPG_REQUIRE(pw->loci + (col_end - col_begin) <= TPG_PW_MAX_LOCI, TPG_EUNSUPPORTED,
+              "%lld loci accumulated + %lld more would overflow the int32 pair counts (limit %lld)", (long long)pw->loci,
+              (long long)(col_end - col_begin), (long long)TPG_PW_MAX_LOCI);
+  pw->loci += col_end - col_begin;
   const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
   const int64_t kgs = kg1 - kg0;
   // K split: make units * S fill the resident waves evenly, keep >= 8 K groups (1024 loci) per unit
@@ -278,39 +320,43 @@ struct PwCounts {
 #define TPG_NAN __longlong_as_double(0x7FF8000000000000ll)
 
 // mode: 0 raw counts (six optional outputs), 1 IBS proportion / adjusted counts (scale), 2 KING,
-// 3 allele sharing, 4 IBS + KING + allele sharing together
-__device__ __forceinline__ void tpg_pw_emit(const PwCounts c, int mode, double scale, int64_t idx, double* __restrict__ o0,
-                                            double* __restrict__ o1, double* __restrict__ o2, double* __restrict__ o3,
-                                            double* __restrict__ o4, double* __restrict__ o5) {
+// 3 allele sharing, 4 IBS + KING + allele sharing together.  Sums of products are formed in 64 bits (a single
+// product is bounded by the loci accumulated, < 2^31; V + D + H and 2 V are not).  quirk = reference quirk Q1: the
+// number of narrower blocks of the R driver, each of which adds 1 to every allele-sharing numerator
+// (src/snp_as.cpp:57-63); 0 unless the caller asked for the emulation.
+__device__ __forceinline__ void tpg_pw_emit(const PwCounts c, int mode, double scale, long long quirk, int64_t idx,
+                                            double* __restrict__ o0, double* __restrict__ o1, double* __restrict__ o2,
+                                            double* __restrict__ o3, double* __restrict__ o4, double* __restrict__ o5) {
+  const long long V = c.V, D = c.D, H = c.H, Aij = c.Aij, Aji = c.Aji;
   if (mode == 0) {
-    if (o0) o0[idx] = (double)(c.V + c.D + c.H);
-    if (o1) o1[idx] = (double)(2 * c.V);
-    if (o2) o2[idx] = (double)(c.D - c.V + c.Aij + c.Aji);
-    if (o3) o3[idx] = (double)c.Aij;
-    if (o4) o4[idx] = (double)c.D;
-    if (o5) o5[idx] = (double)c.V;
+    if (o0) o0[idx] = (double)(V + D + H);
+    if (o1) o1[idx] = (double)(2 * V);
+    if (o2) o2[idx] = (double)(D - V + Aij + Aji);
+    if (o3) o3[idx] = (double)Aij;
+    if (o4) o4[idx] = (double)(D + quirk);
+    if (o5) o5[idx] = (double)V;
   } else if (mode == 1) {
-    const double prop = (double)(c.V + c.D + c.H) / (double)(2 * c.V);  // R/snp_ibs.R:88-95
-    o0[idx] = scale == 1.0 ? prop : prop * scale;                        // :100
+    const double prop = (double)(V + D + H) / (double)(2 * V);  // R/snp_ibs.R:88-95
+    o0[idx] = scale == 1.0 ? prop : prop * scale;               // :100
   } else if (mode == 2) {
-    const double K = (double)(c.D - c.V + c.Aij + c.Aji), Ni = (double)c.Aij, Nj = (double)c.Aji;
+    const double K = (double)(D - V + Aij + Aji), Ni = (double)Aij, Nj = (double)Aji;
     const double mn = Ni < Nj ? Ni : Nj;
     o0[idx] = K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn;  // R/snp_king.R:86-89
   } else if (mode == 3) {
-    const double num = (double)c.D, den = (double)c.V;
-    o0[idx] = c.V == 0 ? TPG_NAN : 0.5 * (1 + num / den);  // R/snp_allele_sharing.R:79-80
+    const double num = (double)(D + quirk), den = (double)V;
+    o0[idx] = V == 0 ? TPG_NAN : 0.5 * (1 + num / den);  // R/snp_allele_sharing.R:79-80
   } else {
     // mode 4: IBS (o0, scale), KING (o1) and allele sharing (o2) from one fetch
     if (o0) {
-      const double prop = (double)(c.V + c.D + c.H) / (double)(2 * c.V);
+      const double prop = (double)(V + D + H) / (double)(2 * V);
       o0[idx] = scale == 1.0 ? prop : prop * scale;
     }
     if (o1) {
-      const double K = (double)(c.D - c.V + c.Aij + c.Aji), Ni = (double)c.Aij, Nj = (double)c.Aji;
+      const double K = (double)(D - V + Aij + Aji), Ni = (double)Aij, Nj = (double)Aji;
       const double mn = Ni < Nj ? Ni : Nj;
       o1[idx] = K / (2 * mn) + 0.5 - 0.25 * (Ni + Nj) / mn;
     }
-    if (o2) o2[idx] = c.V == 0 ? TPG_NAN : 0.5 * (1 + (double)c.D / (double)c.V);
+    if (o2) o2[idx] = V == 0 ? TPG_NAN : 0.5 * (1 + (double)(D + quirk) / (double)V);
   }
 }
 
@@ -320,7 +366,8 @@ __device__ __forceinline__ void tpg_pw_emit(const PwCounts c, int mode, double s
 // along the slab's column index -- so that every store instruction writes 32 contiguous doubles and no slab element
 // is fetched more than once.
 __global__ __launch_bounds__(256) void tpg_pairwise_epilogue_kernel(const int32_t* __restrict__ acc, int nst, int n,
-                                                                    int mode, double scale, double* __restrict__ o0,
+                                                                    int mode, double scale, long long quirk,
+                                                                    double* __restrict__ o0,
                                                                     double* __restrict__ o1, double* __restrict__ o2,
                                                                     double* __restrict__ o3, double* __restrict__ o4,
                                                                     double* __restrict__ o5) {
@@ -344,7 +391,7 @@ __global__ __launch_bounds__(256) void tpg_pairwise_epilogue_kernel(const int32_
       const int gi = 32 * ti + row, gj = 32 * tj + col;
       if (gi < n && gj < n) {
         const PwCounts c = {sp[0][row][col], sp[1][row][col], sp[2][row][col], sp[3][row][col], sp[4][row][col]};
-        tpg_pw_emit(c, mode, scale, gi + (int64_t)gj * n, o0, o1, o2, o3, o4, o5);
+        tpg_pw_emit(c, mode, scale, quirk, gi + (int64_t)gj * n, o0, o1, o2, o3, o4, o5);
       }
     }
     if (ti != tj) {  // mirrored: output row = 32 tj + col (contiguous), column = 32 ti + row
@@ -352,7 +399,7 @@ __global__ __launch_bounds__(256) void tpg_pairwise_epilogue_kernel(const int32_
       const int gi = 32 * ti + row, gj = 32 * tj + col;
       if (gi < n && gj < n) {
         const PwCounts c = {sp[0][row][col], sp[1][row][col], sp[2][row][col], sp[4][row][col], sp[3][row][col]};
-        tpg_pw_emit(c, mode, scale, gj + (int64_t)gi * n, o0, o1, o2, o3, o4, o5);
+        tpg_pw_emit(c, mode, scale, quirk, gj + (int64_t)gi * n, o0, o1, o2, o3, o4, o5);
       }
     }
   }
@@ -365,7 +412,8 @@ static int run_epilogue(tpg_ctx* ctx, const tpg_pairwise* pw, int mode, double s
     if (outs[k]) TPG_TRY(b[k].init(outs[k], bytes));
   const unsigned nt = (unsigned)ceil_div(pw->n, 32);
   TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(nt, nt), dim3(256), 0,
-             (const int32_t*)pw->acc, (int)pw->nst, (int)pw->n, mode, scale, b[0].dev<double>(), b[1].dev<double>(),
+             (const int32_t*)pw->acc, (int)pw->nst, (int)pw->n, mode, scale, (long long)pw->as_pad_quirk,
+             b[0].dev<double>(), b[1].dev<double>(),
              b[2].dev<double>(), b[3].dev<double>(), b[4].dev<double>(), b[5].dev<double>());
   TPG_CHECK_LAUNCH();
   for (int k = 0; k < 6; k++)
@@ -375,12 +423,14 @@ static int run_epilogue(tpg_ctx* ctx, const tpg_pairwise* pw, int mode, double s
 
 extern "C" int tpg_pairwise_counts(tpg_ctx* ctx, const tpg_pairwise* pw, double* ibs, double* ibs_valid,
                                    double* king_num, double* n_Aa_i, double* as_num, double* as_den) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
   double* outs[6] = {ibs, ibs_valid, king_num, n_Aa_i, as_num, as_den};
   return run_epilogue(ctx, pw, 0, 1.0, outs);
 }
 
 extern "C" int tpg_pairwise_ibs(tpg_ctx* ctx, const tpg_pairwise* pw, int type, int64_t m, double* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(type == TPG_IBS_PROPORTION || type == TPG_IBS_ADJUSTED_COUNTS, TPG_EINVAL, "bad IBS type %d", type);
   double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -388,12 +438,14 @@ extern "C" int tpg_pairwise_ibs(tpg_ctx* ctx, const tpg_pairwise* pw, int type, 
 }
 
 extern "C" int tpg_pairwise_king(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
   double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
   return run_epilogue(ctx, pw, 2, 1.0, outs);
 }
 
 extern "C" int tpg_pairwise_allele_sharing(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
   double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
   return run_epilogue(ctx, pw, 3, 1.0, outs);
@@ -404,6 +456,7 @@ static int grm_from_as(tpg_ctx* ctx, int n, double* d_M);
 // IBS, KING, allele sharing and GRM in one pass over the accumulators (any output may be NULL)
 extern "C" int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int ibs_type, int64_t m, double* ibs,
                                       double* king, double* allele_sharing, double* grm) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
   TPG_REQUIRE(ibs_type == TPG_IBS_PROPORTION || ibs_type == TPG_IBS_ADJUSTED_COUNTS, TPG_EINVAL, "bad IBS type");
   const int n = (int)pw->n;
@@ -418,7 +471,7 @@ extern "C" int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int 
   const unsigned nt = (unsigned)ceil_div(pw->n, 32);
   TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(nt, nt), dim3(256), 0,
              (const int32_t*)pw->acc, (int)pw->nst, n, 4, ibs_type == TPG_IBS_PROPORTION ? 1.0 : (double)m,
-             bi.dev<double>(), bk.dev<double>(), as_dst, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+             (long long)pw->as_pad_quirk, bi.dev<double>(), bk.dev<double>(), as_dst, (double*)nullptr, (double*)nullptr, (double*)nullptr);
   TPG_CHECK_LAUNCH();
   if (grm) {
     if (allele_sharing) TPG_HIP(hipMemcpyAsync(bg.dev<double>(), ba.dev<double>(), bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -492,6 +545,7 @@ static int grm_from_as(tpg_ctx* ctx, int n, double* d_M) {
 }
 
 extern "C" int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
   return tpg_pairwise_epilogues(ctx, pw, TPG_IBS_PROPORTION, 0, nullptr, nullptr, nullptr, out);
 }
@@ -537,6 +591,7 @@ __global__ void tpg_block_combine_kernel(const double* __restrict__ colsum, cons
 
 extern "C" int tpg_block_means(tpg_ctx* ctx, const double* A, int64_t n, const int32_t* groupIds0, int ngroups,
                                int skip_diag, double* mean, double* count) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && A && groupIds0 && mean, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && ngroups > 0, TPG_EINVAL, "bad n = %lld or ngroups = %d", (long long)n, ngroups);
   std::vector<int32_t> goff((size_t)ngroups + 1, 0), perm((size_t)n);
@@ -584,51 +639,140 @@ extern "C" int tpg_block_means(tpg_ctx* ctx, const double* A, int64_t n, const i
 }
 
 // ---------------------------------------------------------------------------
-// literal per-block mirrors of increment_{ibs,king,as}_counts
+// Literal per-block mirrors of increment_{ibs,king,as}_counts, RESIDENT: the R drivers call these once per locus
+// block (38 times at 5 000 x 1 000 000 with the default block size) on the same FBM and the same pair of N x N
+// accumulators.  The FBM is uploaded on first sight (cache keyed by its host address and shape) and every (K, K2)
+// pair gets device accumulators that live across the calls, so a block costs one pack + one MFMA pass and moves
+// nothing over PCIe; the sums are added to the caller's matrices when it asks (tpg_increment_flush -- one D2H of
+// two N x N matrices per analysis instead of per block).
+struct ResidentFbm {
+  const uint8_t* host;
+  int64_t nrow, ncol;
+  tpg_fbm* fbm;
+};
+struct ResidentAcc {
+  int which;  // 0 IBS, 1 KING, 2 allele sharing
+  double *A, *B;
+  std::vector<int32_t> rows;
+  tpg_pairwise* pw;
+};
+struct Resident {
+  std::vector<ResidentFbm> fbms;
+  std::vector<ResidentAcc> accs;
+};
+
+static Resident* resident_of(tpg_ctx* ctx) {
+  if (!ctx->resident) ctx->resident = new Resident();
+  return (Resident*)ctx->resident;
+}
+
+void tpg_resident_release(tpg_ctx* ctx) {  // called by tpg_ctx_destroy and tpg_resident_drop
+  Resident* r = (Resident*)ctx->resident;
+  if (!r) return;
+  for (auto& f : r->fbms) tpg_fbm_free(f.fbm);
+  for (auto& a : r->accs) tpg_pairwise_free(a.pw);
+  delete r;
+  ctx->resident = nullptr;
+}
+
 static int increment_common(tpg_ctx* ctx, int which, double* A, double* B, const uint8_t* fbm_bytes, int64_t nrow,
                             int64_t ncol, const int32_t* rowInd1, int64_t n, const int32_t* colInd1, int64_t m) {
   TPG_REQUIRE(ctx && A && B && fbm_bytes && rowInd1 && colInd1, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty block");
-  // gather the block's columns (each is nrow contiguous bytes of the mmapped FBM)
-  std::vector<uint8_t> cols((size_t)nrow * (size_t)m);
-  for (int64_t j = 0; j < m; j++) {
-    TPG_REQUIRE(colInd1[j] >= 1 && colInd1[j] <= ncol, TPG_EINVAL, "colInd[%lld] = %d out of range", (long long)j,
-                colInd1[j]);
-    memcpy(cols.data() + (size_t)j * (size_t)nrow, fbm_bytes + (size_t)(colInd1[j] - 1) * (size_t)nrow, (size_t)nrow);
-  }
+  Resident* r = resident_of(ctx);
   tpg_fbm* f = nullptr;
-  tpg_view* v = nullptr;
-  tpg_pairwise* pw = nullptr;
-  int rc = tpg_fbm_from_host(ctx, cols.data(), nrow, m, &f);
-  if (rc == TPG_OK) rc = tpg_view_create(ctx, f, rowInd1, n, nullptr, m, nullptr, &v);
-  if (rc == TPG_OK) rc = tpg_pairwise_create(ctx, n, nullptr, &pw);
-  if (rc == TPG_OK) rc = tpg_pairwise_accumulate(ctx, pw, v, 0, -1);
-  std::vector<double> a((size_t)n * (size_t)n), b((size_t)n * (size_t)n);
-  if (rc == TPG_OK) {
-    if (which == 0) rc = tpg_pairwise_counts(ctx, pw, a.data(), b.data(), nullptr, nullptr, nullptr, nullptr);
-    else if (which == 1) rc = tpg_pairwise_counts(ctx, pw, nullptr, nullptr, a.data(), b.data(), nullptr, nullptr);
-    else rc = tpg_pairwise_counts(ctx, pw, nullptr, nullptr, nullptr, nullptr, a.data(), b.data());
+  for (auto& e : r->fbms)
+    if (e.host == fbm_bytes && e.nrow == nrow && e.ncol == ncol) f = e.fbm;
+  if (!f) {
+    TPG_TRY(tpg_fbm_from_host(ctx, fbm_bytes, nrow, ncol, &f));
+    r->fbms.push_back(ResidentFbm{fbm_bytes, nrow, ncol, f});
   }
-  if (rc == TPG_OK)
-    for (size_t k = 0; k < a.size(); k++) { A[k] += a[k]; B[k] += b[k]; }
-  tpg_pairwise_free(pw);
-  tpg_view_free(v);
-  tpg_fbm_free(f);
+  ResidentAcc* acc = nullptr;
+  for (auto& e : r->accs)
+    if (e.A == A && e.B == B) acc = &e;
+  if (acc) {
+    TPG_REQUIRE(acc->which == which, TPG_EINVAL, "these accumulators are pending for another increment_* function; flush first");
+    TPG_REQUIRE((int64_t)acc->rows.size() == n && memcmp(acc->rows.data(), rowInd1, sizeof(int32_t) * (size_t)n) == 0,
+                TPG_EINVAL, "rowInd changed between blocks that accumulate into the same matrices; flush first");
+  } else {
+    tpg_pairwise* pw = nullptr;
+    TPG_TRY(tpg_pairwise_create(ctx, n, nullptr, &pw));
+    r->accs.push_back(ResidentAcc{which, A, B, std::vector<int32_t>(rowInd1, rowInd1 + n), pw});
+    acc = &r->accs.back();
+  }
+  tpg_view* v = nullptr;
+  TPG_TRY(tpg_view_create(ctx, f, rowInd1, n, colInd1, m, nullptr /* raw bytes, src/snp_ibs.cpp:47-54 */, &v));
+  int rc = tpg_pairwise_accumulate(ctx, acc->pw, v, 0, -1);
+  tpg_view_free(v);  // stream-ordered: the block returns to this context's pool
   return rc;
+}
+
+extern "C" int tpg_increment_flush(tpg_ctx* ctx) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
+  Resident* r = (Resident*)ctx->resident;
+  if (!r) return TPG_OK;
+  int rc = TPG_OK;
+  for (auto& a : r->accs) {
+    if (rc == TPG_OK) {
+      const size_t nn = (size_t)a.pw->n * (size_t)a.pw->n;
+      std::vector<double> ta(nn), tb(nn);
+      if (a.which == 0) rc = tpg_pairwise_counts(ctx, a.pw, ta.data(), tb.data(), nullptr, nullptr, nullptr, nullptr);
+      else if (a.which == 1) rc = tpg_pairwise_counts(ctx, a.pw, nullptr, nullptr, ta.data(), tb.data(), nullptr, nullptr);
+      else rc = tpg_pairwise_counts(ctx, a.pw, nullptr, nullptr, nullptr, nullptr, ta.data(), tb.data());
+      if (rc == TPG_OK) {  // K += sums: exact (integer-valued doubles), the order of the blocks does not matter
+        const int NT = 8;
+        std::thread th[NT];
+        for (int t = 0; t < NT; t++)
+          th[t] = std::thread([&, t]() {
+            for (size_t k = nn * t / NT; k < nn * (t + 1) / NT; k++) { a.A[k] += ta[k]; a.B[k] += tb[k]; }
+          });
+        for (int t = 0; t < NT; t++) th[t].join();
+      }
+    }
+    tpg_pairwise_free(a.pw);
+  }
+  r->accs.clear();
+  return rc;
+}
+
+extern "C" int tpg_resident_drop(tpg_ctx* ctx) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
+  Resident* r = (Resident*)ctx->resident;
+  TPG_REQUIRE(!r || r->accs.empty(), TPG_EINVAL, "increments are pending: call tpg_increment_flush first");
+  tpg_resident_release(ctx);
+  return TPG_OK;
+}
+
+// quirk Q1 for the literal mirror: the shim calls this for a block whose scratch matrices are one column wider than
+// the block (src/snp_as.cpp:57-63) when the emulation is wanted
+extern "C" int tpg_increment_as_note_narrow_block(tpg_ctx* ctx, const double* K) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && K, TPG_EINVAL, "null argument");
+  Resident* r = (Resident*)ctx->resident;
+  if (r)
+    for (auto& a : r->accs)
+      if (a.A == K && a.which == 2) { a.pw->as_pad_quirk += 1; return TPG_OK; }
+  tpg_set_error("no pending allele-sharing increment for this matrix");
+  return TPG_EINVAL;
 }
 
 extern "C" int tpg_increment_ibs_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes, int64_t nrow,
                                         int64_t ncol, const int32_t* rowInd1, int64_t n, const int32_t* colInd1,
                                         int64_t m) {
+  TpgEnter _enter(ctx);
   return increment_common(ctx, 0, K, K2, fbm_bytes, nrow, ncol, rowInd1, n, colInd1, m);
 }
 extern "C" int tpg_increment_king_numerator(tpg_ctx* ctx, double* K, double* N_Aa_i, const uint8_t* fbm_bytes,
                                             int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
                                             const int32_t* colInd1, int64_t m) {
+  TpgEnter _enter(ctx);
   return increment_common(ctx, 1, K, N_Aa_i, fbm_bytes, nrow, ncol, rowInd1, n, colInd1, m);
 }
 extern "C" int tpg_increment_as_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes, int64_t nrow,
                                        int64_t ncol, const int32_t* rowInd1, int64_t n, const int32_t* colInd1,
                                        int64_t m) {
+  TpgEnter _enter(ctx);
   return increment_common(ctx, 2, K, K2, fbm_bytes, nrow, ncol, rowInd1, n, colInd1, m);
 }

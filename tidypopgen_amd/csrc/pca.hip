@@ -104,6 +104,7 @@ static int pca_counts_center_scale(tpg_ctx* ctx, const tpg_view* v, int32_t* d_c
 }
 
 extern "C" int tpg_pca_center_scale(tpg_ctx* ctx, const tpg_view* v, double* center, double* scale) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && center && scale, TPG_EINVAL, "null argument");
   OutBuf oc, os;
   TPG_TRY(oc.init(center, sizeof(double) * (size_t)v->m));
@@ -137,6 +138,7 @@ static int frobenius_from_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t*
 
 extern "C" int tpg_square_frobenius(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale,
                                     double* out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && center && scale && out, TPG_EINVAL, "null argument");
   InBuf ic, is;
   TPG_TRY(ic.init(ctx, center, sizeof(double) * (size_t)v->m));
@@ -300,6 +302,7 @@ __global__ void tpg_inv_kernel(const double* __restrict__ x, int64_t n, double* 
 
 extern "C" int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx* ctx, const tpg_view* v, const double* center,
                                              const double* scale, const double* V, int K, double* XV, double* rss) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && center && scale && V && XV && rss, TPG_EINVAL, "null argument");
   TPG_REQUIRE(K > 0, TPG_EINVAL, "V has no columns");
   InBuf ic, is, iv;
@@ -825,6 +828,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
 }
 
 extern "C" int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale, double* K) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && center && scale && K, TPG_EINVAL, "null argument");
   InBuf ic, is;
   TPG_TRY(ic.init(ctx, center, sizeof(double) * (size_t)v->m));
@@ -1494,6 +1498,7 @@ static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_
 // ---------------------------------------------------------------------------
 extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,
                                    double* center, double* scale, double* square_frobenius) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && d && u && vload && center && scale, TPG_EINVAL, "null argument");
   TPG_REQUIRE(k >= 1 && k <= 52 && k <= v->n && k <= v->m, TPG_EINVAL, "k = %d out of range", k);
   const int64_t n = v->n, m = v->m;
@@ -1741,6 +1746,7 @@ static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_
 }
 
 extern "C" int tpg_sym_eig_topk(tpg_ctx* ctx, const double* K, int64_t n, int k, double* lambda, double* U) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && K && lambda && U, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && k >= 1 && k <= 52 && k <= n, TPG_EINVAL, "bad n = %lld / k = %d", (long long)n, k);
   InBuf ik;
@@ -1757,6 +1763,7 @@ extern "C" int tpg_sym_eig_topk(tpg_ctx* ctx, const double* K, int64_t n, int k,
 
 extern "C" int tpg_pca_loadings(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale,
                                 const double* U, const double* d, int k, double* vload) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && center && scale && U && d && vload, TPG_EINVAL, "null argument");
   TPG_REQUIRE(k >= 1, TPG_EINVAL, "k must be positive");
   const int64_t n = v->n, m = v->m;

@@ -17,11 +17,34 @@
 static thread_local char g_err[1024] = "";
 
 // ---------------------------------------------------------------------------
+// device-memory pools, one per context (see common.h)
+struct Pool {
+  std::multimap<size_t, void*> free_blocks;  // rounded size -> block
+  size_t cached_bytes = 0;
+  int device = 0;
+  bool alive = true;  // false once its context is destroyed: blocks still out are hipFree'd when they come back
+};
+struct LiveRec {
+  size_t rb;
+  int pool;
+};
 static std::mutex g_pool_mu;
-static std::multimap<size_t, void*> g_pool_free;       // rounded size -> block
-static std::unordered_map<void*, size_t> g_pool_live;  // block -> rounded size
-static size_t g_pool_cached_bytes = 0;
+static std::unordered_map<int, Pool> g_pools;        // pool id -> pool (id 0: calls made outside any context)
+static std::unordered_map<void*, LiveRec> g_live;    // block handed out -> its size and home pool
+static int g_next_pool_id = 1;
 static const size_t POOL_MAX_CACHED = (size_t)48 << 30;
+static thread_local tpg_ctx* g_cur_ctx = nullptr;
+
+TpgEnter::TpgEnter(tpg_ctx* ctx) : prev(g_cur_ctx) {
+  if (!ctx) return;
+  g_cur_ctx = ctx;
+  (void)hipSetDevice(ctx->device);  // HIP's current device is per host thread
+}
+TpgEnter::~TpgEnter() {
+  if (prev && prev != g_cur_ctx) (void)hipSetDevice(prev->device);
+  g_cur_ctx = prev;
+}
+tpg_ctx* tpg_current_ctx() { return g_cur_ctx; }
 
 static size_t pool_round(size_t b) {
   if (b < 256) return 256;
@@ -31,26 +54,28 @@ static size_t pool_round(size_t b) {
 
 hipError_t tpg_pmalloc(void** p, size_t bytes) {
   const size_t rb = pool_round(bytes);
+  const int pid = g_cur_ctx ? g_cur_ctx->pool_id : 0;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool_free.find(rb);
-    if (it != g_pool_free.end()) {
+    Pool& pool = g_pools[pid];
+    auto it = pool.free_blocks.find(rb);
+    if (it != pool.free_blocks.end()) {
       *p = it->second;
-      g_pool_free.erase(it);
-      g_pool_cached_bytes -= rb;
-      g_pool_live[*p] = rb;
+      pool.free_blocks.erase(it);
+      pool.cached_bytes -= rb;
+      g_live[*p] = LiveRec{rb, pid};
       return hipSuccess;
     }
   }
   hipError_t e = hipMalloc(p, rb);
-  if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+  if (e != hipSuccess) {  // out of memory: drop this pool's cache and retry once
     (void)hipGetLastError();
-    tpg_pool_trim();
+    tpg_pool_trim(pid);
     e = hipMalloc(p, rb);
     if (e != hipSuccess) return e;
   }
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  g_pool_live[*p] = rb;
+  g_live[*p] = LiveRec{rb, pid};
   return hipSuccess;
 }
 
@@ -58,13 +83,14 @@ void tpg_pfree(void* p) {
   if (!p) return;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool_live.find(p);
-    if (it != g_pool_live.end()) {
-      const size_t rb = it->second;
-      g_pool_live.erase(it);
-      if (g_pool_cached_bytes + rb <= POOL_MAX_CACHED) {
-        g_pool_free.emplace(rb, p);
-        g_pool_cached_bytes += rb;
+    auto it = g_live.find(p);
+    if (it != g_live.end()) {
+      const LiveRec rec = it->second;
+      g_live.erase(it);
+      auto pit = g_pools.find(rec.pool);
+      if (pit != g_pools.end() && pit->second.alive && pit->second.cached_bytes + rec.rb <= POOL_MAX_CACHED) {
+        pit->second.free_blocks.emplace(rec.rb, p);
+        pit->second.cached_bytes += rec.rb;
         return;
       }
     }
@@ -72,15 +98,31 @@ void tpg_pfree(void* p) {
   (void)hipFree(p);
 }
 
-void tpg_pool_trim(void) {
+void tpg_pool_trim(int pool_id) {
   std::vector<void*> blocks;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (auto& kv : g_pool_free) blocks.push_back(kv.second);
-    g_pool_free.clear();
-    g_pool_cached_bytes = 0;
+    auto pit = g_pools.find(pool_id);
+    if (pit == g_pools.end()) return;
+    for (auto& kv : pit->second.free_blocks) blocks.push_back(kv.second);
+    pit->second.free_blocks.clear();
+    pit->second.cached_bytes = 0;
   }
   for (void* b : blocks) (void)hipFree(b);
+}
+
+static int pool_open(int device) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  const int id = g_next_pool_id++;
+  g_pools[id].device = device;
+  return id;
+}
+
+static void pool_close(int pool_id) {  // cached blocks are released now, blocks still out when they are freed
+  tpg_pool_trim(pool_id);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto pit = g_pools.find(pool_id);
+  if (pit != g_pools.end()) pit->second.alive = false;
 }
 
 void tpg_set_error(const char* fmt, ...) {
@@ -130,18 +172,21 @@ int tpg_prof_resolve(tpg_ctx* ctx) {
 }
 
 extern "C" int tpg_prof_enable(tpg_ctx* ctx, int on) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
   TPG_TRY(tpg_prof_resolve(ctx));
   ctx->prof = on != 0;
   return TPG_OK;
 }
 extern "C" int tpg_prof_reset(tpg_ctx* ctx) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
   TPG_TRY(tpg_prof_resolve(ctx));
   ctx->prof_acc.clear();
   return TPG_OK;
 }
 extern "C" int tpg_prof_get(tpg_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && prefix, TPG_EINVAL, "null argument");
   TPG_TRY(tpg_prof_resolve(ctx));
   double ms = 0;
@@ -154,6 +199,7 @@ extern "C" int tpg_prof_get(tpg_ctx* ctx, const char* prefix, double* total_ms, 
   return TPG_OK;
 }
 extern "C" int tpg_prof_dump(tpg_ctx* ctx, char* buf, size_t cap) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && buf && cap > 0, TPG_EINVAL, "null argument");
   TPG_TRY(tpg_prof_resolve(ctx));
   size_t off = 0;
@@ -184,29 +230,36 @@ extern "C" int tpg_ctx_create(int device, tpg_ctx** out) {
   tpg_ctx* c = new tpg_ctx();
   c->device = device;
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  TPG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (es != hipSuccess) { delete c; tpg_set_error("hipStreamCreate: %s", hipGetErrorString(es)); return TPG_EHIP; }
   c->own_stream = true;
+  c->pool_id = pool_open(device);
   *out = c;
   return TPG_OK;
 }
 
 extern "C" void tpg_ctx_destroy(tpg_ctx* ctx) {
   if (!ctx) return;
-  (void)tpg_prof_resolve(ctx);
-  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  tpg_pool_trim();
-  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  {
+    TpgEnter _enter(ctx);
+    (void)tpg_prof_resolve(ctx);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    tpg_resident_release(ctx);
+    pool_close(ctx->pool_id);  // only this context's blocks
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  }
+  if (g_cur_ctx == ctx) g_cur_ctx = nullptr;
   delete ctx;
 }
 
 extern "C" int tpg_ctx_set_stream(tpg_ctx* ctx, void* hip_stream) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
   TPG_TRY(tpg_prof_resolve(ctx));
-  if (ctx->own_stream && ctx->stream) {
-    TPG_HIP(hipStreamSynchronize(ctx->stream));
-    TPG_HIP(hipStreamDestroy(ctx->stream));
-  }
+  // the pool's blocks are ordered on the old stream: drain it, whoever owns it, before work moves to the new one
+  if (ctx->stream) TPG_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->stream) TPG_HIP(hipStreamDestroy(ctx->stream));
   if (hip_stream) {
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
@@ -218,12 +271,14 @@ extern "C" int tpg_ctx_set_stream(tpg_ctx* ctx, void* hip_stream) {
 }
 
 extern "C" int tpg_ctx_sync(tpg_ctx* ctx) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
   TPG_HIP(hipStreamSynchronize(ctx->stream));
   return TPG_OK;
 }
 
 extern "C" int tpg_dev_alloc(tpg_ctx* ctx, size_t bytes, void** out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
   TPG_HIP(hipSetDevice(ctx->device));
   TPG_HIP(tpg_pmalloc(out, bytes > 0 ? bytes : 16));
@@ -233,6 +288,7 @@ extern "C" void tpg_dev_free(void* p) {
   if (p) tpg_pfree(p);
 }
 extern "C" int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && host_dst && dev_src, TPG_EINVAL, "null argument");
   TPG_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   TPG_HIP(hipStreamSynchronize(ctx->stream));
@@ -240,6 +296,7 @@ extern "C" int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src
 }
 
 extern "C" int tpg_dev_from_host(tpg_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && dev_dst && host_src, TPG_EINVAL, "null argument");
   TPG_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   TPG_HIP(hipStreamSynchronize(ctx->stream));
@@ -313,12 +370,20 @@ hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes, bo
   std::lock_guard<std::mutex> lk(mu);
   static uint8_t* slot[UPLOAD_SLOTS] = {nullptr};
   static hipEvent_t done[UPLOAD_SLOTS];
-  if (!slot[0]) {
+  static bool ready = false;
+  if (!ready) {
     for (int b = 0; b < UPLOAD_SLOTS; b++) {
       hipError_t e = hipHostMalloc((void**)&slot[b], UPLOAD_CHUNK, hipHostMallocDefault);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
-      if (e != hipSuccess) { slot[0] = nullptr; return e; }
+      if (e == hipSuccess) {
+        e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
+        if (e != hipSuccess) { (void)hipHostFree(slot[b]); slot[b] = nullptr; }
+      }
+      if (e != hipSuccess) {  // give back what was created so far; the next call starts over
+        for (int c = 0; c < b; c++) { (void)hipHostFree(slot[c]); (void)hipEventDestroy(done[c]); slot[c] = nullptr; }
+        return e;
+      }
     }
+    ready = true;
   }
   const uint8_t* s = (const uint8_t*)src;
   uint8_t* d = (uint8_t*)dst;
@@ -348,6 +413,7 @@ hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes, bo
 }
 
 extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, tpg_fbm** out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && bytes && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(nrow > 0 && ncol > 0, TPG_EINVAL, "empty FBM (%lld x %lld)", (long long)nrow, (long long)ncol);
   TPG_HIP(hipSetDevice(ctx->device));
@@ -362,6 +428,7 @@ extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nro
 }
 
 extern "C" int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int64_t ncol, tpg_fbm** out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && path && out, TPG_EINVAL, "null argument");
   int fd = open(path, O_RDONLY);
   TPG_REQUIRE(fd >= 0, TPG_EINVAL, "cannot open backing file %s", path);
@@ -384,6 +451,7 @@ extern "C" int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int
 
 extern "C" int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0, int npop,
                              uint32_t miss_thresh, int imputed_bytes, tpg_fbm** out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(nrow > 0 && ncol > 0 && npop > 0 && npop <= 1024, TPG_EINVAL, "bad synth shape");
   TPG_HIP(hipSetDevice(ctx->device));
@@ -398,6 +466,7 @@ extern "C" int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t 
 }
 
 extern "C" int tpg_fbm_from_bed_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t n, int64_t m, tpg_fbm** out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && bytes && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty .bed (%lld x %lld)", (long long)n, (long long)m);
   TPG_HIP(hipSetDevice(ctx->device));
@@ -414,6 +483,7 @@ extern "C" int tpg_fbm_from_bed_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t
 }
 
 extern "C" int tpg_fbm_open_bed(tpg_ctx* ctx, const char* path, int64_t n, int64_t m, tpg_fbm** out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && path && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty .bed (%lld x %lld)", (long long)n, (long long)m);
   int fd = open(path, O_RDONLY);
@@ -443,6 +513,7 @@ extern "C" int tpg_fbm_open_bed(tpg_ctx* ctx, const char* path, int64_t n, int64
 }
 
 extern "C" int tpg_fbm_to_host(tpg_ctx* ctx, const tpg_fbm* fbm, uint8_t* bytes) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && fbm && bytes, TPG_EINVAL, "null argument");
   TPG_REQUIRE(fbm->bed_bpl == 0, TPG_EUNSUPPORTED, "a .bed store has no FBM bytes; unpack a view instead");
   TPG_HIP(hipMemcpyAsync(bytes, fbm->d_bytes, (size_t)fbm->nrow * (size_t)fbm->ncol, hipMemcpyDeviceToHost, ctx->stream));
@@ -459,6 +530,7 @@ extern "C" void tpg_fbm_free(tpg_fbm* fbm) {
 // ---------------------------------------------------------------------------
 extern "C" int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n,
                                const int32_t* colInd1, int64_t m, const double* code256, tpg_view** out) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && fbm && out, TPG_EINVAL, "null argument");
   if (!rowInd1) n = fbm->nrow;
   if (!colInd1) m = fbm->ncol;
@@ -545,6 +617,7 @@ extern "C" int64_t tpg_view_n(const tpg_view* v) { return v ? v->n : 0; }
 extern "C" int64_t tpg_view_m(const tpg_view* v) { return v ? v->m : 0; }
 
 extern "C" int tpg_view_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* codes) {
+  TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && codes, TPG_EINVAL, "null argument");
   // codes from T, cross-checked against L on the device: both layouts must agree
   OutBuf o;
