@@ -224,6 +224,14 @@ int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int ibs_type, i
 int tpg_block_means(tpg_ctx* ctx, const double* A, int64_t n, const int32_t* groupIds0, int ngroups, int skip_diag,
                     double* mean, double* count);
 
+/* filter_high_relatedness (R/filter_high_relatedness.R:26-145) on an n x n relatedness matrix (host
+ * or device memory, e.g. the KING matrix tpg_pairwise_king left in HBM): keep[i] = 1 for the individuals that pass,
+ * in the ORIGINAL order (the reference's third list element); new_order0 (may be NULL) = the order of decreasing mean
+ * relatedness the loop walks in (0-based), so that the ids to keep, in the reference's order, are
+ * new_order0[k] for the k with keep[new_order0[k]] = 1.  An NA among the compared relatednesses is an error, as in R. */
+int tpg_filter_high_relatedness(tpg_ctx* ctx, const double* matrix, int64_t n, double kings_threshold, uint8_t* keep,
+                                int32_t* new_order0);
+
 /* Literal per-block mirrors of the three increment_* entry points
  * (src/snp_ibs.cpp:22-74, src/snp_king.cpp:21-74, src/snp_as.cpp:22-67); the scratch matrices of the reference
  * are not needed.  fbm_bytes is the host (mmapped) FBM.  RESIDENT and DEFERRED: the FBM is uploaded the first time
@@ -257,9 +265,14 @@ int tpg_pca_center_scale(tpg_ctx* ctx, const tpg_view* v, double* center, double
  * (call site R/gt_pca_partialSVD.R:82-89) */
 int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale, double* K);
 /* full partial SVD: d[k], u n x k, v m x k, center[m], scale[m]; square_frobenius may be NULL
- * (R/square_frobenius.R:19-35) */
+ * (R/square_frobenius.R:19-35).  k <= 52 (the eigen solver works on a block of 2k + 12 <= 64 vectors). */
 int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,
                         double* center, double* scale, double* square_frobenius);
+/* gt_pca_randomSVD (R/gt_pca_randomSVD.R:77-135; k <= 52 as above): the same truncated SVD accepted at the
+ * relative residual `tol` of the reference's big_randomSVD / RSpectra path (default there 1e-4):
+ * |K u_j - d_j^2 u_j| <= tol * d_1^2 for every returned pair. */
+int tpg_pca_random_svd(tpg_ctx* ctx, const tpg_view* v, int k, double tol, double* d, double* u, double* vload,
+                       double* center, double* scale, double* square_frobenius);
 /* The pieces of tpg_pca_partial_svd for SNP-block shards on several GPUs: every rank computes the Gram
  * matrix of its loci (tpg_pca_gram, additive over loci), the N x N partials are summed (one all-reduce),
  * then tpg_sym_eig_topk gives lambda[k] (descending) and U (n x k) of the summed matrix and
@@ -273,6 +286,9 @@ int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx* ctx, const tpg_view* v, const double*
                                   const double* scale, const double* V, int K, double* XV, double* rss);
 int tpg_square_frobenius(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale,
                          double* out);
+/* out (n x K) [i, k] = sum of Tab[j, k] (m x K) over the loci j at which individual i is typed: the masked sums
+ * behind predict(project_method = "least_squares") (R/predict_gt_pca.R:221-228) */
+int tpg_fbm256_valid_prod(tpg_ctx* ctx, const tpg_view* v, const double* Tab, int K, double* out);
 
 #ifdef __cplusplus
 }

@@ -214,6 +214,17 @@ def gt_ind_hetero(fbm, rowInd=None, colInd=None, code256=CODE_012):
     return out
 
 
+def indiv_het_obs(fbm, rowInd=None, colInd=None, as_counts=False, code256=CODE_012):
+    """R/indiv_het_obs.R:42-75 on top of gt_ind_hetero: het_n / (ncol(X) - na_n) -- ncol(X) is the column count of
+    the whole FBM (:69), as the reference writes it -- or the (n, 2) count matrix {het_n, na_n}."""
+    fbm_, r, c = _view(fbm, rowInd, colInd)
+    cnt = gt_ind_hetero(fbm_, r, c, code256)
+    if as_counts:
+        return cnt.T.copy()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return cnt[0] / (fbm_.shape[1] - cnt[1])
+
+
 def gt_pi_diploid(fbm, rowInd=None, colInd=None, code256=CODE_012):
     """src/gt_pi_diploid.cpp:7-38"""
     fbm, r, c = _view(fbm, rowInd, colInd)
@@ -682,6 +693,104 @@ def blas_increment_as(K, K2, fbm, r, c):
     dos = (sub.astype(np.float64) - 1.0) * na
     K += dos @ dos.T
     K2 += na @ na.T
+
+
+# --------------------------------------------------------------------------
+# relatedness filter and PCA projection (host-side consumers of the N x N / loadings outputs)
+
+def r_mean(x) -> float:
+    """R's mean() of a double vector after na.rm (src/main/summary.c, recalled): long double sum / n, then one
+    refinement pass sum(x - mean) / n, rounded to double at the end."""
+    x = np.asarray(x, dtype=np.float64)
+    x = x[~np.isnan(x)]
+    n = len(x)
+    if n == 0:
+        return float("nan")
+    xl = x.astype(np.longdouble)
+    s = np.longdouble(0)
+    for v in xl:          # sequential long double accumulation, as the C loop
+        s += v
+    s /= n
+    t = np.longdouble(0)
+    for v in xl:
+        t += v - s
+    return float(s + t / n)
+
+
+def filter_high_relatedness(matrix, kings_threshold):
+    """R/filter_high_relatedness.R:26-145, statement by statement (names are 1..n as strings when the matrix has
+    none).  -> (passed_filter ids in the new order, to_remove ids, logical keep vector in the original order).
+    Quadratic work per comparison, as the reference: small matrices only."""
+    M = np.array(matrix, dtype=np.float64, copy=True)
+    var_num = M.shape[0]
+    var_names = np.arange(1, var_num + 1)
+    if var_num == 1:                                                       # :46-52
+        return var_names.copy(), np.zeros(0, dtype=int), np.ones(1, dtype=bool)
+    M = np.abs(M)                                                          # :55
+    tmp = M.copy()
+    np.fill_diagonal(tmp, np.nan)                                          # :69
+    col_means = np.array([r_mean(tmp[:, j]) for j in range(var_num)])      # :72-73 apply(tmp, 2, mean, na.rm)
+    # order(decreasing = TRUE): stable, NaN last
+    key = np.where(np.isnan(col_means), -np.inf, col_means)
+    order = np.argsort(-key, kind="stable")
+    M = M[np.ix_(order, order)]                                            # :76
+    new_order = order                                                      # :79 (0-based here)
+    col_to_delete = np.zeros(var_num, dtype=bool)                          # :83
+    M2 = M.copy()
+    np.fill_diagonal(M2, np.nan)                                           # :85
+    for i in range(var_num - 1):                                           # :90
+        with np.errstate(invalid="ignore"):
+            if not np.any(M2[~np.isnan(M2)] > kings_threshold):            # :91-96
+                break
+        if col_to_delete[i]:
+            continue
+        for j in range(i + 1, var_num):                                    # :100
+            if not col_to_delete[i] and not col_to_delete[j]:
+                if np.isnan(M[i, j]):
+                    raise ValueError("missing value where TRUE/FALSE needed")  # R: if (NA)
+                if M[i, j] > kings_threshold:                              # :102
+                    mn1 = r_mean(M2[i, :])                                 # :103
+                    mn2 = r_mean(np.delete(M2, j, axis=0).ravel(order="F"))  # :104 mean(matrix2[-j, ]): ALL other rows
+                    if mn1 > mn2:                                          # :119
+                        col_to_delete[i] = True
+                        M2[i, :] = np.nan
+                        M2[:, i] = np.nan
+                    else:
+                        col_to_delete[j] = True
+                        M2[j, :] = np.nan
+                        M2[:, j] = np.nan
+    passed = var_names[new_order][~col_to_delete]                          # :138
+    keep = np.isin(var_names, passed)
+    return passed, var_names[~keep], keep
+
+
+def predict_gt_pca(pca, fbm=None, ind_row=None, ind_col=None, project_method="none", lsq_pcs=(1, 2),
+                   code256=CODE_IMPUTE_PRED):
+    """R/predict_gt_pca.R:73-236 (numeric part; the loci-name matching is done by the caller through ind_col).
+    pca = dict(d, u, v, center, scale).  "OADP" needs bigsnpr's OADP_proj, which is not in the reference checkout."""
+    if fbm is None:
+        return pca["u"] * pca["d"]                                         # :103 sweep(u, 2, d, "*")
+    fbm, r, c = _view(fbm, ind_row, ind_col)
+    if project_method in ("none", "simple"):
+        # "none": bigstatsr::big_prodMat on the imputed code (third-party, recalled: (X - center) / scale %*% V);
+        # "simple": fbm256_prod_and_rowSumsSq, missing -> 0 (:157-170, src/fbm_prod_and_rowSumSq.cpp:30-44)
+        XV, _ = fbm256_prod_and_rowSumsSq(fbm, r, c, pca["center"], pca["scale"], pca["v"], code256)
+        return XV
+    if project_method == "least_squares":                                  # :187-232
+        lsq = np.asarray(lsq_pcs)
+        if len(lsq) == 0 or np.any(lsq < 1) or np.any(lsq > pca["v"].shape[1]) or np.any(lsq != lsq.astype(int)):
+            raise ValueError("lsq_pcs should be a vector of valid component indices")
+        if len(set(lsq.tolist())) != len(lsq):
+            raise ValueError("lsq_pcs should not contain duplicate values")
+        g = np.asarray(code256)[fbm[np.ix_(r - 1, c - 1)]]
+        out = np.zeros((len(r), len(lsq)))
+        for i in range(len(r)):
+            gs = (g[i] - pca["center"]) / pca["scale"]
+            ok = ~np.isnan(gs)
+            vs = pca["v"][np.ix_(np.where(ok)[0], lsq - 1)]
+            out[i] = np.linalg.solve(vs.T @ vs, vs.T @ gs[ok])             # solve(crossprod(v_sub), crossprod(v_sub, g))
+        return out
+    raise ValueError("project_method 'OADP' calls bigsnpr's OADP_proj (third-party, not in the reference checkout)")
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,472 @@
+/*
+ * tpg_rshim.c -- the R side of the drop-in boundary: `.Call` entry points with the reference's own symbol names and
+ * arities (src/RcppExports.cpp:348-371 of the reference; R side R/RcppExports.R:4-91), forwarding to the C ABI of
+ * libtpg_hip.so (include/tpg.h).  Plain C against R's C API only: no Rcpp, no bigstatsr headers -- everything the
+ * reference's C++ takes from `BM` through bigstatsr's accessors is taken here from the FBM's plain R fields
+ * (`backingfile`, `nrow`, `ncol`, `code256`) and the backing file itself.
+ *
+ * STATUS: written against R's documented C API, NOT compiled in the build image (R is not installed there; see
+ * INTEGRATION.md).  The C ABI underneath is exercised through ctypes by tests/ on the GPU.
+ *
+ * Where it goes: tidypopgen/src/tpg_rshim.c, replacing the `[[Rcpp::export]]` bodies of the functions listed in
+ * tpg_rshim_entries[] (INTEGRATION.md section 2 says how the registration tables are merged).  R code is unchanged,
+ * except that the three pairwise drivers gain ONE line after their block loop (`tpg_flush()`, see
+ * _tidypopgen_tpg_flush below); without that line set TPG_RSHIM_EAGER=1 and every block call flushes itself.
+ *
+ * Threading: R calls these from its main thread only; the shim holds one tpg_ctx per R session.
+ */
+#define _POSIX_C_SOURCE 200809L /* strdup, mmap */
+#include <fcntl.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+
+#include "tpg.h"
+
+/* ---- session state -------------------------------------------------------------------------------------------- */
+
+static tpg_ctx* g_ctx = NULL;
+
+static tpg_ctx* ctx(void) {
+  if (!g_ctx) {
+    const char* dev = getenv("TPG_DEVICE");
+    if (tpg_ctx_create(dev ? atoi(dev) : 0, &g_ctx) != TPG_OK) Rf_error("tidypopgen (GPU): %s", tpg_last_error());
+  }
+  return g_ctx;
+}
+
+/* every failure of the library becomes an R error, as BEGIN_RCPP / END_RCPP turn C++ exceptions into R errors */
+#define TPG_R(call)                                                         \
+  do {                                                                      \
+    if ((call) != TPG_OK) Rf_error("tidypopgen (GPU): %s", tpg_last_error()); \
+  } while (0)
+
+static SEXP field(SEXP env, const char* name) { /* a field or an active binding of the reference-class object */
+  SEXP v = Rf_eval(Rf_install(name), env);
+  if (v == R_UnboundValue) Rf_error("FBM object has no field '%s'", name);
+  return v;
+}
+
+static int64_t field_i64(SEXP env, const char* name) {
+  SEXP v = field(env, name);
+  return TYPEOF(v) == REALSXP ? (int64_t)REAL(v)[0] : (int64_t)Rf_asInteger(v);
+}
+
+static const char* field_path(SEXP env, const char* name) {
+  SEXP v = field(env, name);
+  if (TYPEOF(v) != STRSXP || XLENGTH(v) < 1) Rf_error("FBM field '%s' is not a file name", name);
+  return R_ExpandFileName(CHAR(STRING_ELT(v, 0)));
+}
+
+/* A backing file mapped into this process, and (for genotype FBMs) its copy in HBM.  Keyed by path: the 5 GB upload
+ * happens once per data set and session, not once per call or per block (SURVEY.md 8b "Ownership"). */
+typedef struct {
+  char* path;
+  void* map;
+  size_t bytes;
+  int writable;
+  int64_t nrow, ncol;
+  tpg_fbm* dev; /* NULL for the double N x N accumulators */
+} mapped_file;
+
+static mapped_file* g_files = NULL;
+static int g_nfiles = 0;
+
+static mapped_file* map_file(const char* path, size_t bytes, int writable, int64_t nrow, int64_t ncol) {
+  for (int k = 0; k < g_nfiles; k++)
+    if (strcmp(g_files[k].path, path) == 0 && g_files[k].bytes == bytes && g_files[k].writable == writable)
+      return &g_files[k];
+  int fd = open(path, writable ? O_RDWR : O_RDONLY);
+  if (fd < 0) Rf_error("cannot open backing file '%s'", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) {
+    close(fd);
+    Rf_error("backing file '%s' is smaller than the FBM it should hold", path);
+  }
+  /* MAP_SHARED: the same pages bigstatsr's own mapping of the file reads and writes */
+  void* p = mmap(NULL, bytes, writable ? (PROT_READ | PROT_WRITE) : PROT_READ, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) Rf_error("mmap of '%s' failed", path);
+  mapped_file* nf = (mapped_file*)realloc(g_files, sizeof(mapped_file) * (size_t)(g_nfiles + 1));
+  if (!nf) {
+    munmap(p, bytes);
+    Rf_error("out of memory");
+  }
+  g_files = nf;
+  mapped_file* f = &g_files[g_nfiles++];
+  f->path = strdup(path);
+  f->map = p;
+  f->bytes = bytes;
+  f->writable = writable;
+  f->nrow = nrow;
+  f->ncol = ncol;
+  f->dev = NULL;
+  return f;
+}
+
+/* the genotype FBM.code256 behind `BM`: host mapping (for the increment_* mirrors) and HBM copy (everything else) */
+static mapped_file* genotype_fbm(SEXP BM) {
+  const int64_t nrow = field_i64(BM, "nrow"), ncol = field_i64(BM, "ncol");
+  return map_file(field_path(BM, "backingfile"), (size_t)nrow * (size_t)ncol, 0, nrow, ncol);
+}
+
+static tpg_fbm* genotype_fbm_dev(SEXP BM) {
+  mapped_file* f = genotype_fbm(BM);
+  if (!f->dev) TPG_R(tpg_fbm_from_host(ctx(), (const uint8_t*)f->map, f->nrow, f->ncol, &f->dev));
+  return f->dev;
+}
+
+static const double* code256_of(SEXP BM) {
+  SEXP c = field(BM, "code256");
+  if (TYPEOF(c) != REALSXP || XLENGTH(c) != 256) Rf_error("BM$code256 is not a double[256]");
+  return REAL(c);
+}
+
+/* a double FBM (the N x N accumulators the R drivers allocate with bigstatsr::FBM(n, n, init = 0)) */
+static double* double_fbm(SEXP K, int64_t n) {
+  const int64_t nrow = field_i64(K, "nrow"), ncol = field_i64(K, "ncol");
+  if (nrow != n || ncol != n) Rf_error("accumulator FBM is %lld x %lld, expected %lld x %lld", (long long)nrow,
+                                       (long long)ncol, (long long)n, (long long)n);
+  return (double*)map_file(field_path(K, "backingfile"), sizeof(double) * (size_t)n * (size_t)n, 1, n, n)->map;
+}
+
+static tpg_view* view_of(SEXP BM, SEXP rowInd, SEXP colInd, int raw_bytes) {
+  if (TYPEOF(rowInd) != INTSXP || TYPEOF(colInd) != INTSXP) Rf_error("rowInd / colInd must be integer vectors");
+  tpg_view* v = NULL;
+  TPG_R(tpg_view_create(ctx(), genotype_fbm_dev(BM), INTEGER(rowInd), (int64_t)XLENGTH(rowInd), INTEGER(colInd),
+                        (int64_t)XLENGTH(colInd), raw_bytes ? NULL : code256_of(BM), &v));
+  return v;
+}
+
+static SEXP named_list(int n, const char** names, SEXP* values) {
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, n));
+  SEXP nm = PROTECT(Rf_allocVector(STRSXP, n));
+  for (int k = 0; k < n; k++) {
+    SET_VECTOR_ELT(out, k, values[k]);
+    SET_STRING_ELT(nm, k, Rf_mkChar(names[k]));
+  }
+  Rf_setAttrib(out, R_NamesSymbol, nm);
+  UNPROTECT(2);
+  return out;
+}
+
+static void set_colnames2(SEXP mat, const char* a, const char* b) {
+  SEXP cn = PROTECT(Rf_allocVector(STRSXP, 2));
+  SET_STRING_ELT(cn, 0, Rf_mkChar(a));
+  SET_STRING_ELT(cn, 1, Rf_mkChar(b));
+  SEXP dn = PROTECT(Rf_allocVector(VECSXP, 2));
+  SET_VECTOR_ELT(dn, 0, R_NilValue);
+  SET_VECTOR_ELT(dn, 1, cn);
+  Rf_setAttrib(mat, R_DimNamesSymbol, dn);
+  UNPROTECT(2);
+}
+
+/* views are released even when the library call fails (Rf_error does not return) */
+#define TPG_R_VIEW(v, call)          \
+  do {                               \
+    int _rc = (call);                \
+    tpg_view_free(v);                \
+    if (_rc != TPG_OK) Rf_error("tidypopgen (GPU): %s", tpg_last_error()); \
+  } while (0)
+
+/* ---- per-locus sweeps --------------------------------------------------------------------------------------- */
+
+/* alt_freq_dip_pseudo_cpp(BM, rowInd, colInd, ploidy, ncores, as_counts)   src/alt_freq_dip_pseudo_cpp.cpp:8-58 */
+SEXP _tidypopgen_alt_freq_dip_pseudo_cpp(SEXP BM, SEXP rowInd, SEXP colInd, SEXP ploidy, SEXP ncores, SEXP as_counts) {
+  (void)ncores;
+  const int counts = Rf_asLogical(as_counts);
+  SEXP pl = PROTECT(Rf_coerceVector(ploidy, REALSXP));
+  tpg_view* v = view_of(BM, rowInd, colInd, 0);
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)XLENGTH(colInd), 2));
+  TPG_R_VIEW(v, tpg_alt_freq_dip_pseudo(ctx(), v, REAL(pl), counts, REAL(out)));
+  set_colnames2(out, counts ? "n_alt" : "freq", "n_valid"); /* :44, :56 */
+  UNPROTECT(2);
+  return out;
+}
+
+/* grouped_alt_freq_dip_pseudo_cpp(BM, rowInd, colInd, groupIds, ngroups, ploidy, ncores, as_counts)
+   src/grouped_alt_freq_dip_pseudo_cpp.cpp:8-58 -> m x 2G */
+SEXP _tidypopgen_grouped_alt_freq_dip_pseudo_cpp(SEXP BM, SEXP rowInd, SEXP colInd, SEXP groupIds, SEXP ngroups,
+                                                 SEXP ploidy, SEXP ncores, SEXP as_counts) {
+  (void)ncores;
+  const int G = Rf_asInteger(ngroups);
+  SEXP pl = PROTECT(Rf_coerceVector(ploidy, REALSXP));
+  SEXP gid = PROTECT(Rf_coerceVector(groupIds, INTSXP));
+  tpg_view* v = view_of(BM, rowInd, colInd, 0);
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)XLENGTH(colInd), 2 * G));
+  TPG_R_VIEW(v, tpg_grouped_alt_freq_dip_pseudo(ctx(), v, INTEGER(gid), G, REAL(pl), Rf_asLogical(as_counts), REAL(out)));
+  UNPROTECT(3);
+  return out;
+}
+
+/* grouped_missingness_cpp(BM, rowInd, colInd, groupIds, ngroups, ncores)   src/grouped_missingness_cpp.cpp:8-33 */
+SEXP _tidypopgen_grouped_missingness_cpp(SEXP BM, SEXP rowInd, SEXP colInd, SEXP groupIds, SEXP ngroups, SEXP ncores) {
+  (void)ncores;
+  const int G = Rf_asInteger(ngroups);
+  SEXP gid = PROTECT(Rf_coerceVector(groupIds, INTSXP));
+  tpg_view* v = view_of(BM, rowInd, colInd, 0);
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)XLENGTH(colInd), G));
+  TPG_R_VIEW(v, tpg_grouped_missingness(ctx(), v, INTEGER(gid), G, REAL(out)));
+  UNPROTECT(2);
+  return out;
+}
+
+/* grouped_summaries_dip_pseudo_cpp(BM, rowInd, colInd, groupIds, ngroups, ploidy, ncores)
+   src/grouped_summaries_dip_pseudo_cpp.cpp:11-63 -> list(freq_alt, freq_ref, n, het_obs), each m x G */
+SEXP _tidypopgen_grouped_summaries_dip_pseudo_cpp(SEXP BM, SEXP rowInd, SEXP colInd, SEXP groupIds, SEXP ngroups,
+                                                  SEXP ploidy, SEXP ncores) {
+  (void)ncores;
+  const int G = Rf_asInteger(ngroups);
+  const int m = (int)XLENGTH(colInd);
+  SEXP pl = PROTECT(Rf_coerceVector(ploidy, REALSXP));
+  SEXP gid = PROTECT(Rf_coerceVector(groupIds, INTSXP));
+  tpg_view* v = view_of(BM, rowInd, colInd, 0);
+  SEXP mats[4];
+  for (int k = 0; k < 4; k++) mats[k] = PROTECT(Rf_allocMatrix(REALSXP, m, G));
+  TPG_R_VIEW(v, tpg_grouped_summaries_dip_pseudo(ctx(), v, INTEGER(gid), G, REAL(pl), REAL(mats[0]), REAL(mats[1]),
+                                                 REAL(mats[2]), REAL(mats[3])));
+  static const char* names[4] = {"freq_alt", "freq_ref", "n", "het_obs"}; /* :59-62 */
+  SEXP out = named_list(4, names, mats);
+  UNPROTECT(6);
+  return out;
+}
+
+/* gt_ind_hetero(BM, rowInd, colInd, ncores)   src/gt_ind_hetero.cpp:11-42 -> integer 2 x n {n_het; n_na} */
+SEXP _tidypopgen_gt_ind_hetero(SEXP BM, SEXP rowInd, SEXP colInd, SEXP ncores) {
+  (void)ncores;
+  tpg_view* v = view_of(BM, rowInd, colInd, 0);
+  SEXP out = PROTECT(Rf_allocMatrix(INTSXP, 2, (int)XLENGTH(rowInd)));
+  TPG_R_VIEW(v, tpg_gt_ind_hetero(ctx(), v, INTEGER(out)));
+  UNPROTECT(1);
+  return out;
+}
+
+/* gt_pi_diploid(BM, rowInd, colInd, ncores)   src/gt_pi_diploid.cpp:7-38 */
+SEXP _tidypopgen_gt_pi_diploid(SEXP BM, SEXP rowInd, SEXP colInd, SEXP ncores) {
+  (void)ncores;
+  tpg_view* v = view_of(BM, rowInd, colInd, 0);
+  SEXP out = PROTECT(Rf_allocVector(REALSXP, XLENGTH(colInd)));
+  TPG_R_VIEW(v, tpg_gt_pi_diploid(ctx(), v, REAL(out)));
+  UNPROTECT(1);
+  return out;
+}
+
+/* gt_grouped_pi_diploid(BM, rowInd, colInd, groupIds, ngroups, ncores)   src/gt_grouped_pi_diploid.cpp:7-42 */
+SEXP _tidypopgen_gt_grouped_pi_diploid(SEXP BM, SEXP rowInd, SEXP colInd, SEXP groupIds, SEXP ngroups, SEXP ncores) {
+  (void)ncores;
+  const int G = Rf_asInteger(ngroups);
+  const int m = (int)XLENGTH(colInd);
+  SEXP gid = PROTECT(Rf_coerceVector(groupIds, INTSXP));
+  tpg_view* v = view_of(BM, rowInd, colInd, 0);
+  SEXP mats[2];
+  for (int k = 0; k < 2; k++) mats[k] = PROTECT(Rf_allocMatrix(REALSXP, m, G));
+  TPG_R_VIEW(v, tpg_gt_grouped_pi_diploid(ctx(), v, INTEGER(gid), G, REAL(mats[0]), REAL(mats[1])));
+  static const char* names[2] = {"pi", "n"};
+  SEXP out = named_list(2, names, mats);
+  UNPROTECT(3);
+  return out;
+}
+
+/* ---- pairwise population Fst loops --------------------------------------------------------------------------- */
+
+/* common body of the three loop functions.  pairwise_combn arrives as a 2 x P double matrix (NumericMatrix). */
+static SEXP fst_loop(int method, SEXP pairwise_combn, SEXP n, SEXP freq_alt, SEXP freq_ref, SEXP het_obs, SEXP by_locus,
+                     SEXP return_num_dem) {
+  SEXP dim = Rf_getAttrib(n, R_DimSymbol);
+  if (TYPEOF(n) != REALSXP || Rf_length(dim) != 2) Rf_error("n must be a numeric matrix");
+  const int m = INTEGER(dim)[0], G = INTEGER(dim)[1];
+  SEXP pc = PROTECT(Rf_coerceVector(pairwise_combn, INTSXP));
+  const int P = (int)(XLENGTH(pc) / 2);
+  int byl = Rf_asLogical(by_locus);
+  const int rnd = Rf_asLogical(return_num_dem);
+  const int want_a = byl || rnd;
+  SEXP tot = PROTECT(Rf_allocVector(REALSXP, P));
+  SEXP a = PROTECT(Rf_allocMatrix(REALSXP, want_a ? m : 0, want_a ? P : 0)); /* empty 0 x 0 when not asked, :17-21 */
+  SEXP b = PROTECT(Rf_allocMatrix(REALSXP, rnd ? m : 0, rnd ? P : 0));
+  TPG_R(tpg_pairwise_fst_loop(ctx(), method, INTEGER(pc), P, m, G, REAL(n), REAL(freq_alt),
+                              freq_ref == R_NilValue ? NULL : REAL(freq_ref), het_obs == R_NilValue ? NULL : REAL(het_obs),
+                              byl, rnd, REAL(tot), want_a ? REAL(a) : NULL, rnd ? REAL(b) : NULL));
+  SEXP out;
+  if (!rnd) { /* :54-60 */
+    static const char* names[2] = {"fst_locus", "fst_tot"};
+    SEXP vals[2] = {a, tot};
+    out = named_list(2, names, vals);
+  } else {
+    static const char* names[2] = {"Fst_by_locus_num", "Fst_by_locus_den"};
+    SEXP vals[2] = {a, b};
+    out = named_list(2, names, vals);
+  }
+  UNPROTECT(4);
+  return out;
+}
+
+/* pairwise_fst_hudson_loop(pairwise_combn, n, freq_alt, freq_ref, by_locus, return_num_dem)
+   src/pairwise_fst_hudson_loop.cpp:5-63 */
+SEXP _tidypopgen_pairwise_fst_hudson_loop(SEXP pairwise_combn, SEXP n, SEXP freq_alt, SEXP freq_ref, SEXP by_locus,
+                                          SEXP return_num_dem) {
+  return fst_loop(TPG_FST_HUDSON, pairwise_combn, n, freq_alt, freq_ref, R_NilValue, by_locus, return_num_dem);
+}
+
+/* pairwise_fst_wc84_loop(pairwise_combn, n, freq_alt, het_obs, by_locus, return_num_dem)
+   src/pairwise_fst_wc84_loop.cpp:5-121 */
+SEXP _tidypopgen_pairwise_fst_wc84_loop(SEXP pairwise_combn, SEXP n, SEXP freq_alt, SEXP het_obs, SEXP by_locus,
+                                        SEXP return_num_dem) {
+  return fst_loop(TPG_FST_WC84, pairwise_combn, n, freq_alt, R_NilValue, het_obs, by_locus, return_num_dem);
+}
+
+/* pairwise_fst_nei87_loop(pairwise_combn, n, het_obs, freq_alt, freq_ref, by_locus, return_num_dem)
+   src/pairwise_fst_nei87_loop.cpp:5-115 */
+SEXP _tidypopgen_pairwise_fst_nei87_loop(SEXP pairwise_combn, SEXP n, SEXP het_obs, SEXP freq_alt, SEXP freq_ref,
+                                         SEXP by_locus, SEXP return_num_dem) {
+  return fst_loop(TPG_FST_NEI87, pairwise_combn, n, freq_alt, freq_ref, het_obs, by_locus, return_num_dem);
+}
+
+/* ---- pairwise individual matrices: the per-block increment functions ----------------------------------------------
+ * The R drivers (R/snp_ibs.R:59-82, R/snp_king.R:51-77, R/snp_allele_sharing.R:49-70) call these once per locus block
+ * with the same FBM and the same two N x N double FBMs.  The library keeps the genotype FBM and the accumulators in
+ * HBM across the calls; the sums reach k / k2 when _tidypopgen_tpg_flush is called (or at every call under
+ * TPG_RSHIM_EAGER=1).  The scratch matrices the reference fills are not touched. */
+
+static int eager(void) {
+  const char* e = getenv("TPG_RSHIM_EAGER");
+  return e && e[0] == '1';
+}
+
+/* increment_ibs_counts(k, k2, genotype0, genotype1, genotype2, BM, rowInd, colInd)   src/snp_ibs.cpp:22-74 */
+SEXP _tidypopgen_increment_ibs_counts(SEXP k, SEXP k2, SEXP g0, SEXP g1, SEXP g2, SEXP BM, SEXP rowInd, SEXP colInd) {
+  (void)g0; (void)g1; (void)g2;
+  mapped_file* f = genotype_fbm(BM);
+  const int64_t n = (int64_t)XLENGTH(rowInd);
+  TPG_R(tpg_increment_ibs_counts(ctx(), double_fbm(k, n), double_fbm(k2, n), (const uint8_t*)f->map, f->nrow, f->ncol,
+                                 INTEGER(rowInd), n, INTEGER(colInd), (int64_t)XLENGTH(colInd)));
+  if (eager()) TPG_R(tpg_increment_flush(ctx()));
+  return R_NilValue;
+}
+
+/* increment_king_numerator(k, n_Aa_i, genotype0, genotype1, genotype2, genotype_valid, BM, rowInd, colInd)
+   src/snp_king.cpp:21-74 */
+SEXP _tidypopgen_increment_king_numerator(SEXP k, SEXP n_Aa_i, SEXP g0, SEXP g1, SEXP g2, SEXP gv, SEXP BM, SEXP rowInd,
+                                          SEXP colInd) {
+  (void)g0; (void)g1; (void)g2; (void)gv;
+  mapped_file* f = genotype_fbm(BM);
+  const int64_t n = (int64_t)XLENGTH(rowInd);
+  TPG_R(tpg_increment_king_numerator(ctx(), double_fbm(k, n), double_fbm(n_Aa_i, n), (const uint8_t*)f->map, f->nrow,
+                                     f->ncol, INTEGER(rowInd), n, INTEGER(colInd), (int64_t)XLENGTH(colInd)));
+  if (eager()) TPG_R(tpg_increment_flush(ctx()));
+  return R_NilValue;
+}
+
+/* increment_as_counts(k, k2, na_mat, dos_mat, BM, rowInd, colInd)   src/snp_as.cpp:22-67
+ * Quirk Q1: the reference adds +1 to every numerator for a block one column narrower than the scratch
+ * matrices.  Off by default (the intended value, what the reference's own test asserts); TPG_EMULATE_AS_PAD_QUIRK=1
+ * reproduces the reference binary bit for bit. */
+SEXP _tidypopgen_increment_as_counts(SEXP k, SEXP k2, SEXP na_mat, SEXP dos_mat, SEXP BM, SEXP rowInd, SEXP colInd) {
+  (void)na_mat;
+  mapped_file* f = genotype_fbm(BM);
+  const int64_t n = (int64_t)XLENGTH(rowInd), m = (int64_t)XLENGTH(colInd);
+  double* K = double_fbm(k, n);
+  TPG_R(tpg_increment_as_counts(ctx(), K, double_fbm(k2, n), (const uint8_t*)f->map, f->nrow, f->ncol, INTEGER(rowInd),
+                                n, INTEGER(colInd), m));
+  const char* q = getenv("TPG_EMULATE_AS_PAD_QUIRK");
+  if (q && q[0] == '1') {
+    SEXP dim = Rf_getAttrib(dos_mat, R_DimSymbol);
+    if (Rf_length(dim) == 2 && (int64_t)INTEGER(dim)[1] == m + 1) TPG_R(tpg_increment_as_note_narrow_block(ctx(), K));
+  }
+  if (eager()) TPG_R(tpg_increment_flush(ctx()));
+  return R_NilValue;
+}
+
+/* tpg_flush(): the one line the three pairwise drivers gain after their block loop -- writes the sums held in HBM
+ * into the k / k2 FBMs (one download of two N x N matrices per analysis).  Not a reference symbol. */
+SEXP _tidypopgen_tpg_flush(void) {
+  if (g_ctx) TPG_R(tpg_increment_flush(g_ctx));
+  return R_NilValue;
+}
+
+/* tpg_release(): drop the HBM copies and mappings (e.g. after the FBM was modified, or to free the GPU) */
+SEXP _tidypopgen_tpg_release(void) {
+  if (g_ctx) {
+    TPG_R(tpg_increment_flush(g_ctx));
+    TPG_R(tpg_resident_drop(g_ctx));
+  }
+  for (int k = 0; k < g_nfiles; k++) {
+    if (g_files[k].dev) tpg_fbm_free(g_files[k].dev);
+    munmap(g_files[k].map, g_files[k].bytes);
+    free(g_files[k].path);
+  }
+  free(g_files);
+  g_files = NULL;
+  g_nfiles = 0;
+  return R_NilValue;
+}
+
+/* ---- PCA projection -------------------------------------------------------------------------------------------- */
+
+/* fbm256_prod_and_rowSumsSq(BM, ind_row, ind_col, center, scale, V)   src/fbm_prod_and_rowSumSq.cpp:10-47
+   -> list(XV n x K, rowSumsSq n), unnamed as in the reference (:46) */
+SEXP _tidypopgen_fbm256_prod_and_rowSumsSq(SEXP BM, SEXP ind_row, SEXP ind_col, SEXP center, SEXP scale, SEXP V) {
+  SEXP dim = Rf_getAttrib(V, R_DimSymbol);
+  if (TYPEOF(V) != REALSXP || Rf_length(dim) != 2) Rf_error("V must be a numeric matrix");
+  const int K = INTEGER(dim)[1];
+  if ((R_xlen_t)INTEGER(dim)[0] != XLENGTH(ind_col)) Rf_error("Incompatibility between dimensions."); /* myassert_size, :23 */
+  SEXP ce = PROTECT(Rf_coerceVector(center, REALSXP));
+  SEXP sc = PROTECT(Rf_coerceVector(scale, REALSXP));
+  tpg_view* v = view_of(BM, ind_row, ind_col, 0);
+  SEXP XV = PROTECT(Rf_allocMatrix(REALSXP, (int)XLENGTH(ind_row), K));
+  SEXP rss = PROTECT(Rf_allocVector(REALSXP, XLENGTH(ind_row)));
+  TPG_R_VIEW(v, tpg_fbm256_prod_and_rowSumsSq(ctx(), v, REAL(ce), REAL(sc), REAL(V), K, REAL(XV), REAL(rss)));
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 2));
+  SET_VECTOR_ELT(out, 0, XV);
+  SET_VECTOR_ELT(out, 1, rss);
+  UNPROTECT(5);
+  return out;
+}
+
+/* ---- registration ------------------------------------------------------------------------------------------------
+ * Same names and arities as the reference's table (src/RcppExports.cpp:348-371).  These rows replace the rows of the
+ * same name there; the other rows of that table (compute_np_mn, the HWE functions, the VCF / packedancestry readers,
+ * write_to_FBM) keep pointing at the reference's own C++. */
+const R_CallMethodDef tpg_rshim_entries[] = {
+    {"_tidypopgen_alt_freq_dip_pseudo_cpp", (DL_FUNC)&_tidypopgen_alt_freq_dip_pseudo_cpp, 6},
+    {"_tidypopgen_fbm256_prod_and_rowSumsSq", (DL_FUNC)&_tidypopgen_fbm256_prod_and_rowSumsSq, 6},
+    {"_tidypopgen_grouped_alt_freq_dip_pseudo_cpp", (DL_FUNC)&_tidypopgen_grouped_alt_freq_dip_pseudo_cpp, 8},
+    {"_tidypopgen_grouped_missingness_cpp", (DL_FUNC)&_tidypopgen_grouped_missingness_cpp, 6},
+    {"_tidypopgen_grouped_summaries_dip_pseudo_cpp", (DL_FUNC)&_tidypopgen_grouped_summaries_dip_pseudo_cpp, 7},
+    {"_tidypopgen_gt_grouped_pi_diploid", (DL_FUNC)&_tidypopgen_gt_grouped_pi_diploid, 6},
+    {"_tidypopgen_gt_ind_hetero", (DL_FUNC)&_tidypopgen_gt_ind_hetero, 4},
+    {"_tidypopgen_gt_pi_diploid", (DL_FUNC)&_tidypopgen_gt_pi_diploid, 4},
+    {"_tidypopgen_pairwise_fst_hudson_loop", (DL_FUNC)&_tidypopgen_pairwise_fst_hudson_loop, 6},
+    {"_tidypopgen_pairwise_fst_nei87_loop", (DL_FUNC)&_tidypopgen_pairwise_fst_nei87_loop, 7},
+    {"_tidypopgen_pairwise_fst_wc84_loop", (DL_FUNC)&_tidypopgen_pairwise_fst_wc84_loop, 6},
+    {"_tidypopgen_increment_as_counts", (DL_FUNC)&_tidypopgen_increment_as_counts, 7},
+    {"_tidypopgen_increment_ibs_counts", (DL_FUNC)&_tidypopgen_increment_ibs_counts, 8},
+    {"_tidypopgen_increment_king_numerator", (DL_FUNC)&_tidypopgen_increment_king_numerator, 9},
+    /* additions (not in the reference): */
+    {"_tidypopgen_tpg_flush", (DL_FUNC)&_tidypopgen_tpg_flush, 0},
+    {"_tidypopgen_tpg_release", (DL_FUNC)&_tidypopgen_tpg_release, 0},
+    {NULL, NULL, 0}};
+
+#ifdef TPG_RSHIM_STANDALONE
+/* The shim as a package of its own (useDynLib(tpgshim, .registration = TRUE)): used to try the GPU path beside an
+ * unmodified tidypopgen by assigning these functions over tidypopgen's internal wrappers. */
+void R_init_tpgshim(DllInfo* dll) {
+  R_registerRoutines(dll, NULL, tpg_rshim_entries, NULL, NULL);
+  R_useDynamicSymbols(dll, FALSE);
+}
+#endif
+
+void R_unload_tpgshim(DllInfo* dll) {
+  (void)dll;
+  _tidypopgen_tpg_release();
+  if (g_ctx) {
+    tpg_ctx_destroy(g_ctx);
+    g_ctx = NULL;
+  }
+}

@@ -724,3 +724,106 @@ def test_pop_basic_stats(tpg, n, m, G):
         tpg.pop_fis(X, None, None, gid, G, method="Nei87", allele_sharing_mat=np.ones((n, n)))
     with pytest.raises(ValueError):
         tpg.pop_fis(X, None, None, gid, G, method="WG17", by_locus=True)
+
+
+# ---------------------------------------------------------------- SURVEY.md 8f(3), 8f(4)
+def test_filter_high_relatedness(tpg):
+    # reference case (tests/testthat/test_filter_high_relatedness.R): families, KING, threshold 0.2; re-filtering keeps all
+    fam = fx.families_fbm()
+    X = tpg.FBM.from_numpy(fam)
+    king = tpg.snp_king(X)
+    res = tpg.filter_high_relatedness(king, 0.2)
+    o_passed, o_removed, o_keep = orc.filter_high_relatedness(king, 0.2)
+    assert list(res[0]) == [str(k) for k in o_passed] and list(res[1]) == [str(k) for k in o_removed]
+    assert np.array_equal(res[2], o_keep) and res[2].sum() == 10
+    sub = king[np.ix_(res[2], res[2])]
+    assert tpg.filter_high_relatedness(sub, 0.2)[2].all()
+    assert tpg.filter_high_relatedness(np.array([[0.5]]), 0.2)[2].all()
+    # the matrix straight out of HBM (no host copy of the KING matrix in between)
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, 12)
+    pw.accumulate(v)
+    d_king = X.ctx.dev_alloc(8 * 144)
+    tpg._lib.check(tpg._lib.lib.tpg_pairwise_king(X.ctx.h, pw.h, d_king))
+    res_d = tpg.filter_high_relatedness(d_king, 0.2, ids=[f"ind{k}" for k in range(12)])
+    X.ctx.dev_free(d_king)
+    assert np.array_equal(res_d[2], o_keep) and list(res_d[1]) == [f"ind{k - 1}" for k in o_removed]
+    # random symmetric matrices with many pairs over the threshold, duplicates (exact ties of the two means) and signs
+    rng = np.random.default_rng(5)
+    for n, thr in ((25, 0.3), (40, 0.15), (33, 0.05)):
+        A = rng.random((n, n)) * 0.5 - 0.1
+        A = (A + A.T) / 2
+        A[3] = A[7]; A[:, 3] = A[:, 7]          # two identical individuals
+        np.fill_diagonal(A, 0.5)
+        t = tpg.filter_high_relatedness(A, thr)
+        o = orc.filter_high_relatedness(A, thr)
+        assert np.array_equal(t[2], o[2]) and list(t[0]) == [str(k) for k in o[0]], (n, thr)
+    # an NA among the compared coefficients stops, as `if (NA)` does in R
+    B = A.copy()
+    B[0, 1] = B[1, 0] = np.nan
+    B[2, 5] = B[5, 2] = 0.49
+    with pytest.raises(tpg._lib.TpgError):
+        tpg.filter_high_relatedness(B * np.where(np.isnan(B), 1, 1), 0.01)
+
+
+def test_predict_gt_pca_projections(tpg):
+    # R/predict_gt_pca.R:73-236: no new data, "none", "simple", "least_squares" against the oracle's restatement
+    n, m, k = 150, 1200, 6
+    fbm = orc.synth_fbm(41, n, m, npop=4, miss=0.0)
+    keep = np.where((fbm.sum(axis=0) > 0) & (fbm.sum(axis=0) < 2 * n))[0]
+    cols = (keep + 1).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    pca = tpg.gt_pca_partialSVD(X, None, cols, k=k)
+    opca = dict(d=pca["d"], u=pca["u"], v=pca["v"], center=pca["center"], scale=pca["scale"])
+    assert np.array_equal(tpg.predict_gt_pca(pca), pca["u"] * pca["d"])
+    # new data: other individuals, some genotypes missing (stored as imputed bytes and as plain NA)
+    new = orc.synth_fbm(42, 60, m, npop=4, miss=0.06, imputed_bytes=True)
+    Xn = tpg.FBM.from_numpy(new)
+    for method in ("none", "simple"):
+        t = tpg.predict_gt_pca(pca, Xn, None, cols, project_method=method)
+        o = orc.predict_gt_pca(opca, new, None, cols, project_method=method)
+        assert np.allclose(t, o, rtol=1e-9, atol=1e-9 * np.abs(o).max()), method
+    # projecting the data the PCA was built on reproduces U D
+    self_proj = tpg.predict_gt_pca(pca, X, None, cols, project_method="simple")
+    assert np.allclose(self_proj, pca["u"] * pca["d"], atol=1e-7 * pca["d"][0])
+    new_na = orc.synth_fbm(42, 60, m, npop=4, miss=0.06)           # byte 3: missing also under the imputed code table
+    Xna = tpg.FBM.from_numpy(new_na)
+    with pytest.raises(ValueError):
+        tpg.predict_gt_pca(pca, Xna, None, cols, project_method="none")
+    t = tpg.predict_gt_pca(pca, Xna, None, cols, project_method="simple")
+    o = orc.predict_gt_pca(opca, new_na, None, cols, project_method="simple")
+    assert np.allclose(t, o, rtol=1e-9, atol=1e-9 * np.abs(o).max())
+    for lsq in ((1, 2), (1, 2, 3), (2, 5)):
+        t = tpg.predict_gt_pca(pca, Xna, None, cols, project_method="least_squares", lsq_pcs=lsq)
+        o = orc.predict_gt_pca(opca, new_na, None, cols, project_method="least_squares", lsq_pcs=lsq)
+        assert np.allclose(t, o, rtol=1e-8, atol=1e-8 * np.abs(o).max()), lsq
+    for bad in ((), (0, 1), (1, 1), (1, 7), (1.5, 2)):
+        with pytest.raises(ValueError):
+            tpg.predict_gt_pca(pca, Xna, None, cols, project_method="least_squares", lsq_pcs=bad)
+    with pytest.raises(NotImplementedError):
+        tpg.predict_gt_pca(pca, Xna, None, cols, project_method="OADP")
+    XV, xnorm = tpg.oadp_inputs(pca, Xna, None, cols)
+    oXV, orss = orc.fbm256_prod_and_rowSumsSq(new_na, None, cols, pca["center"], pca["scale"], pca["v"],
+                                              code256=orc.CODE_IMPUTE_PRED)
+    assert np.allclose(XV, oXV, rtol=1e-9, atol=1e-9 * np.abs(oXV).max()) and np.allclose(xnorm, orss, rtol=1e-9)
+
+
+def test_gt_pca_randomSVD_tolerance(tpg):
+    # R/gt_pca_randomSVD.R:77-135: same truncated SVD, accepted at the relative residual tol
+    n, m, k = 300, 4000, 8
+    fbm = orc.synth_fbm(77, n, m, npop=6, miss=0.0)
+    keep = np.where((fbm.sum(axis=0) > 0) & (fbm.sum(axis=0) < 2 * n))[0]
+    cols = (keep + 1).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    exact = tpg.gt_pca_partialSVD(X, None, cols, k=k)
+    K = tpg.pca_gram(tpg.View(X, None, cols, code256=tpg.CODE_IMPUTE_PRED), exact["center"], exact["scale"])
+    for tol in (1e-4, 1e-8):
+        r = tpg.gt_pca_randomSVD(X, None, cols, k=k, tol=tol)
+        assert r["method"] == "randomSVD"
+        res = np.linalg.norm(K @ r["u"] - r["u"] * r["d"] ** 2, axis=0)
+        assert np.all(res <= tol * r["d"][0] ** 2 * 1.001)
+        assert np.allclose(r["d"], exact["d"], rtol=max(10 * tol ** 2, 1e-10))
+        assert np.allclose(r["u"].T @ r["u"], np.eye(k), atol=1e-9)
+        assert r["square_frobenius"] == exact["square_frobenius"]
+    with pytest.raises(ValueError):
+        tpg.gt_pca_randomSVD(X, None, cols, k=k, tol=0.0)

@@ -240,3 +240,68 @@ def test_windows_stats_generic_reference_expectations():
     assert wb["stat"][c2 & (wb["start"] == 251)][0] == 31
     c1 = wb["chromosome"] == "chr1"
     assert np.isnan(wb["stat"][c1 & (wb["start"] == 251)][0])  # chr1 window 251-350 is empty
+
+
+def test_loci_pi_by_hand():
+    # tests/testthat/test_loci_pi.R:28-55: the test's own `pi` function, on the full matrix and on the subset
+    # without individual 2 and loci 3, 5; a single individual gives NA
+    def pi_by_hand(x):
+        n = (~np.isnan(x)).sum(axis=0) * 2
+        c0 = np.nansum(x, axis=0)
+        c1 = n - c0
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return c0 * c1 / (n * (n - 1) / 2)
+
+    g = fx.FREQ_3x6
+    fbm = orc.fbm_from_genotypes(g)
+    assert np.array_equal(orc.gt_pi_diploid(fbm), pi_by_hand(g))
+    sub = g[np.ix_([0, 2], [0, 1, 3, 5])]
+    assert np.array_equal(orc.gt_pi_diploid(fbm, [1, 3], [1, 2, 4, 6]), pi_by_hand(sub), equal_nan=True)
+    # grouped: column g of the grouped result is the ungrouped result of that group's individuals (:98-101)
+    gid = fx.FST_GROUPS_3
+    f7 = orc.fbm_from_genotypes(fx.FST_7x6)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        grp = orc.gt_grouped_pi_diploid(f7, None, None, gid, 3)["pi"]
+        for k in range(3):
+            rows = np.where(gid == k)[0] + 1
+            assert np.array_equal(grp[:, k], orc.gt_pi_diploid(f7, rows, None), equal_nan=True)
+            assert np.array_equal(grp[:, k], pi_by_hand(fx.FST_7x6[gid == k]), equal_nan=True)
+
+
+def test_indiv_het_obs_by_hand():
+    # tests/testthat/test_indiv_het_obs.R:35-51 (rowMeans(x == 1, na.rm = TRUE); counts het_n / na_n) and :56-95
+    g = fx.FREQ_3x6
+    fbm = orc.fbm_from_genotypes(g)
+    by_hand = np.array([np.nanmean(np.where(np.isnan(r), np.nan, (r == 1).astype(float))) for r in g])
+    assert np.array_equal(orc.indiv_het_obs(fbm), by_hand)
+    counts = orc.indiv_het_obs(fbm, as_counts=True)
+    assert np.array_equal(counts[:, 0], np.nansum(g == 1, axis=1)) and np.array_equal(counts[:, 1], np.isnan(g).sum(axis=1))
+    homo = np.array([[2, 2, 0, 0, 2, 0]] * 3, dtype=float)
+    assert np.array_equal(orc.indiv_het_obs(orc.fbm_from_genotypes(homo)), np.zeros(3))
+
+
+def test_filter_high_relatedness_families():
+    # tests/testthat/test_filter_high_relatedness.R:8-60: KING of the families data, threshold 0.2.  The test's
+    # comments name the two pairs over it (individuals 11-12 and 9-10; the KING golden file test_king.kin0 holds their
+    # coefficients, 0.2248 and 0.2741); filtering the kept sub-matrix again keeps everybody.
+    king = orc.snp_king(fx.families_fbm())
+    gold = fx.king_kin0_matrix()
+    assert round(king[10, 11], 4) == gold[10, 11] == 0.2248 and round(king[8, 9], 4) == gold[8, 9] == 0.2741
+    off = king.copy()
+    np.fill_diagonal(off, 0)
+    assert sorted(map(tuple, np.argwhere(np.triu(off > 0.2)))) == [(8, 9), (10, 11)]
+    passed, removed, keep = orc.filter_high_relatedness(king, 0.2)
+    assert len(removed) == 2 and keep.sum() == 10
+    assert len({9, 10} & set(removed.tolist())) == 1 and len({11, 12} & set(removed.tolist())) == 1
+    sub = king[np.ix_(passed - 1, passed - 1)]
+    assert orc.filter_high_relatedness(sub, 0.2)[2].all()
+    assert orc.filter_high_relatedness(np.array([[0.5]]), 0.2)[2].all()      # a single individual passes (:46-52)
+    assert orc.filter_high_relatedness(king, 0.6)[2].all()                   # nothing over the threshold
+
+
+def test_r_mean_two_pass():
+    rng = np.random.default_rng(0)
+    x = rng.random(1000)
+    assert orc.r_mean(x) == pytest.approx(np.mean(x), rel=1e-15)
+    assert np.isnan(orc.r_mean([np.nan]))
+    assert orc.r_mean([1.0, np.nan, 3.0]) == 2.0

@@ -55,6 +55,7 @@ lib.tpg_view_m.argtypes = [vp]
 lib.tpg_as_pad_quirk_blocks.restype = C.c_int64
 lib.tpg_as_pad_quirk_blocks.argtypes = [C.c_int64, C.c_int64]
 lib.tpg_pairwise_set_as_pad_quirk.argtypes = [vp, C.c_int64]
+lib.tpg_filter_high_relatedness.argtypes = [vp, vp, C.c_int64, C.c_double, vp, vp]
 for _name in ("tpg_ctx_destroy", "tpg_fbm_free", "tpg_view_free", "tpg_pairwise_free", "tpg_dev_free"):
     getattr(lib, _name).restype = None
     getattr(lib, _name).argtypes = [vp]
@@ -74,7 +75,8 @@ SYMBOLS = [
     "tpg_increment_king_numerator", "tpg_increment_as_counts", "tpg_pca_center_scale", "tpg_pca_gram",
     "tpg_pca_partial_svd", "tpg_fbm256_prod_and_rowSumsSq", "tpg_square_frobenius",
     "tpg_pairwise_set_as_pad_quirk", "tpg_as_pad_quirk_blocks", "tpg_increment_flush", "tpg_resident_drop",
-    "tpg_increment_as_note_narrow_block",
+    "tpg_increment_as_note_narrow_block", "tpg_filter_high_relatedness", "tpg_pca_random_svd",
+    "tpg_fbm256_valid_prod",
 ]
 
 

@@ -400,6 +400,32 @@ def pop_fis_wg17(X: FBM, ind_row, ind_col, groupIds, ngroups: int, include_globa
     return out
 
 
+def filter_high_relatedness(matrix, kings_threshold, ids=None, ctx: Optional[Context] = None):
+    """R/filter_high_relatedness.R:26-145 -> [ids that pass (in the order of decreasing mean relatedness), ids to
+    remove, logical keep vector in the original order].  `matrix`: (n, n) numpy array, or a raw device pointer together
+    with ids (its length gives n) -- e.g. the KING matrix left in HBM by Pairwise.king into a dev_alloc'ed buffer.
+    ids default to "1" .. "n", as the reference names an unnamed matrix."""
+    ctx = ctx or default_context()
+    if kings_threshold is None:
+        raise ValueError("argument \"kings_threshold\" is missing")
+    if isinstance(matrix, (int, np.integer, C.c_void_p)):
+        if ids is None:
+            raise ValueError("ids are needed with a device matrix")
+        n, mp = len(ids), (matrix if isinstance(matrix, C.c_void_p) else C.c_void_p(int(matrix)))
+    else:
+        A = np.asfortranarray(matrix, dtype=np.float64)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("matrix should be a square matrix")
+        n, mp = A.shape[0], _ptr(A)
+    ids = np.array([str(k) for k in range(1, n + 1)]) if ids is None else np.asarray(ids)
+    keep, order = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.int32)
+    check(lib.tpg_filter_high_relatedness(ctx.h, mp, C.c_int64(n), C.c_double(float(kings_threshold)), _ptr(keep),
+                                          _ptr(order)))
+    keepb = keep.astype(bool)
+    passed = ids[order][keepb[order]]
+    return [passed, ids[~keepb], keepb]
+
+
 def increment_ibs_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] = None, flush: bool = True):
     """Literal mirror of src/snp_ibs.cpp:22-74 (X_bytes is the host FBM).  The FBM and the accumulators stay resident
     on the device between calls; with flush = True (default) k, k2 are incremented when the call returns, as in the
@@ -896,13 +922,92 @@ def gt_pca_partialSVD(X: FBM, ind_row=None, ind_col=None, k: int = 10, total_var
 
 def gt_pca_randomSVD(X: FBM, ind_row=None, ind_col=None, k: int = 10, tol: float = 1e-4, total_var: bool = True,
                      code256=CODE_IMPUTE_PRED) -> dict:
-    """R/gt_pca_randomSVD.R:77-135.  The reference reaches the same truncated SVD of the scaled matrix through
-    bigstatsr::big_randomSVD (implicitly restarted Lanczos on Z x / Z'x, stopped at `tol`); here it is the same
-    device computation as gt_pca_partialSVD (Gram matrix + eigen step, residual 1e-12), which meets any `tol`.
-    Only the method label differs."""
-    out = gt_pca_partialSVD(X, ind_row, ind_col, k=k, total_var=total_var, code256=code256)
-    out["method"] = "randomSVD"
+    """R/gt_pca_randomSVD.R:77-135.  The reference reaches the truncated SVD of the scaled matrix through
+    bigstatsr::big_randomSVD (RSpectra::svds on the implicit operator), which accepts a singular triplet at the
+    relative residual `tol`; the device path runs the same Gram + subspace iteration as gt_pca_partialSVD and stops
+    at that tolerance: |K u_j - d_j^2 u_j| <= tol * d_1^2."""
+    if not (0 < tol < 1):
+        raise ValueError("tol must be in (0, 1)")
+    v = View(X, ind_row, ind_col, code256=code256)
+    d = np.zeros(k)
+    u = np.zeros((v.n, k), order="F")
+    vl = np.zeros((v.m, k), order="F")
+    center, scale = np.zeros(v.m), np.zeros(v.m)
+    fro = C.c_double()
+    check(lib.tpg_pca_random_svd(v.ctx.h, v.h, C.c_int(k), C.c_double(tol), _ptr(d), _ptr(u), _ptr(vl), _ptr(center),
+                                 _ptr(scale), C.byref(fro) if total_var else None))
+    out = dict(d=d, u=u, v=vl, center=center, scale=scale, method="randomSVD")
+    if total_var:
+        out["square_frobenius"] = fro.value
     return out
+
+
+def predict_gt_pca(pca: dict, X: Optional[FBM] = None, ind_row=None, ind_col=None, project_method: str = "none",
+                   lsq_pcs=(1, 2), code256=CODE_IMPUTE_PRED):
+    """predict.gt_pca (R/predict_gt_pca.R:73-236), numeric part: `pca` = the dict gt_pca_partialSVD returns; ind_col =
+    the FBM columns of new_data that match the loci of the PCA, in the PCA's order (the reference derives them by
+    matching locus names, :113-127).  X = None -> the scores U D of the data the PCA was built on (:101-106).
+      "none"           X V on the imputed code table (bigstatsr::big_prodMat, :141-149; missing values are not allowed)
+      "simple"         fbm256_prod_and_rowSumsSq, missing genotypes count as 0 (:157-175)
+      "least_squares"  per individual, regress its non-missing scaled genotypes on v[, lsq_pcs] (:187-232)
+      "OADP"           XV and the squared norms come from the same device sweep, but the final K x K transform is
+                       bigsnpr's OADP_proj, which is not in the reference checkout: use oadp_inputs() and bigsnpr."""
+    if project_method not in ("none", "simple", "OADP", "least_squares"):
+        raise ValueError("'arg' should be one of 'none', 'simple', 'OADP', 'least_squares'")
+    if X is None:
+        return np.asfortranarray(pca["u"] * pca["d"])
+    if project_method == "OADP":
+        raise NotImplementedError("OADP projection calls bigsnpr::OADP_proj (third-party, not in the reference checkout); "
+                                  "oadp_inputs() returns the XV and X_norm it takes")
+    Vl = np.asfortranarray(pca["v"], dtype=float)
+    if project_method in ("none", "simple"):
+        v = View(X, ind_row, ind_col, code256=code256)
+        if project_method == "none" and loci_counts(v)[:, 3].any():
+            raise ValueError("You can't have missing values in 'X'.")  # bigstatsr's check on the code table
+        XV, _ = _prod_and_rss(v, pca["center"], pca["scale"], Vl)
+        return XV
+    lsq = np.asarray(lsq_pcs)
+    if (len(lsq) == 0 or np.any(np.isnan(lsq.astype(float))) or np.any(lsq < 1) or np.any(lsq > Vl.shape[1])
+            or np.any(lsq != lsq.astype(int))):
+        raise ValueError(f"lsq_pcs should be a vector of valid component indices (positive integers between 1 and "
+                         f"{Vl.shape[1]}), e.g., c(1, 2) or c(1, 2, 3)")
+    if len(set(lsq.tolist())) != len(lsq):
+        raise ValueError("lsq_pcs should not contain duplicate values")
+    lsq = lsq.astype(int) - 1
+    L = len(lsq)
+    v = View(X, ind_row, ind_col, code256=code256)
+    Vs = np.asfortranarray(Vl[:, lsq])
+    # right-hand sides crossprod(v_sub, g_scaled): the missing -> 0 product; matrices crossprod(v_sub): masked sums of
+    # the pairwise products of the chosen columns of v
+    rhs, _ = _prod_and_rss(v, pca["center"], pca["scale"], Vs)
+    pairs = [(a, b) for a in range(L) for b in range(a, L)]
+    tab = np.asfortranarray(np.stack([Vs[:, a] * Vs[:, b] for a, b in pairs], axis=1))
+    masked = np.zeros((v.n, len(pairs)), order="F")
+    check(lib.tpg_fbm256_valid_prod(v.ctx.h, v.h, _ptr(tab), C.c_int(len(pairs)), _ptr(masked)))
+    out = np.zeros((v.n, L), order="F")
+    for i in range(v.n):
+        A = np.zeros((L, L))
+        for (a, b), val in zip(pairs, masked[i]):
+            A[a, b] = A[b, a] = val
+        out[i] = np.linalg.solve(A, rhs[i])  # solve(crossprod(v_sub), crossprod(v_sub, genotypes_scaled)), :228
+    return out
+
+
+def oadp_inputs(pca: dict, X: FBM, ind_row=None, ind_col=None, code256=CODE_IMPUTE_PRED):
+    """(XV, X_norm) that predict(project_method = "OADP") hands to bigsnpr::OADP_proj (R/predict_gt_pca.R:157-181)"""
+    v = View(X, ind_row, ind_col, code256=code256)
+    return _prod_and_rss(v, pca["center"], pca["scale"], np.asfortranarray(pca["v"], dtype=float))
+
+
+def _prod_and_rss(v: View, center, scale, V):
+    if V.shape[0] != v.m:
+        raise ValueError("Incompatibility between dimensions.")  # bigstatsr myassert_size
+    XV = np.zeros((v.n, V.shape[1]), order="F")
+    rss = np.zeros(v.n)
+    center, scale = _f64(center), _f64(scale)
+    check(lib.tpg_fbm256_prod_and_rowSumsSq(v.ctx.h, v.h, _ptr(center), _ptr(scale), _ptr(V), C.c_int(V.shape[1]),
+                                            _ptr(XV), _ptr(rss)))
+    return XV, rss
 
 
 def fbm256_prod_and_rowSumsSq(X: FBM, ind_row, ind_col, center, scale, V, code256="fbm"):

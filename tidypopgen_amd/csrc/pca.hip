@@ -161,7 +161,7 @@ extern "C" int tpg_square_frobenius(tpg_ctx* ctx, const tpg_view* v, const doubl
 //   RAW:      z = g, no centering (the r_i sums of the Gram correction)
 // One wave per 32-row tile; the 128-column slice of Tab for the current block is staged in LDS and
 // shared by the workgroup's 4 waves.  KC (<= 8) output columns per pass.
-enum { SW_COLSCALE = 0, SW_ROWSCALE = 1, SW_RAW = 2 };
+enum { SW_COLSCALE = 0, SW_ROWSCALE = 1, SW_RAW = 2, SW_VALID = 3 };  // SW_VALID: z = 1 for a typed genotype (0 if missing)
 
 template <int KC, int MODE>
 __global__ __launch_bounds__(256) void tpg_sweep_kernel(const uint4* __restrict__ P, int64_t nrowtiles, int64_t nblocks,
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void tpg_sweep_kernel(const uint4* __restrict_
           double z;
           if (MODE == SW_COLSCALE) z = ((double)code - cs[cl][0]) * cs[cl][1];
           else if (MODE == SW_ROWSCALE) z = ((double)code - rc) * ris;
+          else if (MODE == SW_VALID) z = 1.0;
           else z = (double)code;
           if (code == 3) z = 0;
           rss += z * z;
@@ -278,10 +279,12 @@ static int run_sweep(tpg_ctx* ctx, int mode, const uint4* P, int64_t nrowtiles, 
     if (KC == 4) {
       if (mode == SW_COLSCALE) SWEEP_LAUNCH(4, SW_COLSCALE, "sweep_colscale");
       else if (mode == SW_ROWSCALE) SWEEP_LAUNCH(4, SW_ROWSCALE, "sweep_rowscale");
+      else if (mode == SW_VALID) SWEEP_LAUNCH(4, SW_VALID, "sweep_valid");
       else SWEEP_LAUNCH(4, SW_RAW, "sweep_raw");
     } else {
       if (mode == SW_COLSCALE) SWEEP_LAUNCH(20, SW_COLSCALE, "sweep_colscale");
       else if (mode == SW_ROWSCALE) SWEEP_LAUNCH(20, SW_ROWSCALE, "sweep_rowscale");
+      else if (mode == SW_VALID) SWEEP_LAUNCH(20, SW_VALID, "sweep_valid");
       else SWEEP_LAUNCH(20, SW_RAW, "sweep_raw");
     }
 #undef SWEEP_LAUNCH
@@ -321,6 +324,23 @@ extern "C" int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx* ctx, const tpg_view* v, co
   TPG_TRY(rc);
   TPG_TRY(oxv.commit(ctx));
   return orss.commit(ctx);
+}
+
+// out[i][k] = sum over the loci j where individual i is typed of Tab[j][k]: the per-individual masked sums behind
+// predict(project_method = "least_squares") (R/predict_gt_pca.R:221-228), where every individual solves its own
+// normal equations over its non-missing loci: crossprod(v_sub) = sum_j typed v_j v_j' is this sweep with
+// Tab = the pairwise products of the columns of v.
+extern "C" int tpg_fbm256_valid_prod(tpg_ctx* ctx, const tpg_view* v, const double* Tab, int K, double* out) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && v && Tab && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(K > 0, TPG_EINVAL, "Tab has no columns");
+  InBuf it;
+  TPG_TRY(it.init(ctx, Tab, sizeof(double) * (size_t)v->m * (size_t)K));
+  OutBuf oo;
+  TPG_TRY(oo.init(out, sizeof(double) * (size_t)v->n * (size_t)K));
+  TPG_TRY(run_sweep(ctx, SW_VALID, v->T, v->Q * 4, v->KG, v->n, v->m, nullptr, nullptr, it.dev<double>(), v->m, K,
+                    oo.dev<double>(), nullptr, nullptr));
+  return oo.commit(ctx);
 }
 
 // ---------------------------------------------------------------------------
@@ -1331,7 +1351,7 @@ struct StageTimer {
   }
 };
 
-static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambda_host, double* d_U) {
+static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambda_host, double* d_U, double tol = 1e-12) {
   // block = 2k + 12 (RSpectra, which the reference calls, keeps ncv = 2k + 1 Lanczos vectors): K Q is bound by
   // reading K, so extra columns are nearly free, and a block that reaches past the k wanted values into the
   // bulk of the spectrum converges in far fewer filter / Rayleigh-Ritz rounds than k + 12 columns do
@@ -1406,7 +1426,7 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
   std::vector<double> lam((size_t)b, 0.0), theta, X, H;
   int nl = 0;
   const int MAXIT = 200;
-  const double TOL = 1e-12, AMP = 1e6;
+  const double TOL = tol, AMP = 1e6;  // a pair is accepted when its residual |K u - lambda u| <= TOL * lambda_1
   double lam1 = 0;
   for (int it = 0; it < MAXIT && nl < k; it++) {
     const int act = b - nl;
@@ -1496,9 +1516,29 @@ static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_
                                const double* d_U, const double* d_dk, int k, double* d_V);
 
 // ---------------------------------------------------------------------------
+static int pca_svd_impl(tpg_ctx* ctx, const tpg_view* v, int k, double tol, double* d, double* u, double* vload,
+                        double* center, double* scale, double* square_frobenius);
+
 extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,
                                    double* center, double* scale, double* square_frobenius) {
   TpgEnter _enter(ctx);
+  return pca_svd_impl(ctx, v, k, 1e-12, d, u, vload, center, scale, square_frobenius);
+}
+
+// gt_pca_randomSVD (R/gt_pca_randomSVD.R:77-135): the reference reaches the same truncated SVD through
+// bigstatsr::big_randomSVD -> RSpectra::svds on the implicit operator (third-party, recalled), whose `tol` is the
+// relative residual at which a singular triplet is accepted (default 1e-4).  Same Gram + subspace iteration here,
+// stopped at that tolerance: residual |K u - d^2 u| <= tol * d_1^2 for every returned pair (the eigenvalue error is
+// then of order tol^2, the vector error of order tol / gap) -- fewer iterations than the partialSVD path's 1e-12.
+extern "C" int tpg_pca_random_svd(tpg_ctx* ctx, const tpg_view* v, int k, double tol, double* d, double* u,
+                                  double* vload, double* center, double* scale, double* square_frobenius) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(tol > 0 && tol < 1, TPG_EINVAL, "tol = %g out of (0, 1)", tol);
+  return pca_svd_impl(ctx, v, k, tol < 1e-12 ? 1e-12 : tol, d, u, vload, center, scale, square_frobenius);
+}
+
+static int pca_svd_impl(tpg_ctx* ctx, const tpg_view* v, int k, double tol, double* d, double* u, double* vload,
+                        double* center, double* scale, double* square_frobenius) {
   TPG_REQUIRE(ctx && v && d && u && vload && center && scale, TPG_EINVAL, "null argument");
   TPG_REQUIRE(k >= 1 && k <= 52 && k <= v->n && k <= v->m, TPG_EINVAL, "k = %d out of range", k);
   const int64_t n = v->n, m = v->m;
@@ -1521,7 +1561,7 @@ extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, doubl
   TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true));
   st.mark("gram");
   std::vector<double> lam((size_t)k);
-  TPG_TRY(eig_topk(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>()));
+  TPG_TRY(eig_topk(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>(), tol));
   st.mark("eig_topk");
   std::vector<double> dh((size_t)k);
   for (int j = 0; j < k; j++) dh[(size_t)j] = sqrt(lam[(size_t)j] > 0 ? lam[(size_t)j] : 0.0);
