@@ -46,6 +46,8 @@ typedef struct tpg_ctx tpg_ctx;   /* one GPU, one stream */
 typedef struct tpg_fbm tpg_fbm;   /* FBM bytes resident in HBM */
 typedef struct tpg_view tpg_view; /* (FBM, rowInd, colInd, code256) packed to 2 bits in HBM */
 typedef struct tpg_pairwise tpg_pairwise; /* int32 N x N cross-product accumulators in HBM */
+typedef struct tpg_comm tpg_comm;   /* one rank (= one context = one GPU) of a group that shares an analysis sharded by loci */
+typedef struct tpg_multi tpg_multi; /* one process driving several GPUs: a context and a communicator per device */
 
 const char* tpg_last_error(void);
 const char* tpg_version(void);
@@ -257,6 +259,61 @@ int tpg_resident_drop(tpg_ctx* ctx);
 /* quirk Q1 through the literal mirror (opt-in): note that the block just passed to tpg_increment_as_counts for
  * matrix K was one column narrower than the R driver's scratch matrices */
 int tpg_increment_as_note_narrow_block(tpg_ctx* ctx, const double* K);
+
+/* ---- SNP-block shards over the GPUs of one node -------------------------------------------------
+ * The locus axis is the reference's own block axis (R/snp_ibs.R:59-82): a shard is a contiguous range of loci.
+ * Per-locus outputs are disjoint slices (no exchange).  What is additive over loci is exchanged by the LIBRARY, over
+ * RCCL (xGMI): the int32 pairwise slabs by ONE reduce-scatter -- rank r then finishes band r of the tiles (1 / nranks
+ * of the epilogue work and of the output bytes) --, Fst sums, the PCA Gram matrix and the GRM mean by all-reduces of
+ * doubles.  With one rank every exchange is the identity: the code path is the same for 1 .. 8 GPUs.
+ *
+ * One process per GPU (torchrun, mpirun): rank 0 calls tpg_comm_unique_id, the launcher broadcasts the 128 bytes,
+ * every rank calls tpg_comm_init_rank with its own context.  One process for all GPUs (an R session): tpg_multi_*. */
+int tpg_comm_unique_id(uint8_t* id128);
+int tpg_comm_init_rank(tpg_ctx* ctx, int nranks, int rank, const uint8_t* id128, tpg_comm** out);
+/* Rehearsal transport (tests): the caller's in-place all-reduce (sum) of `count` elements in HOST memory, dtype 0 =
+ * int32, 1 = float64, returning 0 on success -- e.g. torch.distributed over gloo, so that several ranks can share
+ * one GPU, which RCCL refuses. */
+int tpg_comm_init_host(tpg_ctx* ctx, int nranks, int rank,
+                       int (*allreduce)(void* user, void* buf, int64_t count, int dtype), void* user, tpg_comm** out);
+void tpg_comm_destroy(tpg_comm* comm);
+int tpg_comm_rank(const tpg_comm* comm);
+int tpg_comm_size(const tpg_comm* comm);
+/* loci [begin, end) of `rank`: contiguous, boundaries on multiples of 128 loci, sizes differ by at most 128 */
+int tpg_shard_loci(int64_t m_total, int nranks, int rank, int64_t* begin, int64_t* end);
+/* in-place sum over the ranks of `count` doubles (host or device memory): Fst numerator / denominator sums
+ * (tpg_pairwise_pop_fst_sums), the Gram matrix (tpg_pca_gram), the squared Frobenius norm */
+int tpg_comm_allreduce_f64(tpg_ctx* ctx, tpg_comm* comm, double* buf, int64_t count);
+/* pairwise accumulators laid out for the reduce-scatter; accumulate as usual, then tpg_pairwise_reduce: this rank
+ * is left with the complete sums of its band of tiles, and tpg_pairwise_counts / tpg_pairwise_epilogues_sharded write
+ * only the part of the N x N outputs the band covers -- rows [row0, row1) x columns [row0, n) and the mirror image
+ * rows [row0, n) x columns [row0, row1) (tpg_pairwise_band); the bands of all ranks tile the matrices. */
+size_t tpg_pairwise_buffer_bytes_sharded(int64_t n, int nranks);
+int tpg_pairwise_create_sharded(tpg_ctx* ctx, const tpg_comm* comm, int64_t n, tpg_pairwise** out);
+int tpg_pairwise_reduce(tpg_ctx* ctx, tpg_comm* comm, tpg_pairwise* pw);
+int tpg_pairwise_band(const tpg_pairwise* pw, int64_t* row0, int64_t* row1);
+/* the band rank `rank` of `nranks` gets for n individuals (host arithmetic; no GPU needed) */
+int tpg_pairwise_band_of(int64_t n, int nranks, int rank, int64_t* row0, int64_t* row1);
+int tpg_pairwise_epilogues_sharded(tpg_ctx* ctx, tpg_comm* comm, const tpg_pairwise* pw, int ibs_type, int64_t m,
+                                   double* ibs, double* king, double* allele_sharing, double* grm);
+/* gt_pca_partialSVD with the loci sharded over the ranks: `v` holds this rank's loci; center, scale and the rows of
+ * the loadings come back for those loci; d and u are the same on every rank (the Gram matrix is summed over the ranks
+ * inside, the eigen step is replicated); one rank: identical to tpg_pca_partial_svd */
+int tpg_pca_partial_svd_sharded(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, double* d, double* u,
+                                double* vload, double* center, double* scale, double* square_frobenius);
+/* one process, `ndev` GPUs (devices == NULL: 0 .. ndev-1): a context and a communicator (ncclCommInitAll) each */
+int tpg_multi_create(int ndev, const int* devices, tpg_multi** out);
+void tpg_multi_destroy(tpg_multi* mg);
+int tpg_multi_ndev(const tpg_multi* mg);
+tpg_ctx* tpg_multi_ctx(tpg_multi* mg, int i);
+tpg_comm* tpg_multi_comm(tpg_multi* mg, int i);
+/* snp_ibs + snp_king + snp_allele_sharing + pairwise_grm of one HOST FBM on all devices: every device uploads and
+ * packs its share of colInd (raw-byte semantics, src/snp_ibs.cpp:47-54), one reduce-scatter, every device writes its
+ * band of IBS / KING / allele sharing / GRM straight into the caller's n x n host matrices (any may be NULL).
+ * m for TPG_IBS_ADJUSTED_COUNTS is the number of loci kept. */
+int tpg_multi_pairwise(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1,
+                       int64_t n, const int32_t* colInd1, int64_t m, int ibs_type, double* ibs, double* king,
+                       double* allele_sharing, double* grm);
 
 /* ---- PCA (gt_pca_partialSVD) ---------------------------------------------- */
 /* center / scale of bigsnpr::snp_scaleBinom; TPG_ENUMERIC on a missing value or zero scale */

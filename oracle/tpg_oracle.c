@@ -154,6 +154,7 @@ void orc_alt_freq_dip_pseudo(const uint8_t* fbm, int64_t nrow, const int32_t* ro
   double* mult = (double*)malloc(sizeof(double) * (size_t)n);
   for (int i = 0; i < n; i++) mult[i] = 1 / (3 - ploidy[i]);                   /* :25-27 */
   for (int j = 0; j < m; j++) { out[j] = 0; out[(size_t)m + j] = 0; }
+#pragma omp parallel for schedule(static)
   for (int j = 0; j < m; j++)                                                   /* :33-41 */
     for (int i = 0; i < n; i++) {
       double x = code256[FBM(i, j)];
@@ -176,6 +177,7 @@ void orc_grouped_alt_freq_dip_pseudo(const uint8_t* fbm, int64_t nrow, const int
   double* mult = (double*)malloc(sizeof(double) * (size_t)n);
   for (int i = 0; i < n; i++) mult[i] = 1 / (3 - ploidy[i]);
   memset(out, 0, sizeof(double) * (size_t)m * 2 * (size_t)ngroups);
+#pragma omp parallel for schedule(static)
   for (int j = 0; j < m; j++)
     for (int i = 0; i < n; i++) {
       double x = code256[FBM(i, j)];
@@ -196,6 +198,7 @@ void orc_grouped_missingness(const uint8_t* fbm, int64_t nrow, const int32_t* ro
                              const int32_t* colInd, int m, const double* code256,
                              const int32_t* groupIds, int ngroups, double* out) {
   memset(out, 0, sizeof(double) * (size_t)m * (size_t)ngroups);
+#pragma omp parallel for schedule(static)
   for (int j = 0; j < m; j++)
     for (int i = 0; i < n; i++) {
       double x = code256[FBM(i, j)];
@@ -214,6 +217,7 @@ void orc_grouped_summaries_dip_pseudo(const uint8_t* fbm, int64_t nrow, const in
   memset(freq, 0, sz); memset(ref_freq, 0, sz); memset(valid_alleles, 0, sz); memset(heterozygotes, 0, sz);
   double* mult = (double*)malloc(sizeof(double) * (size_t)n);
   for (int i = 0; i < n; i++) mult[i] = 1 / (3 - ploidy[i]);
+#pragma omp parallel for schedule(static)
   for (int j = 0; j < m; j++) {
     for (int i = 0; i < n; i++) {
       double x = code256[FBM(i, j)];
@@ -287,6 +291,7 @@ void orc_gt_grouped_pi_diploid(const uint8_t* fbm, int64_t nrow, const int32_t* 
 void orc_pairwise_fst_hudson_loop(const int32_t* pairs1, int P, int m, const double* n,
                                   const double* freq_alt, const double* freq_ref, int by_locus,
                                   int return_num_dem, double* fst_tot, double* out_a, double* out_b) {
+#pragma omp parallel for schedule(dynamic, 4)
   for (int c = 0; c < P; c++) {
     const double *p1 = freq_alt + (size_t)(pairs1[2 * c] - 1) * m, *p2 = freq_alt + (size_t)(pairs1[2 * c + 1] - 1) * m;
     const double *q1 = freq_ref + (size_t)(pairs1[2 * c] - 1) * m, *q2 = freq_ref + (size_t)(pairs1[2 * c + 1] - 1) * m;
@@ -311,6 +316,7 @@ void orc_pairwise_fst_wc84_loop(const int32_t* pairs1, int P, int m, const doubl
                                 const double* freq_alt, const double* het_obs, int by_locus,
                                 int return_num_dem, double* fst_tot, double* out_a, double* out_b) {
   const int r = 2;
+#pragma omp parallel for schedule(dynamic, 4)
   for (int c = 0; c < P; c++) {
     const double* an[2]; const double* p[2]; const double* h[2];
     for (int j = 0; j < r; j++) {
@@ -352,6 +358,7 @@ void orc_pairwise_fst_nei87_loop(const int32_t* pairs1, int P, int m, const doub
                                  const double* het_obs, const double* freq_alt, const double* freq_ref,
                                  int by_locus, int return_num_dem, double* fst_tot, double* out_a,
                                  double* out_b) {
+#pragma omp parallel for schedule(dynamic, 4)
   for (int c = 0; c < P; c++) {
     size_t o1 = (size_t)(pairs1[2 * c] - 1) * m, o2 = (size_t)(pairs1[2 * c + 1] - 1) * m;
     double mean_num = 0.0, mean_den = 0.0;

@@ -1,6 +1,8 @@
-"""CPU, world_size 2 over gloo: the N > 1 path.  Each rank computes its SNP shard's partial results
-with the oracle as the compute stand-in, the package's sharding helpers reduce them, and the result must
-equal the whole-panel answer (exactly for the integer matrices, to rounding for Fst / Gram)."""
+"""CPU, world_size 2 over gloo: the N > 1 path without a GPU.  Each rank computes its SNP shard's partial results
+with the oracle as the compute stand-in, the partials are summed over gloo, every rank keeps what the library would
+leave it with -- its band of the N x N matrices after the reduce-scatter, the all-reduced Fst sums and Gram matrix --
+and the pieces must assemble to the whole-panel answer (exactly for the integer matrices, to rounding for Fst / Gram).
+The partitions themselves (which loci, which band) come from the library (tpg_shard_loci, tpg_pairwise_band_of)."""
 import os
 import sys
 
@@ -10,6 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, M, G = 200, 1000, 4
 
 
 def _worker(rank, world, port, q):
@@ -20,43 +23,45 @@ def _worker(rank, world, port, q):
     from oracle import oracle as orc
     from tidypopgen_amd import sharding
 
-    n, m, G = 60, 1000, 4
+    n, m = N, M
     fbm = orc.synth_fbm(5, n, m, npop=G, miss=0.05, imputed_bytes=True)
     gid = (np.arange(n) % G).astype(np.int32)
     b, e = sharding.shard_loci(m, world, rank)
     cols = np.arange(b + 1, e + 1, dtype=np.int32)
-    out = {}
-    # integer pairwise partials
+    out = {"rank": rank, "band": sharding.band_rows(n, world, rank)}
+    # integer pairwise partials of this rank's loci, summed over the ranks; the rank keeps its band
     parts = []
     for inc in (orc.increment_ibs_counts, orc.increment_king_numerator, orc.increment_as_counts):
         A = np.zeros((n, n), order="F"); B = np.zeros((n, n), order="F")
         inc(A, B, fbm, None, cols)
         parts += [A, B]
-    stack = np.stack(parts).astype(np.int64)
+    stack = np.ascontiguousarray(np.stack(parts))
     sharding.all_reduce_numpy(stack)
-    out["pairwise"] = stack
+    mask = sharding.band_mask(n, world, rank)
+    out["pairwise_band"] = np.where(mask, stack, np.nan)
     # Fst sums
     for method in ("Hudson", "WC84"):
         with np.errstate(invalid="ignore", divide="ignore"):
             nd = orc.pairwise_pop_fst(fbm, None, cols, gid, G, method=method, return_num_dem=True)
         num, den = nd["Fst_by_locus_num"], nd["Fst_by_locus_den"]
         ok = ~np.isnan(num) & ~np.isnan(den)
-        sn = np.where(ok, num, 0).sum(axis=0); sd = np.where(ok, den, 0).sum(axis=0)
-        out["fst_" + method] = sharding.fst_from_sums(sn, sd)
+        sums = np.ascontiguousarray(np.stack([np.where(ok, num, 0).sum(axis=0), np.where(ok, den, 0).sum(axis=0)]))
+        sharding.all_reduce_numpy(sums)
+        out["fst_" + method] = sums[0] / sums[1]
     # PCA Gram (additive over loci; center/scale are per locus, hence local)
     dec = np.where(fbm > 3, fbm - 4, fbm)
     poly = (dec.sum(axis=0) > 0) & (dec.sum(axis=0) < 2 * n)
     pc = cols[poly[b:e]]
     _, _, K = orc.pca_gram(fbm, None, pc)
+    K = np.ascontiguousarray(K)
     sharding.all_reduce_numpy(K)
     out["gram"] = K
-    if rank == 0:
-        q.put(out)
+    q.put(out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_shard_loci_partition():
+def test_partitions():
     from tidypopgen_amd import sharding
 
     for m, w in ((1000, 2), (1_000_000, 8), (130, 4), (127, 3)):
@@ -64,8 +69,21 @@ def test_shard_loci_partition():
         assert ranges[0][0] == 0 and ranges[-1][1] == m
         for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
             assert a1 == b0 and a0 % 128 == 0 and b0 % 128 == 0
-    with pytest.raises(ValueError):
+    with pytest.raises(Exception):
         sharding.shard_loci(10, 2, 2)
+    # the bands of all ranks tile the N x N matrices exactly once, for awkward sizes too
+    for n, w in ((5000, 8), (1000, 8), (60, 2), (12, 4), (130, 3), (64, 5), (1, 2)):
+        bands = [sharding.band_rows(n, w, r) for r in range(w)]
+        assert bands[0][0] == 0 and bands[-1][1] == n
+        for (a0, a1), (b0, b1) in zip(bands, bands[1:]):
+            assert a1 == b0 and a0 <= a1
+        if n <= 1000:
+            cover = sum(sharding.band_mask(n, w, r).astype(int) for r in range(w))
+            assert cover.min() == 1 and cover.max() == 1
+    # 8 ranks at the bench size: no band carries more than 10 % over its fair share of the slabs
+    nst = -(-5000 // 64)
+    units = [sum(2 * (nst - i) for i in range(a // 64, -(-b // 64))) for a, b in (sharding.band_rows(5000, 8, r) for r in range(8))]
+    assert sum(units) == nst * (nst + 1) and max(units) * 8 <= 1.10 * sum(units)
 
 
 @pytest.mark.timeout(120)
@@ -78,11 +96,11 @@ def test_two_rank_reduction_equals_whole_panel():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = q.get(timeout=100)
+    outs = sorted([q.get(timeout=100), q.get(timeout=100)], key=lambda o: o["rank"])
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    n, m, G = 60, 1000, 4
+    n, m = N, M
     fbm = orc.synth_fbm(5, n, m, npop=G, miss=0.05, imputed_bytes=True)
     gid = (np.arange(n) % G).astype(np.int32)
     whole = []
@@ -90,12 +108,19 @@ def test_two_rank_reduction_equals_whole_panel():
         A = np.zeros((n, n), order="F"); B = np.zeros((n, n), order="F")
         inc(A, B, fbm, None, None)
         whole += [A, B]
-    assert np.array_equal(out["pairwise"], np.stack(whole).astype(np.int64))
-    for method in ("Hudson", "WC84"):
-        with np.errstate(invalid="ignore", divide="ignore"):
-            t = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method)["fst_tot"]
-        assert np.allclose(out["fst_" + method], t, rtol=1e-12)
+    whole = np.stack(whole)
+    # every element is delivered by exactly one rank, and it is the whole-panel value
+    have = np.stack([~np.isnan(o["pairwise_band"]) for o in outs]).sum(axis=0)
+    assert have.min() == 1 and have.max() == 1
+    assembled = np.nansum(np.stack([o["pairwise_band"] for o in outs]), axis=0)
+    assert np.array_equal(assembled, whole)
+    assert outs[0]["band"][1] == outs[1]["band"][0] and 0 < outs[0]["band"][1] < n
+    for o in outs:
+        for method in ("Hudson", "WC84"):
+            with np.errstate(invalid="ignore", divide="ignore"):
+                t = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method)["fst_tot"]
+            assert np.allclose(o["fst_" + method], t, rtol=1e-12)
     dec = np.where(fbm > 3, fbm - 4, fbm)
     cols = (np.where((dec.sum(axis=0) > 0) & (dec.sum(axis=0) < 2 * n))[0] + 1).astype(np.int32)
     _, _, K = orc.pca_gram(fbm, None, cols)
-    assert np.allclose(out["gram"], K, rtol=1e-12, atol=1e-9)
+    assert np.allclose(outs[0]["gram"], K, rtol=1e-12, atol=1e-9) and np.array_equal(outs[0]["gram"], outs[1]["gram"])

@@ -56,7 +56,18 @@ lib.tpg_as_pad_quirk_blocks.restype = C.c_int64
 lib.tpg_as_pad_quirk_blocks.argtypes = [C.c_int64, C.c_int64]
 lib.tpg_pairwise_set_as_pad_quirk.argtypes = [vp, C.c_int64]
 lib.tpg_filter_high_relatedness.argtypes = [vp, vp, C.c_int64, C.c_double, vp, vp]
-for _name in ("tpg_ctx_destroy", "tpg_fbm_free", "tpg_view_free", "tpg_pairwise_free", "tpg_dev_free"):
+lib.tpg_multi_ctx.restype = vp
+lib.tpg_multi_comm.restype = vp
+lib.tpg_multi_ctx.argtypes = [vp, C.c_int]
+lib.tpg_multi_comm.argtypes = [vp, C.c_int]
+lib.tpg_multi_ndev.argtypes = [vp]
+lib.tpg_comm_rank.argtypes = [vp]
+lib.tpg_comm_size.argtypes = [vp]
+lib.tpg_pairwise_buffer_bytes_sharded.restype = C.c_size_t
+lib.tpg_pairwise_buffer_bytes_sharded.argtypes = [C.c_int64, C.c_int]
+HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int64, C.c_int)
+for _name in ("tpg_ctx_destroy", "tpg_fbm_free", "tpg_view_free", "tpg_pairwise_free", "tpg_dev_free",
+              "tpg_comm_destroy", "tpg_multi_destroy"):
     getattr(lib, _name).restype = None
     getattr(lib, _name).argtypes = [vp]
 
@@ -76,7 +87,10 @@ SYMBOLS = [
     "tpg_pca_partial_svd", "tpg_fbm256_prod_and_rowSumsSq", "tpg_square_frobenius",
     "tpg_pairwise_set_as_pad_quirk", "tpg_as_pad_quirk_blocks", "tpg_increment_flush", "tpg_resident_drop",
     "tpg_increment_as_note_narrow_block", "tpg_filter_high_relatedness", "tpg_pca_random_svd",
-    "tpg_fbm256_valid_prod",
+    "tpg_fbm256_valid_prod", "tpg_comm_unique_id", "tpg_comm_init_rank", "tpg_comm_init_host", "tpg_comm_destroy",
+    "tpg_comm_rank", "tpg_comm_size", "tpg_shard_loci", "tpg_comm_allreduce_f64", "tpg_pairwise_buffer_bytes_sharded",
+    "tpg_pairwise_create_sharded", "tpg_pairwise_reduce", "tpg_pairwise_band", "tpg_pairwise_band_of", "tpg_pairwise_epilogues_sharded",
+    "tpg_pca_partial_svd_sharded", "tpg_multi_create", "tpg_multi_destroy", "tpg_multi_ndev", "tpg_multi_ctx", "tpg_multi_comm", "tpg_multi_pairwise",
 ]
 
 

@@ -288,6 +288,143 @@ class Pairwise:
             pass
 
 
+class Comm:
+    """One rank of a group of GPUs that share an analysis sharded by loci (tpg_comm; include/tpg.h "SNP-block
+    shards").  The library owns the collectives (RCCL); the launcher only has to deliver the 128-byte id."""
+
+    def __init__(self, ctx: Context, handle, nranks: int, rank: int, keep=None):
+        self.ctx, self.h, self.nranks, self.rank, self._keep = ctx, handle, nranks, rank, keep
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        check(lib.tpg_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def init_rank(cls, ctx: Context, nranks: int, rank: int, unique_id: Optional[bytes]) -> "Comm":
+        h = C.c_void_p()
+        idbuf = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        check(lib.tpg_comm_init_rank(ctx.h, C.c_int(nranks), C.c_int(rank), idbuf, C.byref(h)))
+        return cls(ctx, h, nranks, rank)
+
+    @classmethod
+    def from_torch_distributed(cls, ctx: Context) -> "Comm":
+        """Under torchrun: the process group (any backend -- gloo is enough) is only the control plane that carries
+        the RCCL id from rank 0 to the others; the data path never goes through torch."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return cls.init_rank(ctx, 1, 0, None)
+        box = [cls.unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls.init_rank(ctx, dist.get_world_size(), dist.get_rank(), box[0])
+
+    @classmethod
+    def host(cls, ctx: Context, nranks: int, rank: int, allreduce) -> "Comm":
+        """Rehearsal transport (tests): allreduce(numpy array) sums the array in place over the ranks through host
+        memory -- e.g. torch.distributed over gloo with several ranks on one GPU."""
+        def _cb(user, buf, count, dtype):
+            try:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int32 if dtype == 0 else C.c_double)), shape=(count,))
+                allreduce(a)
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                return 1
+
+        cb = _lib.HOST_ALLREDUCE(_cb)
+        h = C.c_void_p()
+        check(lib.tpg_comm_init_host(ctx.h, C.c_int(nranks), C.c_int(rank), cb, None, C.byref(h)))
+        return cls(ctx, h, nranks, rank, keep=cb)
+
+    def shard_loci(self, m_total: int):
+        b, e = C.c_int64(), C.c_int64()
+        check(lib.tpg_shard_loci(C.c_int64(m_total), C.c_int(self.nranks), C.c_int(self.rank), C.byref(b), C.byref(e)))
+        return b.value, e.value
+
+    def allreduce_f64(self, buf, count: Optional[int] = None):
+        """in-place sum over the ranks of a float64 numpy array, or of `count` doubles at a device pointer"""
+        if isinstance(buf, np.ndarray):
+            assert buf.dtype == np.float64 and buf.flags.c_contiguous or buf.flags.f_contiguous
+            check(lib.tpg_comm_allreduce_f64(self.ctx.h, self.h, _ptr(buf), C.c_int64(buf.size)))
+            return buf
+        check(lib.tpg_comm_allreduce_f64(self.ctx.h, self.h, _ptr(buf), C.c_int64(int(count))))
+        return buf
+
+    def close(self):
+        if self.h:
+            lib.tpg_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedPairwise(Pairwise):
+    """Pairwise accumulators of one rank: accumulate this rank's loci, reduce() (one reduce-scatter over the ranks),
+    then counts() / epilogues() give this rank's band of the N x N outputs (band() tells which rows)."""
+
+    def __init__(self, comm: Comm, n: int):
+        self.ctx, self.n, self.comm = comm.ctx, n, comm
+        h = C.c_void_p()
+        check(lib.tpg_pairwise_create_sharded(comm.ctx.h, comm.h, C.c_int64(n), C.byref(h)))
+        self.h = h
+
+    def reduce(self):
+        check(lib.tpg_pairwise_reduce(self.ctx.h, self.comm.h, self.h))
+
+    def band(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(lib.tpg_pairwise_band(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def epilogues(self, which=("ibs", "king", "allele_sharing", "grm"), ibs_type: str = "proportion", m: int = 0) -> dict:
+        names = ("ibs", "king", "allele_sharing", "grm")
+        outs = {k: np.full((self.n, self.n), np.nan, order="F") for k in which}  # outside the band: left as NaN
+        check(lib.tpg_pairwise_epilogues_sharded(self.ctx.h, self.comm.h, self.h, C.c_int(0 if ibs_type == "proportion" else 1),
+                                                 C.c_int64(m), *[_ptr(outs.get(k)) for k in names]))
+        return outs
+
+
+class Multi:
+    """One process, several GPUs (tpg_multi): what an R session uses."""
+
+    def __init__(self, ndev: int, devices=None):
+        h = C.c_void_p()
+        dv = _i32(devices)
+        check(lib.tpg_multi_create(C.c_int(ndev), _ptr(dv), C.byref(h)))
+        self.h, self.ndev = h, ndev
+
+    def pairwise(self, X_bytes, ind_row=None, ind_col=None, which=("ibs", "king", "allele_sharing", "grm"),
+                 ibs_type: str = "proportion") -> dict:
+        """snp_ibs / snp_king / snp_allele_sharing / pairwise_grm of a host FBM (uint8, Fortran order) on all devices"""
+        X_bytes = np.asarray(X_bytes)
+        assert X_bytes.dtype == np.uint8 and X_bytes.flags.f_contiguous
+        r, c = _i32(ind_row), _i32(ind_col)
+        n = X_bytes.shape[0] if r is None else len(r)
+        m = X_bytes.shape[1] if c is None else len(c)
+        names = ("ibs", "king", "allele_sharing", "grm")
+        outs = {k: np.full((n, n), np.nan, order="F") for k in which}
+        check(lib.tpg_multi_pairwise(self.h, _ptr(X_bytes), C.c_int64(X_bytes.shape[0]), C.c_int64(X_bytes.shape[1]),
+                                     _ptr(r), C.c_int64(n), _ptr(c), C.c_int64(m), C.c_int(0 if ibs_type == "proportion" else 1),
+                                     *[_ptr(outs.get(k)) for k in names]))
+        return outs
+
+    def close(self):
+        if self.h:
+            lib.tpg_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------
 # R-level functions
 

@@ -136,6 +136,15 @@ struct tpg_pairwise {
   int64_t nun;
   int64_t loci;          // loci accumulated since the last zero (all ranks' loci after a reduction): overflow guard
   int64_t as_pad_quirk;  // reference quirk Q1: added to every allele-sharing numerator (tpg_pairwise_set_as_pad_quirk)
+  // Sharding over the ranks of a tpg_comm (comm.hip).  The slab of unit (I, jt) sits at tpg_pw_unit_index + rowpad[I]:
+  // super-tile rows are dealt to the ranks in contiguous bands of (nearly) equal unit counts, every band padded to
+  // `chunk_units` slabs, so that ONE reduce-scatter with equal counts leaves rank r with the sums of band r.  A
+  // single rank has one band, rowpad = 0 and chunk_units = ntp: the unsharded layout.
+  int nranks = 1, rank = 0;
+  int64_t chunk_units = 0;
+  std::vector<int32_t> band;   // nranks + 1 super-tile boundaries: band r = rows [band[r], band[r + 1])
+  int64_t* rowpad = nullptr;   // device int64[nst]
+  bool reduced = false;        // after tpg_pairwise_reduce: only this rank's band holds (complete) sums
 };
 #define TPG_PW_MAX_LOCI 2147483647ll
 
@@ -188,6 +197,19 @@ struct InBuf {
 };
 
 void tpg_resident_release(tpg_ctx* ctx);
+
+// collectives over the ranks of a communicator (comm.hip).  One rank = one context.  Transport: RCCL (production:
+// one process per GPU, or one process driving several GPUs), or a caller-supplied all-reduce through host memory
+// (rehearsals of the sharded paths without RCCL: tests with gloo, several ranks sharing one GPU).
+struct tpg_comm {
+  tpg_ctx* ctx = nullptr;
+  int nranks = 1, rank = 0;
+  void* nccl = nullptr;  // ncclComm_t
+  int (*host_fn)(void* user, void* buf, int64_t count, int dtype) = nullptr;  // in-place sum; dtype 0 int32, 1 float64
+  void* host_user = nullptr;
+};
+int tpg_comm_reduce_scatter_i32(tpg_comm* comm, int32_t* d_buf, int64_t chunk_count);  // in place, chunk r -> rank r
+int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype);          // in place, device memory
 
 // ---- cross-TU entry points (one per .hip file) -----------------------------
 int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,

@@ -72,6 +72,7 @@ __device__ __forceinline__ int64_t tpg_pw_unit_index(int nst, int I, int jt) {
 __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __restrict__ T, int64_t KG,
                                                                  int64_t kg_begin, int64_t kg_end, int nst,
                                                                  const int2* __restrict__ order, int64_t nun, int S,
+                                                                 const int64_t* __restrict__ rowpad,
                                                                  int32_t* __restrict__ acc_out) {
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
     const int ks = (int)(un / nun);
     const int2 ijt = order[un % nun];
     const int I = ijt.x, jt = ijt.y;
-    const int64_t tp0 = tpg_pw_unit_index(nst, I, jt);
+    const int64_t tp0 = tpg_pw_unit_index(nst, I, jt) + rowpad[I];
     const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
 
     const uint4* pa0 = T + ((int64_t)(2 * I) * KG) * 64 + lane;
@@ -182,18 +183,50 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
 }
 
 // ---------------------------------------------------------------------------
-extern "C" size_t tpg_pairwise_buffer_bytes(int64_t n) {
-  const int64_t nst = ceil_div(n, 64);
-  return (size_t)(nst * (nst + 1)) * TPG_PW_TILE_INTS * sizeof(int32_t);
+// Bands: super-tile rows dealt to `nranks` ranks in contiguous runs of (nearly) equal unit counts (row I holds
+// 2 (nst - I) units).  -> band boundaries and the padded chunk size (units) every band gets in the buffer.
+static void pw_bands(int64_t nst, int nranks, std::vector<int32_t>& band, int64_t& chunk) {
+  const int64_t total = nst * (nst + 1);
+  band.assign((size_t)nranks + 1, (int32_t)nst);
+  band[0] = 0;
+  // boundary r = the row boundary whose cumulative unit count is nearest to r / nranks of the total
+  int64_t cum = 0;
+  int r = 1;
+  for (int64_t I = 0; I < nst && r < nranks; I++) {
+    const int64_t before = cum;
+    cum += 2 * (nst - I);
+    while (r < nranks && cum * nranks >= total * r) {
+      const bool cut_before = (total * r - before * nranks) < (cum * nranks - total * r) && (int32_t)I > band[(size_t)r - 1];
+      band[(size_t)r] = (int32_t)(cut_before ? I : I + 1);
+      r++;
+    }
+  }
+  chunk = 0;
+  auto off = [&](int64_t I) { return 2 * (I * nst - (I * (I - 1)) / 2); };
+  for (int q = 0; q < nranks; q++) chunk = std::max(chunk, off(band[(size_t)q + 1]) - off(band[(size_t)q]));
+  if (chunk < 1) chunk = 1;
 }
 
-extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tpg_pairwise** out) {
-  TpgEnter _enter(ctx);
+static size_t pw_buffer_bytes(int64_t n, int nranks) {
+  const int64_t nst = ceil_div(n, 64);
+  std::vector<int32_t> band;
+  int64_t chunk;
+  pw_bands(nst, nranks, band, chunk);
+  return (size_t)(chunk * nranks) * TPG_PW_TILE_INTS * sizeof(int32_t);
+}
+
+extern "C" size_t tpg_pairwise_buffer_bytes(int64_t n) { return pw_buffer_bytes(n, 1); }
+extern "C" size_t tpg_pairwise_buffer_bytes_sharded(int64_t n, int nranks) { return pw_buffer_bytes(n, nranks < 1 ? 1 : nranks); }
+
+static int pairwise_create(tpg_ctx* ctx, int64_t n, int nranks, int rank, void* ext_buffer, tpg_pairwise** out) {
   TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && n < (1 << 22), TPG_EINVAL, "bad n = %lld", (long long)n);
-  TPG_HIP(hipSetDevice(ctx->device));
+  TPG_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, TPG_EINVAL, "bad rank %d of %d", rank, nranks);
   tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 64), 0, nullptr, false, nullptr, 0, 0, 0};
   pw->ntp = pw->nst * (pw->nst + 1);
+  pw->nranks = nranks;
+  pw->rank = rank;
+  pw_bands(pw->nst, nranks, pw->band, pw->chunk_units);
   {
     // units (I, jt), jt >= 2 I, in patch order: blocks of 16 column tiles, inside a block row after row.  Column
     // tiles that hold only padding (32 jt >= n: all-missing codes, zero products) are left out -- their slabs stay
@@ -207,15 +240,23 @@ extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tp
         for (int jt = std::max(pc * 16, 2 * I); jt < c1; jt++) order.push_back(make_int2(I, jt));
     }
     pw->nun = (int64_t)order.size();
+    std::vector<int64_t> rowpad((size_t)nst);
+    auto off = [&](int64_t I) { return 2 * (I * nst - (I * (I - 1)) / 2); };
+    for (int r = 0; r < nranks; r++)
+      for (int I = pw->band[(size_t)r]; I < pw->band[(size_t)r + 1]; I++)
+        rowpad[(size_t)I] = (int64_t)r * pw->chunk_units - off(pw->band[(size_t)r]);
     hipError_t e = tpg_pmalloc(&pw->order, sizeof(int2) * order.size());
-    if (e == hipSuccess) e = hipMemcpy(pw->order, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { tpg_pairwise_free(pw); tpg_set_error("pairwise order table: %s", hipGetErrorString(e)); return TPG_EHIP; }
+    if (e == hipSuccess) e = hipMemcpyAsync(pw->order, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = tpg_pmalloc((void**)&pw->rowpad, sizeof(int64_t) * rowpad.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(pw->rowpad, rowpad.data(), sizeof(int64_t) * rowpad.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host vectors go out of scope
+    if (e != hipSuccess) { tpg_pairwise_free(pw); tpg_set_error("pairwise tables: %s", hipGetErrorString(e)); return TPG_EHIP; }
   }
   if (ext_buffer) {
     if (!tpg_is_device_ptr(ext_buffer)) { tpg_pairwise_free(pw); tpg_set_error("ext_buffer is not device memory"); return TPG_EINVAL; }
     pw->acc = (int32_t*)ext_buffer;
   } else {
-    hipError_t e = tpg_pmalloc((void**)&pw->acc, tpg_pairwise_buffer_bytes(n));
+    hipError_t e = tpg_pmalloc((void**)&pw->acc, pw_buffer_bytes(n, nranks));
     if (e != hipSuccess) { tpg_pairwise_free(pw); tpg_set_error("hipMalloc pairwise buffer: %s", hipGetErrorString(e)); return TPG_EHIP; }
     pw->owns = true;
   }
@@ -225,10 +266,82 @@ extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tp
   return TPG_OK;
 }
 
+extern "C" int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tpg_pairwise** out) {
+  TpgEnter _enter(ctx);
+  return pairwise_create(ctx, n, 1, 0, ext_buffer, out);
+}
+
+// Accumulators of one rank of a communicator: same kernel, the buffer laid out for one reduce-scatter
+// (tpg_pairwise_reduce); see tpg_pairwise in common.h.
+extern "C" int tpg_pairwise_create_sharded(tpg_ctx* ctx, const tpg_comm* comm, int64_t n, tpg_pairwise** out) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(comm, TPG_EINVAL, "null communicator");
+  TPG_REQUIRE(comm->ctx == ctx, TPG_EINVAL, "the communicator belongs to another context");
+  return pairwise_create(ctx, n, comm->nranks, comm->rank, nullptr, out);
+}
+
+// Sum the partial cross-products of all ranks: one reduce-scatter of the int32 slabs (exact, order independent).
+// Afterwards this rank holds the complete sums of ITS band of super-tile rows only, and the count / epilogue entry
+// points write only the part of the N x N outputs that band covers: rows [row0, row1) x columns >= row0 and its
+// mirror image (tpg_pairwise_band).
+extern "C" int tpg_pairwise_reduce(tpg_ctx* ctx, tpg_comm* comm, tpg_pairwise* pw) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && comm && pw, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(comm->ctx == ctx && pw->ctx == ctx, TPG_EINVAL, "communicator / accumulators belong to another context");
+  TPG_REQUIRE(pw->nranks == comm->nranks && pw->rank == comm->rank, TPG_EINVAL,
+              "accumulators were created for rank %d of %d, the communicator is rank %d of %d", pw->rank, pw->nranks,
+              comm->rank, comm->nranks);
+  TPG_REQUIRE(!pw->reduced, TPG_EINVAL, "already reduced: zero the accumulators first");
+  {
+    ProfScope ps(ctx, "pairwise_reduce_scatter");
+    TPG_TRY(tpg_comm_reduce_scatter_i32(comm, pw->acc, pw->chunk_units * TPG_PW_TILE_INTS));
+  }
+  // the locus count behind the overflow guard is the total over the ranks
+  double loci = (double)pw->loci;
+  if (comm->nranks > 1) {
+    double* d_l = nullptr;
+    TPG_HIP(tpg_pmalloc((void**)&d_l, sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d_l, &loci, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    int rc = e == hipSuccess ? tpg_comm_allreduce(comm, d_l, 1, 1) : TPG_EHIP;
+    if (rc == TPG_OK) {
+      e = hipMemcpyAsync(&loci, d_l, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    tpg_pfree(d_l);
+    TPG_HIP(e);
+    TPG_TRY(rc);
+  }
+  TPG_REQUIRE(loci <= (double)TPG_PW_MAX_LOCI, TPG_EUNSUPPORTED, "%.0f loci over all ranks overflow the int32 pair counts", loci);
+  pw->loci = (int64_t)loci;
+  pw->reduced = true;
+  return TPG_OK;
+}
+
+// the band of rank `rank` when n individuals are shared among nranks ranks (host arithmetic only: no GPU needed)
+extern "C" int tpg_pairwise_band_of(int64_t n, int nranks, int rank, int64_t* row0, int64_t* row1) {
+  TPG_REQUIRE(row0 && row1 && n > 0 && nranks >= 1 && rank >= 0 && rank < nranks, TPG_EINVAL, "bad argument");
+  std::vector<int32_t> band;
+  int64_t chunk;
+  pw_bands(ceil_div(n, 64), nranks, band, chunk);
+  *row0 = std::min<int64_t>(n, 64 * (int64_t)band[(size_t)rank]);
+  *row1 = std::min<int64_t>(n, 64 * (int64_t)band[(size_t)rank + 1]);
+  return TPG_OK;
+}
+
+// rows [row0, row1) of the individuals whose pairs this rank's outputs cover (all of them before a reduction)
+extern "C" int tpg_pairwise_band(const tpg_pairwise* pw, int64_t* row0, int64_t* row1) {
+  TPG_REQUIRE(pw && row0 && row1, TPG_EINVAL, "null argument");
+  if (!pw->reduced || pw->nranks == 1) { *row0 = 0; *row1 = pw->n; return TPG_OK; }
+  *row0 = std::min<int64_t>(pw->n, 64 * (int64_t)pw->band[(size_t)pw->rank]);
+  *row1 = std::min<int64_t>(pw->n, 64 * (int64_t)pw->band[(size_t)pw->rank + 1]);
+  return TPG_OK;
+}
+
 extern "C" void tpg_pairwise_free(tpg_pairwise* pw) {
   if (!pw) return;
   if (pw->owns && pw->acc) tpg_pfree(pw->acc);
   tpg_pfree(pw->order);
+  tpg_pfree(pw->rowpad);
   delete pw;
 }
 
@@ -236,8 +349,9 @@ extern "C" int tpg_pairwise_zero(tpg_ctx* ctx, tpg_pairwise* pw) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
   ProfScope ps(ctx, "pairwise_zero");
-  TPG_HIP(hipMemsetAsync(pw->acc, 0, tpg_pairwise_buffer_bytes(pw->n), ctx->stream));
+  TPG_HIP(hipMemsetAsync(pw->acc, 0, pw_buffer_bytes(pw->n, pw->nranks), ctx->stream));
   pw->loci = 0;
+  pw->reduced = false;
   return TPG_OK;
 }
 
@@ -277,6 +391,7 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && v, TPG_EINVAL, "null argument");
   TPG_REQUIRE(pw->n == v->n, TPG_EINVAL, "pairwise n = %lld but view n = %lld", (long long)pw->n, (long long)v->n);
+  TPG_REQUIRE(!pw->reduced, TPG_EINVAL, "the accumulators were reduced over the ranks: zero them before accumulating again");
   if (col_end < 0) col_end = v->m;
   TPG_REQUIRE(col_begin >= 0 && col_begin <= col_end && col_end <= v->m, TPG_EINVAL, "bad locus range [%lld,%lld)",
               (long long)col_begin, (long long)col_end);
@@ -305,7 +420,7 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
     if (eff > best + 0.01) { best = eff; bestS = (int)S; }
   }
   TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T, v->KG,
-             kg0, kg1, (int)pw->nst, (const int2*)pw->order, pw->nun, bestS, pw->acc);
+             kg0, kg1, (int)pw->nst, (const int2*)pw->order, pw->nun, bestS, (const int64_t*)pw->rowpad, pw->acc);
   TPG_CHECK_LAUNCH();
   return TPG_OK;
 }
@@ -365,16 +480,18 @@ __device__ __forceinline__ void tpg_pw_emit(const PwCounts c, int mode, double s
 // threads running down a column of the column-major outputs, and mirrored for the lower triangle, threads running
 // along the slab's column index -- so that every store instruction writes 32 contiguous doubles and no slab element
 // is fetched more than once.
-__global__ __launch_bounds__(256) void tpg_pairwise_epilogue_kernel(const int32_t* __restrict__ acc, int nst, int n,
+__global__ __launch_bounds__(256) void tpg_pairwise_epilogue_kernel(const int32_t* __restrict__ acc,
+                                                                    const int64_t* __restrict__ rowpad, int ti0,
+                                                                    int nst, int n,
                                                                     int mode, double scale, long long quirk,
                                                                     double* __restrict__ o0,
                                                                     double* __restrict__ o1, double* __restrict__ o2,
                                                                     double* __restrict__ o3, double* __restrict__ o4,
                                                                     double* __restrict__ o5) {
-  const int ti = blockIdx.y, tj = blockIdx.x;
+  const int ti = blockIdx.y + ti0, tj = blockIdx.x + ti0;  // tile rows of this rank's band, columns from its first one
   if (ti > tj) return;
   __shared__ int sp[5][32][33];
-  const int32_t* p = acc + tpg_pw_unit_index(nst, ti >> 1, tj) * TPG_PW_TILE_INTS + ((ti & 1) * 16) * 64;
+  const int32_t* p = acc + (tpg_pw_unit_index(nst, ti >> 1, tj) + rowpad[ti >> 1]) * TPG_PW_TILE_INTS + ((ti & 1) * 16) * 64;
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const int idx = threadIdx.x + 256 * e, reg = idx >> 6, lane = idx & 63;
@@ -405,19 +522,57 @@ __global__ __launch_bounds__(256) void tpg_pairwise_epilogue_kernel(const int32_
   }
 }
 
+// The part of the N x N outputs a rank's accumulators cover: all of it for unsharded (or not yet reduced)
+// accumulators, else rows [r0, r1) x columns [r0, n) (as stored) and its mirror image rows [r0, n) x columns [r0, r1).
+struct PwBand {
+  int ti0, nti;     // first tile row, number of tile rows
+  int64_t r0, r1;   // individuals
+  bool whole;
+};
+static PwBand pw_band(const tpg_pairwise* pw) {
+  PwBand b;
+  const int nt = (int)ceil_div(pw->n, 32);
+  if (!pw->reduced || pw->nranks == 1) return PwBand{0, nt, 0, pw->n, true};
+  const int i0 = pw->band[(size_t)pw->rank], i1 = pw->band[(size_t)pw->rank + 1];
+  b.ti0 = std::min(nt, 2 * i0);
+  b.nti = std::min(nt, 2 * i1) - b.ti0;
+  b.r0 = std::min<int64_t>(pw->n, 64 * (int64_t)i0);
+  b.r1 = std::min<int64_t>(pw->n, 64 * (int64_t)i1);
+  b.whole = false;
+  return b;
+}
+
+// device -> caller for an output the caller holds in host memory: everything, or just the band's two rectangles
+static int pw_commit(tpg_ctx* ctx, OutBuf& o, int64_t n, const PwBand& b) {
+  if (!o.owned || !o.user) return TPG_OK;  // the caller's pointer is device memory: written in place
+  if (b.whole) return o.commit(ctx);
+  if (b.r1 > b.r0) {
+    const size_t pitch = sizeof(double) * (size_t)n, offs = (size_t)b.r0 + (size_t)b.r0 * (size_t)n;
+    TPG_HIP(hipMemcpy2DAsync((double*)o.user + offs, pitch, (const double*)o.d + offs, pitch,
+                             sizeof(double) * (size_t)(b.r1 - b.r0), (size_t)(n - b.r0), hipMemcpyDeviceToHost, ctx->stream));
+    TPG_HIP(hipMemcpy2DAsync((double*)o.user + offs, pitch, (const double*)o.d + offs, pitch,
+                             sizeof(double) * (size_t)(n - b.r0), (size_t)(b.r1 - b.r0), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return TPG_OK;
+}
+
 static int run_epilogue(tpg_ctx* ctx, const tpg_pairwise* pw, int mode, double scale, double* outs[6]) {
   const size_t bytes = sizeof(double) * (size_t)pw->n * (size_t)pw->n;
+  const PwBand band = pw_band(pw);
   OutBuf b[6];
   for (int k = 0; k < 6; k++)
     if (outs[k]) TPG_TRY(b[k].init(outs[k], bytes));
   const unsigned nt = (unsigned)ceil_div(pw->n, 32);
-  TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(nt, nt), dim3(256), 0,
-             (const int32_t*)pw->acc, (int)pw->nst, (int)pw->n, mode, scale, (long long)pw->as_pad_quirk,
-             b[0].dev<double>(), b[1].dev<double>(),
-             b[2].dev<double>(), b[3].dev<double>(), b[4].dev<double>(), b[5].dev<double>());
-  TPG_CHECK_LAUNCH();
+  if (band.nti > 0) {
+    TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(nt - (unsigned)band.ti0, (unsigned)band.nti),
+               dim3(256), 0, (const int32_t*)pw->acc, (const int64_t*)pw->rowpad, band.ti0, (int)pw->nst, (int)pw->n, mode,
+               scale, (long long)pw->as_pad_quirk, b[0].dev<double>(), b[1].dev<double>(), b[2].dev<double>(),
+               b[3].dev<double>(), b[4].dev<double>(), b[5].dev<double>());
+    TPG_CHECK_LAUNCH();
+  }
   for (int k = 0; k < 6; k++)
-    if (outs[k]) TPG_TRY(b[k].commit(ctx));
+    if (outs[k]) TPG_TRY(pw_commit(ctx, b[k], pw->n, band));
   return TPG_OK;
 }
 
@@ -452,14 +607,18 @@ extern "C" int tpg_pairwise_allele_sharing(tpg_ctx* ctx, const tpg_pairwise* pw,
 }
 
 static int grm_from_as(tpg_ctx* ctx, int n, double* d_M);
+static int grm_from_as_band(tpg_ctx* ctx, tpg_comm* comm, int n, const PwBand& band, double* d_M);
 
 // IBS, KING, allele sharing and GRM in one pass over the accumulators (any output may be NULL)
-extern "C" int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int ibs_type, int64_t m, double* ibs,
-                                      double* king, double* allele_sharing, double* grm) {
-  TpgEnter _enter(ctx);
+static int epilogues_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_pairwise* pw, int ibs_type, int64_t m, double* ibs,
+                          double* king, double* allele_sharing, double* grm) {
   TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
   TPG_REQUIRE(ibs_type == TPG_IBS_PROPORTION || ibs_type == TPG_IBS_ADJUSTED_COUNTS, TPG_EINVAL, "bad IBS type");
   const int n = (int)pw->n;
+  const PwBand band = pw_band(pw);
+  TPG_REQUIRE(band.whole || !grm || comm, TPG_EINVAL,
+              "the GRM of reduced, sharded accumulators needs the communicator (its mean runs over all pairs): "
+              "use tpg_pairwise_epilogues_sharded");
   const size_t bytes = sizeof(double) * (size_t)n * (size_t)n;
   OutBuf bi, bk, ba, bg;
   if (ibs) TPG_TRY(bi.init(ibs, bytes));
@@ -469,19 +628,49 @@ extern "C" int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int 
   // GRM needs the allele-sharing matrix: write it into the GRM buffer when the caller does not want both
   double* as_dst = allele_sharing ? ba.dev<double>() : bg.dev<double>();
   const unsigned nt = (unsigned)ceil_div(pw->n, 32);
-  TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(nt, nt), dim3(256), 0,
-             (const int32_t*)pw->acc, (int)pw->nst, n, 4, ibs_type == TPG_IBS_PROPORTION ? 1.0 : (double)m,
-             (long long)pw->as_pad_quirk, bi.dev<double>(), bk.dev<double>(), as_dst, (double*)nullptr, (double*)nullptr, (double*)nullptr);
-  TPG_CHECK_LAUNCH();
-  if (grm) {
-    if (allele_sharing) TPG_HIP(hipMemcpyAsync(bg.dev<double>(), ba.dev<double>(), bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    TPG_TRY(grm_from_as(ctx, n, bg.dev<double>()));
+  if (band.nti > 0) {
+    TPG_LAUNCH(ctx, "pairwise_epilogue", tpg_pairwise_epilogue_kernel, dim3(nt - (unsigned)band.ti0, (unsigned)band.nti),
+               dim3(256), 0, (const int32_t*)pw->acc, (const int64_t*)pw->rowpad, band.ti0, (int)pw->nst, n, 4,
+               ibs_type == TPG_IBS_PROPORTION ? 1.0 : (double)m, (long long)pw->as_pad_quirk, bi.dev<double>(),
+               bk.dev<double>(), as_dst, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+    TPG_CHECK_LAUNCH();
   }
-  if (ibs) TPG_TRY(bi.commit(ctx));
-  if (king) TPG_TRY(bk.commit(ctx));
-  if (allele_sharing) TPG_TRY(ba.commit(ctx));
-  if (grm) TPG_TRY(bg.commit(ctx));
+  if (grm) {
+    if (band.whole) {
+      if (allele_sharing) TPG_HIP(hipMemcpyAsync(bg.dev<double>(), ba.dev<double>(), bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      TPG_TRY(grm_from_as(ctx, n, bg.dev<double>()));
+    } else {
+      if (allele_sharing && band.r1 > band.r0) {  // copy the band's two rectangles
+        const size_t pitch = sizeof(double) * (size_t)n, offs = (size_t)band.r0 + (size_t)band.r0 * (size_t)n;
+        TPG_HIP(hipMemcpy2DAsync(bg.dev<double>() + offs, pitch, ba.dev<double>() + offs, pitch,
+                                 sizeof(double) * (size_t)(band.r1 - band.r0), (size_t)(n - band.r0), hipMemcpyDeviceToDevice, ctx->stream));
+        TPG_HIP(hipMemcpy2DAsync(bg.dev<double>() + offs, pitch, ba.dev<double>() + offs, pitch,
+                                 sizeof(double) * (size_t)(n - band.r0), (size_t)(band.r1 - band.r0), hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      TPG_TRY(grm_from_as_band(ctx, comm, n, band, bg.dev<double>()));
+    }
+  }
+  if (ibs) TPG_TRY(pw_commit(ctx, bi, n, band));
+  if (king) TPG_TRY(pw_commit(ctx, bk, n, band));
+  if (allele_sharing) TPG_TRY(pw_commit(ctx, ba, n, band));
+  if (grm) TPG_TRY(pw_commit(ctx, bg, n, band));
   return TPG_OK;
+}
+
+extern "C" int tpg_pairwise_epilogues(tpg_ctx* ctx, const tpg_pairwise* pw, int ibs_type, int64_t m, double* ibs,
+                                      double* king, double* allele_sharing, double* grm) {
+  TpgEnter _enter(ctx);
+  return epilogues_impl(ctx, nullptr, pw, ibs_type, m, ibs, king, allele_sharing, grm);
+}
+
+// The same on accumulators that tpg_pairwise_reduce left sharded: every rank finishes ITS band (1 / nranks of the
+// tiles) and writes only that part of the outputs; the one number that needs all pairs, the mean of the off-diagonal
+// allele-sharing values behind the GRM, is summed over the ranks (two doubles).
+extern "C" int tpg_pairwise_epilogues_sharded(tpg_ctx* ctx, tpg_comm* comm, const tpg_pairwise* pw, int ibs_type,
+                                              int64_t m, double* ibs, double* king, double* allele_sharing, double* grm) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(comm && comm->ctx == ctx, TPG_EINVAL, "bad communicator");
+  return epilogues_impl(ctx, comm, pw, ibs_type, m, ibs, king, allele_sharing, grm);
 }
 
 // GRM (R/pairwise_grm.R:42-50): mb = mean of the off-diagonal allele-sharing values (na.rm), then
@@ -542,6 +731,80 @@ static int grm_from_as(tpg_ctx* ctx, int n, double* d_M) {
   TPG_CHECK_LAUNCH();
   TPG_HIP(hipStreamSynchronize(ctx->stream));
   return TPG_OK;
+}
+
+// The band form: partial sums over the band's stored elements above the diagonal (rows [r0, r1), columns > row),
+// doubled -- the matrix is symmetric -- and summed over the ranks; then the band's two rectangles are rescaled.
+__global__ __launch_bounds__(256) void tpg_offdiag_sum_band_kernel(const double* __restrict__ M, int n, int r0, int r1,
+                                                                   double* __restrict__ part_sum,
+                                                                   double* __restrict__ part_cnt) {
+  __shared__ double ssum[256], scnt[256];
+  double s = 0, c = 0;
+  const int64_t rows = r1 - r0, total = rows * (int64_t)n;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = r0 + (int)(idx % rows), j = (int)(idx / rows);
+    if (j <= i) continue;
+    const double x = M[i + (int64_t)j * n];
+    if (x == x) { s += x; c += 1; }
+  }
+  ssum[threadIdx.x] = s;
+  scnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { ssum[threadIdx.x] += ssum[threadIdx.x + w]; scnt[threadIdx.x] += scnt[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part_sum[blockIdx.x] = ssum[0]; part_cnt[blockIdx.x] = scnt[0]; }
+}
+
+__global__ void tpg_sum2_kernel(const double* __restrict__ a, const double* __restrict__ b, int nb, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0, c = 0;
+    for (int k = 0; k < nb; k++) { s += a[k]; c += b[k]; }
+    out[0] = 2 * s;  // both triangles
+    out[1] = 2 * c;
+  }
+}
+
+// rows [ra, rb) x columns [ca, cb) of the column-major n x n matrix
+__global__ void tpg_grm_rect_kernel(double* __restrict__ M, int n, int ra, int rb, int ca, int cb, const double* __restrict__ sc) {
+  const double mb = sc[0] / sc[1];
+  const int64_t rows = rb - ra, total = rows * (int64_t)(cb - ca);
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = (ra + idx % rows) + (ca + idx / rows) * (int64_t)n;
+    M[o] = (M[o] - mb) / (1 - mb) * 2;
+  }
+}
+
+static int grm_from_as_band(tpg_ctx* ctx, tpg_comm* comm, int n, const PwBand& band, double* d_M) {
+  const int NB = 256;
+  double* d_part = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_part, sizeof(double) * (2 * NB + 2)));
+  double* d_sc = d_part + 2 * NB;
+  int rc = TPG_OK;
+  hipError_t e = hipMemsetAsync(d_part, 0, sizeof(double) * (2 * NB + 2), ctx->stream);
+  if (e == hipSuccess) {
+    if (band.r1 > band.r0)
+      TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_offdiag_sum_band_kernel, dim3(NB), dim3(256), 0, (const double*)d_M, n,
+                 (int)band.r0, (int)band.r1, d_part, d_part + NB);
+    TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_sum2_kernel, dim3(1), dim3(64), 0, (const double*)d_part,
+               (const double*)(d_part + NB), NB, d_sc);
+    rc = tpg_comm_allreduce(comm, d_sc, 2, 1);  // sum and count over all ranks
+    if (rc == TPG_OK && band.r1 > band.r0) {
+      TPG_LAUNCH(ctx, "grm_scale", tpg_grm_rect_kernel, dim3(1024), dim3(256), 0, d_M, n, (int)band.r0, (int)band.r1,
+                 (int)band.r0, n, (const double*)d_sc);  // as stored
+      if (n > band.r1)
+        TPG_LAUNCH(ctx, "grm_scale", tpg_grm_rect_kernel, dim3(1024), dim3(256), 0, d_M, n, (int)band.r1, n, (int)band.r0,
+                   (int)band.r1, (const double*)d_sc);  // mirror image below the band's diagonal block
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  tpg_pfree(d_part);
+  if (e != hipSuccess) { tpg_set_error("grm (band): %s", hipGetErrorString(e)); return TPG_EHIP; }
+  return rc;
 }
 
 extern "C" int tpg_pairwise_grm(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {

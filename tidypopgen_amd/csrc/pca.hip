@@ -1516,13 +1516,24 @@ static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_
                                const double* d_U, const double* d_dk, int k, double* d_V);
 
 // ---------------------------------------------------------------------------
-static int pca_svd_impl(tpg_ctx* ctx, const tpg_view* v, int k, double tol, double* d, double* u, double* vload,
-                        double* center, double* scale, double* square_frobenius);
+static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, double tol, double* d, double* u,
+                        double* vload, double* center, double* scale, double* square_frobenius);
 
 extern "C" int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,
                                    double* center, double* scale, double* square_frobenius) {
   TpgEnter _enter(ctx);
-  return pca_svd_impl(ctx, v, k, 1e-12, d, u, vload, center, scale, square_frobenius);
+  return pca_svd_impl(ctx, nullptr, v, k, 1e-12, d, u, vload, center, scale, square_frobenius);
+}
+
+// The same with the loci sharded over the ranks of a communicator: `v` holds this rank's loci; center, scale and the
+// loadings are per locus (this rank's rows of v come back); the Gram matrix and the squared Frobenius norm are
+// additive over loci and summed over the ranks inside (one N x N all-reduce of doubles); the eigen step is replicated.
+// One rank: identical to tpg_pca_partial_svd.
+extern "C" int tpg_pca_partial_svd_sharded(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, double* d, double* u,
+                                           double* vload, double* center, double* scale, double* square_frobenius) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(comm && comm->ctx == ctx, TPG_EINVAL, "bad communicator");
+  return pca_svd_impl(ctx, comm, v, k, 1e-12, d, u, vload, center, scale, square_frobenius);
 }
 
 // gt_pca_randomSVD (R/gt_pca_randomSVD.R:77-135): the reference reaches the same truncated SVD through
@@ -1534,11 +1545,11 @@ extern "C" int tpg_pca_random_svd(tpg_ctx* ctx, const tpg_view* v, int k, double
                                   double* vload, double* center, double* scale, double* square_frobenius) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(tol > 0 && tol < 1, TPG_EINVAL, "tol = %g out of (0, 1)", tol);
-  return pca_svd_impl(ctx, v, k, tol < 1e-12 ? 1e-12 : tol, d, u, vload, center, scale, square_frobenius);
+  return pca_svd_impl(ctx, nullptr, v, k, tol < 1e-12 ? 1e-12 : tol, d, u, vload, center, scale, square_frobenius);
 }
 
-static int pca_svd_impl(tpg_ctx* ctx, const tpg_view* v, int k, double tol, double* d, double* u, double* vload,
-                        double* center, double* scale, double* square_frobenius) {
+static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, double tol, double* d, double* u,
+                        double* vload, double* center, double* scale, double* square_frobenius) {
   TPG_REQUIRE(ctx && v && d && u && vload && center && scale, TPG_EINVAL, "null argument");
   TPG_REQUIRE(k >= 1 && k <= 52 && k <= v->n && k <= v->m, TPG_EINVAL, "k = %d out of range", k);
   const int64_t n = v->n, m = v->m;
@@ -1554,12 +1565,19 @@ static int pca_svd_impl(tpg_ctx* ctx, const tpg_view* v, int k, double tol, doub
   StageTimer st(ctx, "svd");
   TPG_TRY(pca_counts_center_scale(ctx, v, d_counts, oc.dev<double>(), os.dev<double>()));
   st.mark("counts, center, scale");
-  if (square_frobenius) TPG_TRY(frobenius_from_counts(ctx, v, d_counts, oc.dev<double>(), os.dev<double>(), square_frobenius));
+  if (square_frobenius) {
+    TPG_TRY(frobenius_from_counts(ctx, v, d_counts, oc.dev<double>(), os.dev<double>(), square_frobenius));
+    if (comm && comm->nranks > 1) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, square_frobenius, 1));
+  }
   TPG_HIP(tpg_pmalloc((void**)&d_K, sizeof(double) * (size_t)n * (size_t)n));
   fr.b = d_K;
   st.mark("frobenius + alloc K");
   TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true));
   st.mark("gram");
+  if (comm && comm->nranks > 1) {  // K = sum over the ranks' loci of z_j z_j'
+    ProfScope ps(ctx, "pca_gram_allreduce");
+    TPG_TRY(tpg_comm_allreduce(comm, d_K, (int64_t)n * n, 1));
+  }
   std::vector<double> lam((size_t)k);
   TPG_TRY(eig_topk(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>(), tol));
   st.mark("eig_topk");
