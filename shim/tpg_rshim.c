@@ -119,7 +119,8 @@ static mapped_file* genotype_fbm(SEXP BM) {
 
 static tpg_fbm* genotype_fbm_dev(SEXP BM) {
   mapped_file* f = genotype_fbm(BM);
-  if (!f->dev) TPG_R(tpg_fbm_from_host(ctx(), (const uint8_t*)f->map, f->nrow, f->ncol, &f->dev));
+  /* straight from the file (pread into pinned memory, no page faults on the mapping) */
+  if (!f->dev) TPG_R(tpg_fbm_open_bk(ctx(), f->path, f->nrow, f->ncol, &f->dev));
   return f->dev;
 }
 

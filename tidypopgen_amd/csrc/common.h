@@ -53,7 +53,13 @@ struct tpg_ctx {
   int num_cu = 256;
   int pool_id = 0;  // this context's device-memory pool (runtime.hip): blocks are reused in the order of ITS stream
   void* resident = nullptr;  // pairwise.hip: FBM uploads and accumulators kept across increment_* calls
-  bool upload_from_mapped_file = false;  // set by tpg_fbm_open_bk / open_bed around the upload (runtime.hip: tpg_upload)
+  // small host -> device copies without a stream synchronisation: a ring of pinned slots (runtime.hip: tpg_h2d_async)
+  static constexpr int H2D_SLOTS = 8;
+  static constexpr size_t H2D_SLOT_BYTES = 256u << 10;
+  uint8_t* h2d_pinned = nullptr;
+  hipEvent_t h2d_done[H2D_SLOTS] = {};
+  bool h2d_used[H2D_SLOTS] = {};
+  int h2d_next = 0;
 };
 
 struct ProfScope {
@@ -166,6 +172,13 @@ struct TpgEnter {
   ~TpgEnter();
 };
 tpg_ctx* tpg_current_ctx();
+
+// host -> device on the context's stream.  Up to a slot's size the source is copied into pinned memory first, so the
+// caller's buffer is free at return and nothing waits for the stream; larger copies are waited for.
+hipError_t tpg_h2d_async(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);
+// bulk transfers (waited for): large ones are chunked through pinned slots with a team of copying threads
+hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);
+hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 // device allocation helpers
 template <typename T>

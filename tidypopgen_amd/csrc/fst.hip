@@ -301,8 +301,7 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
     if (fst_tot || sum_num)
       TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 16)), dim3(256), 0, d_part,
                  nblocks, P, ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipGetLastError();  // no wait: d_part returns to the pool in stream order, commit() waits for host outputs
     if (e != hipSuccess) { tpg_set_error("fst kernels: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   }
   tpg_pfree(d_part);

@@ -163,56 +163,109 @@ __global__ void tpg_onehot_kernel(const int32_t* __restrict__ cls, int64_t n, in
   }
 }
 
-// cnt[plane][locus][class] (row-major by locus, Cpad classes), planes: 0 het, 1 hom-alt, 2 valid
+// cnt[plane][locus][class] (row-major by locus, Cpad classes), planes: 0 het, 1 hom-alt, 2 valid.
+// One wave owns GC_NLT consecutive 32-locus tiles and GT class tiles (3 planes x GT x GC_NLT accumulator tiles); the
+// four waves of a workgroup share the one-hot fragments of a 128-individual group through double-buffered LDS (each
+// wave fetches a quarter, one barrier per group), so a 1-KiB fragment fetched from L2 feeds 4 x 3 x GC_NLT MFMAs.
+// (With one locus tile per wave and a fragment per MFMA straight from global memory, every wave re-read the whole
+// one-hot array: 10 GB through the L1s per launch at 5 000 x 1 000 000 x 51 groups, 1.07 ms for 1.25 GB of genotypes.)
+// Per 32 loci x 128 individuals the MFMA pipe does 4 x 3 x GT instructions: at GT = 2 the kernel is bound by the
+// int8 MFMA rate (3 * 2 * N * 64 ops per locus), not by the N / 4 bytes per locus it streams.
+#define GC_NLT 2
 template <int GT>
-__global__ __launch_bounds__(256) void tpg_grouped_counts_kernel(const uint4* __restrict__ L,
-                                                                 const uint4* __restrict__ OH, int64_t n_lt,
-                                                                 int64_t Q, int gt0, int GT_total,
-                                                                 int32_t* __restrict__ cnt, int64_t Mpad,
-                                                                 int Cpad) {
-  const int lane = threadIdx.x & 63;
-  const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (lt >= n_lt) return;
-  v16i acc[3][GT];
+__global__ __launch_bounds__(256, 1) void tpg_grouped_counts_kernel(const uint4* __restrict__ L,
+                                                                    const uint4* __restrict__ OH, int64_t n_lt,
+                                                                    int64_t Q, int gt0, int GT_total,
+                                                                    int32_t* __restrict__ cnt, int64_t Mpad,
+                                                                    int Cpad) {
+  __shared__ __attribute__((aligned(16))) uint4 ohb[2][4 * GT][64];  // [buffer][K step * GT + class tile][lane]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t lt0 = ((int64_t)blockIdx.x * 4 + wv) * GC_NLT;  // may lie past n_lt: the wave still serves the LDS
+  v16i acc[3][GC_NLT][GT];
 #pragma unroll
   for (int p = 0; p < 3; p++)
 #pragma unroll
-    for (int g = 0; g < GT; g++)
+    for (int t = 0; t < GC_NLT; t++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[p][g][r] = 0;
-  const uint4* pa = L + (lt * Q) * 64 + lane;
+      for (int g = 0; g < GT; g++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[p][t][g][r] = 0;
+  const uint4* pa[GC_NLT];
+#pragma unroll
+  for (int t = 0; t < GC_NLT; t++) pa[t] = L + ((lt0 + t < n_lt ? lt0 + t : 0) * Q) * 64 + lane;  // past the end: a copy
+  // this wave's share of a group's 4 * GT one-hot fragments: items wv, wv + 4, ... (fragment (s, g) of group q sits at
+  // OH[((q * 4 + s) * GT_total + gt0 + g) * 64 + lane])
+  constexpr int NIT = (4 * GT + 3) / 4;
+  const uint4* po = OH + (int64_t)gt0 * 64 + lane;
+  auto frag = [&](int64_t q, int it) { return po[((q * 4 + it / GT) * GT_total + it % GT) * 64]; };
+  uint4 a[GC_NLT], an[GC_NLT], on[NIT];
+#pragma unroll
+  for (int t = 0; t < GC_NLT; t++) a[t] = pa[t][0];
+#pragma unroll
+  for (int j = 0; j < NIT; j++) {
+    const int it = wv + 4 * j;
+    if (it < 4 * GT) ohb[0][it][lane] = frag(0, it);
+  }
+  __syncthreads();
   for (int64_t q = 0; q < Q; q++) {
-    const uint4 a = pa[q * 64];
-    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+    const int64_t qn = q + 1 < Q ? q + 1 : q;
+    const int cur = (int)(q & 1);
+#pragma unroll
+    for (int t = 0; t < GC_NLT; t++) an[t] = pa[t][qn * 64];
+#pragma unroll
+    for (int j = 0; j < NIT; j++) {
+      const int it = wv + 4 * j;
+      if (it < 4 * GT) on[j] = frag(qn, it);
+    }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-      v4i fh, f2, fv;
+      v4i fh[GC_NLT], f2[GC_NLT], fv[GC_NLT];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t c = tpg_codes(aw[s], k);
-        fh[k] = tpg_lut(TPG_LUT_H, c);
-        f2[k] = tpg_lut(TPG_LUT_E2, c);
-        fv[k] = tpg_lut(TPG_LUT_V, c);
+      for (int t = 0; t < GC_NLT; t++) {
+        const uint32_t w = s == 0 ? a[t].x : s == 1 ? a[t].y : s == 2 ? a[t].z : a[t].w;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t c = tpg_codes(w, k);
+          fh[t][k] = tpg_lut(TPG_LUT_H, c);
+          f2[t][k] = tpg_lut(TPG_LUT_E2, c);
+          fv[t][k] = tpg_lut(TPG_LUT_V, c);
+        }
       }
 #pragma unroll
       for (int g = 0; g < GT; g++) {
-        const uint4 b = OH[((q * 4 + s) * GT_total + gt0 + g) * 64 + lane];
+        const uint4 b = ohb[cur][s * GT + g][lane];
         v4i fb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
-        acc[0][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fh, fb, acc[0][g], 0, 0, 0);
-        acc[1][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f2, fb, acc[1][g], 0, 0, 0);
-        acc[2][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fv, fb, acc[2][g], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < GC_NLT; t++) {
+          acc[0][t][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fh[t], fb, acc[0][t][g], 0, 0, 0);
+          acc[1][t][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f2[t], fb, acc[1][t][g], 0, 0, 0);
+          acc[2][t][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fv[t], fb, acc[2][t][g], 0, 0, 0);
+        }
       }
     }
+#pragma unroll
+    for (int t = 0; t < GC_NLT; t++) a[t] = an[t];
+    // the other buffer was last read in group q - 1, which every wave left through the barrier below
+#pragma unroll
+    for (int j = 0; j < NIT; j++) {
+      const int it = wv + 4 * j;
+      if (it < 4 * GT) ohb[cur ^ 1][it][lane] = on[j];
+    }
+    __syncthreads();
   }
 #pragma unroll
-  for (int p = 0; p < 3; p++)
+  for (int t = 0; t < GC_NLT; t++) {
+    if (lt0 + t >= n_lt) break;
 #pragma unroll
-    for (int g = 0; g < GT; g++)
+    for (int p = 0; p < 3; p++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int64_t row = lt * 32 + tpg_cd_row(r, lane);
-        cnt[((int64_t)p * Mpad + row) * Cpad + 32 * (gt0 + g) + (lane & 31)] = acc[p][g][r];
-      }
+      for (int g = 0; g < GT; g++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int64_t row = (lt0 + t) * 32 + tpg_cd_row(r, lane);
+          cnt[((int64_t)p * Mpad + row) * Cpad + 32 * (gt0 + g) + (lane & 31)] = acc[p][t][g][r];
+        }
+  }
 }
 
 GroupedCounts::~GroupedCounts() {
@@ -243,11 +296,11 @@ int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, in
   hipError_t e = tpg_pmalloc((void**)&d_oh, (size_t)v->Q * 4 * GT * 1024);
   if (e != hipSuccess) { tpg_pfree(d_cls); tpg_set_error("hipMalloc one-hot: %s", hipGetErrorString(e)); return TPG_EHIP; }
   int rc = TPG_OK;
-  e = hipMemcpyAsync(d_cls, h_cls, sizeof(int32_t) * (size_t)v->n, hipMemcpyHostToDevice, ctx->stream);
+  e = tpg_h2d_async(ctx, d_cls, h_cls, sizeof(int32_t) * (size_t)v->n);
   if (e != hipSuccess) { tpg_set_error("class upload: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   if (rc == TPG_OK) {
     TPG_LAUNCH(ctx, "onehot", tpg_onehot_kernel, dim3(1024), dim3(256), 0, d_cls, v->n, v->Q, GT, d_oh);
-    const unsigned grid = (unsigned)ceil_div(n_lt, 4);
+    const unsigned grid = (unsigned)ceil_div(n_lt, 4 * GC_NLT);
     int g0 = 0;
     while (g0 < GT) {
       if (GT - g0 >= 2) {
@@ -260,8 +313,7 @@ int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, in
         g0 += 1;
       }
     }
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // d_cls / d_oh are freed below
+    e = hipGetLastError();  // d_cls / d_oh go back to this context's pool below: reuse is stream-ordered, no wait needed
     if (e != hipSuccess) { tpg_set_error("grouped counts: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   }
   tpg_pfree(d_cls);
@@ -733,7 +785,7 @@ extern "C" int tpg_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const do
     if (rc == TPG_OK) {
       TPG_LAUNCH(ctx, "alt_freq_finalize", tpg_alt_freq_finalize_kernel, dim3(1024), dim3(256), 0,
                  (const int4*)d_counts, v->m, as_counts, o.dev<double>());
-      hipError_t e = hipStreamSynchronize(ctx->stream);
+      hipError_t e = hipGetLastError();
       if (e != hipSuccess) { tpg_set_error("alt_freq: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
     }
     tpg_pfree(d_counts);
@@ -773,8 +825,7 @@ static int grouped_common(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupI
   TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3((unsigned)ceil_div(v->m, 64)), dim3(256), 0,
              gc.cnt, gc.Mpad, gc.Cpad, v->m, ngroups, cp.has_hap, mode, as_counts, gs.dev<int32_t>(), b0.dev<double>(),
              b1.dev<double>(), b2.dev<double>(), b3.dev<double>());
-  TPG_CHECK_LAUNCH();
-  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  TPG_CHECK_LAUNCH();  // outputs in device memory are ready in stream order; host outputs are waited for in commit()
   if (o0) TPG_TRY(b0.commit(ctx));
   if (o1) TPG_TRY(b1.commit(ctx));
   if (o2) TPG_TRY(b2.commit(ctx));

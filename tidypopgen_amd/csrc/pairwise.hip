@@ -606,7 +606,6 @@ extern "C" int tpg_pairwise_allele_sharing(tpg_ctx* ctx, const tpg_pairwise* pw,
   return run_epilogue(ctx, pw, 3, 1.0, outs);
 }
 
-static int grm_from_as(tpg_ctx* ctx, int n, double* d_M);
 static int grm_from_as_band(tpg_ctx* ctx, tpg_comm* comm, int n, const PwBand& band, double* d_M);
 
 // IBS, KING, allele sharing and GRM in one pass over the accumulators (any output may be NULL)
@@ -638,7 +637,7 @@ static int epilogues_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_pairwise* pw, 
   if (grm) {
     if (band.whole) {
       if (allele_sharing) TPG_HIP(hipMemcpyAsync(bg.dev<double>(), ba.dev<double>(), bytes, hipMemcpyDeviceToDevice, ctx->stream));
-      TPG_TRY(grm_from_as(ctx, n, bg.dev<double>()));
+      TPG_TRY(grm_from_as_band(ctx, nullptr, n, band, bg.dev<double>()));
     } else {
       if (allele_sharing && band.r1 > band.r0) {  // copy the band's two rectangles
         const size_t pitch = sizeof(double) * (size_t)n, offs = (size_t)band.r0 + (size_t)band.r0 * (size_t)n;
@@ -674,67 +673,11 @@ extern "C" int tpg_pairwise_epilogues_sharded(tpg_ctx* ctx, tpg_comm* comm, cons
 }
 
 // GRM (R/pairwise_grm.R:42-50): mb = mean of the off-diagonal allele-sharing values (na.rm), then
-// 2 (M - mb) / (1 - mb).  The mean is reduced per block in double and finished on the host in long
-// double (R's mean() accumulates in long double too).
-__global__ __launch_bounds__(256) void tpg_offdiag_sum_kernel(const double* __restrict__ M, int n,
-                                                              double* __restrict__ part_sum,
-                                                              unsigned long long* __restrict__ part_cnt) {
-  __shared__ double ssum[256];
-  __shared__ unsigned long long scnt[256];
-  double s = 0;
-  unsigned long long c = 0;
-  const int64_t total = (int64_t)n * n;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int i = (int)(idx % n), j = (int)(idx / n);
-    const double x = M[idx];
-    if (i != j && x == x) { s += x; c++; }
-  }
-  ssum[threadIdx.x] = s;
-  scnt[threadIdx.x] = c;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) { ssum[threadIdx.x] += ssum[threadIdx.x + w]; scnt[threadIdx.x] += scnt[threadIdx.x + w]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { part_sum[blockIdx.x] = ssum[0]; part_cnt[blockIdx.x] = scnt[0]; }
-}
-
-__global__ void tpg_grm_kernel(double* __restrict__ M, int64_t total, double mb) {
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x)
-    M[idx] = (M[idx] - mb) / (1 - mb) * 2;
-}
-
-// in place: allele-sharing matrix (device) -> GRM
-static int grm_from_as(tpg_ctx* ctx, int n, double* d_M) {
-  const int NB = 512;
-  double* d_sum = nullptr;
-  unsigned long long* d_cnt = nullptr;
-  TPG_HIP(tpg_pmalloc((void**)&d_sum, sizeof(double) * NB));
-  hipError_t e = tpg_pmalloc((void**)&d_cnt, sizeof(unsigned long long) * NB);
-  if (e != hipSuccess) { tpg_pfree(d_sum); tpg_set_error("hipMalloc: %s", hipGetErrorString(e)); return TPG_EHIP; }
-  TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_offdiag_sum_kernel, dim3(NB), dim3(256), 0, (const double*)d_M, n, d_sum, d_cnt);
-  std::vector<double> hs(NB);
-  std::vector<unsigned long long> hc(NB);
-  e = hipMemcpyAsync(hs.data(), d_sum, sizeof(double) * NB, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(hc.data(), d_cnt, sizeof(unsigned long long) * NB, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  tpg_pfree(d_sum);
-  tpg_pfree(d_cnt);
-  if (e != hipSuccess) { tpg_set_error("grm reduce: %s", hipGetErrorString(e)); return TPG_EHIP; }
-  long double s = 0;
-  unsigned long long c = 0;
-  for (int b = 0; b < NB; b++) { s += hs[b]; c += hc[b]; }
-  const double mb = c ? (double)(s / (long double)c) : NAN;
-  TPG_LAUNCH(ctx, "grm_scale", tpg_grm_kernel, dim3(2048), dim3(256), 0, d_M, (int64_t)n * n, mb);
-  TPG_CHECK_LAUNCH();
-  TPG_HIP(hipStreamSynchronize(ctx->stream));
-  return TPG_OK;
-}
-
-// The band form: partial sums over the band's stored elements above the diagonal (rows [r0, r1), columns > row),
-// doubled -- the matrix is symmetric -- and summed over the ranks; then the band's two rectangles are rescaled.
+// 2 (M - mb) / (1 - mb).  The mean stays on the device (no host round trip in the middle of the step): per-block
+// partial sums in double over the stored elements above the diagonal, doubled (the matrix is symmetric), one thread
+// adds the partials in a fixed order.
+// Band form (one band = everything for unsharded accumulators): rows [r0, r1), columns > row; the partial sums of
+// the ranks are added by an all-reduce; then the band's two rectangles are rescaled.
 __global__ __launch_bounds__(256) void tpg_offdiag_sum_band_kernel(const double* __restrict__ M, int n, int r0, int r1,
                                                                    double* __restrict__ part_sum,
                                                                    double* __restrict__ part_cnt) {
@@ -791,7 +734,7 @@ static int grm_from_as_band(tpg_ctx* ctx, tpg_comm* comm, int n, const PwBand& b
                  (int)band.r0, (int)band.r1, d_part, d_part + NB);
     TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_sum2_kernel, dim3(1), dim3(64), 0, (const double*)d_part,
                (const double*)(d_part + NB), NB, d_sc);
-    rc = tpg_comm_allreduce(comm, d_sc, 2, 1);  // sum and count over all ranks
+    if (comm) rc = tpg_comm_allreduce(comm, d_sc, 2, 1);  // sum and count over all ranks
     if (rc == TPG_OK && band.r1 > band.r0) {
       TPG_LAUNCH(ctx, "grm_scale", tpg_grm_rect_kernel, dim3(1024), dim3(256), 0, d_M, n, (int)band.r0, (int)band.r1,
                  (int)band.r0, n, (const double*)d_sc);  // as stored
@@ -800,9 +743,8 @@ static int grm_from_as_band(tpg_ctx* ctx, tpg_comm* comm, int n, const PwBand& b
                    (int)band.r1, (const double*)d_sc);  // mirror image below the band's diagonal block
     }
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
-  tpg_pfree(d_part);
+  tpg_pfree(d_part);  // stream-ordered: the pool hands it out again behind the kernels above
   if (e != hipSuccess) { tpg_set_error("grm (band): %s", hipGetErrorString(e)); return TPG_EHIP; }
   return rc;
 }

@@ -245,6 +245,11 @@ extern "C" void tpg_ctx_destroy(tpg_ctx* ctx) {
     (void)tpg_prof_resolve(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->h2d_pinned) {
+      for (int k = 0; k < tpg_ctx::H2D_SLOTS; k++)
+        if (ctx->h2d_done[k]) (void)hipEventDestroy(ctx->h2d_done[k]);
+      (void)hipHostFree(ctx->h2d_pinned);
+    }
     tpg_resident_release(ctx);
     pool_close(ctx->pool_id);  // only this context's blocks
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -290,8 +295,7 @@ extern "C" void tpg_dev_free(void* p) {
 extern "C" int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && host_dst && dev_src, TPG_EINVAL, "null argument");
-  TPG_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  TPG_HIP(tpg_download(ctx, host_dst, dev_src, bytes));
   return TPG_OK;
 }
 
@@ -328,14 +332,39 @@ int OutBuf::init(void* user_ptr, size_t nbytes) {
   return TPG_OK;
 }
 int OutBuf::commit(tpg_ctx* ctx) {
-  if (owned && user && bytes) {
-    TPG_HIP(hipMemcpyAsync(user, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    TPG_HIP(hipStreamSynchronize(ctx->stream));
-  }
+  if (owned && user && bytes) TPG_HIP(tpg_download(ctx, user, d, bytes));
   return TPG_OK;
 }
 OutBuf::~OutBuf() {
   if (owned && d) tpg_pfree(d);
+}
+
+hipError_t tpg_h2d_async(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  if (bytes > tpg_ctx::H2D_SLOT_BYTES) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+  }
+  if (!ctx->h2d_pinned) {
+    hipError_t e = hipHostMalloc((void**)&ctx->h2d_pinned, tpg_ctx::H2D_SLOT_BYTES * tpg_ctx::H2D_SLOTS, hipHostMallocDefault);
+    if (e != hipSuccess) { ctx->h2d_pinned = nullptr; return e; }
+    for (int k = 0; k < tpg_ctx::H2D_SLOTS; k++) {
+      e = hipEventCreateWithFlags(&ctx->h2d_done[k], hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+  }
+  const int k = ctx->h2d_next;
+  ctx->h2d_next = (k + 1) % tpg_ctx::H2D_SLOTS;
+  if (ctx->h2d_used[k]) {  // the copy that last used this slot (8 copies ago) has long finished; make sure
+    hipError_t e = hipEventSynchronize(ctx->h2d_done[k]);
+    if (e != hipSuccess) return e;
+  }
+  uint8_t* slot = ctx->h2d_pinned + (size_t)k * tpg_ctx::H2D_SLOT_BYTES;
+  memcpy(slot, src, bytes);
+  hipError_t e = hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipEventRecord(ctx->h2d_done[k], ctx->stream);
+  ctx->h2d_used[k] = true;
+  return e;
 }
 
 int InBuf::init(tpg_ctx* ctx, const void* user_ptr, size_t nbytes) {
@@ -344,8 +373,7 @@ int InBuf::init(tpg_ctx* ctx, const void* user_ptr, size_t nbytes) {
     return TPG_OK;
   }
   TPG_HIP(tpg_pmalloc(&owned_ptr, nbytes > 0 ? nbytes : 16));
-  if (nbytes) TPG_HIP(hipMemcpyAsync(owned_ptr, user_ptr, nbytes, hipMemcpyHostToDevice, ctx->stream));
-  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  TPG_HIP(tpg_h2d_async(ctx, owned_ptr, user_ptr, nbytes));  // the caller's buffer is free once this returns
   d = owned_ptr;
   return TPG_OK;
 }
@@ -355,61 +383,144 @@ InBuf::~InBuf() {
 
 // ---------------------------------------------------------------------------
 // Host -> HBM upload, the cold-start cost of every analysis (5 GB for a 5 000 x 1 000 000 FBM).  Memory the caller
-// already holds goes up with one hipMemcpy (measured 45-56 GB/s from pageable memory on the MI355X boxes).  An
-// mmapped backing file does better in pieces (46 against 35 GB/s with a warm page cache): UPLOAD_SLOTS pinned 32-MiB
-// slots are filled by UPLOAD_THREADS host threads in parallel and sent with hipMemcpyAsync, so the page faults, the
-// host copy and the DMA of consecutive chunks overlap.  The slots are allocated once per process.
+// already holds goes up with one hipMemcpy (pageable: the runtime stages it).  A backing FILE goes up in pieces:
+// UPLOAD_SLOTS pinned 32-MiB slots are filled by UPLOAD_THREADS host threads with pread() straight from the page
+// cache (no mapping of the file: an mmap costs a page fault per 4 KiB on first touch, which capped the mapped-file path
+// at ~13 GB/s on a RAM-backed file) and sent with hipMemcpyAsync, so file reads and DMA of consecutive chunks overlap.
+// The slots are allocated once per process.
 static constexpr size_t UPLOAD_CHUNK = 32u << 20;
-static constexpr int UPLOAD_SLOTS = 4, UPLOAD_THREADS = 8;
-hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes, bool mapped_file) {
-  if (!mapped_file || bytes <= (4u << 20)) {
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
-    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
-  }
-  static std::mutex mu;  // one upload at a time per process: the slots are shared
-  std::lock_guard<std::mutex> lk(mu);
-  static uint8_t* slot[UPLOAD_SLOTS] = {nullptr};
-  static hipEvent_t done[UPLOAD_SLOTS];
-  static bool ready = false;
-  if (!ready) {
-    for (int b = 0; b < UPLOAD_SLOTS; b++) {
-      hipError_t e = hipHostMalloc((void**)&slot[b], UPLOAD_CHUNK, hipHostMallocDefault);
-      if (e == hipSuccess) {
-        e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
-        if (e != hipSuccess) { (void)hipHostFree(slot[b]); slot[b] = nullptr; }
-      }
-      if (e != hipSuccess) {  // give back what was created so far; the next call starts over
-        for (int c = 0; c < b; c++) { (void)hipHostFree(slot[c]); (void)hipEventDestroy(done[c]); slot[c] = nullptr; }
-        return e;
-      }
+static constexpr int UPLOAD_SLOTS = 4, UPLOAD_THREADS = 16;
+static std::mutex g_upload_mu;  // one chunked transfer at a time per process: the slots are shared
+static uint8_t* g_upload_slot[UPLOAD_SLOTS] = {nullptr};
+static hipEvent_t g_upload_done[UPLOAD_SLOTS];
+static bool g_upload_ready = false;
+
+static hipError_t upload_slots_init() {
+  if (g_upload_ready) return hipSuccess;
+  for (int b = 0; b < UPLOAD_SLOTS; b++) {
+    hipError_t e = hipHostMalloc((void**)&g_upload_slot[b], UPLOAD_CHUNK, hipHostMallocDefault);
+    if (e == hipSuccess) {
+      e = hipEventCreateWithFlags(&g_upload_done[b], hipEventDisableTiming);
+      if (e != hipSuccess) { (void)hipHostFree(g_upload_slot[b]); g_upload_slot[b] = nullptr; }
     }
-    ready = true;
+    if (e != hipSuccess) {  // give back what was created so far; the next call starts over
+      for (int c = 0; c < b; c++) { (void)hipHostFree(g_upload_slot[c]); (void)hipEventDestroy(g_upload_done[c]); g_upload_slot[c] = nullptr; }
+      return e;
+    }
   }
-  const uint8_t* s = (const uint8_t*)src;
+  g_upload_ready = true;
+  return hipSuccess;
+}
+
+// fill(dst_pinned, offset, len) copies bytes [offset, offset + len) of the source into pinned memory; returns false on
+// a read error
+template <typename Fill>
+static hipError_t upload_chunked(tpg_ctx* ctx, void* dst, size_t bytes, Fill fill, bool* io_error) {
+  std::lock_guard<std::mutex> lk(g_upload_mu);
+  hipError_t e = upload_slots_init();
+  if (e != hipSuccess) return e;
   uint8_t* d = (uint8_t*)dst;
   bool used[UPLOAD_SLOTS] = {false};
-  hipError_t e = hipSuccess;
   int b = 0;
-  for (size_t off = 0; off < bytes && e == hipSuccess; off += UPLOAD_CHUNK, b = (b + 1) % UPLOAD_SLOTS) {
+  for (size_t off = 0; off < bytes && e == hipSuccess && !*io_error; off += UPLOAD_CHUNK, b = (b + 1) % UPLOAD_SLOTS) {
     const size_t len = bytes - off < UPLOAD_CHUNK ? bytes - off : UPLOAD_CHUNK;
-    if (used[b]) e = hipEventSynchronize(done[b]);  // the DMA out of this slot has finished
+    if (used[b]) e = hipEventSynchronize(g_upload_done[b]);  // the DMA out of this slot has finished
     if (e != hipSuccess) break;
-    const size_t part = (len + UPLOAD_THREADS - 1) / UPLOAD_THREADS;
+    const size_t part = ((len + UPLOAD_THREADS - 1) / UPLOAD_THREADS + 4095) & ~(size_t)4095;
+    std::thread th[UPLOAD_THREADS];
+    bool ok[UPLOAD_THREADS];
+    int nth = 0;
+    for (int t = 0; t < UPLOAD_THREADS; t++) {
+      const size_t a = (size_t)t * part;
+      if (a >= len) break;
+      const size_t l = len - a < part ? len - a : part;
+      ok[nth] = true;
+      bool* okp = &ok[nth];
+      uint8_t* slot = g_upload_slot[b];
+      th[nth++] = std::thread([=]() { *okp = fill(slot + a, off + a, l); });
+    }
+    for (int t = 0; t < nth; t++) { th[t].join(); if (!ok[t]) *io_error = true; }
+    if (*io_error) break;
+    e = hipMemcpyAsync(d + off, g_upload_slot[b], len, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(g_upload_done[b], ctx->stream);
+    used[b] = true;
+  }
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  return e != hipSuccess ? e : e2;
+}
+
+// the bytes [file_off, file_off + bytes) of an open file -> device memory
+static int upload_from_file(tpg_ctx* ctx, void* dst, int fd, size_t file_off, size_t bytes, const char* what) {
+  bool io_error = false;
+  hipError_t e = upload_chunked(ctx, dst, bytes, [=](uint8_t* p, size_t off, size_t len) {
+    size_t got = 0;
+    while (got < len) {
+      const ssize_t r = pread(fd, p + got, len - got, (off_t)(file_off + off + got));
+      if (r <= 0) return false;
+      got += (size_t)r;
+    }
+    return true;
+  }, &io_error);
+  if (io_error) { tpg_set_error("%s: read error", what); return TPG_EINVAL; }
+  if (e != hipSuccess) { tpg_set_error("%s: upload failed: %s", what, hipGetErrorString(e)); return TPG_EHIP; }
+  return TPG_OK;
+}
+
+// device memory -> host memory the caller owns (pageable): large results come down through the pinned slots, the DMA of
+// chunk c + 1 .. c + 3 running while UPLOAD_THREADS threads copy chunk c out of its slot (a single hipMemcpy into
+// pageable memory measured 19 GB/s on N x N matrices of doubles).
+hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes < (64u << 20)) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+  }
+  std::lock_guard<std::mutex> lk(g_upload_mu);
+  hipError_t e = upload_slots_init();
+  if (e != hipSuccess) return e;
+  const uint8_t* sp = (const uint8_t*)src;
+  uint8_t* dp = (uint8_t*)dst;
+  const size_t nchunks = (bytes + UPLOAD_CHUNK - 1) / UPLOAD_CHUNK;
+  auto issue = [&](size_t c) {
+    const size_t off = c * UPLOAD_CHUNK, len = bytes - off < UPLOAD_CHUNK ? bytes - off : UPLOAD_CHUNK;
+    const int b = (int)(c % UPLOAD_SLOTS);
+    hipError_t ee = hipMemcpyAsync(g_upload_slot[b], sp + off, len, hipMemcpyDeviceToHost, ctx->stream);
+    return ee == hipSuccess ? hipEventRecord(g_upload_done[b], ctx->stream) : ee;
+  };
+  for (size_t c = 0; c < nchunks && c < (size_t)UPLOAD_SLOTS && e == hipSuccess; c++) e = issue(c);
+  for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
+    const size_t off = c * UPLOAD_CHUNK, len = bytes - off < UPLOAD_CHUNK ? bytes - off : UPLOAD_CHUNK;
+    const int b = (int)(c % UPLOAD_SLOTS);
+    e = hipEventSynchronize(g_upload_done[b]);
+    if (e != hipSuccess) break;
+    const size_t part = ((len + UPLOAD_THREADS - 1) / UPLOAD_THREADS + 4095) & ~(size_t)4095;
     std::thread th[UPLOAD_THREADS];
     int nth = 0;
     for (int t = 0; t < UPLOAD_THREADS; t++) {
       const size_t a = (size_t)t * part;
       if (a >= len) break;
       const size_t l = len - a < part ? len - a : part;
-      th[nth++] = std::thread([=]() { memcpy(slot[b] + a, s + off + a, l); });
+      const uint8_t* slot = g_upload_slot[b];
+      th[nth++] = std::thread([=]() { memcpy(dp + off + a, slot + a, l); });
     }
     for (int t = 0; t < nth; t++) th[t].join();
-    e = hipMemcpyAsync(d + off, slot[b], len, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipEventRecord(done[b], ctx->stream);
-    used[b] = true;
+    if (c + UPLOAD_SLOTS < nchunks) e = issue(c + UPLOAD_SLOTS);  // the slot is free again
   }
   hipError_t e2 = hipStreamSynchronize(ctx->stream);
   return e != hipSuccess ? e : e2;
+}
+
+// host memory -> device memory.  Large buffers go through the pinned slots with UPLOAD_THREADS threads copying (and,
+// for a file mapping touched for the first time -- the FBM pointer an R session holds --, faulting pages in) in
+// parallel; small ones with one hipMemcpy.
+hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes < (64u << 20)) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+  }
+  bool io_error = false;
+  const uint8_t* sp = (const uint8_t*)src;
+  return upload_chunked(ctx, dst, bytes, [=](uint8_t* p, size_t off, size_t len) { memcpy(p, sp + off, len); return true; },
+                        &io_error);
 }
 
 extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, tpg_fbm** out) {
@@ -421,7 +532,7 @@ extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nro
   size_t sz = (size_t)nrow * (size_t)ncol;
   hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
   if (e != hipSuccess) { delete f; tpg_set_error("tpg_pmalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
-  e = tpg_upload(ctx, f->d_bytes, bytes, sz, ctx->upload_from_mapped_file);
+  e = tpg_upload(ctx, f->d_bytes, bytes, sz);
   if (e != hipSuccess) { (void)hipFree(f->d_bytes); delete f; tpg_set_error("FBM upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
   *out = f;
   return TPG_OK;
@@ -430,6 +541,7 @@ extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nro
 extern "C" int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int64_t ncol, tpg_fbm** out) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && path && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(nrow > 0 && ncol > 0, TPG_EINVAL, "empty FBM (%lld x %lld)", (long long)nrow, (long long)ncol);
   int fd = open(path, O_RDONLY);
   TPG_REQUIRE(fd >= 0, TPG_EINVAL, "cannot open backing file %s", path);
   struct stat st;
@@ -438,15 +550,15 @@ extern "C" int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int
     tpg_set_error("backing file %s is smaller than %lld x %lld bytes", path, (long long)nrow, (long long)ncol);
     return TPG_EINVAL;
   }
-  size_t sz = (size_t)nrow * (size_t)ncol;
-  void* p = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+  const size_t sz = (size_t)nrow * (size_t)ncol;
+  tpg_fbm* f = new tpg_fbm{ctx, nullptr, nrow, ncol};
+  hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
+  if (e != hipSuccess) { close(fd); delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
+  const int rc = upload_from_file(ctx, f->d_bytes, fd, 0, sz, path);
   close(fd);
-  TPG_REQUIRE(p != MAP_FAILED, TPG_EINVAL, "mmap of %s failed", path);
-  ctx->upload_from_mapped_file = true;
-  int rc = tpg_fbm_from_host(ctx, (const uint8_t*)p, nrow, ncol, out);
-  ctx->upload_from_mapped_file = false;
-  munmap(p, sz);
-  return rc;
+  if (rc != TPG_OK) { (void)hipFree(f->d_bytes); delete f; return rc; }
+  *out = f;
+  return TPG_OK;
 }
 
 extern "C" int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0, int npop,
@@ -476,7 +588,7 @@ extern "C" int tpg_fbm_from_bed_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t
   const size_t sz = (size_t)bpl * (size_t)m;
   hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
   if (e != hipSuccess) { delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
-  e = tpg_upload(ctx, f->d_bytes, bytes, sz, ctx->upload_from_mapped_file);
+  e = tpg_upload(ctx, f->d_bytes, bytes, sz);
   if (e != hipSuccess) { (void)hipFree(f->d_bytes); delete f; tpg_set_error(".bed upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
   *out = f;
   return TPG_OK;
@@ -488,28 +600,29 @@ extern "C" int tpg_fbm_open_bed(tpg_ctx* ctx, const char* path, int64_t n, int64
   TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty .bed (%lld x %lld)", (long long)n, (long long)m);
   int fd = open(path, O_RDONLY);
   TPG_REQUIRE(fd >= 0, TPG_EINVAL, "cannot open %s", path);
-  const size_t sz = 3 + (size_t)((n + 3) / 4) * (size_t)m;
+  const int64_t bpl = (n + 3) / 4;
+  const size_t sz = (size_t)bpl * (size_t)m;
   struct stat st;
-  if (fstat(fd, &st) != 0 || (size_t)st.st_size < sz) {
+  uint8_t magic[3] = {0, 0, 0};
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < sz + 3 || pread(fd, magic, 3, 0) != 3) {
     close(fd);
     tpg_set_error("%s is smaller than a %lld x %lld .bed", path, (long long)n, (long long)m);
     return TPG_EINVAL;
   }
-  void* p = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
-  close(fd);
-  TPG_REQUIRE(p != MAP_FAILED, TPG_EINVAL, "mmap of %s failed", path);
-  const uint8_t* b = (const uint8_t*)p;
-  int rc;
-  if (b[0] != 0x6C || b[1] != 0x1B || b[2] != 0x01) {
-    tpg_set_error("%s is not a SNP-major PLINK .bed (magic %02x %02x %02x)", path, b[0], b[1], b[2]);
-    rc = TPG_EINVAL;
-  } else {
-    ctx->upload_from_mapped_file = true;
-    rc = tpg_fbm_from_bed_host(ctx, b + 3, n, m, out);
-    ctx->upload_from_mapped_file = false;
+  if (magic[0] != 0x6C || magic[1] != 0x1B || magic[2] != 0x01) {
+    close(fd);
+    tpg_set_error("%s is not a SNP-major PLINK .bed (magic %02x %02x %02x)", path, magic[0], magic[1], magic[2]);
+    return TPG_EINVAL;
   }
-  munmap(p, sz);
-  return rc;
+  tpg_fbm* f = new tpg_fbm{ctx, nullptr, n, m};
+  f->bed_bpl = bpl;
+  hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
+  if (e != hipSuccess) { close(fd); delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
+  const int rc = upload_from_file(ctx, f->d_bytes, fd, 3, sz, path);
+  close(fd);
+  if (rc != TPG_OK) { (void)hipFree(f->d_bytes); delete f; return rc; }
+  *out = f;
+  return TPG_OK;
 }
 
 extern "C" int tpg_fbm_to_host(tpg_ctx* ctx, const tpg_fbm* fbm, uint8_t* bytes) {
