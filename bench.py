@@ -121,8 +121,13 @@ class Step:
         tpg, api, lib, ctx, a = self.tpg, self.api, self.lib, self.ctx, self.args
         chk = tpg._lib.check
         n, G, P = a.n, a.pops, self.P
-        # ---- raw view (bytes 0/1/2 valid, the rest missing) ----
-        v = api.View(self.X, None, None, code256=self.code_012)
+        # ---- raw view (bytes 0/1/2 valid, the rest missing); when the PCA takes the same loci, its imputed view is
+        # packed from the same read of the FBM bytes (tpg_view_create_pair) ----
+        v_pca = None
+        if self.has_pca and self.pca_cols is None:
+            v, v_pca = api.View.pair(self.X, None, None, self.code_012, self.code_imp)
+        else:
+            v = api.View(self.X, None, None, code256=self.code_012)
         chk(lib.tpg_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(self.ploidy), C.c_int(0), self.d_freq))
         chk(lib.tpg_grouped_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(self.gid), C.c_int(G), api._ptr(self.ploidy),
                                                 C.c_int(0), self.d_gfreq))
@@ -144,7 +149,7 @@ class Step:
         # ---- imputed view + PCA ----
         if self.has_pca:
             try:
-                v = api.View(self.X, None, self.pca_cols, code256=self.code_imp)
+                v = v_pca if v_pca is not None else api.View(self.X, None, self.pca_cols, code256=self.code_imp)
                 chk(lib.tpg_pca_partial_svd_sharded(ctx.h, self.comm.h, v.h, C.c_int(a.k), api._ptr(self.pca_d),
                                                     self.d_pca["u"], self.d_pca["v"], self.d_pca["center"],
                                                     self.d_pca["scale"], C.byref(self.pca_fro)))
@@ -153,6 +158,8 @@ class Step:
                 if e.code != 3:
                     raise
                 self.has_pca = False
+        elif v_pca is not None:
+            v_pca.free()
         ctx.sync()
 
 
@@ -395,7 +402,9 @@ def main():
                     "note": note}
 
         others = [
-            hbm_roof("pack", "tpg_pack_fast_kernel", 1.5 * n * m, "FBM bytes -> two 2-bit layouts: N M read + N M / 2 written"),
+            hbm_roof("pack", "tpg_pack_fast_kernel<1>", 1.5 * n * m, "FBM bytes -> two 2-bit layouts: N M read + N M / 2 written"),
+            hbm_roof("pack2", "tpg_pack_fast_kernel<2>", 2.0 * n * m,
+                     "FBM bytes -> the raw AND the imputed view from one read: N M read + 2 x N M / 2 written"),
             hbm_roof("loci_counts", "tpg_loci_counts_kernel", 0.25 * n * m + 16.0 * m,
                      "per-locus genotype counts: N M / 4 read + 16 B per locus written"),
             hbm_roof("grouped_counts", "tpg_grouped_counts_kernel (int8 MFMA one-hot contraction)",

@@ -92,6 +92,12 @@ void tpg_fbm_free(tpg_fbm* fbm);
  * rowInd NULL = all rows, colInd NULL = all columns. */
 int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n,
                     const int32_t* colInd1, int64_t m, const double* code256, tpg_view** out);
+/* two views of the same (rowInd, colInd) through two code tables, packed from ONE read of the FBM bytes: e.g. the raw
+ * view (code256_a = NULL) for the pairwise statistics and the imputed view (CODE_IMPUTE_PRED) for the PCA of the same
+ * gen_tibble (R/gt_has_imputed.R:101-106 flips the FBM's code256 between exactly these two) */
+int tpg_view_create_pair(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n, const int32_t* colInd1,
+                         int64_t m, const double* code256_a, const double* code256_b, tpg_view** out_a,
+                         tpg_view** out_b);
 void tpg_view_free(tpg_view* v);
 int64_t tpg_view_n(const tpg_view* v);
 int64_t tpg_view_m(const tpg_view* v);

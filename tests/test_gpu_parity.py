@@ -46,6 +46,29 @@ def test_pack_roundtrip_and_views(tpg, n, m):
     assert np.array_equal(tpg.View(Xi, code256=None).unpack(), np.where(fbi > 2, 3, fbi))
 
 
+@pytest.mark.parametrize("n,m", [(12, 961), (256, 1024), (300, 1000), (1000, 2500)])
+def test_view_pair_equals_two_views(tpg, n, m):
+    # the raw and the imputed view from one read of the FBM bytes == the two views packed one after the other
+    fbi = orc.synth_fbm(7, n, m, npop=3, miss=0.1, imputed_bytes=True)
+    X = tpg.FBM.from_numpy(fbi)
+    va, vb = tpg.View.pair(X)
+    assert np.array_equal(va.unpack(), tpg.View(X, code256=None).unpack())
+    assert np.array_equal(vb.unpack(), tpg.View(X, code256=tpg.CODE_IMPUTE_PRED).unpack())
+    assert np.array_equal(va.unpack(), np.where(fbi > 2, 3, fbi)) and np.array_equal(vb.unpack(), np.where(fbi > 3, fbi - 4, fbi))
+    rng = np.random.default_rng(n)
+    rows = (rng.permutation(n)[: max(1, n // 2)] + 1).astype(np.int32)
+    cols = (rng.permutation(m)[: max(1, m // 3)] + 1).astype(np.int32)
+    for r, c in ((rows, cols), (None, cols)):
+        pa, pb = tpg.View.pair(X, r, c, tpg.CODE_012, tpg.CODE_IMPUTE_PRED)
+        assert np.array_equal(pa.unpack(), tpg.View(X, r, c, code256=tpg.CODE_012).unpack())
+        assert np.array_equal(pb.unpack(), tpg.View(X, r, c, code256=tpg.CODE_IMPUTE_PRED).unpack())
+    bad = tpg.CODE_IMPUTE_PRED.copy()
+    bad[5] = 0.5  # a value the second table cannot represent, and byte 5 occurs
+    with pytest.raises(tpg._lib.TpgError) as e:
+        tpg.View.pair(X, None, None, None, bad)
+    assert e.value.code == 3
+
+
 def test_direct_bed_ingest(tpg):
     # the .bed payload is the store; views, counts and IBS equal the FBM route
     import os
@@ -758,12 +781,26 @@ def test_filter_high_relatedness(tpg):
         t = tpg.filter_high_relatedness(A, thr)
         o = orc.filter_high_relatedness(A, thr)
         assert np.array_equal(t[2], o[2]) and list(t[0]) == [str(k) for k in o[0]], (n, thr)
-    # an NA among the compared coefficients stops, as `if (NA)` does in R
-    B = A.copy()
-    B[0, 1] = B[1, 0] = np.nan
-    B[2, 5] = B[5, 2] = 0.49
-    with pytest.raises(tpg._lib.TpgError):
-        tpg.filter_high_relatedness(B * np.where(np.isnan(B), 1, 1), 0.01)
+    # an NA among the coefficients: if the greedy walk gets to compare it, R stops (`if (NA)`), and so do we; if the
+    # pair is never compared (one of the two was dropped before), the result is the oracle's
+    saw_error = saw_result = False
+    for seed in range(12):
+        r2 = np.random.default_rng(100 + seed)
+        B = r2.random((15, 15)) * 0.3
+        B = (B + B.T) / 2
+        i, j = r2.choice(15, 2, replace=False)
+        B[i, j] = B[j, i] = np.nan
+        try:
+            o = orc.filter_high_relatedness(B, 0.25)
+        except ValueError:
+            with pytest.raises(tpg._lib.TpgError):
+                tpg.filter_high_relatedness(B, 0.25)
+            saw_error = True
+            continue
+        t = tpg.filter_high_relatedness(B, 0.25)
+        assert np.array_equal(t[2], o[2]) and list(t[0]) == [str(k) for k in o[0]]
+        saw_result = True
+    assert saw_error and saw_result
 
 
 def test_predict_gt_pca_projections(tpg):

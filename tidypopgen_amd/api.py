@@ -199,6 +199,23 @@ class View:
         self.n = int(lib.tpg_view_n(h))
         self.m = int(lib.tpg_view_m(h))
 
+    @classmethod
+    def pair(cls, X: FBM, ind_row=None, ind_col=None, code256_a=None, code256_b=CODE_IMPUTE_PRED):
+        """two views of the same rows / columns through two code tables from one read of the FBM bytes
+        (tpg_view_create_pair): by default the raw view of the pairwise statistics and the imputed view of the PCA"""
+        r, c = _i32(ind_row), _i32(ind_col)
+        ca, cb = _f64(code256_a), _f64(code256_b)
+        ha, hb = C.c_void_p(), C.c_void_p()
+        check(lib.tpg_view_create_pair(X.ctx.h, X.h, _ptr(r), C.c_int64(0 if r is None else len(r)), _ptr(c),
+                                       C.c_int64(0 if c is None else len(c)), _ptr(ca), _ptr(cb), C.byref(ha), C.byref(hb)))
+        out = []
+        for h in (ha, hb):
+            v = cls.__new__(cls)
+            v.X, v.ctx, v.h = X, X.ctx, h
+            v.n, v.m = int(lib.tpg_view_n(h)), int(lib.tpg_view_m(h))
+            out.append(v)
+        return out[0], out[1]
+
     def unpack(self) -> np.ndarray:
         out = np.zeros((self.n, self.m), dtype=np.uint8, order="F")
         check(lib.tpg_view_unpack(self.ctx.h, self.h, _ptr(out)))

@@ -226,7 +226,7 @@ int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype);  
 
 // ---- cross-TU entry points (one per .hip file) -----------------------------
 int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,
-                    const uint8_t* d_lut, tpg_view* v);
+                    const uint8_t* d_lut, tpg_view* v, tpg_view* v2);
 int tpg_launch_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* d_codes, int from_L);
 int tpg_launch_synth(tpg_ctx* ctx, uint8_t* d_bytes, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0,
                      int npop, uint32_t miss_thresh, int imputed_bytes);

@@ -26,3 +26,12 @@ __host__ __device__ __forceinline__ int tpg_elem_shift(int e) { return 8 * (e & 
 
 // MFMA 32x32 C/D register -> row inside the 32x32 tile (col = lane & 31)
 __device__ __forceinline__ int tpg_cd_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for every global load in
+// flight (s_waitcnt vmcnt(0)), i.e. for the prefetch a K loop has just issued for its next iteration: a full memory
+// latency per iteration.  The workgroup-scope fences order the LDS accesses (s_waitcnt lgkmcnt(0)) and leave vmcnt alone.
+__device__ __forceinline__ void tpg_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "common.h"
+#include <type_traits>
 #include "devfrag.h"
 
 // ---------------------------------------------------------------------------
@@ -198,20 +199,23 @@ __global__ __launch_bounds__(256, 1) void tpg_grouped_counts_kernel(const uint4*
   constexpr int NIT = (4 * GT + 3) / 4;
   const uint4* po = OH + (int64_t)gt0 * 64 + lane;
   auto frag = [&](int64_t q, int it) { return po[((q * 4 + it / GT) * GT_total + it % GT) * 64]; };
-  uint4 a[GC_NLT], an[GC_NLT], on[NIT];
+  // genotype blocks of groups q, q + 1, q + 2 in three rotating register slots (the HBM stream is fetched two groups
+  // ahead; the loop is unrolled by three so that no slot is copied -- a copy would wait for the load just issued)
+  uint4 R[3][GC_NLT], on[NIT];
 #pragma unroll
-  for (int t = 0; t < GC_NLT; t++) a[t] = pa[t][0];
+  for (int t = 0; t < GC_NLT; t++) { R[0][t] = pa[t][0]; R[1][t] = pa[t][(Q > 1 ? 1 : 0) * 64]; }
 #pragma unroll
   for (int j = 0; j < NIT; j++) {
     const int it = wv + 4 * j;
     if (it < 4 * GT) ohb[0][it][lane] = frag(0, it);
   }
-  __syncthreads();
-  for (int64_t q = 0; q < Q; q++) {
-    const int64_t qn = q + 1 < Q ? q + 1 : q;
+  tpg_lds_barrier();
+  auto group = [&](auto Cc, auto Mm, int64_t q) {
+    constexpr int C = decltype(Cc)::value, M = decltype(Mm)::value;
+    const int64_t qn = q + 1 < Q ? q + 1 : q, qn2 = q + 2 < Q ? q + 2 : Q - 1;
     const int cur = (int)(q & 1);
 #pragma unroll
-    for (int t = 0; t < GC_NLT; t++) an[t] = pa[t][qn * 64];
+    for (int t = 0; t < GC_NLT; t++) R[M][t] = pa[t][qn2 * 64];
 #pragma unroll
     for (int j = 0; j < NIT; j++) {
       const int it = wv + 4 * j;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void tpg_grouped_counts_kernel(const uint4*
       v4i fh[GC_NLT], f2[GC_NLT], fv[GC_NLT];
 #pragma unroll
       for (int t = 0; t < GC_NLT; t++) {
-        const uint32_t w = s == 0 ? a[t].x : s == 1 ? a[t].y : s == 2 ? a[t].z : a[t].w;
+        const uint32_t w = s == 0 ? R[C][t].x : s == 1 ? R[C][t].y : s == 2 ? R[C][t].z : R[C][t].w;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const uint32_t c = tpg_codes(w, k);
@@ -243,15 +247,21 @@ __global__ __launch_bounds__(256, 1) void tpg_grouped_counts_kernel(const uint4*
         }
       }
     }
-#pragma unroll
-    for (int t = 0; t < GC_NLT; t++) a[t] = an[t];
     // the other buffer was last read in group q - 1, which every wave left through the barrier below
 #pragma unroll
     for (int j = 0; j < NIT; j++) {
       const int it = wv + 4 * j;
       if (it < 4 * GT) ohb[cur ^ 1][it][lane] = on[j];
     }
-    __syncthreads();
+    tpg_lds_barrier();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  for (int64_t q = 0; q < Q; q += 3) {  // Q is the same for every wave: all of them meet every barrier
+    group(I0{}, I2{}, q);
+    if (q + 1 < Q) group(I1{}, I0{}, q + 1);
+    if (q + 2 < Q) group(I2{}, I1{}, q + 2);
   }
 #pragma unroll
   for (int t = 0; t < GC_NLT; t++) {

@@ -110,13 +110,18 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
 //            words.  Rows are rotated by 32 bytes per 16 loci so that both phases are free of bank conflicts.
 // ~20 VALU and ~6 LDS instructions per output word pair instead of ~100 and ~50: the kernel sits on the HBM
 // roofline (reads n*m bytes, writes n*m/2).
+// NV = 2: the same bytes decoded through TWO code tables into two views from one read of the FBM (the raw view of the
+// pairwise statistics and the imputed view of the PCA: R/gt_has_imputed.R:101-106 switches between exactly these two
+// tables on one FBM) -- 10 GB of traffic instead of 15 GB at 5 000 x 1 000 000.
+template <int NV>
 __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __restrict__ fbm, int64_t nrow,
                                                             const int32_t* __restrict__ cols, uint8_t* lut_and_flag,
                                                             int64_t n, int64_t m, int64_t Q, int64_t KG,
-                                                            uint32_t* __restrict__ T, uint32_t* __restrict__ L) {
-  __shared__ __attribute__((aligned(16))) uint8_t smem[256 + TILE * TILE];
-  uint8_t* lut = smem;
-  uint8_t* codes = smem + 256;  // codes[locus][(individual + 32 * (locus >> 4)) & 127]
+                                                            uint32_t* __restrict__ T0, uint32_t* __restrict__ L0,
+                                                            uint32_t* __restrict__ T1, uint32_t* __restrict__ L1) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[NV * (256 + 16) + NV * TILE * TILE];
+  // lut_and_flag: NV tables of 256 bytes, each followed by its 16-byte flag area
+  uint8_t* codes_all = smem + NV * (256 + 16);  // codes[view][locus][(individual + 32 * (locus >> 4)) & 127]
   const int tid = threadIdx.x;
   // 1-D grid, individual chunk fastest: neighbouring workgroups read neighbouring pieces of the same 128 columns
   // (columns are only 8-byte aligned, so the pieces share cache lines and DRAM pages).  A workgroup does NSUB
@@ -125,11 +130,21 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
   const int64_t QB = (Q + NSUB - 1) / NSUB;
   const int64_t bj = blockIdx.x / QB;          // locus group (kg)
   const int64_t bi0 = (blockIdx.x % QB) * NSUB;  // first individual chunk (q)
-  lut[tid] = lut_and_flag[tid];
+#pragma unroll
+  for (int vw = 0; vw < NV; vw++) smem[vw * (256 + 16) + tid] = lut_and_flag[vw * (256 + 16) + tid];
   __syncthreads();
-  const uint32_t lo = *reinterpret_cast<const uint32_t*>(lut), hi = *reinterpret_cast<const uint32_t*>(lut + 4);
-  bool bad = false;
-  auto conv = [&](uint32_t w) -> uint32_t {
+  uint32_t lo_[NV], hi_[NV];
+  bool bad_[NV];
+#pragma unroll
+  for (int vw = 0; vw < NV; vw++) {
+    lo_[vw] = *reinterpret_cast<const uint32_t*>(smem + vw * (256 + 16));
+    hi_[vw] = *reinterpret_cast<const uint32_t*>(smem + vw * (256 + 16) + 4);
+    bad_[vw] = false;
+  }
+  auto conv = [&](uint32_t w, int vw) -> uint32_t {
+    const uint8_t* lut = smem + vw * (256 + 16);
+    const uint32_t lo = lo_[vw], hi = hi_[vw];
+    bool& bad = bad_[vw];
     uint32_t c;
     if ((w & 0xF8F8F8F8u) == 0) c = __builtin_amdgcn_perm(hi, lo, w);
     else
@@ -171,19 +186,28 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
     for (int it = 0; it < 4; it++) {
       const int l = (tid >> 3) + 32 * it;
       const bool inside = bj * TILE + l < m;
-      uint32_t c[4] = {0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u};
-      if (inside && i0 + 8 <= n) { c[0] = conv(va[sub][it].x); c[1] = conv(va[sub][it].y); }
-      if (inside && i0 + 16 <= n) { c[2] = conv(vb[sub][it].x); c[3] = conv(vb[sub][it].y); }
-      *reinterpret_cast<uint4*>(codes + l * TILE + ((16 * c16 + 32 * (l >> 4)) & 127)) = make_uint4(c[0], c[1], c[2], c[3]);
-      const int64_t lt = bj * 4 + (l >> 5);
-      const int lane = (l & 31) + 32 * (c16 & 1);
-      L[((lt * Q + bi) * 64 + lane) * 4 + (c16 >> 1)] = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
+#pragma unroll
+      for (int vw = 0; vw < NV; vw++) {
+        uint8_t* codes = codes_all + vw * TILE * TILE;
+        uint32_t* L = vw ? L1 : L0;
+        uint32_t c[4] = {0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u};
+        if (inside && i0 + 8 <= n) { c[0] = conv(va[sub][it].x, vw); c[1] = conv(va[sub][it].y, vw); }
+        if (inside && i0 + 16 <= n) { c[2] = conv(vb[sub][it].x, vw); c[3] = conv(vb[sub][it].y, vw); }
+        *reinterpret_cast<uint4*>(codes + l * TILE + ((16 * c16 + 32 * (l >> 4)) & 127)) = make_uint4(c[0], c[1], c[2], c[3]);
+        const int64_t lt = bj * 4 + (l >> 5);
+        const int lane = (l & 31) + 32 * (c16 & 1);
+        L[((lt * Q + bi) * 64 + lane) * 4 + (c16 >> 1)] = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
+      }
     }
   }
   __syncthreads();
   {
     const int wv = tid >> 6, t = tid & 63;
     const int g = t >> 3, iqq = t & 7;  // loci 16 g .. 16 g + 15, individuals 32 wv + 4 iqq .. + 3
+#pragma unroll
+    for (int vw = 0; vw < NV; vw++) {
+    const uint8_t* codes = codes_all + vw * TILE * TILE;
+    uint32_t* T = vw ? T1 : T0;
     uint32_t d[16];
 #pragma unroll
     for (int e = 0; e < 16; e++)
@@ -203,25 +227,37 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
     uint32_t* dst = T + ((rt * KG + bj) * 64 + 4 * iqq + 32 * (g & 1)) * 4 + (g >> 1);
 #pragma unroll
     for (int b = 0; b < 4; b++) dst[b * 4] = W[b];
+    }  // view
   }
   }  // sub
-  if (bad) atomicOr((unsigned int*)(lut_and_flag + 256), 1u);
+#pragma unroll
+  for (int vw = 0; vw < NV; vw++)
+    if (bad_[vw]) atomicOr((unsigned int*)(lut_and_flag + vw * (256 + 16) + 256), 1u);
 }
 
+// d_lut: one (v2 == NULL) or two consecutive {256-byte table, 16-byte flag area} records
 int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,
-                    const uint8_t* d_lut, tpg_view* v) {
+                    const uint8_t* d_lut, tpg_view* v, tpg_view* v2) {
   TPG_REQUIRE(v->KG < 2147483647ll && v->Q <= 65535, TPG_EINVAL, "view too large for the pack grid");
   dim3 grid((unsigned)v->KG, (unsigned)v->Q);
   if (fbm->bed_bpl == 0 && d_rows == nullptr && (fbm->nrow & 7) == 0 && (((uintptr_t)fbm->d_bytes) & 7) == 0 &&
       !getenv("TPG_PACK_GENERIC")) {
     TPG_REQUIRE(v->KG * v->Q < 2147483647ll, TPG_EINVAL, "view too large for the pack grid");
-    TPG_LAUNCH(ctx, "pack", tpg_pack_fast_kernel, dim3((unsigned)(v->KG * ((v->Q + 1) / 2))), dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
-               v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L);
+    const dim3 g1((unsigned)(v->KG * ((v->Q + 1) / 2)));
+    if (v2)
+      TPG_LAUNCH(ctx, "pack2", tpg_pack_fast_kernel<2>, g1, dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
+                 v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)v2->T, (uint32_t*)v2->L);
+    else
+      TPG_LAUNCH(ctx, "pack", tpg_pack_fast_kernel<1>, g1, dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
+                 v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)nullptr, (uint32_t*)nullptr);
     TPG_CHECK_LAUNCH();
     return TPG_OK;
   }
   TPG_LAUNCH(ctx, "pack", tpg_pack_kernel, grid, dim3(256), 0, fbm->d_bytes, fbm->nrow, fbm->bed_bpl, d_rows, d_cols,
              (uint8_t*)d_lut, v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L);
+  if (v2)  // no fused form of the generic kernel: a second pass with the second table
+    TPG_LAUNCH(ctx, "pack", tpg_pack_kernel, grid, dim3(256), 0, fbm->d_bytes, fbm->nrow, fbm->bed_bpl, d_rows, d_cols,
+               (uint8_t*)d_lut + 256 + 16, v2->n, v2->m, v2->Q, v2->KG, (uint32_t*)v2->T, (uint32_t*)v2->L);
   TPG_CHECK_LAUNCH();
   return TPG_OK;
 }

@@ -1691,7 +1691,7 @@ __global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* 
     const int it = wv + 4 * j;
     ubuf[0][it][lane] = pu[((int64_t)(it / CTP) * CT + it % CTP) * 64];
   }
-  __syncthreads();
+  tpg_lds_barrier();
   for (int64_t q = 0; q < Q; q++) {
     const int64_t qn = q + 1 < Q ? q + 1 : q;
     const int cur = (int)(q & 1);
@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* 
     // the other buffer was last read in group q - 1, which every wave left through the barrier below
 #pragma unroll
     for (int j = 0; j < CTP; j++) ubuf[cur ^ 1][wv + 4 * j][lane] = un[j];
-    __syncthreads();
+    tpg_lds_barrier();
   }
 #pragma unroll
   for (int t = 0; t < LD_NLT; t++) {

@@ -382,71 +382,119 @@ InBuf::~InBuf() {
 }
 
 // ---------------------------------------------------------------------------
-// Host -> HBM upload, the cold-start cost of every analysis (5 GB for a 5 000 x 1 000 000 FBM).  Memory the caller
-// already holds goes up with one hipMemcpy (pageable: the runtime stages it).  A backing FILE goes up in pieces:
-// UPLOAD_SLOTS pinned 32-MiB slots are filled by UPLOAD_THREADS host threads with pread() straight from the page
-// cache (no mapping of the file: an mmap costs a page fault per 4 KiB on first touch, which capped the mapped-file path
-// at ~13 GB/s on a RAM-backed file) and sent with hipMemcpyAsync, so file reads and DMA of consecutive chunks overlap.
-// The slots are allocated once per process.
-static constexpr size_t UPLOAD_CHUNK = 32u << 20;
-static constexpr int UPLOAD_SLOTS = 4, UPLOAD_THREADS = 16;
-static std::mutex g_upload_mu;  // one chunked transfer at a time per process: the slots are shared
-static uint8_t* g_upload_slot[UPLOAD_SLOTS] = {nullptr};
-static hipEvent_t g_upload_done[UPLOAD_SLOTS];
-static bool g_upload_ready = false;
+// Host <-> HBM bulk transfers, the cold-start cost of every analysis (5 GB for a 5 000 x 1 000 000 FBM).  A team of
+// XFER_THREADS host threads each takes a contiguous stripe of the transfer and moves it in 4-MiB pieces through two
+// pinned slots of its own on a stream of its own: while the DMA engine works on one slot the thread fills (upload:
+// pread() from the page cache or memcpy from the caller's memory) or drains (download: memcpy into the caller's
+// pageable memory) the other.  No per-piece thread creation, no mapping of the file (an mmap costs a page fault per
+// 4 KiB on first touch).  Slots, streams and events are created once per process and device.
+static constexpr size_t XFER_PIECE = 4u << 20;
+static constexpr int XFER_THREADS = 16;
+struct XferLane {
+  uint8_t* slot[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {};
+  hipStream_t stream = nullptr;
+};
+struct XferTeam {
+  int device = -1;
+  XferLane lane[XFER_THREADS];
+};
+static std::mutex g_xfer_mu;  // one bulk transfer at a time per process: the slots are shared
+static std::vector<XferTeam*> g_xfer_teams;
 
-static hipError_t upload_slots_init() {
-  if (g_upload_ready) return hipSuccess;
-  for (int b = 0; b < UPLOAD_SLOTS; b++) {
-    hipError_t e = hipHostMalloc((void**)&g_upload_slot[b], UPLOAD_CHUNK, hipHostMallocDefault);
-    if (e == hipSuccess) {
-      e = hipEventCreateWithFlags(&g_upload_done[b], hipEventDisableTiming);
-      if (e != hipSuccess) { (void)hipHostFree(g_upload_slot[b]); g_upload_slot[b] = nullptr; }
-    }
-    if (e != hipSuccess) {  // give back what was created so far; the next call starts over
-      for (int c = 0; c < b; c++) { (void)hipHostFree(g_upload_slot[c]); (void)hipEventDestroy(g_upload_done[c]); g_upload_slot[c] = nullptr; }
-      return e;
+static hipError_t xfer_team(int device, XferTeam** out) {  // caller holds g_xfer_mu and has made `device` current
+  for (auto t : g_xfer_teams)
+    if (t->device == device) { *out = t; return hipSuccess; }
+  XferTeam* t = new XferTeam();
+  t->device = device;
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < XFER_THREADS && e == hipSuccess; k++) {
+    e = hipStreamCreateWithFlags(&t->lane[k].stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+      e = hipHostMalloc((void**)&t->lane[k].slot[b], XFER_PIECE, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&t->lane[k].done[b], hipEventDisableTiming);
     }
   }
-  g_upload_ready = true;
+  if (e != hipSuccess) {
+    for (int k = 0; k < XFER_THREADS; k++) {
+      for (int b = 0; b < 2; b++) {
+        if (t->lane[k].slot[b]) (void)hipHostFree(t->lane[k].slot[b]);
+        if (t->lane[k].done[b]) (void)hipEventDestroy(t->lane[k].done[b]);
+      }
+      if (t->lane[k].stream) (void)hipStreamDestroy(t->lane[k].stream);
+    }
+    delete t;
+    return e;
+  }
+  g_xfer_teams.push_back(t);
+  *out = t;
   return hipSuccess;
 }
 
-// fill(dst_pinned, offset, len) copies bytes [offset, offset + len) of the source into pinned memory; returns false on
-// a read error
+// upload: host_fill(pinned_dst, offset, len) -> false on a read error.  download: host_drain(pinned_src, offset, len).
+// The caller's stream is drained first (the transfer runs on the team's own streams) and the team is waited for at
+// the end, so the transfer is ordered with the context's work on both sides.
+template <typename HostSide>
+static hipError_t xfer_striped(tpg_ctx* ctx, uint8_t* dev, size_t bytes, bool to_device, HostSide host_side, bool* io_error) {
+  std::lock_guard<std::mutex> lk(g_xfer_mu);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return e;
+  XferTeam* team = nullptr;
+  e = xfer_team(ctx->device, &team);
+  if (e != hipSuccess) return e;
+  const size_t npieces = (bytes + XFER_PIECE - 1) / XFER_PIECE;
+  const int nth = (int)std::min<size_t>(XFER_THREADS, npieces);
+  std::vector<hipError_t> errs((size_t)nth, hipSuccess);
+  std::vector<char> bad((size_t)nth, 0);
+  std::vector<std::thread> th;
+  const int device = ctx->device;
+  for (int t = 0; t < nth; t++)
+    th.emplace_back([=, &errs, &bad]() {
+      hipError_t ee = hipSetDevice(device);
+      XferLane& ln = team->lane[t];
+      const size_t p0 = npieces * (size_t)t / (size_t)nth, p1 = npieces * ((size_t)t + 1) / (size_t)nth;
+      bool used[2] = {false, false};
+      if (to_device) {
+        for (size_t p = p0; p < p1 && ee == hipSuccess; p++) {
+          const int b = (int)((p - p0) & 1);
+          const size_t off = p * XFER_PIECE, len = std::min(XFER_PIECE, bytes - off);
+          if (used[b]) ee = hipEventSynchronize(ln.done[b]);  // the DMA out of this slot has finished
+          if (ee != hipSuccess) break;
+          if (!host_side(ln.slot[b], off, len)) { bad[(size_t)t] = 1; break; }
+          ee = hipMemcpyAsync(dev + off, ln.slot[b], len, hipMemcpyHostToDevice, ln.stream);
+          if (ee == hipSuccess) ee = hipEventRecord(ln.done[b], ln.stream);
+          used[b] = true;
+        }
+      } else {
+        auto issue = [&](size_t p) {
+          const int b = (int)((p - p0) & 1);
+          const size_t off = p * XFER_PIECE, len = std::min(XFER_PIECE, bytes - off);
+          hipError_t e2 = hipMemcpyAsync(ln.slot[b], dev + off, len, hipMemcpyDeviceToHost, ln.stream);
+          return e2 == hipSuccess ? hipEventRecord(ln.done[b], ln.stream) : e2;
+        };
+        if (p0 < p1) ee = issue(p0);
+        for (size_t p = p0; p < p1 && ee == hipSuccess; p++) {
+          const int b = (int)((p - p0) & 1);
+          const size_t off = p * XFER_PIECE, len = std::min(XFER_PIECE, bytes - off);
+          if (p + 1 < p1) ee = issue(p + 1);  // the other slot fills while this one is drained
+          if (ee == hipSuccess) ee = hipEventSynchronize(ln.done[b]);
+          if (ee == hipSuccess) host_side(ln.slot[b], off, len);
+        }
+      }
+      hipError_t es = hipStreamSynchronize(ln.stream);
+      errs[(size_t)t] = ee != hipSuccess ? ee : es;
+    });
+  for (auto& t : th) t.join();
+  for (int t = 0; t < nth; t++) {
+    if (bad[(size_t)t]) *io_error = true;
+    if (errs[(size_t)t] != hipSuccess) e = errs[(size_t)t];
+  }
+  return e;
+}
+
 template <typename Fill>
 static hipError_t upload_chunked(tpg_ctx* ctx, void* dst, size_t bytes, Fill fill, bool* io_error) {
-  std::lock_guard<std::mutex> lk(g_upload_mu);
-  hipError_t e = upload_slots_init();
-  if (e != hipSuccess) return e;
-  uint8_t* d = (uint8_t*)dst;
-  bool used[UPLOAD_SLOTS] = {false};
-  int b = 0;
-  for (size_t off = 0; off < bytes && e == hipSuccess && !*io_error; off += UPLOAD_CHUNK, b = (b + 1) % UPLOAD_SLOTS) {
-    const size_t len = bytes - off < UPLOAD_CHUNK ? bytes - off : UPLOAD_CHUNK;
-    if (used[b]) e = hipEventSynchronize(g_upload_done[b]);  // the DMA out of this slot has finished
-    if (e != hipSuccess) break;
-    const size_t part = ((len + UPLOAD_THREADS - 1) / UPLOAD_THREADS + 4095) & ~(size_t)4095;
-    std::thread th[UPLOAD_THREADS];
-    bool ok[UPLOAD_THREADS];
-    int nth = 0;
-    for (int t = 0; t < UPLOAD_THREADS; t++) {
-      const size_t a = (size_t)t * part;
-      if (a >= len) break;
-      const size_t l = len - a < part ? len - a : part;
-      ok[nth] = true;
-      bool* okp = &ok[nth];
-      uint8_t* slot = g_upload_slot[b];
-      th[nth++] = std::thread([=]() { *okp = fill(slot + a, off + a, l); });
-    }
-    for (int t = 0; t < nth; t++) { th[t].join(); if (!ok[t]) *io_error = true; }
-    if (*io_error) break;
-    e = hipMemcpyAsync(d + off, g_upload_slot[b], len, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipEventRecord(g_upload_done[b], ctx->stream);
-    used[b] = true;
-  }
-  hipError_t e2 = hipStreamSynchronize(ctx->stream);
-  return e != hipSuccess ? e : e2;
+  return xfer_striped(ctx, (uint8_t*)dst, bytes, true, fill, io_error);
 }
 
 // the bytes [file_off, file_off + bytes) of an open file -> device memory
@@ -466,50 +514,20 @@ static int upload_from_file(tpg_ctx* ctx, void* dst, int fd, size_t file_off, si
   return TPG_OK;
 }
 
-// device memory -> host memory the caller owns (pageable): large results come down through the pinned slots, the DMA of
-// chunk c + 1 .. c + 3 running while UPLOAD_THREADS threads copy chunk c out of its slot (a single hipMemcpy into
-// pageable memory measured 19 GB/s on N x N matrices of doubles).
+// device memory -> host memory the caller owns (pageable): large results come down through the transfer team (a single
+// hipMemcpy into pageable memory measured 19 GB/s on N x N matrices of doubles).
 hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes < (64u << 20)) {
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
     return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
   }
-  std::lock_guard<std::mutex> lk(g_upload_mu);
-  hipError_t e = upload_slots_init();
-  if (e != hipSuccess) return e;
-  const uint8_t* sp = (const uint8_t*)src;
+  bool io_error = false;
   uint8_t* dp = (uint8_t*)dst;
-  const size_t nchunks = (bytes + UPLOAD_CHUNK - 1) / UPLOAD_CHUNK;
-  auto issue = [&](size_t c) {
-    const size_t off = c * UPLOAD_CHUNK, len = bytes - off < UPLOAD_CHUNK ? bytes - off : UPLOAD_CHUNK;
-    const int b = (int)(c % UPLOAD_SLOTS);
-    hipError_t ee = hipMemcpyAsync(g_upload_slot[b], sp + off, len, hipMemcpyDeviceToHost, ctx->stream);
-    return ee == hipSuccess ? hipEventRecord(g_upload_done[b], ctx->stream) : ee;
-  };
-  for (size_t c = 0; c < nchunks && c < (size_t)UPLOAD_SLOTS && e == hipSuccess; c++) e = issue(c);
-  for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
-    const size_t off = c * UPLOAD_CHUNK, len = bytes - off < UPLOAD_CHUNK ? bytes - off : UPLOAD_CHUNK;
-    const int b = (int)(c % UPLOAD_SLOTS);
-    e = hipEventSynchronize(g_upload_done[b]);
-    if (e != hipSuccess) break;
-    const size_t part = ((len + UPLOAD_THREADS - 1) / UPLOAD_THREADS + 4095) & ~(size_t)4095;
-    std::thread th[UPLOAD_THREADS];
-    int nth = 0;
-    for (int t = 0; t < UPLOAD_THREADS; t++) {
-      const size_t a = (size_t)t * part;
-      if (a >= len) break;
-      const size_t l = len - a < part ? len - a : part;
-      const uint8_t* slot = g_upload_slot[b];
-      th[nth++] = std::thread([=]() { memcpy(dp + off + a, slot + a, l); });
-    }
-    for (int t = 0; t < nth; t++) th[t].join();
-    if (c + UPLOAD_SLOTS < nchunks) e = issue(c + UPLOAD_SLOTS);  // the slot is free again
-  }
-  hipError_t e2 = hipStreamSynchronize(ctx->stream);
-  return e != hipSuccess ? e : e2;
+  return xfer_striped(ctx, (uint8_t*)const_cast<void*>(src), bytes, false,
+                      [=](uint8_t* p, size_t off, size_t len) { memcpy(dp + off, p, len); return true; }, &io_error);
 }
 
-// host memory -> device memory.  Large buffers go through the pinned slots with UPLOAD_THREADS threads copying (and,
+// host memory -> device memory.  Large buffers go through the transfer team, its threads copying (and,
 // for a file mapping touched for the first time -- the FBM pointer an R session holds --, faulting pages in) in
 // parallel; small ones with one hipMemcpy.
 hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
@@ -641,10 +659,24 @@ extern "C" void tpg_fbm_free(tpg_fbm* fbm) {
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n,
-                               const int32_t* colInd1, int64_t m, const double* code256, tpg_view** out) {
-  TpgEnter _enter(ctx);
-  TPG_REQUIRE(ctx && fbm && out, TPG_EINVAL, "null argument");
+// byte -> 2-bit code table from a code256 (NULL = raw bytes: 0 / 1 / 2 valid, everything else missing)
+static void make_lut(const double* code256, uint8_t* lut) {
+  for (int b = 0; b < 256; b++) {
+    if (!code256) { lut[b] = b < 3 ? (uint8_t)b : 3; continue; }
+    double x = code256[b];
+    if (!(x > -1)) lut[b] = 3;  // NA (NaN), same test as the reference
+    else if (x == 0.0) lut[b] = 0;
+    else if (x == 1.0) lut[b] = 1;
+    else if (x == 2.0) lut[b] = 2;
+    else lut[b] = 0xFF;  // unsupported value: flagged by the pack kernel only if it occurs
+  }
+}
+
+// one view, or two views of the same (rows, columns) through two code tables packed from one read of the FBM
+static int view_create_impl(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n, const int32_t* colInd1,
+                            int64_t m, const double* code256_a, const double* code256_b, bool two, tpg_view** out_a,
+                            tpg_view** out_b) {
+  TPG_REQUIRE(ctx && fbm && out_a && (!two || out_b), TPG_EINVAL, "null argument");
   if (!rowInd1) n = fbm->nrow;
   if (!colInd1) m = fbm->ncol;
   TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty view (%lld x %lld)", (long long)n, (long long)m);
@@ -658,28 +690,20 @@ extern "C" int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* 
     for (int64_t j = 0; j < m; j++)
       TPG_REQUIRE(colInd1[j] >= 1 && colInd1[j] <= fbm->ncol, TPG_EINVAL, "colInd[%lld] = %d out of [1,%lld]",
                   (long long)j, colInd1[j], (long long)fbm->ncol);
-  // byte -> 2-bit code table
-  uint8_t lut[256];
-  for (int b = 0; b < 256; b++) {
-    if (!code256) { lut[b] = b < 3 ? (uint8_t)b : 3; continue; }
-    double x = code256[b];
-    if (!(x > -1)) lut[b] = 3;  // NA (NaN), same test as the reference
-    else if (x == 0.0) lut[b] = 0;
-    else if (x == 1.0) lut[b] = 1;
-    else if (x == 2.0) lut[b] = 2;
-    else lut[b] = 0xFF;  // unsupported value: flagged by the pack kernel only if it occurs
-  }
-  TPG_HIP(hipSetDevice(ctx->device));
-  tpg_view* v = new tpg_view{ctx, n, m, ceil_div(n, 128), ceil_div(m, 128), nullptr, nullptr, 0};
-  v->bytes_each = (size_t)v->Q * (size_t)v->KG * 4096;
+  const int nv = two ? 2 : 1;
+  uint8_t lut[2 * (256 + 16)];
+  memset(lut, 0, sizeof(lut));  // table, then its 16-byte flag area (zero)
+  make_lut(code256_a, lut);
+  if (two) make_lut(code256_b, lut + 256 + 16);
+  tpg_view* v[2] = {nullptr, nullptr};
   int32_t *d_rows = nullptr, *d_cols = nullptr;
   uint8_t* d_lut = nullptr;
-  int rc = TPG_OK;
   auto fail = [&](int code) {
     if (d_rows) tpg_pfree(d_rows);
     if (d_cols) tpg_pfree(d_cols);
     if (d_lut) tpg_pfree(d_lut);
-    tpg_view_free(v);
+    tpg_view_free(v[0]);
+    tpg_view_free(v[1]);
     return code;
   };
 #define VHIP(call)                                                                       \
@@ -690,34 +714,59 @@ extern "C" int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* 
       return fail(TPG_EHIP);                                                             \
     }                                                                                    \
   } while (0)
-  VHIP(tpg_pmalloc((void**)&v->T, v->bytes_each));
-  VHIP(tpg_pmalloc((void**)&v->L, v->bytes_each));
-  VHIP(tpg_pmalloc((void**)&d_lut, 256 + 16));
-  VHIP(hipMemcpyAsync(d_lut, lut, 256, hipMemcpyHostToDevice, ctx->stream));
-  VHIP(hipMemsetAsync(d_lut + 256, 0, 16, ctx->stream));
+  for (int k = 0; k < nv; k++) {
+    v[k] = new tpg_view{ctx, n, m, ceil_div(n, 128), ceil_div(m, 128), nullptr, nullptr, 0};
+    v[k]->bytes_each = (size_t)v[k]->Q * (size_t)v[k]->KG * 4096;
+    VHIP(tpg_pmalloc((void**)&v[k]->T, v[k]->bytes_each));
+    VHIP(tpg_pmalloc((void**)&v[k]->L, v[k]->bytes_each));
+  }
+  VHIP(tpg_pmalloc((void**)&d_lut, sizeof(lut)));
+  VHIP(tpg_h2d_async(ctx, d_lut, lut, (size_t)nv * (256 + 16)));
   if (rowInd1) {
     VHIP(tpg_pmalloc((void**)&d_rows, sizeof(int32_t) * (size_t)n));
-    VHIP(hipMemcpyAsync(d_rows, rowInd1, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    VHIP(tpg_h2d_async(ctx, d_rows, rowInd1, sizeof(int32_t) * (size_t)n));
   }
   if (colInd1) {
     VHIP(tpg_pmalloc((void**)&d_cols, sizeof(int32_t) * (size_t)m));
-    VHIP(hipMemcpyAsync(d_cols, colInd1, sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    VHIP(tpg_h2d_async(ctx, d_cols, colInd1, sizeof(int32_t) * (size_t)m));
   }
-  rc = tpg_launch_pack(ctx, fbm, d_rows, d_cols, d_lut, v);
+  int rc = tpg_launch_pack(ctx, fbm, d_rows, d_cols, d_lut, v[0], v[1]);
   if (rc != TPG_OK) return fail(rc);
-  int32_t bad = 0;
-  VHIP(hipMemcpyAsync(&bad, d_lut + 256, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  // the "a byte that occurs maps to no 2-bit code" flags: the one host round trip of a view creation
+  uint8_t back[2 * (256 + 16)];
+  VHIP(hipMemcpyAsync(back, d_lut, (size_t)nv * (256 + 16), hipMemcpyDeviceToHost, ctx->stream));
   VHIP(hipStreamSynchronize(ctx->stream));
 #undef VHIP
-  if (bad) {
-    tpg_set_error("code256 maps an occurring FBM byte to a value outside {0,1,2,NA}; the 2-bit device path cannot represent it");
-    return fail(TPG_EUNSUPPORTED);
+  for (int k = 0; k < nv; k++) {
+    int32_t bad;
+    memcpy(&bad, back + k * (256 + 16) + 256, sizeof(bad));
+    if (bad) {
+      tpg_set_error("code256 maps an occurring FBM byte to a value outside {0,1,2,NA}; the 2-bit device path cannot represent it");
+      return fail(TPG_EUNSUPPORTED);
+    }
   }
   if (d_rows) tpg_pfree(d_rows);
   if (d_cols) tpg_pfree(d_cols);
   tpg_pfree(d_lut);
-  *out = v;
+  *out_a = v[0];
+  if (two) *out_b = v[1];
   return TPG_OK;
+}
+
+extern "C" int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n,
+                               const int32_t* colInd1, int64_t m, const double* code256, tpg_view** out) {
+  TpgEnter _enter(ctx);
+  return view_create_impl(ctx, fbm, rowInd1, n, colInd1, m, code256, nullptr, false, out, nullptr);
+}
+
+// Two views of the same (rowInd, colInd) through two code tables from ONE read of the FBM bytes: the raw view of
+// the pairwise statistics (code256_a = NULL or CODE_012) and the imputed view of the PCA (CODE_IMPUTE_PRED) that an
+// analysis of one gen_tibble needs (R/gt_has_imputed.R:101-106 flips the FBM's code256 between exactly these).
+extern "C" int tpg_view_create_pair(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n,
+                                    const int32_t* colInd1, int64_t m, const double* code256_a, const double* code256_b,
+                                    tpg_view** out_a, tpg_view** out_b) {
+  TpgEnter _enter(ctx);
+  return view_create_impl(ctx, fbm, rowInd1, n, colInd1, m, code256_a, code256_b, true, out_a, out_b);
 }
 
 extern "C" void tpg_view_free(tpg_view* v) {
