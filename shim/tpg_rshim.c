@@ -119,7 +119,7 @@ static mapped_file* genotype_fbm(SEXP BM) {
 
 static tpg_fbm* genotype_fbm_dev(SEXP BM) {
   mapped_file* f = genotype_fbm(BM);
-  /* straight from the file (pread into pinned memory, no page faults on the mapping) */
+  /* the library maps the file, touches its pages with a team of threads and uploads it with one copy */
   if (!f->dev) TPG_R(tpg_fbm_open_bk(ctx(), f->path, f->nrow, f->ncol, &f->dev));
   return f->dev;
 }

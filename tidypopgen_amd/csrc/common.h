@@ -127,15 +127,17 @@ struct tpg_view {
   mutable std::vector<int32_t> gc_cls;
 };
 
-// tile-packed int32 accumulators of the pairwise kernel: per unit (64-row super-tile I, 32-column
-// tile jt >= 2I) 5 products x 2 sub-tiles x 16 accumulator registers x 64 lanes (MFMA C/D order)
+// tile-packed int32 accumulators of the pairwise kernel: per unit (super-tile I of TPG_PW_TA row tiles, 32-column
+// tile jt >= TA I) 5 products x TA sub-tiles x 16 accumulator registers x 64 lanes (MFMA C/D order)
 #define TPG_PW_PRODUCTS 5  // V, D, H, HV (= A[i][j]), VH (= A[j][i])
-#define TPG_PW_TILE_INTS (TPG_PW_PRODUCTS * 2 * 16 * 64)
+#define TPG_PW_TA 3        // A row tiles per wave: 96 x 32 pairs, 15 accumulator tiles (240 AGPRs); see pairwise.hip
+#define TPG_PW_PLANE_INTS (TPG_PW_TA * 16 * 64)
+#define TPG_PW_TILE_INTS (TPG_PW_PRODUCTS * TPG_PW_PLANE_INTS)
 struct tpg_pairwise {
   tpg_ctx* ctx;
   int64_t n;
-  int64_t nst;  // super-tiles of 64 individuals
-  int64_t ntp;  // number of (I, jt) units = nst*(nst+1)
+  int64_t nst;  // super-tiles of 32 TPG_PW_TA individuals
+  int64_t ntp;  // number of (I, jt) unit slots = TA nst (nst + 1) / 2
   int32_t* acc;
   bool owns;
   void* order;  // device int2[nun]: the units (I, jt) that hold data, in XCD patch order (pairwise.hip)

@@ -52,37 +52,42 @@ __device__ __forceinline__ Frag3 tpg_decode3(uint32_t w) {
   return f;
 }
 
-// unit (I, jt): rows = super-tile I (row tiles 2I, 2I+1), columns = row tile jt >= 2I.
-// slab index u = 2 (I nst - I (I-1)/2) + (jt - 2I); slab = [product][ta][reg][lane] int32.
-__device__ __forceinline__ int64_t tpg_pw_unit_index(int nst, int I, int jt) {
-  return 2 * ((int64_t)I * nst - ((int64_t)I * (I - 1)) / 2) + (jt - 2 * I);
+// unit (I, jt): rows = super-tile I (row tiles TA I .. TA I + TA - 1), columns = row tile jt >= TA I.
+// slab index u = TA (I nst - I (I-1)/2) + (jt - TA I); slab = [product][ta][reg][lane] int32.
+constexpr int TA = TPG_PW_TA;
+__host__ __device__ __forceinline__ int64_t tpg_pw_unit_index(int nst, int I, int jt) {
+  return TA * ((int64_t)I * nst - ((int64_t)I * (I - 1)) / 2) + (jt - TA * I);
 }
 
-// The pairwise kernel.  One wave = one (I, jt) unit: a 64 x 32 tile of pairs, five products, ten accumulator
-// tiles (160 AGPRs), one wave per SIMD.  The fragment decode is SOFTWARE-PIPELINED one K step ahead: an MFMA
-// whose A/B operands were written by VALU instructions 0 / 1 / 2 MFMAs earlier takes 47.6 / 41.6 / 36.4 cycles
-// instead of 32 (tools/ubench_mfma_dep.hip), so the three fragments of K step s+1 are decoded into a second
-// register set while the 10 MFMAs of step s issue (one MFMA, then six decode VALU, enforced with
-// sched_group_barrier) and every operand is ~10 MFMAs old when it is read.  Operand words are prefetched two
-// 128-locus groups ahead through three rotating register slots.  Earlier forms of this kernel (decode placed by
-// the compiler; 2 waves per SIMD; a workgroup-shared 2-bit -> byte spread through LDS) measured 10-20% slower
-// and are gone; DESIGN.md 3.4 keeps the numbers.
+// The pairwise kernel.  One wave = one (I, jt) unit: a (32 TA) x 32 tile of pairs, five products, 5 TA accumulator
+// tiles (240 AGPRs at TA = 3), one wave per SIMD.  Per 32 loci: TA + 1 fragment dwords -> 7 bit ops + 12 v_perm_b32
+// each -> 5 TA MFMAs.  The kernel is bound by VALU issue, not by the MFMA pipe: an MFMA holds the SIMD's issue for 8
+// of its 32 cycles and every decode instruction costs about 5 more, so a wave runs at ~8 + 5 x (VALU per MFMA) cycles
+// per MFMA when that exceeds 32 -- 19 (TA + 1) / (5 TA) = 5.7 VALU per MFMA at TA = 2 (64 x 32 tiles, measured 36.8
+// cycles per MFMA), 5.07 at TA = 3.  TA = 4 would need 320 accumulator registers.
+// The fragment decode is SOFTWARE-PIPELINED one K step ahead: an MFMA whose A/B operands were written by VALU
+// instructions 0 / 1 / 2 MFMAs earlier takes 47.6 / 41.6 / 36.4 cycles instead of 32 (tools/ubench_mfma_dep.hip), so
+// the fragments of K step s+1 are decoded into a second register set while the MFMAs of step s issue (one MFMA,
+// then five or six decode VALU, enforced with sched_group_barrier).  Operand words are prefetched two 128-locus groups
+// ahead through three rotating register slots.  Earlier forms of this kernel (decode placed by the compiler; 2 waves
+// per SIMD; a workgroup-shared 2-bit -> byte spread through LDS) measured 10-20% slower and are gone; DESIGN.md 3.4
+// keeps the numbers.
 #define SGB_MFMA 0x008
 #define SGB_VALU 0x002
 __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __restrict__ T, int64_t KG,
-                                                                 int64_t kg_begin, int64_t kg_end, int nst,
+                                                                 int64_t kg_begin, int64_t kg_end, int nst, int nct,
                                                                  const int2* __restrict__ order, int64_t nun, int S,
                                                                  const int64_t* __restrict__ rowpad,
                                                                  int32_t* __restrict__ acc_out) {
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int64_t kgs = kg_end - kg_begin;
-  // Work distribution.  `order` (host-built, tpg_pairwise_create) lists the (I, jt) units of the triangle in
+  // Work distribution.  `order` (host-built, pairwise_create) lists the (I, jt) units of the triangle in
   // PATCH order: blocks of 16 column tiles, inside a block row after row, so four consecutive entries nearly
-  // always share the 64-row super-tile I (the four waves of a workgroup then fetch the A stream into the CU
+  // always share the super-tile I (the four waves of a workgroup then fetch the A stream into the CU
   // once) and a run of 128 consecutive entries is ~8 rows x 16 columns.  Workgroups are dispatched round-robin
   // over the 8 XCDs (blockIdx % 8); in every round XCD x takes such a run for its 128 waves (same K range):
-  // ~16 A and ~16 B tiles per 128 loci instead of ~100 distinct ones with a plain strided assignment, so the
+  // a few dozen distinct tiles per 128 loci instead of ~100 with a plain strided assignment, so the
   // re-reads hit that XCD's own L2.
   const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
   for (int64_t round = 0;; round++) {
@@ -94,13 +99,21 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
     const int64_t tp0 = tpg_pw_unit_index(nst, I, jt) + rowpad[I];
     const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
 
-    const uint4* pa0 = T + ((int64_t)(2 * I) * KG) * 64 + lane;
-    const uint4* pa1 = T + ((int64_t)(2 * I + 1) * KG) * 64 + lane;
+    // A row tiles past the last one with data (the last super-tile may be partial; the view holds 4 ceil(n / 128)
+    // row tiles) read tile 0 instead and are forced to all-missing codes: zero planes, zero products
+    const uint4* pa[TA];
+    uint32_t gone[TA];
+#pragma unroll
+    for (int t = 0; t < TA; t++) {
+      const bool there = TA * I + t < nct;
+      pa[t] = T + ((int64_t)(there ? TA * I + t : 0) * KG) * 64 + lane;
+      gone[t] = there ? 0u : ~0u;
+    }
     const uint4* pb0 = T + ((int64_t)jt * KG) * 64 + lane;
 
-    v16i cV[2], cD[2], cH[2], cHV[2], cVH[2];
+    v16i cV[TA], cD[TA], cH[TA], cHV[TA], cVH[TA];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < TA; t++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { cV[t][r] = 0; cD[t][r] = 0; cH[t][r] = 0; cHV[t][r] = 0; cVH[t][r] = 0; }
 
@@ -112,48 +125,58 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       // native vectors, not HIP's uint4 struct: with the struct the register allocator splits the loaded tuple right
       // after the load (v_mov behind an s_waitcnt vmcnt: a full memory latency at the top of every group)
       typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-      v4u R0[3], R1[3], RB[3];
+      v4u RA[3][TA], RB[3];
       auto LD = [&](const uint4* p) { return *(const v4u*)p; };
-      R0[0] = LD(pa0 + k0 * 64); R1[0] = LD(pa1 + k0 * 64); RB[0] = LD(pb0 + k0 * 64);
       const int64_t i1 = k0 + 1 < k1 ? k0 + 1 : kl;
-      R0[1] = LD(pa0 + i1 * 64); R1[1] = LD(pa1 + i1 * 64); RB[1] = LD(pb0 + i1 * 64);
-      Frag3 P[2][3];
-      P[0][0] = tpg_decode3(R0[0].x); P[0][1] = tpg_decode3(R1[0].x); P[0][2] = tpg_decode3(RB[0].x);
+#pragma unroll
+      for (int t = 0; t < TA; t++) { RA[0][t] = LD(pa[t] + k0 * 64); RA[1][t] = LD(pa[t] + i1 * 64); }
+      RB[0] = LD(pb0 + k0 * 64);
+      RB[1] = LD(pb0 + i1 * 64);
+      Frag3 P[2][TA + 1];
+#pragma unroll
+      for (int t = 0; t < TA; t++) P[0][t] = tpg_decode3(RA[0][t].x | gone[t]);
+      P[0][TA] = tpg_decode3(RB[0].x);
       auto group = [&](auto Cc, auto Nn, auto Mm, int64_t kg) {
         constexpr int C = decltype(Cc)::value, N = decltype(Nn)::value, M = decltype(Mm)::value;
         const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
-        // the three loads of the group after next go out one per step (behind a step barrier, so the scheduler
+        // the loads of the group after next go out one per step (behind a step barrier, so the scheduler
         // cannot sink them to their use): back-to-back loads hold this wave's issue while the MFMA pipe drains
         // words of the 4 K steps of this group, followed by step 0 of the next group; past k1: all missing
         const uint32_t dead = kg < k1 ? 0u : ~0u, dead1 = kg + 1 < k1 ? 0u : ~0u;
-        const uint32_t wa0[4] = {R0[C].x | dead, R0[C].y | dead, R0[C].z | dead, R0[C].w | dead};
-        const uint32_t wa1[4] = {R1[C].x | dead, R1[C].y | dead, R1[C].z | dead, R1[C].w | dead};
+        uint32_t wa[TA][4];
+#pragma unroll
+        for (int t = 0; t < TA; t++) {
+          const uint32_t off = dead | gone[t];
+          wa[t][0] = RA[C][t].x | off; wa[t][1] = RA[C][t].y | off; wa[t][2] = RA[C][t].z | off; wa[t][3] = RA[C][t].w | off;
+        }
         const uint32_t wb[4] = {RB[C].x, RB[C].y, RB[C].z, RB[C].w};
 #pragma unroll
         for (int s = 0; s < 4; s++) {
           const int cur = s & 1, nx = cur ^ 1;
-          if (s == 0) R0[M] = LD(pa0 + i2 * 64);
-          if (s == 1) R1[M] = LD(pa1 + i2 * 64);
-          if (s == 2) RB[M] = LD(pb0 + i2 * 64);
+          if (s < TA) RA[M][s] = LD(pa[s] + i2 * 64);
+          if (s == 3) RB[M] = LD(pb0 + i2 * 64);
+          if (TA < 3 && s == 2) RB[M] = LD(pb0 + i2 * 64);
           // the next group's slot is first touched in the last step's region (one barrier per step), so the wait
           // for its loads comes as late as possible
-          P[nx][0] = tpg_decode3(s < 3 ? wa0[s < 3 ? s + 1 : 0] : (R0[N].x | dead1));
-          P[nx][1] = tpg_decode3(s < 3 ? wa1[s < 3 ? s + 1 : 0] : (R1[N].x | dead1));
-          P[nx][2] = tpg_decode3(s < 3 ? wb[s < 3 ? s + 1 : 0] : RB[N].x);
 #pragma unroll
-          for (int t = 0; t < 2; t++) cV[t] = MFMA_I8(P[cur][t].v, P[cur][2].v, cV[t]);  // product-major order: ~1 % faster
+          for (int t = 0; t < TA; t++) P[nx][t] = tpg_decode3(s < 3 ? wa[t][s < 3 ? s + 1 : 0] : (RA[N][t].x | dead1 | gone[t]));
+          P[nx][TA] = tpg_decode3(s < 3 ? wb[s < 3 ? s + 1 : 0] : RB[N].x);
 #pragma unroll
-          for (int t = 0; t < 2; t++) cD[t] = MFMA_I8(P[cur][t].d, P[cur][2].d, cD[t]);  // than tile-major (measured)
+          for (int t = 0; t < TA; t++) cV[t] = MFMA_I8(P[cur][t].v, P[cur][TA].v, cV[t]);  // product-major order: ~1 % faster
 #pragma unroll
-          for (int t = 0; t < 2; t++) cH[t] = MFMA_I8(P[cur][t].h, P[cur][2].h, cH[t]);
+          for (int t = 0; t < TA; t++) cD[t] = MFMA_I8(P[cur][t].d, P[cur][TA].d, cD[t]);  // than tile-major (measured)
 #pragma unroll
-          for (int t = 0; t < 2; t++) cHV[t] = MFMA_I8(P[cur][t].h, P[cur][2].v, cHV[t]);
+          for (int t = 0; t < TA; t++) cH[t] = MFMA_I8(P[cur][t].h, P[cur][TA].h, cH[t]);
 #pragma unroll
-          for (int t = 0; t < 2; t++) cVH[t] = MFMA_I8(P[cur][t].v, P[cur][2].h, cVH[t]);
+          for (int t = 0; t < TA; t++) cHV[t] = MFMA_I8(P[cur][t].h, P[cur][TA].v, cHV[t]);
 #pragma unroll
-          for (int q = 0; q < 10; q++) {
+          for (int t = 0; t < TA; t++) cVH[t] = MFMA_I8(P[cur][t].v, P[cur][TA].h, cVH[t]);
+          // 19 (TA + 1) decode VALU (plus the masks) spread over the 5 TA MFMAs of the step
+#pragma unroll
+          for (int q = 0; q < 5 * TA; q++) {
             __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SGB_VALU, 6, 0);
+            if (TA == 2 || q % 3 == 2) __builtin_amdgcn_sched_group_barrier(SGB_VALU, 6, 0);
+            else __builtin_amdgcn_sched_group_barrier(SGB_VALU, 5, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -169,24 +192,25 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
     }
     int32_t* slab = acc_out + tp0 * TPG_PW_TILE_INTS + lane;
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < TA; t++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int o = (t * 16 + r) * 64;
-        atomicAdd(slab + 0 * 2048 + o, cV[t][r]);
-        atomicAdd(slab + 1 * 2048 + o, cD[t][r]);
-        atomicAdd(slab + 2 * 2048 + o, cH[t][r]);
-        atomicAdd(slab + 3 * 2048 + o, cHV[t][r]);
-        atomicAdd(slab + 4 * 2048 + o, cVH[t][r]);
+        atomicAdd(slab + 0 * TPG_PW_PLANE_INTS + o, cV[t][r]);
+        atomicAdd(slab + 1 * TPG_PW_PLANE_INTS + o, cD[t][r]);
+        atomicAdd(slab + 2 * TPG_PW_PLANE_INTS + o, cH[t][r]);
+        atomicAdd(slab + 3 * TPG_PW_PLANE_INTS + o, cHV[t][r]);
+        atomicAdd(slab + 4 * TPG_PW_PLANE_INTS + o, cVH[t][r]);
       }
   }
 }
 
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
 // Bands: super-tile rows dealt to `nranks` ranks in contiguous runs of (nearly) equal unit counts (row I holds
-// 2 (nst - I) units).  -> band boundaries and the padded chunk size (units) every band gets in the buffer.
+// TA (nst - I) units).  -> band boundaries and the padded chunk size (units) every band gets in the buffer.
 static void pw_bands(int64_t nst, int nranks, std::vector<int32_t>& band, int64_t& chunk) {
-  const int64_t total = nst * (nst + 1);
+  const int64_t total = TA * nst * (nst + 1) / 2;
   band.assign((size_t)nranks + 1, (int32_t)nst);
   band[0] = 0;
   // boundary r = the row boundary whose cumulative unit count is nearest to r / nranks of the total
@@ -194,7 +218,7 @@ static void pw_bands(int64_t nst, int nranks, std::vector<int32_t>& band, int64_
   int r = 1;
   for (int64_t I = 0; I < nst && r < nranks; I++) {
     const int64_t before = cum;
-    cum += 2 * (nst - I);
+    cum += TA * (nst - I);
     while (r < nranks && cum * nranks >= total * r) {
       const bool cut_before = (total * r - before * nranks) < (cum * nranks - total * r) && (int32_t)I > band[(size_t)r - 1];
       band[(size_t)r] = (int32_t)(cut_before ? I : I + 1);
@@ -202,13 +226,13 @@ static void pw_bands(int64_t nst, int nranks, std::vector<int32_t>& band, int64_
     }
   }
   chunk = 0;
-  auto off = [&](int64_t I) { return 2 * (I * nst - (I * (I - 1)) / 2); };
+  auto off = [&](int64_t I) { return TA * (I * nst - (I * (I - 1)) / 2); };
   for (int q = 0; q < nranks; q++) chunk = std::max(chunk, off(band[(size_t)q + 1]) - off(band[(size_t)q]));
   if (chunk < 1) chunk = 1;
 }
 
 static size_t pw_buffer_bytes(int64_t n, int nranks) {
-  const int64_t nst = ceil_div(n, 64);
+  const int64_t nst = ceil_div(n, 32 * TA);
   std::vector<int32_t> band;
   int64_t chunk;
   pw_bands(nst, nranks, band, chunk);
@@ -222,8 +246,8 @@ static int pairwise_create(tpg_ctx* ctx, int64_t n, int nranks, int rank, void* 
   TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(n > 0 && n < (1 << 22), TPG_EINVAL, "bad n = %lld", (long long)n);
   TPG_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, TPG_EINVAL, "bad rank %d of %d", rank, nranks);
-  tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 64), 0, nullptr, false, nullptr, 0, 0, 0};
-  pw->ntp = pw->nst * (pw->nst + 1);
+  tpg_pairwise* pw = new tpg_pairwise{ctx, n, ceil_div(n, 32 * TA), 0, nullptr, false, nullptr, 0, 0, 0};
+  pw->ntp = TA * pw->nst * (pw->nst + 1) / 2;
   pw->nranks = nranks;
   pw->rank = rank;
   pw_bands(pw->nst, nranks, pw->band, pw->chunk_units);
@@ -236,12 +260,12 @@ static int pairwise_create(tpg_ctx* ctx, int64_t n, int nranks, int rank, void* 
     order.reserve((size_t)pw->ntp);
     for (int pc = 0; pc * 16 < nct; pc++) {
       const int c1 = std::min(nct, pc * 16 + 16);
-      for (int I = 0; I < nst && 2 * I < c1; I++)
-        for (int jt = std::max(pc * 16, 2 * I); jt < c1; jt++) order.push_back(make_int2(I, jt));
+      for (int I = 0; I < nst && TA * I < c1; I++)
+        for (int jt = std::max(pc * 16, TA * I); jt < c1; jt++) order.push_back(make_int2(I, jt));
     }
     pw->nun = (int64_t)order.size();
     std::vector<int64_t> rowpad((size_t)nst);
-    auto off = [&](int64_t I) { return 2 * (I * nst - (I * (I - 1)) / 2); };
+    auto off = [&](int64_t I) { return TA * (I * nst - (I * (I - 1)) / 2); };
     for (int r = 0; r < nranks; r++)
       for (int I = pw->band[(size_t)r]; I < pw->band[(size_t)r + 1]; I++)
         rowpad[(size_t)I] = (int64_t)r * pw->chunk_units - off(pw->band[(size_t)r]);
@@ -322,9 +346,9 @@ extern "C" int tpg_pairwise_band_of(int64_t n, int nranks, int rank, int64_t* ro
   TPG_REQUIRE(row0 && row1 && n > 0 && nranks >= 1 && rank >= 0 && rank < nranks, TPG_EINVAL, "bad argument");
   std::vector<int32_t> band;
   int64_t chunk;
-  pw_bands(ceil_div(n, 64), nranks, band, chunk);
-  *row0 = std::min<int64_t>(n, 64 * (int64_t)band[(size_t)rank]);
-  *row1 = std::min<int64_t>(n, 64 * (int64_t)band[(size_t)rank + 1]);
+  pw_bands(ceil_div(n, 32 * TA), nranks, band, chunk);
+  *row0 = std::min<int64_t>(n, 32 * TA * (int64_t)band[(size_t)rank]);
+  *row1 = std::min<int64_t>(n, 32 * TA * (int64_t)band[(size_t)rank + 1]);
   return TPG_OK;
 }
 
@@ -332,8 +356,8 @@ extern "C" int tpg_pairwise_band_of(int64_t n, int nranks, int rank, int64_t* ro
 extern "C" int tpg_pairwise_band(const tpg_pairwise* pw, int64_t* row0, int64_t* row1) {
   TPG_REQUIRE(pw && row0 && row1, TPG_EINVAL, "null argument");
   if (!pw->reduced || pw->nranks == 1) { *row0 = 0; *row1 = pw->n; return TPG_OK; }
-  *row0 = std::min<int64_t>(pw->n, 64 * (int64_t)pw->band[(size_t)pw->rank]);
-  *row1 = std::min<int64_t>(pw->n, 64 * (int64_t)pw->band[(size_t)pw->rank + 1]);
+  *row0 = std::min<int64_t>(pw->n, 32 * TA * (int64_t)pw->band[(size_t)pw->rank]);
+  *row1 = std::min<int64_t>(pw->n, 32 * TA * (int64_t)pw->band[(size_t)pw->rank + 1]);
   return TPG_OK;
 }
 
@@ -420,7 +444,8 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
     if (eff > best + 0.01) { best = eff; bestS = (int)S; }
   }
   TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T, v->KG,
-             kg0, kg1, (int)pw->nst, (const int2*)pw->order, pw->nun, bestS, (const int64_t*)pw->rowpad, pw->acc);
+             kg0, kg1, (int)pw->nst, (int)ceil_div(pw->n, 32), (const int2*)pw->order, pw->nun, bestS, (const int64_t*)pw->rowpad,
+             pw->acc);
   TPG_CHECK_LAUNCH();
   return TPG_OK;
 }
@@ -491,13 +516,13 @@ __global__ __launch_bounds__(256) void tpg_pairwise_epilogue_kernel(const int32_
   const int ti = blockIdx.y + ti0, tj = blockIdx.x + ti0;  // tile rows of this rank's band, columns from its first one
   if (ti > tj) return;
   __shared__ int sp[5][32][33];
-  const int32_t* p = acc + (tpg_pw_unit_index(nst, ti >> 1, tj) + rowpad[ti >> 1]) * TPG_PW_TILE_INTS + ((ti & 1) * 16) * 64;
+  const int32_t* p = acc + (tpg_pw_unit_index(nst, ti / TA, tj) + rowpad[ti / TA]) * TPG_PW_TILE_INTS + ((ti % TA) * 16) * 64;
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const int idx = threadIdx.x + 256 * e, reg = idx >> 6, lane = idx & 63;
     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
 #pragma unroll
-    for (int q = 0; q < 5; q++) sp[q][row][col] = p[q * 2048 + reg * 64 + lane];
+    for (int q = 0; q < 5; q++) sp[q][row][col] = p[q * TPG_PW_PLANE_INTS + reg * 64 + lane];
   }
   __syncthreads();
 #pragma unroll
@@ -534,10 +559,10 @@ static PwBand pw_band(const tpg_pairwise* pw) {
   const int nt = (int)ceil_div(pw->n, 32);
   if (!pw->reduced || pw->nranks == 1) return PwBand{0, nt, 0, pw->n, true};
   const int i0 = pw->band[(size_t)pw->rank], i1 = pw->band[(size_t)pw->rank + 1];
-  b.ti0 = std::min(nt, 2 * i0);
-  b.nti = std::min(nt, 2 * i1) - b.ti0;
-  b.r0 = std::min<int64_t>(pw->n, 64 * (int64_t)i0);
-  b.r1 = std::min<int64_t>(pw->n, 64 * (int64_t)i1);
+  b.ti0 = std::min(nt, TA * i0);
+  b.nti = std::min(nt, TA * i1) - b.ti0;
+  b.r0 = std::min<int64_t>(pw->n, 32 * TA * (int64_t)i0);
+  b.r1 = std::min<int64_t>(pw->n, 32 * TA * (int64_t)i1);
   b.whole = false;
   return b;
 }

@@ -382,163 +382,47 @@ InBuf::~InBuf() {
 }
 
 // ---------------------------------------------------------------------------
-// Host <-> HBM bulk transfers, the cold-start cost of every analysis (5 GB for a 5 000 x 1 000 000 FBM).  A team of
-// XFER_THREADS host threads each takes a contiguous stripe of the transfer and moves it in 4-MiB pieces through two
-// pinned slots of its own on a stream of its own: while the DMA engine works on one slot the thread fills (upload:
-// pread() from the page cache or memcpy from the caller's memory) or drains (download: memcpy into the caller's
-// pageable memory) the other.  No per-piece thread creation, no mapping of the file (an mmap costs a page fault per
-// 4 KiB on first touch).  Slots, streams and events are created once per process and device.
-static constexpr size_t XFER_PIECE = 4u << 20;
+// Host <-> HBM bulk transfers, the cold-start cost of every analysis (5 GB for a 5 000 x 1 000 000 FBM).  On the
+// MI355X boxes one hipMemcpy between device memory and pageable host memory whose pages are present runs at the
+// PCIe rate (52-57 GB/s measured, tools/xfer_probe.py) -- faster than anything this library staged by hand through
+// pinned slots (30-41 GB/s).  What makes a transfer slow is page faults inside it: a result matrix the caller has
+// just allocated, or an FBM file mapping touched for the first time (19 and 13 GB/s measured).  So:
+// large host buffers -- a backing file is simply mapped -- are first touched by XFER_THREADS threads in parallel (one
+// access per 4-KiB page), then moved with ONE hipMemcpy.  (Reading the file with pread() into pinned or pageable staging
+// buffers, piece by piece beside the DMA, measured 7-41 GB/s, and pinned staging adds a set-up cost to the first call.)
 static constexpr int XFER_THREADS = 16;
-struct XferLane {
-  uint8_t* slot[2] = {nullptr, nullptr};
-  hipEvent_t done[2] = {};
-  hipStream_t stream = nullptr;
-};
-struct XferTeam {
-  int device = -1;
-  XferLane lane[XFER_THREADS];
-};
-static std::mutex g_xfer_mu;  // one bulk transfer at a time per process: the slots are shared
-static std::vector<XferTeam*> g_xfer_teams;
+static constexpr size_t XFER_BIG = 64u << 20;
 
-static hipError_t xfer_team(int device, XferTeam** out) {  // caller holds g_xfer_mu and has made `device` current
-  for (auto t : g_xfer_teams)
-    if (t->device == device) { *out = t; return hipSuccess; }
-  XferTeam* t = new XferTeam();
-  t->device = device;
-  hipError_t e = hipSuccess;
-  for (int k = 0; k < XFER_THREADS && e == hipSuccess; k++) {
-    e = hipStreamCreateWithFlags(&t->lane[k].stream, hipStreamNonBlocking);
-    for (int b = 0; b < 2 && e == hipSuccess; b++) {
-      e = hipHostMalloc((void**)&t->lane[k].slot[b], XFER_PIECE, hipHostMallocDefault);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&t->lane[k].done[b], hipEventDisableTiming);
-    }
-  }
-  if (e != hipSuccess) {
-    for (int k = 0; k < XFER_THREADS; k++) {
-      for (int b = 0; b < 2; b++) {
-        if (t->lane[k].slot[b]) (void)hipHostFree(t->lane[k].slot[b]);
-        if (t->lane[k].done[b]) (void)hipEventDestroy(t->lane[k].done[b]);
-      }
-      if (t->lane[k].stream) (void)hipStreamDestroy(t->lane[k].stream);
-    }
-    delete t;
-    return e;
-  }
-  g_xfer_teams.push_back(t);
-  *out = t;
-  return hipSuccess;
-}
-
-// upload: host_fill(pinned_dst, offset, len) -> false on a read error.  download: host_drain(pinned_src, offset, len).
-// The caller's stream is drained first (the transfer runs on the team's own streams) and the team is waited for at
-// the end, so the transfer is ordered with the context's work on both sides.
-template <typename HostSide>
-static hipError_t xfer_striped(tpg_ctx* ctx, uint8_t* dev, size_t bytes, bool to_device, HostSide host_side, bool* io_error) {
-  std::lock_guard<std::mutex> lk(g_xfer_mu);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) return e;
-  XferTeam* team = nullptr;
-  e = xfer_team(ctx->device, &team);
-  if (e != hipSuccess) return e;
-  const size_t npieces = (bytes + XFER_PIECE - 1) / XFER_PIECE;
-  const int nth = (int)std::min<size_t>(XFER_THREADS, npieces);
-  std::vector<hipError_t> errs((size_t)nth, hipSuccess);
-  std::vector<char> bad((size_t)nth, 0);
+template <typename F>  // f(thread, lo, hi) over [0, bytes) cut into page-aligned stripes
+static void xfer_parallel(size_t bytes, F f) {
+  const size_t pages = (bytes + 4095) / 4096;
+  const int nth = (int)std::min<size_t>(XFER_THREADS, std::max<size_t>(1, pages / 256));
   std::vector<std::thread> th;
-  const int device = ctx->device;
-  for (int t = 0; t < nth; t++)
-    th.emplace_back([=, &errs, &bad]() {
-      hipError_t ee = hipSetDevice(device);
-      XferLane& ln = team->lane[t];
-      const size_t p0 = npieces * (size_t)t / (size_t)nth, p1 = npieces * ((size_t)t + 1) / (size_t)nth;
-      bool used[2] = {false, false};
-      if (to_device) {
-        for (size_t p = p0; p < p1 && ee == hipSuccess; p++) {
-          const int b = (int)((p - p0) & 1);
-          const size_t off = p * XFER_PIECE, len = std::min(XFER_PIECE, bytes - off);
-          if (used[b]) ee = hipEventSynchronize(ln.done[b]);  // the DMA out of this slot has finished
-          if (ee != hipSuccess) break;
-          if (!host_side(ln.slot[b], off, len)) { bad[(size_t)t] = 1; break; }
-          ee = hipMemcpyAsync(dev + off, ln.slot[b], len, hipMemcpyHostToDevice, ln.stream);
-          if (ee == hipSuccess) ee = hipEventRecord(ln.done[b], ln.stream);
-          used[b] = true;
-        }
-      } else {
-        auto issue = [&](size_t p) {
-          const int b = (int)((p - p0) & 1);
-          const size_t off = p * XFER_PIECE, len = std::min(XFER_PIECE, bytes - off);
-          hipError_t e2 = hipMemcpyAsync(ln.slot[b], dev + off, len, hipMemcpyDeviceToHost, ln.stream);
-          return e2 == hipSuccess ? hipEventRecord(ln.done[b], ln.stream) : e2;
-        };
-        if (p0 < p1) ee = issue(p0);
-        for (size_t p = p0; p < p1 && ee == hipSuccess; p++) {
-          const int b = (int)((p - p0) & 1);
-          const size_t off = p * XFER_PIECE, len = std::min(XFER_PIECE, bytes - off);
-          if (p + 1 < p1) ee = issue(p + 1);  // the other slot fills while this one is drained
-          if (ee == hipSuccess) ee = hipEventSynchronize(ln.done[b]);
-          if (ee == hipSuccess) host_side(ln.slot[b], off, len);
-        }
-      }
-      hipError_t es = hipStreamSynchronize(ln.stream);
-      errs[(size_t)t] = ee != hipSuccess ? ee : es;
-    });
-  for (auto& t : th) t.join();
   for (int t = 0; t < nth; t++) {
-    if (bad[(size_t)t]) *io_error = true;
-    if (errs[(size_t)t] != hipSuccess) e = errs[(size_t)t];
+    const size_t lo = std::min(bytes, pages * (size_t)t / (size_t)nth * 4096), hi = std::min(bytes, pages * ((size_t)t + 1) / (size_t)nth * 4096);
+    if (lo < hi) th.emplace_back([=]() { f(t, lo, hi); });
   }
-  return e;
+  for (auto& t : th) t.join();
 }
 
-template <typename Fill>
-static hipError_t upload_chunked(tpg_ctx* ctx, void* dst, size_t bytes, Fill fill, bool* io_error) {
-  return xfer_striped(ctx, (uint8_t*)dst, bytes, true, fill, io_error);
-}
-
-// the bytes [file_off, file_off + bytes) of an open file -> device memory
-static int upload_from_file(tpg_ctx* ctx, void* dst, int fd, size_t file_off, size_t bytes, const char* what) {
-  bool io_error = false;
-  hipError_t e = upload_chunked(ctx, dst, bytes, [=](uint8_t* p, size_t off, size_t len) {
-    size_t got = 0;
-    while (got < len) {
-      const ssize_t r = pread(fd, p + got, len - got, (off_t)(file_off + off + got));
-      if (r <= 0) return false;
-      got += (size_t)r;
-    }
-    return true;
-  }, &io_error);
-  if (io_error) { tpg_set_error("%s: read error", what); return TPG_EINVAL; }
-  if (e != hipSuccess) { tpg_set_error("%s: upload failed: %s", what, hipGetErrorString(e)); return TPG_EHIP; }
-  return TPG_OK;
-}
-
-// device memory -> host memory the caller owns (pageable): large results come down through the transfer team (a single
-// hipMemcpy into pageable memory measured 19 GB/s on N x N matrices of doubles).
+// device memory -> host memory the caller owns (pageable)
 hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
-  if (bytes < (64u << 20)) {
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+  if (bytes >= XFER_BIG) {  // make the pages present (the buffer is about to be overwritten anyway)
+    volatile uint8_t* d = (volatile uint8_t*)dst;
+    xfer_parallel(bytes, [=](int, size_t lo, size_t hi) { for (size_t o = lo; o < hi; o += 4096) d[o] = 0; });
   }
-  bool io_error = false;
-  uint8_t* dp = (uint8_t*)dst;
-  return xfer_striped(ctx, (uint8_t*)const_cast<void*>(src), bytes, false,
-                      [=](uint8_t* p, size_t off, size_t len) { memcpy(dp + off, p, len); return true; }, &io_error);
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
 }
 
-// host memory -> device memory.  Large buffers go through the transfer team, its threads copying (and,
-// for a file mapping touched for the first time -- the FBM pointer an R session holds --, faulting pages in) in
-// parallel; small ones with one hipMemcpy.
+// host memory -> device memory
 hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
-  if (bytes < (64u << 20)) {
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
-    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+  if (bytes >= XFER_BIG) {  // fault the source in (an FBM file mapping an R session has not read yet)
+    const volatile uint8_t* sp = (const volatile uint8_t*)src;
+    xfer_parallel(bytes, [=](int, size_t lo, size_t hi) { uint8_t acc = 0; for (size_t o = lo; o < hi; o += 4096) acc ^= sp[o]; (void)acc; });
   }
-  bool io_error = false;
-  const uint8_t* sp = (const uint8_t*)src;
-  return upload_chunked(ctx, dst, bytes, [=](uint8_t* p, size_t off, size_t len) { memcpy(p, sp + off, len); return true; },
-                        &io_error);
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+  return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
 }
 
 extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, tpg_fbm** out) {
@@ -569,14 +453,12 @@ extern "C" int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int
     return TPG_EINVAL;
   }
   const size_t sz = (size_t)nrow * (size_t)ncol;
-  tpg_fbm* f = new tpg_fbm{ctx, nullptr, nrow, ncol};
-  hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
-  if (e != hipSuccess) { close(fd); delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
-  const int rc = upload_from_file(ctx, f->d_bytes, fd, 0, sz, path);
+  void* p = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
   close(fd);
-  if (rc != TPG_OK) { (void)hipFree(f->d_bytes); delete f; return rc; }
-  *out = f;
-  return TPG_OK;
+  TPG_REQUIRE(p != MAP_FAILED, TPG_EINVAL, "mmap of %s failed", path);
+  int rc = tpg_fbm_from_host(ctx, (const uint8_t*)p, nrow, ncol, out);  // parallel page touch + one copy (tpg_upload)
+  munmap(p, sz);
+  return rc;
 }
 
 extern "C" int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0, int npop,
@@ -618,29 +500,26 @@ extern "C" int tpg_fbm_open_bed(tpg_ctx* ctx, const char* path, int64_t n, int64
   TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty .bed (%lld x %lld)", (long long)n, (long long)m);
   int fd = open(path, O_RDONLY);
   TPG_REQUIRE(fd >= 0, TPG_EINVAL, "cannot open %s", path);
-  const int64_t bpl = (n + 3) / 4;
-  const size_t sz = (size_t)bpl * (size_t)m;
+  const size_t sz = 3 + (size_t)((n + 3) / 4) * (size_t)m;
   struct stat st;
-  uint8_t magic[3] = {0, 0, 0};
-  if (fstat(fd, &st) != 0 || (size_t)st.st_size < sz + 3 || pread(fd, magic, 3, 0) != 3) {
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < sz) {
     close(fd);
     tpg_set_error("%s is smaller than a %lld x %lld .bed", path, (long long)n, (long long)m);
     return TPG_EINVAL;
   }
-  if (magic[0] != 0x6C || magic[1] != 0x1B || magic[2] != 0x01) {
-    close(fd);
-    tpg_set_error("%s is not a SNP-major PLINK .bed (magic %02x %02x %02x)", path, magic[0], magic[1], magic[2]);
-    return TPG_EINVAL;
-  }
-  tpg_fbm* f = new tpg_fbm{ctx, nullptr, n, m};
-  f->bed_bpl = bpl;
-  hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
-  if (e != hipSuccess) { close(fd); delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
-  const int rc = upload_from_file(ctx, f->d_bytes, fd, 3, sz, path);
+  void* p = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
   close(fd);
-  if (rc != TPG_OK) { (void)hipFree(f->d_bytes); delete f; return rc; }
-  *out = f;
-  return TPG_OK;
+  TPG_REQUIRE(p != MAP_FAILED, TPG_EINVAL, "mmap of %s failed", path);
+  const uint8_t* b = (const uint8_t*)p;
+  int rc;
+  if (b[0] != 0x6C || b[1] != 0x1B || b[2] != 0x01) {
+    tpg_set_error("%s is not a SNP-major PLINK .bed (magic %02x %02x %02x)", path, b[0], b[1], b[2]);
+    rc = TPG_EINVAL;
+  } else {
+    rc = tpg_fbm_from_bed_host(ctx, b + 3, n, m, out);
+  }
+  munmap(p, sz);
+  return rc;
 }
 
 extern "C" int tpg_fbm_to_host(tpg_ctx* ctx, const tpg_fbm* fbm, uint8_t* bytes) {
