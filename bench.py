@@ -190,31 +190,52 @@ def digest(st):
     return out
 
 
-def end_to_end(st):
-    """Host backing file -> HBM -> every result of the step back in host memory, on this rank's panel (rank 0, N = 1):
-    what an R caller holding a bigstatsr .bk file pays, PCIe included.  The .bk is written once from the resident
-    panel (untimed); timed: tpg_fbm_open_bk (mmap + upload), one step, the downloads of IBS / KING / GRM (N x N
-    doubles each), the per-locus frequencies, the grouped frequencies and the PCA factors."""
-    tpg, api, lib, ctx, a = st.tpg, st.api, st.lib, st.ctx, st.args
-    chk = tpg._lib.check
-    n, m, G, k = a.n, st.m, a.pops, a.k
+def _e2e_file(st):
+    """the resident panel written out as a bigstatsr .bk (column-major bytes) in a RAM-backed or temporary directory"""
+    n, m = st.args.n, st.m
     need = n * m + (1 << 28)
-    tmp = None
-    for cand in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")):  # a RAM-backed file if there is room: the page cache is warm anyway
+    # a real file system's page cache first (what a .bk on disk is read from; a hipMemcpy out of a shmem mapping is
+    # slower: tools/xfer_probe.hip), /dev/shm only if there is no room
+    for cand in (os.environ.get("TMPDIR", "/tmp"), "/dev/shm"):
         try:
             s = os.statvfs(cand)
             if s.f_bavail * s.f_frsize > need:
-                tmp = cand
-                break
-        except OSError:
+                path = os.path.join(cand, f"tpg_bench_{os.getpid()}.bk")
+                st.X.to_numpy().T.tofile(path)  # column-major n x m bytes == row-major (m, n)
+                return path
+        except (OSError, MemoryError):
             pass
-    if tmp is None:
-        return {"skipped": "no room for the backing file"}
-    path = os.path.join(tmp, f"tpg_bench_{os.getpid()}.bk")
-    try:
-        st.X.to_numpy().T.tofile(path)  # column-major n x m bytes == row-major (m, n)
-    except (OSError, MemoryError) as e:
-        return {"skipped": f"could not write the backing file: {e}"}
+    return None
+
+
+def _e2e_download(st, ctx, d_nn, d_freq_blocks, d_gfreq_blocks, mbs, host):
+    """results -> host memory (IBS / KING / GRM, per-locus and grouped frequencies)"""
+    api, lib, chk = st.api, st.lib, st.tpg._lib.check
+    n, G = st.args.n, st.args.pops
+    total = 0
+    for name, d in zip(("ibs", "king", "grm"), d_nn):
+        host[name] = np.empty((n, n), order="F")
+        chk(lib.tpg_dev_to_host(ctx.h, api._ptr(host[name]), d, C.c_size_t(8 * n * n)))
+        total += 8 * n * n
+    host["freq"], host["gfreq"] = [], []
+    for d, mb in zip(d_freq_blocks, mbs):
+        a = np.empty((mb, 2), order="F")
+        chk(lib.tpg_dev_to_host(ctx.h, api._ptr(a), d, C.c_size_t(a.nbytes)))
+        host["freq"].append(a)
+        total += a.nbytes
+    for d, mb in zip(d_gfreq_blocks, mbs):
+        a = np.empty((mb, 2 * G), order="F")
+        chk(lib.tpg_dev_to_host(ctx.h, api._ptr(a), d, C.c_size_t(a.nbytes)))
+        host["gfreq"].append(a)
+        total += a.nbytes
+    return total
+
+
+def _e2e_serial(st, path):
+    """upload everything, run the step, download everything"""
+    tpg, api, lib, ctx, a = st.tpg, st.api, st.lib, st.ctx, st.args
+    chk = tpg._lib.check
+    n, m, k = a.n, st.m, a.k
     resident = st.X
     try:
         t0 = time.perf_counter()
@@ -223,28 +244,160 @@ def end_to_end(st):
         t_up = time.perf_counter()
         st.run()
         t_run = time.perf_counter()
-        host = [np.empty((n, n), order="F") for _ in range(3)]
-        for h, d in zip(host, st.d_nn):
-            chk(lib.tpg_dev_to_host(ctx.h, api._ptr(h), d, C.c_size_t(8 * n * n)))
-        freq = np.empty((m, 2), order="F")
-        chk(lib.tpg_dev_to_host(ctx.h, api._ptr(freq), st.d_freq, C.c_size_t(freq.nbytes)))
-        gfreq = np.empty((m, 2 * G), order="F")
-        chk(lib.tpg_dev_to_host(ctx.h, api._ptr(gfreq), st.d_gfreq, C.c_size_t(gfreq.nbytes)))
+        host = {}
+        down = _e2e_download(st, ctx, st.d_nn, [st.d_freq], [st.d_gfreq], [m], host)
         u = np.empty((n, k), order="F")
         chk(lib.tpg_dev_to_host(ctx.h, api._ptr(u), st.d_pca["u"], C.c_size_t(u.nbytes)))
         vl = np.empty((st.m_pca, k), order="F")
         chk(lib.tpg_dev_to_host(ctx.h, api._ptr(vl), st.d_pca["v"], C.c_size_t(vl.nbytes)))
         t1 = time.perf_counter()
-        up_bytes = n * m
-        down_bytes = sum(h.nbytes for h in host) + freq.nbytes + gfreq.nbytes + u.nbytes + vl.nbytes
-        return {"value": n * m / (t1 - t0), "unit": "SNP-genotypes/s", "seconds": t1 - t0,
-                "upload_s": t_up - t0, "step_s": t_run - t_up, "download_s": t1 - t_run,
-                "upload_GBps": up_bytes / (t_up - t0) / 1e9, "download_GBps": down_bytes / (t1 - t_run) / 1e9,
-                "bytes_up": up_bytes, "bytes_down": down_bytes,
-                "route": "bigstatsr .bk (1 byte per genotype), warm page cache -> tpg_fbm_open_bk -> step -> results in host memory; serial (upload, compute, download)"}
+        down += u.nbytes + vl.nbytes
+        return {"value": n * m / (t1 - t0), "seconds": t1 - t0, "upload_s": t_up - t0, "step_s": t_run - t_up,
+                "download_s": t1 - t_run, "upload_GBps": n * m / (t_up - t0) / 1e9,
+                "download_GBps": down / (t1 - t_run) / 1e9, "bytes_up": n * m, "bytes_down": down}
     finally:
         st.X.free()
         st.X = resident
+
+
+def _e2e_overlapped(st, path, nblocks=8):
+    """The reference's own block loop (R/snp_ibs.R:59-82) as a pipeline: a second host thread, with a context (stream)
+    of its own, uploads block b + 1 of the loci (tpg_fbm_upload_cols) while the main context packs block b (raw and
+    imputed view from one read), takes its per-locus statistics and Fst sums and adds its pairwise cross-products and
+    its Gram matrix to the running totals (all additive over loci).  After the last block: epilogues, then the
+    N x N results go down on the second thread while eigen step and loadings run."""
+    import queue
+    import threading
+
+    tpg, api, lib, ctx, a = st.tpg, st.api, st.lib, st.ctx, st.args
+    chk = tpg._lib.check
+    n, m, G, k, P = a.n, st.m, a.pops, a.k, st.P
+    groups = -(-m // 128)
+    edges = sorted({min(m, 128 * (groups * b // nblocks)) for b in range(nblocks + 1)})
+    blocks = [(c0, c1) for c0, c1 in zip(edges, edges[1:]) if c1 > c0]
+    mbs = [c1 - c0 for c0, c1 in blocks]
+    mm = np.memmap(path, dtype=np.uint8, mode="r", shape=(n, m), order="F")
+    up_ctx = tpg.Context(ctx.device)
+    # device buffers of the results (allocation is not what is being measured)
+    d_freq = [ctx.dev_alloc(16 * mb) for mb in mbs]
+    d_gfreq = [ctx.dev_alloc(16 * G * mb) for mb in mbs]
+    d_K = ctx.dev_alloc(8 * n * n)
+    d_u = ctx.dev_alloc(8 * n * k)
+    pca = []  # per block: (imputed view, d_center, d_scale, d_v, m_pca_block)
+    sums = np.zeros((4, P))
+    part = np.zeros((4, P))
+    host = {}
+    errors = []
+    t0 = time.perf_counter()
+    X = tpg.FBM.alloc(n, m, ctx=ctx, code256=tpg.CODE_012)
+    ready = queue.Queue()
+
+    def uploader():
+        try:
+            for b, (c0, c1) in enumerate(blocks):
+                X.upload_cols(mm[:, c0:c1], c0, ctx=up_ctx)
+                ready.put(b)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            ready.put(None)
+
+    th = threading.Thread(target=uploader)
+    th.start()
+    st.pw.zero()
+    fro = 0.0
+    for _ in blocks:
+        b = ready.get()
+        if b is None:
+            raise errors[0]
+        c0, c1 = blocks[b]
+        cols = np.arange(c0 + 1, c1 + 1, dtype=np.int32)
+        pc = cols if st.pca_cols is None else st.pca_cols[(st.pca_cols > c0) & (st.pca_cols <= c1)]
+        if st.pca_cols is None:
+            v, vi = api.View.pair(X, None, cols, st.code_012, st.code_imp)
+        else:
+            v, vi = api.View(X, None, cols, code256=st.code_012), api.View(X, None, pc, code256=st.code_imp)
+        chk(lib.tpg_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(st.ploidy), C.c_int(0), d_freq[b]))
+        chk(lib.tpg_grouped_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(st.gid), C.c_int(G), api._ptr(st.ploidy), C.c_int(0),
+                                                d_gfreq[b]))
+        for row, code in ((0, 0), (2, 2)):
+            chk(lib.tpg_pairwise_pop_fst_sums(ctx.h, v.h, api._ptr(st.gid), C.c_int(G), api._ptr(st.ploidy), C.c_int(code),
+                                              api._ptr(st.pairs), C.c_int(P), api._ptr(part[row]), api._ptr(part[row + 1])))
+        sums += part
+        st.pw.accumulate(v)
+        v.free()
+        dc, ds, dv = ctx.dev_alloc(8 * len(pc)), ctx.dev_alloc(8 * len(pc)), ctx.dev_alloc(8 * len(pc) * k)
+        chk(lib.tpg_pca_center_scale(ctx.h, vi.h, dc, ds))
+        chk((lib.tpg_pca_gram if not pca else lib.tpg_pca_gram_add)(ctx.h, vi.h, dc, ds, d_K))
+        f = C.c_double()
+        chk(lib.tpg_square_frobenius(ctx.h, vi.h, dc, ds, C.byref(f)))
+        fro += f.value
+        pca.append((vi, dc, ds, dv, len(pc)))
+    th.join()
+    t_up = time.perf_counter()
+    st.pw.reduce()
+    chk(lib.tpg_pairwise_epilogues_sharded(ctx.h, st.comm.h, st.pw.h, C.c_int(0), C.c_int64(m), st.d_nn[0], st.d_nn[1],
+                                           C.c_void_p(None), st.d_nn[2]))
+    ctx.sync()  # the results below are read by another stream
+    down = [0]
+
+    def downloader():
+        try:
+            down[0] = _e2e_download(st, up_ctx, st.d_nn, d_freq, d_gfreq, mbs, host)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = threading.Thread(target=downloader)
+    th.start()
+    lam = np.zeros(k)
+    chk(lib.tpg_sym_eig_topk(ctx.h, d_K, C.c_int64(n), C.c_int(k), api._ptr(lam), d_u))
+    d = np.sqrt(np.maximum(lam, 0))
+    for vi, dc, ds, dv, mp in pca:
+        chk(lib.tpg_pca_loadings(ctx.h, vi.h, dc, ds, d_u, api._ptr(d), C.c_int(k), dv))
+    u = np.empty((n, k), order="F")
+    chk(lib.tpg_dev_to_host(ctx.h, api._ptr(u), d_u, C.c_size_t(u.nbytes)))
+    vls = []
+    for vi, dc, ds, dv, mp in pca:
+        vl = np.empty((mp, k), order="F")
+        chk(lib.tpg_dev_to_host(ctx.h, api._ptr(vl), dv, C.c_size_t(vl.nbytes)))
+        vls.append(vl)
+    th.join()
+    t1 = time.perf_counter()
+    if errors:
+        raise errors[0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        fst_h = sums[0] / sums[1]
+    # the pipeline must give what the resident step gives
+    check = {"fst_hudson_max_rel_diff": float(np.nanmax(np.abs(fst_h / st.fst["Hudson"] - 1))),
+             "pca_d_max_rel_diff": float(np.max(np.abs(d / st.pca_d - 1))) if st.has_pca else None,
+             "frobenius_rel_diff": abs(fro / st.pca_fro.value - 1) if st.has_pca else None}
+    for vi, dc, ds, dv, mp in pca:
+        vi.free()
+        for p_ in (dc, ds, dv):
+            ctx.dev_free(p_)
+    for p_ in d_freq + d_gfreq + [d_K, d_u]:
+        ctx.dev_free(p_)
+    X.free()
+    up_ctx.close()
+    bytes_down = down[0] + u.nbytes + sum(x.nbytes for x in vls)
+    return {"value": n * m / (t1 - t0), "seconds": t1 - t0, "last_block_in_HBM_s": t_up - t0, "tail_s": t1 - t_up,
+            "blocks": len(blocks), "bytes_up": n * m, "bytes_down": bytes_down, "agreement_with_resident_step": check}
+
+
+def end_to_end(st):
+    """Host backing file -> HBM -> every result of the step back in host memory, on rank 0's panel at N = 1: what an R
+    caller holding a bigstatsr .bk file pays, PCIe included (never `value`).  Two ways: serial (upload, step,
+    download) and the block pipeline of _e2e_overlapped."""
+    path = _e2e_file(st)
+    if path is None:
+        return {"skipped": "no room for the backing file"}
+    try:
+        ser = _e2e_serial(st, path)
+        ovl = _e2e_overlapped(st, path)
+        return {"value": ovl["value"], "unit": "SNP-genotypes/s", "seconds": ovl["seconds"],
+                "route": "bigstatsr .bk (1 byte per genotype, warm page cache) -> HBM in 8 locus blocks uploaded by a second "
+                         "thread / stream beside pack + accumulate -> all results in host memory",
+                "overlapped": ovl, "serial": ser}
+    finally:
         try:
             os.remove(path)
         except OSError:

@@ -76,6 +76,12 @@ int tpg_dev_from_host(tpg_ctx* ctx, void* dev_dst, const void* host_src, size_t 
 int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, tpg_fbm** out);
 /* mmap bigstatsr's <backingfile>.bk and upload it */
 int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int64_t ncol, tpg_fbm** out);
+/* An FBM that arrives block of columns by block of columns (the reference's own block loop, R/snp_ibs.R:59-82):
+ * tpg_fbm_alloc reserves the HBM, tpg_fbm_upload_cols fills columns [col0, col0 + ncols) (0-based) from host memory.
+ * Called from a second host thread with a context of its own, the upload of block b + 1 overlaps the pack /
+ * accumulate kernels of block b (views over columns already uploaded).  bench.py's end_to_end leg is the worked example. */
+int tpg_fbm_alloc(tpg_ctx* ctx, int64_t nrow, int64_t ncol, tpg_fbm** out);
+int tpg_fbm_upload_cols(tpg_ctx* ctx, tpg_fbm* fbm, const uint8_t* host_cols, int64_t col0, int64_t ncols);
 /* deterministic synthetic panel generated on the device (csrc/synth_common.h) */
 int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0, int npop,
                   uint32_t miss_thresh, int imputed_bytes, tpg_fbm** out);
@@ -327,6 +333,9 @@ int tpg_pca_center_scale(tpg_ctx* ctx, const tpg_view* v, double* center, double
 /* Gram matrix K = Z Z' (n x n) accumulated behind bigstatsr::big_SVD
  * (call site R/gt_pca_partialSVD.R:82-89) */
 int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale, double* K);
+/* K (device memory, n x n) += Gram matrix of this view's loci: block-by-block accumulation for callers that receive
+ * the genotypes in blocks of loci; tpg_sym_eig_topk and tpg_pca_loadings finish the SVD */
+int tpg_pca_gram_add(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale, double* K);
 /* full partial SVD: d[k], u n x k, v m x k, center[m], scale[m]; square_frobenius may be NULL
  * (R/square_frobenius.R:19-35).  k <= 52 (the eigen solver works on a block of 2k + 12 <= 64 vectors). */
 int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,

@@ -140,6 +140,21 @@ class FBM:
         return cls(ctx, h, a.shape[0], a.shape[1], code256)
 
     @classmethod
+    def alloc(cls, nrow: int, ncol: int, ctx: Optional[Context] = None, code256=None) -> "FBM":
+        """HBM for an FBM whose columns arrive block by block (upload_cols)"""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib.tpg_fbm_alloc(ctx.h, C.c_int64(nrow), C.c_int64(ncol), C.byref(h)))
+        return cls(ctx, h, nrow, ncol, code256)
+
+    def upload_cols(self, host_cols, col0: int, ctx: Optional[Context] = None):
+        """columns [col0, col0 + k) <- host bytes (nrow x k, Fortran order, e.g. a slice of a numpy memmap of the .bk);
+        pass another Context (another stream) to run the upload beside kernels of this FBM's own context"""
+        a = np.asarray(host_cols)
+        assert a.dtype == np.uint8 and a.ndim == 2 and a.flags.f_contiguous and a.shape[0] == self.nrow
+        check(lib.tpg_fbm_upload_cols((ctx or self.ctx).h, self.h, _ptr(a), C.c_int64(col0), C.c_int64(a.shape[1])))
+
+    @classmethod
     def open_bk(cls, path: str, nrow: int, ncol: int, ctx: Optional[Context] = None, code256=None) -> "FBM":
         ctx = ctx or default_context()
         h = C.c_void_p()

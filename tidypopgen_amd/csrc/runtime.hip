@@ -440,6 +440,31 @@ extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nro
   return TPG_OK;
 }
 
+// An FBM whose bytes arrive block of columns by block of columns (the reference's own block loop, R/snp_ibs.R:59-82):
+// tpg_fbm_alloc reserves the HBM, tpg_fbm_upload_cols fills columns [col0, col0 + ncols) from host memory.  Called
+// from a second host thread with a context of its own (its own stream) the upload of block b + 1 runs beside the
+// pack / accumulate kernels of block b, which only read columns already uploaded (tpg_view_create with that colInd).
+extern "C" int tpg_fbm_alloc(tpg_ctx* ctx, int64_t nrow, int64_t ncol, tpg_fbm** out) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(nrow > 0 && ncol > 0, TPG_EINVAL, "empty FBM (%lld x %lld)", (long long)nrow, (long long)ncol);
+  tpg_fbm* f = new tpg_fbm{ctx, nullptr, nrow, ncol};
+  hipError_t e = hipMalloc((void**)&f->d_bytes, (size_t)nrow * (size_t)ncol);
+  if (e != hipSuccess) { delete f; tpg_set_error("hipMalloc failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  *out = f;
+  return TPG_OK;
+}
+
+extern "C" int tpg_fbm_upload_cols(tpg_ctx* ctx, tpg_fbm* fbm, const uint8_t* host_cols, int64_t col0, int64_t ncols) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && fbm && host_cols, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(fbm->bed_bpl == 0, TPG_EUNSUPPORTED, "a .bed store is uploaded as a whole");
+  TPG_REQUIRE(col0 >= 0 && ncols >= 0 && col0 + ncols <= fbm->ncol, TPG_EINVAL, "columns [%lld, %lld) outside the FBM",
+              (long long)col0, (long long)(col0 + ncols));
+  TPG_HIP(tpg_upload(ctx, fbm->d_bytes + (size_t)col0 * (size_t)fbm->nrow, host_cols, (size_t)ncols * (size_t)fbm->nrow));
+  return TPG_OK;
+}
+
 extern "C" int tpg_fbm_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int64_t ncol, tpg_fbm** out) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && path && out, TPG_EINVAL, "null argument");
