@@ -878,6 +878,30 @@ extern "C" int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* cente
   return ok.commit(ctx);
 }
 
+// K += Gram matrix of this view's loci (K in device memory): the Gram matrix is additive over loci, so a caller that
+// receives the genotypes block of loci by block of loci (tpg_fbm_upload_cols) accumulates it block by block -- each
+// block with its own per-locus center and scale -- and runs tpg_sym_eig_topk once at the end.
+__global__ void tpg_add_inplace_kernel(double* __restrict__ y, const double* __restrict__ x, int64_t count) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) y[i] += x[i];
+}
+
+extern "C" int tpg_pca_gram_add(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale, double* K) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && v && center && scale && K, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(tpg_is_device_ptr(K), TPG_EINVAL, "K must be device memory");
+  double* d_tmp = nullptr;
+  const int64_t nn = v->n * v->n;
+  TPG_HIP(tpg_pmalloc((void**)&d_tmp, sizeof(double) * (size_t)nn));
+  int rc = tpg_pca_gram(ctx, v, center, scale, d_tmp);
+  if (rc == TPG_OK) {
+    TPG_LAUNCH(ctx, "pca_gram_add", tpg_add_inplace_kernel, dim3(2048), dim3(256), 0, K, (const double*)d_tmp, nn);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { tpg_set_error("gram add: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  }
+  tpg_pfree(d_tmp);
+  return rc;
+}
+
 // ---------------------------------------------------------------------------
 // dense FP64 helpers for the eigen solver (all matrices column-major)
 
