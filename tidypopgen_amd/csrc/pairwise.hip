@@ -431,17 +431,20 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
   pw->loci += col_end - col_begin;
   const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
   const int64_t kgs = kg1 - kg0;
-  // K split: make units * S fill the resident waves evenly, keep >= 8 K groups (1024 loci) per unit
-  int nblk = ctx->num_cu / 8 * 8;  // one workgroup per CU (one wave per SIMD), a multiple of the 8 XCDs
+  // K split S: units x S wave-units over the resident waves (one workgroup per CU, one wave per SIMD; a multiple of
+  // the 8 XCDs), at least 8 K groups (1024 loci) per unit.  Cost model: rounds(S) = ceil(units S / waves) rounds, a
+  // round costs its K range (about 1.0 us per 128-locus group: 60 MFMAs at ~36 cycles) plus the flush of the
+  // accumulators (240 atomic wave-instructions per wave, all waves at once: ~25 us).
+  int nblk = ctx->num_cu / 8 * 8;
   if (nblk < 8) nblk = 8;
   const int64_t nwaves = 4 * (int64_t)nblk;
   int bestS = 1;
   double best = -1;
   const int64_t maxS = kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1;
   for (int64_t S = 1; S <= maxS; S++) {
-    const int64_t U = pw->nun * S;
-    const double eff = (double)U / (double)(ceil_div(U, nwaves) * nwaves);
-    if (eff > best + 0.01) { best = eff; bestS = (int)S; }
+    const int64_t rounds = ceil_div(pw->nun * S, nwaves);
+    const double cost = (double)rounds * ((double)ceil_div(kgs, S) * 1.0 + 25.0);
+    if (best < 0 || cost < best * 0.995) { best = cost; bestS = (int)S; }
   }
   TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T, v->KG,
              kg0, kg1, (int)pw->nst, (int)ceil_div(pw->n, 32), (const int2*)pw->order, pw->nun, bestS, (const int64_t*)pw->rowpad,

@@ -780,16 +780,20 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     GHIP(hipMemcpyAsync(d_order, order.data(), sizeof(int2) * (size_t)nun, hipMemcpyHostToDevice, ctx->stream));
     GHIP(tpg_pmalloc((void**)&d_lut, sizeof(int32_t) * lut.size()));
     GHIP(hipMemcpyAsync(d_lut, lut.data(), sizeof(int32_t) * lut.size(), hipMemcpyHostToDevice, ctx->stream));
-    // K-split: fill the resident workgroups (one per CU, 1 wave per SIMD); grid a multiple of the 8 XCDs
+    // K-split S: units x S wave-units over the resident waves (one workgroup per CU, one wave per SIMD; grid a
+    // multiple of the 8 XCDs).  Cost model: a launch is rounds(S) = ceil(units S / waves) rounds, a round costs its K
+    // range (about 1.17 us per 128-locus group: 64 MFMAs at ~37 cycles) plus the flush of the accumulators (256
+    // 64-bit atomic wave-instructions per wave, all waves at once: ~65 us, fitted on the 1 000 x 650 000 launch).  A
+    // small S leaves waves idle in the last round, a large one pays a flush per round.
     int nblk = ctx->num_cu / 8 * 8;
     if (nblk < 8) nblk = 8;
     int bestS = 1;
     double best = -1;
     const int64_t maxS = v->KG / 8 > 0 ? (v->KG / 8 < 96 ? v->KG / 8 : 96) : 1;
     for (int64_t S = 1; S <= maxS; S++) {
-      const int64_t U = nun * S;
-      const double eff = (double)U / (double)(ceil_div(U, 4 * (int64_t)nblk) * 4 * nblk);
-      if (eff > best + 0.01) { best = eff; bestS = (int)S; }  // every split costs a round of 64-bit atomics per unit
+      const int64_t rounds = ceil_div(nun * S, 4 * (int64_t)nblk);
+      const double cost = (double)rounds * ((double)ceil_div(v->KG, S) * 1.17 + 65.0);
+      if (best < 0 || cost < best * 0.995) { best = cost; bestS = (int)S; }
     }
     const unsigned grid = (unsigned)nblk;
     int64_t pass_base = 0;  // dwords
