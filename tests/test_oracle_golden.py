@@ -305,3 +305,64 @@ def test_r_mean_two_pass():
     assert orc.r_mean(x) == pytest.approx(np.mean(x), rel=1e-15)
     assert np.isnan(orc.r_mean([np.nan]))
     assert orc.r_mean([1.0, np.nan, 3.0]) == 2.0
+
+
+def _slow_r_fst(pf, p1, p2, method):
+    """The reference's own vectorised R implementations (data-raw/reference_r_implementations/pairwise_pop_fst.R:
+    Hudson :99-117, Nei87 :179-215, WC84 :277-313), restated with numpy: a second, independently written form of the
+    three estimators in the reference tree.  -> (by-locus Fst, total)"""
+    fa, fr, n, ho = pf["freq_alt"], pf["freq_ref"], pf["n"], pf["het_obs"]
+    cols = [p1, p2]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        if method == "Hudson":
+            num = (fa[:, p1] - fa[:, p2]) ** 2 - fa[:, p1] * fr[:, p1] / (n[:, p1] - 1) - fa[:, p2] * fr[:, p2] / (n[:, p2] - 1)
+            den = fa[:, p1] * fr[:, p2] + fa[:, p2] * fr[:, p1]
+            return num / den, np.nanmean(num) / np.nanmean(den)
+        if method == "Nei87":
+            nn = n[:, cols] / 2
+            sHo = ho[:, cols]
+            mHo = np.nanmean(sHo, axis=1)
+            sp2 = fa[:, cols] ** 2 + fr[:, cols] ** 2
+            np_ = (~np.isnan(nn)).sum(axis=1)
+            mn = np_ / np.nansum(1 / nn, axis=1)
+            msp2 = np.nanmean(sp2, axis=1)
+            mp2 = fa[:, cols].mean(axis=1) ** 2 + fr[:, cols].mean(axis=1) ** 2
+            mHs = mn / (mn - 1) * (1 - msp2 - mHo / 2 / mn)
+            Ht = 1 - mp2 + mHs / mn / np_ - mHo / 2 / mn / np_
+            Dst = Ht - mHs
+            Dstp = np_ / (np_ - 1) * Dst
+            Htp = mHs + Dstp
+            return Dstp / Htp, np.mean(Dstp) / np.mean(Htp)
+        r = 2
+        n_ind = n[:, cols] / 2
+        n_total = n_ind.sum(axis=1)
+        n_bar = n_ind.mean(axis=1)
+        n_c = (n_total - (n_ind ** 2).sum(axis=1) / n_total) / (r - 1)
+        p = fa[:, cols]
+        p_bar = (p * n_ind).sum(axis=1) / n_total
+        s2 = ((p - p_bar[:, None]) ** 2 * n_ind).sum(axis=1) / n_bar / (r - 1)
+        h_bar = (ho[:, cols] * n_ind).sum(axis=1) / n_total
+        a = n_bar / n_c * (s2 - 1 / (n_bar - 1) * (p_bar * (1 - p_bar) - (r - 1) / r * s2 - h_bar / 4))
+        b = n_bar / (n_bar - 1) * (p_bar * (1 - p_bar) - (r - 1) / r * s2 - (2 * n_bar - 1) / (4 * n_bar) * h_bar)
+        c = h_bar / 2
+        return a / (a + b + c), np.nanmean(a) / np.nanmean(a + b + c)
+
+
+@pytest.mark.parametrize("method", ["Hudson", "Nei87", "WC84"])
+def test_fst_loops_against_the_references_vectorised_r_versions(method):
+    # The reference tree holds every estimator twice: the C++ loops the package calls (src/pairwise_fst_*_loop.cpp,
+    # what the oracle's C restates) and the vectorised R versions they replaced (data-raw/reference_r_implementations/).
+    # Two restatements written from two different sources must agree; for Nei87 this is the only cross-check the
+    # reference offers without hierfstat.
+    n, m, G = 90, 400, 4
+    fbm = orc.synth_fbm(91, n, m, npop=G, miss=0.03)
+    gid = (np.arange(n) % G).astype(np.int32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pf = orc.grouped_summaries_dip_pseudo_cpp(fbm, None, None, gid, G, np.full(n, 2.0))
+        got = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method, by_locus=True)
+    pairs = orc.combn2(G)
+    for c in range(pairs.shape[1]):
+        loc, tot = _slow_r_fst(pf, pairs[0, c] - 1, pairs[1, c] - 1, method)
+        # Nei87's Dst = Ht - mHs cancels: the two operation orders differ by ~1e-14 absolute on by-locus values
+        assert np.allclose(got["fst_locus"][:, c], loc, rtol=1e-11, atol=1e-12, equal_nan=True), (method, c)
+        assert got["fst_tot"][c] == pytest.approx(tot, rel=1e-12), (method, c)
