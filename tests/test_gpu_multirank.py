@@ -135,3 +135,40 @@ def test_band_layout_of_many_ranks_on_one_gpu():
             assert np.isnan(got[k][~mask]).all(), (r, k)  # nothing written outside the band
         comm.close()
     assert cover.min() == 1 and cover.max() == 1
+
+
+def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
+    """What a one-GPU box can rehearse of the RCCL transport: librccl is loaded at run time (dlopen), a real
+    communicator is created (TPG_COMM_FORCE_RCCL=1 makes tpg_comm_init_rank do so for one rank too), and the
+    reduce-scatter of the int32 slabs, the N x N FP64 all-reduce inside the sharded PCA, the GRM mean and the host-staged
+    all-reduce of Fst sums all go through ncclReduceScatter / ncclAllReduce on the context's stream.  With one rank the
+    sums are the inputs, so the results must equal the unsharded entry points bit for bit."""
+    import tidypopgen_amd as tpg
+
+    monkeypatch.setenv("TPG_COMM_FORCE_RCCL", "1")
+    n, m, k = 300, 6000, 6
+    X = tpg.FBM.synth(23, n, m, npop=5, miss=0.0, imputed_bytes=True)
+    comm = tpg.Comm.init_rank(X.ctx, 1, 0, None)
+    v = tpg.View(X, code256=None)
+    ref = tpg.Pairwise(X.ctx, n)
+    ref.accumulate(v)
+    sh = tpg.ShardedPairwise(comm, n)
+    sh.accumulate(v)
+    sh.reduce()                                    # ncclReduceScatter, in place
+    e_ref, e_sh = ref.epilogues(m=m), sh.epilogues(m=m)   # GRM mean: ncclAllReduce of two doubles
+    for key in e_ref:
+        assert np.array_equal(e_ref[key], e_sh[key], equal_nan=True), key
+    arr = np.linspace(0, 1, 1000)
+    assert np.array_equal(comm.allreduce_f64(arr.copy()), arr)      # host array staged through the device
+    import ctypes as C
+    from tidypopgen_amd import api
+
+    vi = tpg.View(X, code256=tpg.CODE_IMPUTE_PRED)
+    exact = tpg.gt_pca_partialSVD(X, k=k)
+    d, u = np.zeros(k), np.zeros((n, k), order="F")
+    vl, ce, sc = np.zeros((m, k), order="F"), np.zeros(m), np.zeros(m)
+    fro = C.c_double()
+    tpg._lib.check(tpg._lib.lib.tpg_pca_partial_svd_sharded(X.ctx.h, comm.h, vi.h, C.c_int(k), api._ptr(d), api._ptr(u),
+                                                            api._ptr(vl), api._ptr(ce), api._ptr(sc), C.byref(fro)))
+    assert np.array_equal(d, exact["d"]) and np.array_equal(u, exact["u"]) and fro.value == exact["square_frobenius"]
+    comm.close()

@@ -17,6 +17,7 @@
 // all-reduce callback through host memory instead: it exists so that the sharded code paths can be rehearsed where
 // RCCL cannot run (several ranks sharing one GPU, gloo on CPUs) -- tests only, never the bench.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <thread>
@@ -94,15 +95,19 @@ extern "C" int tpg_comm_init_rank(tpg_ctx* ctx, int nranks, int rank, const uint
   c->ctx = ctx;
   c->nranks = nranks;
   c->rank = rank;
-  if (nranks > 1) {  // a single rank exchanges nothing: no communicator, every collective is the identity
+  // a single rank exchanges nothing: no communicator, every collective is the identity (TPG_COMM_FORCE_RCCL=1 builds
+  // a real one-rank RCCL communicator all the same: the rehearsal of the RCCL calls a one-GPU box allows)
+  const bool force = getenv("TPG_COMM_FORCE_RCCL") && getenv("TPG_COMM_FORCE_RCCL")[0] == '1';
+  if (nranks > 1 || force) {
     RcclApi* api = rccl();
-    if (!api || !id128) {
+    if (!api || (!id128 && nranks > 1)) {
       delete c;
       tpg_set_error(api ? "null unique id" : "RCCL (librccl.so) could not be loaded");
       return api ? TPG_EINVAL : TPG_EHIP;
     }
     ncclUniqueId id;
-    memcpy(&id, id128, 128);
+    if (id128) memcpy(&id, id128, 128);
+    else if (api->GetUniqueId(&id) != ncclSuccess) { delete c; tpg_set_error("ncclGetUniqueId failed"); return TPG_EHIP; }
     ncclComm_t nc = nullptr;
     ncclResult_t r = api->CommInitRank(&nc, nranks, id, rank);  // the context's device is current (TpgEnter)
     if (r != ncclSuccess) {
@@ -169,7 +174,7 @@ static int host_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype,
 
 int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype) {
   TPG_REQUIRE(comm && d_buf && count >= 0 && (dtype == 0 || dtype == 1), TPG_EINVAL, "bad all-reduce arguments");
-  if (comm->nranks == 1 || count == 0) return TPG_OK;
+  if ((comm->nranks == 1 && !comm->nccl) || count == 0) return TPG_OK;
   if (comm->host_fn) return host_allreduce(comm, d_buf, count, dtype, 0, count);
   RcclApi* api = rccl();
   TPG_REQUIRE(api && comm->nccl, TPG_EHIP, "communicator has no transport");
@@ -182,7 +187,7 @@ int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype) {
 // (the other chunks are left with this rank's own partial values)
 int tpg_comm_reduce_scatter_i32(tpg_comm* comm, int32_t* d_buf, int64_t chunk_count) {
   TPG_REQUIRE(comm && d_buf && chunk_count >= 0, TPG_EINVAL, "bad reduce-scatter arguments");
-  if (comm->nranks == 1 || chunk_count == 0) return TPG_OK;
+  if ((comm->nranks == 1 && !comm->nccl) || chunk_count == 0) return TPG_OK;
   if (comm->host_fn)
     return host_allreduce(comm, d_buf, chunk_count * comm->nranks, 0, chunk_count * comm->rank, chunk_count);
   RcclApi* api = rccl();
@@ -198,7 +203,7 @@ extern "C" int tpg_comm_allreduce_f64(tpg_ctx* ctx, tpg_comm* comm, double* buf,
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && comm && buf && count >= 0, TPG_EINVAL, "bad argument");
   TPG_REQUIRE(comm->ctx == ctx, TPG_EINVAL, "the communicator belongs to another context");
-  if (comm->nranks == 1 || count == 0) return TPG_OK;
+  if ((comm->nranks == 1 && !comm->nccl) || count == 0) return TPG_OK;
   ProfScope ps(ctx, "allreduce_f64");
   if (tpg_is_device_ptr(buf)) return tpg_comm_allreduce(comm, buf, count, 1);
   if (comm->host_fn) {

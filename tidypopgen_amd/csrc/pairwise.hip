@@ -322,7 +322,7 @@ extern "C" int tpg_pairwise_reduce(tpg_ctx* ctx, tpg_comm* comm, tpg_pairwise* p
   }
   // the locus count behind the overflow guard is the total over the ranks
   double loci = (double)pw->loci;
-  if (comm->nranks > 1) {
+  if (comm->nranks > 1 || comm->nccl) {
     double* d_l = nullptr;
     TPG_HIP(tpg_pmalloc((void**)&d_l, sizeof(double)));
     hipError_t e = hipMemcpyAsync(d_l, &loci, sizeof(double), hipMemcpyHostToDevice, ctx->stream);

@@ -1595,14 +1595,14 @@ static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, 
   st.mark("counts, center, scale");
   if (square_frobenius) {
     TPG_TRY(frobenius_from_counts(ctx, v, d_counts, oc.dev<double>(), os.dev<double>(), square_frobenius));
-    if (comm && comm->nranks > 1) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, square_frobenius, 1));
+    if (comm) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, square_frobenius, 1));  // identity on a single rank
   }
   TPG_HIP(tpg_pmalloc((void**)&d_K, sizeof(double) * (size_t)n * (size_t)n));
   fr.b = d_K;
   st.mark("frobenius + alloc K");
   TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true));
   st.mark("gram");
-  if (comm && comm->nranks > 1) {  // K = sum over the ranks' loci of z_j z_j'
+  if (comm && (comm->nranks > 1 || comm->nccl)) {  // K = sum over the ranks' loci of z_j z_j'
     ProfScope ps(ctx, "pca_gram_allreduce");
     TPG_TRY(tpg_comm_allreduce(comm, d_K, (int64_t)n * n, 1));
   }
