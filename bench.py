@@ -8,7 +8,7 @@ bytes (5 000 individuals x 1 000 000 SNPs, 51 populations, 2 % missing kept as i
 configs[2..4]):
 
     pack (raw view)  -> loci_alt_freq / missingness counts -> grouped_alt_freq (51 pops)
-    -> pairwise_pop_fst Hudson + WC84 -> IBS + KING + allele-sharing/GRM cross-products (int8 MFMA)
+    -> pairwise_pop_fst Hudson + WC84 -> IBS + KING + allele-sharing/GRM cross-products (FP4 MFMA, exact)
     -> [N > 1: reduce-scatter of the integer N x N partials, all-reduce of the Fst numerator/denominator sums]
     -> IBS / KING / GRM epilogues (every rank its band of the tiles)
     -> pack (imputed view) -> gt_pca_partialSVD (k = 20): center/scale, Gram [N > 1: all-reduce], eigen, loadings
@@ -511,14 +511,15 @@ def main():
             cnt, ms = prof.get(key, (0, 0.0))
             return (ms / cnt) if cnt else None
 
-        # MFMA-bound kernels, priced on ALGORITHMIC int8 ops per launch
-        def mfma_roof(key, kernel, ops, note):
+        # MFMA-bound kernels, priced on ALGORITHMIC ops per launch against the dense peak of the
+        # MFMA they issue: 5 POP/s int8 (v_mfma_i32_32x32x32_i8), 10 PFLOP/s FP4 (v_mfma_scale_f32_32x32x64_f8f6f4)
+        def mfma_roof(key, kernel, ops, note, peak=5000.0):
             t = avg(key)
             if t is None:
                 return None
             achieved = ops / (t * 1e-3) / 1e12
-            return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": 5000.0, "unit": "TOP/s",
-                    "frac": achieved / 5000.0, "traffic": TRAFFIC.get(key),
+            return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TOP/s",
+                    "frac": achieved / peak, "traffic": TRAFFIC.get(key),
                     "traffic_from": "profiles/traffic.json (rocprofv3 --pmc passes of this workload)" if TRAFFIC.get(key) else None,
                     "avg_launch_ms": t, "algorithmic_ops_per_launch": ops, "note": note}
 
@@ -526,8 +527,11 @@ def main():
         G, P, k = args.pops, st.P, args.k
         Cpad = 32 * -(-G // 32)
         roofs = [
-            mfma_roof("pairwise_mfma", "tpg_pairwise_kernel (v_mfma_i32_32x32x32_i8)", 5.0 * n * n * m,
-                      "fused IBS+KING+AS/GRM: 3 symmetric + 1 general int8 product = 2.5 N^2 M MACs"),
+            mfma_roof("pairwise_mfma", "tpg_pairwise_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 operands)", 5.0 * n * n * m,
+                      "fused IBS+KING+AS/GRM: 3 symmetric + 1 general product = 2.5 N^2 M MACs on exact FP4 planes "
+                      "(0.5 / 1 / +-2 with block scales, integer sums in FP32 below 2^24); peak = dense FP4, "
+                      "the bare instruction loop reaches 7.7 of it at the clock the chip holds (tools/ubench_mfma_fp4.hip)",
+                      peak=10000.0),
             mfma_roof("pca_gram_mfma", "tpg_pca_gram_kernel (v_mfma_i32_32x32x32_i8)", 4.0 * n * n * m_pca,
                       "PCA Gram: 4 weight digits x symmetric int8 product = 4 * N^2 M / 2 MACs"),
         ]
@@ -558,6 +562,8 @@ def main():
             hbm_roof("pack", "tpg_pack_fast_kernel<1>", 1.5 * n * m, "FBM bytes -> two 2-bit layouts: N M read + N M / 2 written"),
             hbm_roof("pack2", "tpg_pack_fast_kernel<2>", 2.0 * n * m,
                      "FBM bytes -> the raw AND the imputed view from one read: N M read + 2 x N M / 2 written"),
+            hbm_roof("t4_expand", "tpg_t4_expand_kernel", 0.75 * n * m,
+                     "2-bit T layout -> FP4 operand nibbles of the pairwise kernel: N M / 4 read + N M / 2 written"),
             hbm_roof("loci_counts", "tpg_loci_counts_kernel", 0.25 * n * m + 16.0 * m,
                      "per-locus genotype counts: N M / 4 read + 16 B per locus written"),
             hbm_roof("grouped_counts", "tpg_grouped_counts_kernel (int8 MFMA one-hot contraction)",
@@ -588,7 +594,7 @@ def main():
             "unit": "SNP-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "int8 (int32 accumulate) for counts and cross-products, f64 for statistics",
+            "dtype": "fp4-e2m1 planes (exact, f32/int32 accumulate) for the cross-products, int8 (int32 accumulate) for counts and the PCA Gram, f64 for statistics",
             "data": "synthetic",
             "config": {"workload": wl, "analyses": analyses, "pca_included": bool(st.has_pca),
                        "collectives": "library-owned RCCL: reduce-scatter of int32 pairwise slabs, all-reduce of Fst sums and of the FP64 Gram"

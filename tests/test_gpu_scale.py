@@ -198,3 +198,31 @@ def test_bench_size_properties():
     XV, rss = tpg.fbm256_prod_and_rowSumsSq(X, None, cols, r["center"], r["scale"], r["v"], code256=tpg.CODE_IMPUTE_PRED)
     assert np.allclose(XV, r["u"] * r["d"], rtol=0, atol=1e-6 * r["d"][0])
     assert rss.sum() == pytest.approx(r["square_frobenius"], rel=1e-9)
+
+
+def test_pair_counts_stay_exact_past_2_pow_24_loci():
+    """The cross-products run on the FP4 matrix cores with FP32 accumulators, which hold integers exactly up to 2^24:
+    a panel with more loci than that, every locus the same genotype column, so that every pair count is a multiple of
+    the number of loci and any lost unit shows.  (A wave-unit's K range is capped at 2^24 loci by the launcher.)"""
+    import tidypopgen_amd as tpg
+
+    n, m = 37, (1 << 24) + 128 * 1003 + 5
+    col = np.array([0, 1, 2, 3, 1, 1, 2, 0, 3, 2] * 4, dtype=np.uint8)[:n]  # 3 = missing
+    Xb = np.empty((n, m), dtype=np.uint8, order="F")
+    Xb[:] = col[:, None]
+    X = tpg.FBM.from_numpy(Xb)
+    del Xb
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, n)
+    pw.accumulate(v)
+    c = pw.counts()
+    typed = (col < 3).astype(np.int64)
+    d = np.where(col < 3, col.astype(np.int64) - 1, 0)
+    h = (col == 1).astype(np.int64)
+    V, D, H, A = np.outer(typed, typed), np.outer(d, d), np.outer(h, h), np.outer(h, typed)
+    assert np.array_equal(c["as_den"], m * V)
+    assert np.array_equal(c["as_num"], m * D)
+    assert np.array_equal(c["n_Aa_i"], m * A)
+    assert np.array_equal(c["ibs"], m * (V + D + H))
+    assert np.array_equal(c["ibs_valid"], 2 * m * V)
+    assert np.array_equal(c["king_num"], m * (D - V + A + A.T))

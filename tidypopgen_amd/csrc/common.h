@@ -121,6 +121,9 @@ struct tpg_view {
   uint4* T;        // (4Q) row tiles x KG blocks
   uint4* L;        // (4KG) locus tiles x Q blocks
   size_t bytes_each;
+  // T re-coded as FP4 (E2M1) operand nibbles for the pairwise kernel (pairwise.hip: tpg_t4_expand_kernel); made on
+  // the first tpg_pairwise_accumulate of the view, 2 x bytes_each
+  mutable uint4* T4 = nullptr;
   // the last per-class counts computed on this view (grouped_alt_freq, grouped_summaries and the Fst
   // methods of one analysis all use the same grouping): reused while the class vector is unchanged
   mutable GroupedCounts gc_cache;

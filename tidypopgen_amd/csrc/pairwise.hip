@@ -1,27 +1,41 @@
-// pairwise.hip -- N x N individual cross-products on int8 MFMA (IBS / KING / allele sharing / GRM).
+// pairwise.hip -- N x N individual cross-products on the FP4 matrix cores (IBS / KING / allele sharing / GRM).
 //
 // Replaces the dense FP64 products of increment_ibs_counts (src/snp_ibs.cpp:67-72),
 // increment_king_numerator (src/snp_king.cpp:70-72) and increment_as_counts (src/snp_as.cpp:64-65)
 // and the R block loops around them (R/snp_ibs.R:69-82, R/snp_king.R:63-77,
 // R/snp_allele_sharing.R:58-70).
 //
-// Per genotype three int8 features are decoded from the 2-bit code: v (valid), d (dosage-1, 0 if
-// missing), h (heterozygous).  With V = vv', D = dd', H = hh', A = hv' (A not symmetric) every count
-// matrix of the reference is an integer combination (derivation in DESIGN.md):
+// Per genotype three features: v (typed), d (dosage-1, 0 if missing), h (heterozygous).  With V = vv', D = dd',
+// H = hh', A = hv' (A not symmetric) every count matrix of the reference is an integer combination (derivation in
+// DESIGN.md):
 //   IBS        = V + D + H          IBS_valid = 2 V
 //   KING_num   = D - V + A + A'     N_Aa_i    = A
 //   AS_num     = D                  AS_den    = V
 // so the fused pass needs 3 symmetric + 1 general product = 2.5 N^2 M MACs instead of the
 // reference's 12 N^2 M FP64 flops for IBS+KING+AS.
 //
-// Kernel (tpg_pairwise_kernel below): one wave owns a 64 x 32 tile of pairs -- super-tile I (row tiles 2I, 2I+1)
-// against column tile jt >= 2I -- and a K range; 5 products x 2 sub-tiles = 10 int32 accumulator tiles (160 AGPRs),
-// one wave per SIMD.  It streams its three operand row tiles from T with 16-B coalesced loads (1 KiB per wave
-// instruction, prefetched two 128-locus groups ahead through rotating register slots), decodes each 16-locus slice
-// with 7 bit ops + 12 v_perm_b32 per fragment one K step ahead of its use, and issues 10 v_mfma_i32_32x32x32_i8 per
-// 32 loci.  No LDS, no barriers.  Units are taken from a host-built table in XCD patch order.  Partial tiles are
-// added to HBM with integer atomics (exact, order independent) into a tile-packed buffer in MFMA register order, so
-// each atomic wave instruction is 256 contiguous bytes.  That buffer is what a multi-GPU run reduces.
+// The features are small enough for FP4 (E2M1: 0, 0.5, 1, 1.5, 2, 3, 4, 6 and their negatives), whose MFMA
+// (v_mfma_scale_f32_32x32x64_f8f6f4) contracts 64 loci in the 32 cycles the int8 form needs for 32.  The view's T
+// layout is re-coded once (tpg_t4_expand_kernel) with one NIBBLE per genotype whose bits ARE the three operand planes:
+//   bit 0 = heterozygous            plane h = nibble & 0x1 -> FP4 0.5
+//   bit 1 = typed                   plane v = nibble & 0x2 -> FP4 1.0
+//   bit 2 = homozygous              plane d = nibble & 0xC -> FP4 +2.0 (dosage 2) / -2.0 (dosage 0: bit 3 = sign)
+// so a plane of 8 loci costs ONE v_and_b32 (the int8 form of this kernel spent 19 VALU per 16 loci on v_perm lookups
+// and was bound by VALU issue at 36.6 cycles per MFMA).  The E8M0 block scales of the instruction undo the 0.5 / 2.0
+// (h x 2, d x 0.5), so every accumulator holds the plain integer count.  FP32 accumulation of integers is exact up to
+// 2^24: a wave-unit never contracts more than 2^24 loci (tpg_pairwise_accumulate splits longer ranges), and what it
+// adds to HBM is converted to int32 first.  tools/ubench_mfma_fp4.hip checks the instruction's exactness at
+// accumulators next to +-2^24 and its rate (7.7 POP/s bare, 7.3 with three VALU per MFMA, at the 1.85 GHz the chip
+// holds under it).
+//
+// Kernel (tpg_pairwise_kernel below): one wave owns a 96 x 32 tile of pairs -- super-tile I (row tiles 3I .. 3I+2)
+// against column tile jt >= 3I -- and a K range; 5 products x 3 sub-tiles = 15 FP32 accumulator tiles (240 AGPRs),
+// one wave per SIMD.  It streams its four operand row tiles from T4 with 16-B coalesced loads (1 KiB per wave
+// instruction = 32 x 64 genotypes, prefetched two 128-locus groups ahead through rotating register slots), masks out
+// the planes one K step ahead of their use and issues 15 MFMAs per 64 loci.  No LDS, no barriers.  Units are taken
+// from a host-built table in XCD patch order.  Partial tiles are added to HBM with integer atomics (exact, order
+// independent) into a tile-packed buffer in MFMA register order, so each atomic wave instruction is 256 contiguous
+// bytes.  That buffer is what a multi-GPU run reduces.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,20 +48,60 @@
 #include <type_traits>
 #include "devfrag.h"
 
-#define MFMA_I8(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8((a), (b), (c), 0, 0, 0)
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+#define TPG_NIB_LUT 0x0006030Eu  // 2-bit code -> nibble: dosage 0 -> 0xE, 1 -> 0x3, 2 -> 0x6, missing -> 0
+#define TPG_NIB_V 0x22222222u
+#define TPG_NIB_H 0x11111111u
+#define TPG_NIB_D 0xCCCCCCCCu
+// E8M0 block scales (one byte per 32 contracted elements; all four bytes equal, so the byte select does not matter)
+#define TPG_SC_ONE 0x7f7f7f7f
+#define TPG_SC_TWO 0x80808080
+#define TPG_SC_HALF 0x7e7e7e7e
+
+__device__ __forceinline__ v8i tpg_w8(v4i a) { return v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0}; }
+// FP4 x FP4 (format code 4), 32 x 32 x 64
+#define MFMA_F4(a, b, c, sa, sb) \
+  __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tpg_w8(a), tpg_w8(b), (c), 4, 4, 0, (sa), 0, (sb))
+
+// T (2-bit codes) -> T4.  Every lane re-codes its own 16 bytes of a T block (4 dwords x 16 loci) as two 16-byte
+// fragments of 32 nibbles: dwords 0, 1 -> block 2 kg, dwords 2, 3 -> block 2 kg + 1.  Which locus lands on which
+// nibble of which lane half is immaterial -- the MFMA sums over all 64 -- as long as every row tile uses the same
+// map, which it does.
+__global__ __launch_bounds__(256) void tpg_t4_expand_kernel(const uint4* __restrict__ T, uint4* __restrict__ T4,
+                                                            int64_t nblocks) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nblocks * 64; i += (int64_t)gridDim.x * 256) {
+    const int64_t blk = i >> 6;
+    const int lane = (int)(i & 63);
+    const uint4 w = T[i];
+    const uint32_t in[4] = {w.x, w.y, w.z, w.w};
+    uint32_t out[8];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      uint32_t nb[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) nb[k] = (uint32_t)tpg_lut(TPG_NIB_LUT, tpg_codes(in[s], k));
+      out[2 * s] = nb[0] | (nb[1] << 4);
+      out[2 * s + 1] = nb[2] | (nb[3] << 4);
+    }
+    T4[(blk * 2) * 64 + lane] = make_uint4(out[0], out[1], out[2], out[3]);
+    T4[(blk * 2 + 1) * 64 + lane] = make_uint4(out[4], out[5], out[6], out[7]);
+  }
+}
 
 struct Frag3 {
   v4i v, d, h;
 };
 
-__device__ __forceinline__ Frag3 tpg_decode3(uint32_t w) {
+__device__ __forceinline__ Frag3 tpg_planes(v4u w, uint32_t mv, uint32_t md, uint32_t mh) {
   Frag3 f;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const uint32_t c = tpg_codes(w, k);
-    f.v[k] = tpg_lut(TPG_LUT_V, c);
-    f.d[k] = tpg_lut(TPG_LUT_D, c);
-    f.h[k] = tpg_lut(TPG_LUT_H, c);
+    f.v[k] = (int)(w[k] & mv);
+    f.d[k] = (int)(w[k] & md);
+    f.h[k] = (int)(w[k] & mh);
   }
   return f;
 }
@@ -60,27 +114,26 @@ __host__ __device__ __forceinline__ int64_t tpg_pw_unit_index(int nst, int I, in
 }
 
 // The pairwise kernel.  One wave = one (I, jt) unit: a (32 TA) x 32 tile of pairs, five products, 5 TA accumulator
-// tiles (240 AGPRs at TA = 3), one wave per SIMD.  Per 32 loci: TA + 1 fragment dwords -> 7 bit ops + 12 v_perm_b32
-// each -> 5 TA MFMAs.  The kernel is bound by VALU issue, not by the MFMA pipe: an MFMA holds the SIMD's issue for 8
-// of its 32 cycles and every decode instruction costs about 5 more, so a wave runs at ~8 + 5 x (VALU per MFMA) cycles
-// per MFMA when that exceeds 32 -- 19 (TA + 1) / (5 TA) = 5.7 VALU per MFMA at TA = 2 (64 x 32 tiles, measured 36.8
-// cycles per MFMA), 5.07 at TA = 3.  TA = 4 would need 320 accumulator registers.
-// The fragment decode is SOFTWARE-PIPELINED one K step ahead: an MFMA whose A/B operands were written by VALU
+// tiles (240 AGPRs at TA = 3), one wave per SIMD.  Per 64 loci: TA + 1 fragments of four dwords -> 12 v_and_b32 each
+// -> 5 TA MFMAs, i.e. 3.2 VALU per MFMA: at ~8 + 5.2 x (VALU per MFMA) cycles of issue per MFMA the
+// wave stays under the 32 cycles of the MFMA itself, which the int8 form of this kernel (5.5 VALU per MFMA for half
+// the loci) did not.  The plane masks of an A row tile past the data, or of a group past the K range, are zero
+// (wave-uniform, so they sit in SGPRs and cost nothing).
+// The masking is SOFTWARE-PIPELINED one K step ahead: an MFMA whose A/B operands were written by VALU
 // instructions 0 / 1 / 2 MFMAs earlier takes 47.6 / 41.6 / 36.4 cycles instead of 32 (tools/ubench_mfma_dep.hip), so
-// the fragments of K step s+1 are decoded into a second register set while the MFMAs of step s issue (one MFMA,
-// then five or six decode VALU, enforced with sched_group_barrier).  Operand words are prefetched two 128-locus groups
-// ahead through three rotating register slots.  Earlier forms of this kernel (decode placed by the compiler; 2 waves
-// per SIMD; a workgroup-shared 2-bit -> byte spread through LDS) measured 10-20% slower and are gone; DESIGN.md 3.4
-// keeps the numbers.
+// the fragments of K step s+1 are made in a second register set while the MFMAs of step s issue (one MFMA, then three
+// or four VALU, enforced with sched_group_barrier).  Operand words are prefetched two 128-locus groups ahead through
+// three rotating register slots.
 #define SGB_MFMA 0x008
 #define SGB_VALU 0x002
-__global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __restrict__ T, int64_t KG,
+#define SGB_VMEM_READ 0x020
+__global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __restrict__ T4, int64_t KG,
                                                                  int64_t kg_begin, int64_t kg_end, int nst, int nct,
                                                                  const int2* __restrict__ order, int64_t nun, int S,
                                                                  const int64_t* __restrict__ rowpad,
                                                                  int32_t* __restrict__ acc_out) {
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: unit, K range and bases in SGPRs
   const int64_t kgs = kg_end - kg_begin;
   // Work distribution.  `order` (host-built, pairwise_create) lists the (I, jt) units of the triangle in
   // PATCH order: blocks of 16 column tiles, inside a block row after row, so four consecutive entries nearly
@@ -90,6 +143,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
   // a few dozen distinct tiles per 128 loci instead of ~100 with a plain strided assignment, so the
   // re-reads hit that XCD's own L2.
   const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+  const int sc1 = TPG_SC_ONE, sc2 = TPG_SC_TWO, sch = TPG_SC_HALF;
   for (int64_t round = 0;; round++) {
     const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
     if (un >= nun * S) break;
@@ -100,83 +154,79 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
     const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
 
     // A row tiles past the last one with data (the last super-tile may be partial; the view holds 4 ceil(n / 128)
-    // row tiles) read tile 0 instead and are forced to all-missing codes: zero planes, zero products
+    // row tiles) read tile 0 instead and get zero plane masks: zero products
     const uint4* pa[TA];
-    uint32_t gone[TA];
+    bool there[TA];
 #pragma unroll
     for (int t = 0; t < TA; t++) {
-      const bool there = TA * I + t < nct;
-      pa[t] = T + ((int64_t)(there ? TA * I + t : 0) * KG) * 64 + lane;
-      gone[t] = there ? 0u : ~0u;
+      there[t] = TA * I + t < nct;
+      pa[t] = T4 + ((int64_t)(there[t] ? TA * I + t : 0) * KG * 2) * 64 + lane;
     }
-    const uint4* pb0 = T + ((int64_t)jt * KG) * 64 + lane;
+    const uint4* pb0 = T4 + ((int64_t)jt * KG * 2) * 64 + lane;
 
-    v16i cV[TA], cD[TA], cH[TA], cHV[TA], cVH[TA];
+    v16f cV[TA], cD[TA], cH[TA], cHV[TA], cVH[TA];
 #pragma unroll
     for (int t = 0; t < TA; t++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) { cV[t][r] = 0; cD[t][r] = 0; cH[t][r] = 0; cHV[t][r] = 0; cVH[t][r] = 0; }
+      for (int r = 0; r < 16; r++) { cV[t][r] = 0.f; cD[t][r] = 0.f; cH[t][r] = 0.f; cHV[t][r] = 0.f; cVH[t][r] = 0.f; }
 
     if (k0 < k1) {
       const int64_t kl = k1 - 1;
       // three rotating load slots (current group, next, two ahead): the K loop is unrolled by three so that no
       // slot is copied -- a copy at the end of a group waits for the loads issued at its start, which cuts the
-      // prefetch distance to one group.  Groups past k1 run with all-missing A words (zero planes).
+      // prefetch distance to one group.  Groups past k1 run with zero A planes.
       // native vectors, not HIP's uint4 struct: with the struct the register allocator splits the loaded tuple right
       // after the load (v_mov behind an s_waitcnt vmcnt: a full memory latency at the top of every group)
-      typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-      v4u RA[3][TA], RB[3];
+      v4u RA[3][TA][2], RB[3][2];
       auto LD = [&](const uint4* p) { return *(const v4u*)p; };
       const int64_t i1 = k0 + 1 < k1 ? k0 + 1 : kl;
 #pragma unroll
-      for (int t = 0; t < TA; t++) { RA[0][t] = LD(pa[t] + k0 * 64); RA[1][t] = LD(pa[t] + i1 * 64); }
-      RB[0] = LD(pb0 + k0 * 64);
-      RB[1] = LD(pb0 + i1 * 64);
+      for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int t = 0; t < TA; t++) { RA[0][t][s] = LD(pa[t] + (k0 * 2 + s) * 64); RA[1][t][s] = LD(pa[t] + (i1 * 2 + s) * 64); }
+        RB[0][s] = LD(pb0 + (k0 * 2 + s) * 64);
+        RB[1][s] = LD(pb0 + (i1 * 2 + s) * 64);
+      }
       Frag3 P[2][TA + 1];
 #pragma unroll
-      for (int t = 0; t < TA; t++) P[0][t] = tpg_decode3(RA[0][t].x | gone[t]);
-      P[0][TA] = tpg_decode3(RB[0].x);
+      for (int t = 0; t < TA; t++)
+        P[0][t] = tpg_planes(RA[0][t][0], there[t] ? TPG_NIB_V : 0u, there[t] ? TPG_NIB_D : 0u, there[t] ? TPG_NIB_H : 0u);
+      P[0][TA] = tpg_planes(RB[0][0], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
       auto group = [&](auto Cc, auto Nn, auto Mm, int64_t kg) {
         constexpr int C = decltype(Cc)::value, N = decltype(Nn)::value, M = decltype(Mm)::value;
         const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
-        // the loads of the group after next go out one per step (behind a step barrier, so the scheduler
-        // cannot sink them to their use): back-to-back loads hold this wave's issue while the MFMA pipe drains
-        // words of the 4 K steps of this group, followed by step 0 of the next group; past k1: all missing
-        const uint32_t dead = kg < k1 ? 0u : ~0u, dead1 = kg + 1 < k1 ? 0u : ~0u;
-        uint32_t wa[TA][4];
+        const bool live = kg < k1, live1 = kg + 1 < k1;
 #pragma unroll
-        for (int t = 0; t < TA; t++) {
-          const uint32_t off = dead | gone[t];
-          wa[t][0] = RA[C][t].x | off; wa[t][1] = RA[C][t].y | off; wa[t][2] = RA[C][t].z | off; wa[t][3] = RA[C][t].w | off;
-        }
-        const uint32_t wb[4] = {RB[C].x, RB[C].y, RB[C].z, RB[C].w};
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < 2; s++) {
           const int cur = s & 1, nx = cur ^ 1;
-          if (s < TA) RA[M][s] = LD(pa[s] + i2 * 64);
-          if (s == 3) RB[M] = LD(pb0 + i2 * 64);
-          if (TA < 3 && s == 2) RB[M] = LD(pb0 + i2 * 64);
-          // the next group's slot is first touched in the last step's region (one barrier per step), so the wait
-          // for its loads comes as late as possible
+          // the loads of the group after next: the first block of every tile in step 0, the second in step 1
 #pragma unroll
-          for (int t = 0; t < TA; t++) P[nx][t] = tpg_decode3(s < 3 ? wa[t][s < 3 ? s + 1 : 0] : (RA[N][t].x | dead1 | gone[t]));
-          P[nx][TA] = tpg_decode3(s < 3 ? wb[s < 3 ? s + 1 : 0] : RB[N].x);
+          for (int t = 0; t < TA; t++) RA[M][t][s] = LD(pa[t] + (i2 * 2 + s) * 64);
+          RB[M][s] = LD(pb0 + (i2 * 2 + s) * 64);
+          // planes of the next K step: the second block of this group, or the first of the next group
 #pragma unroll
-          for (int t = 0; t < TA; t++) cV[t] = MFMA_I8(P[cur][t].v, P[cur][TA].v, cV[t]);  // product-major order: ~1 % faster
+          for (int t = 0; t < TA; t++) {
+            const bool keep = there[t] && (s == 0 ? live : live1);
+            P[nx][t] = tpg_planes(s == 0 ? RA[C][t][1] : RA[N][t][0], keep ? TPG_NIB_V : 0u, keep ? TPG_NIB_D : 0u,
+                                  keep ? TPG_NIB_H : 0u);
+          }
+          P[nx][TA] = tpg_planes(s == 0 ? RB[C][1] : RB[N][0], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
 #pragma unroll
-          for (int t = 0; t < TA; t++) cD[t] = MFMA_I8(P[cur][t].d, P[cur][TA].d, cD[t]);  // than tile-major (measured)
+          for (int t = 0; t < TA; t++) cV[t] = MFMA_F4(P[cur][t].v, P[cur][TA].v, cV[t], sc1, sc1);
 #pragma unroll
-          for (int t = 0; t < TA; t++) cH[t] = MFMA_I8(P[cur][t].h, P[cur][TA].h, cH[t]);
+          for (int t = 0; t < TA; t++) cD[t] = MFMA_F4(P[cur][t].d, P[cur][TA].d, cD[t], sch, sch);
 #pragma unroll
-          for (int t = 0; t < TA; t++) cHV[t] = MFMA_I8(P[cur][t].h, P[cur][TA].v, cHV[t]);
+          for (int t = 0; t < TA; t++) cH[t] = MFMA_F4(P[cur][t].h, P[cur][TA].h, cH[t], sc2, sc2);
 #pragma unroll
-          for (int t = 0; t < TA; t++) cVH[t] = MFMA_I8(P[cur][t].v, P[cur][TA].h, cVH[t]);
-          // 19 (TA + 1) decode VALU (plus the masks) spread over the 5 TA MFMAs of the step
+          for (int t = 0; t < TA; t++) cHV[t] = MFMA_F4(P[cur][t].h, P[cur][TA].v, cHV[t], sc2, sc1);
+#pragma unroll
+          for (int t = 0; t < TA; t++) cVH[t] = MFMA_F4(P[cur][t].v, P[cur][TA].h, cVH[t], sc1, sc2);
+          // 12 (TA + 1) plane masks and TA + 1 loads spread over the 5 TA MFMAs of the step
 #pragma unroll
           for (int q = 0; q < 5 * TA; q++) {
             __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
-            if (TA == 2 || q % 3 == 2) __builtin_amdgcn_sched_group_barrier(SGB_VALU, 6, 0);
-            else __builtin_amdgcn_sched_group_barrier(SGB_VALU, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(SGB_VALU, 4, 0);
+            if (q % 4 == 1 && q / 4 < TA + 1) __builtin_amdgcn_sched_group_barrier(SGB_VMEM_READ, 1, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -190,17 +240,18 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
         group(I2{}, I0{}, I1{}, kg + 2);
       }
     }
+    // the accumulators hold integers (|sum| <= loci of the K range <= 2^24): exact in int32
     int32_t* slab = acc_out + tp0 * TPG_PW_TILE_INTS + lane;
 #pragma unroll
     for (int t = 0; t < TA; t++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int o = (t * 16 + r) * 64;
-        atomicAdd(slab + 0 * TPG_PW_PLANE_INTS + o, cV[t][r]);
-        atomicAdd(slab + 1 * TPG_PW_PLANE_INTS + o, cD[t][r]);
-        atomicAdd(slab + 2 * TPG_PW_PLANE_INTS + o, cH[t][r]);
-        atomicAdd(slab + 3 * TPG_PW_PLANE_INTS + o, cHV[t][r]);
-        atomicAdd(slab + 4 * TPG_PW_PLANE_INTS + o, cVH[t][r]);
+        atomicAdd(slab + 0 * TPG_PW_PLANE_INTS + o, (int)cV[t][r]);
+        atomicAdd(slab + 1 * TPG_PW_PLANE_INTS + o, (int)cD[t][r]);
+        atomicAdd(slab + 2 * TPG_PW_PLANE_INTS + o, (int)cH[t][r]);
+        atomicAdd(slab + 3 * TPG_PW_PLANE_INTS + o, (int)cHV[t][r]);
+        atomicAdd(slab + 4 * TPG_PW_PLANE_INTS + o, (int)cVH[t][r]);
       }
   }
 }
@@ -429,26 +480,42 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
               "%lld loci accumulated + %lld more would overflow the int32 pair counts (limit %lld)", (long long)pw->loci,
               (long long)(col_end - col_begin), (long long)TPG_PW_MAX_LOCI);
   pw->loci += col_end - col_begin;
+  // the FP4 operand form of the view, made on first use
+  if (!v->T4) {
+    uint4* t4 = nullptr;
+    TPG_HIP(tpg_pmalloc((void**)&t4, 2 * v->bytes_each));
+    const int64_t nblocks = 4 * v->Q * v->KG;
+    int grid = (int)std::min<int64_t>(ceil_div(nblocks * 64, 256), (int64_t)ctx->num_cu * 32);
+    TPG_LAUNCH(ctx, "t4_expand", tpg_t4_expand_kernel, dim3((unsigned)grid), dim3(256), 0, (const uint4*)v->T, t4, nblocks);
+    v->T4 = t4;
+  }
   const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
-  const int64_t kgs = kg1 - kg0;
   // K split S: units x S wave-units over the resident waves (one workgroup per CU, one wave per SIMD; a multiple of
   // the 8 XCDs), at least 8 K groups (1024 loci) per unit.  Cost model: rounds(S) = ceil(units S / waves) rounds, a
-  // round costs its K range (about 1.0 us per 128-locus group: 60 MFMAs at ~36 cycles) plus the flush of the
+  // round costs its K range (about 0.55 us per 128-locus group: 30 MFMAs at ~34 cycles) plus the flush of the
   // accumulators (240 atomic wave-instructions per wave, all waves at once: ~25 us).
+  // FP32 accumulators: a wave-unit contracts at most 2^24 loci (131072 groups), so that every count it holds is an
+  // exactly represented integer; longer ranges go out in several launches of at most 8 x 2^24 loci.
+  const int64_t max_groups = 131072;
   int nblk = ctx->num_cu / 8 * 8;
   if (nblk < 8) nblk = 8;
   const int64_t nwaves = 4 * (int64_t)nblk;
-  int bestS = 1;
-  double best = -1;
-  const int64_t maxS = kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1;
-  for (int64_t S = 1; S <= maxS; S++) {
-    const int64_t rounds = ceil_div(pw->nun * S, nwaves);
-    const double cost = (double)rounds * ((double)ceil_div(kgs, S) * 1.0 + 25.0);
-    if (best < 0 || cost < best * 0.995) { best = cost; bestS = (int)S; }
+  for (int64_t c0 = kg0; c0 < kg1; c0 += 8 * max_groups) {
+    const int64_t c1 = std::min(kg1, c0 + 8 * max_groups);
+    const int64_t kgs = c1 - c0;
+    const int64_t minS = ceil_div(kgs, max_groups);
+    int bestS = (int)minS;
+    double best = -1;
+    const int64_t maxS = std::max<int64_t>(minS, kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1);
+    for (int64_t S = minS; S <= maxS; S++) {
+      const int64_t rounds = ceil_div(pw->nun * S, nwaves);
+      const double cost = (double)rounds * ((double)ceil_div(kgs, S) * 0.55 + 25.0);
+      if (best < 0 || cost < best * 0.995) { best = cost; bestS = (int)S; }
+    }
+    TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T4, v->KG,
+               c0, c1, (int)pw->nst, (int)ceil_div(pw->n, 32), (const int2*)pw->order, pw->nun, bestS,
+               (const int64_t*)pw->rowpad, pw->acc);
   }
-  TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T, v->KG,
-             kg0, kg1, (int)pw->nst, (int)ceil_div(pw->n, 32), (const int2*)pw->order, pw->nun, bestS, (const int64_t*)pw->rowpad,
-             pw->acc);
   TPG_CHECK_LAUNCH();
   return TPG_OK;
 }

@@ -677,6 +677,7 @@ extern "C" void tpg_view_free(tpg_view* v) {
   if (!v) return;
   if (v->T) tpg_pfree(v->T);
   if (v->L) tpg_pfree(v->L);
+  if (v->T4) tpg_pfree(v->T4);
   delete v;
 }
 extern "C" int64_t tpg_view_n(const tpg_view* v) { return v ? v->n : 0; }
