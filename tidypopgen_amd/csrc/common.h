@@ -70,6 +70,10 @@ struct ProfScope {
   ~ProfScope();
 };
 int tpg_prof_resolve(tpg_ctx* ctx);
+// gramcls.hip: S' = sum_j w_j g_i g_k' (n x n, column-major, both triangles) into d_K by weight classes; *done = false
+// (nothing written) when the weights take too many distinct values for that to pay.  d_what (may be NULL): the weight
+// actually used for every locus (its class representative, within 2^-47 of w_j)
+int tpg_gram_classes(tpg_ctx* ctx, const struct tpg_view* v, const double* d_w, double* d_what, double* d_K, bool* done);
 
 // Launch a kernel on the context's stream, bracketed by HIP events when profiling is on.
 #define TPG_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                          \

@@ -716,6 +716,16 @@ __global__ void tpg_scale_range_kernel(const double* __restrict__ scale, int64_t
   }
 }
 
+__global__ void tpg_pca_weights_kernel(const double* __restrict__ scale, int64_t m, double* __restrict__ w) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x)
+    w[j] = 1.0 / (scale[j] * scale[j]);
+}
+__global__ void tpg_pca_wc_kernel(const double* __restrict__ what, const double* __restrict__ center, int64_t m,
+                                  double* __restrict__ wc) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x)
+    wc[j] = what[j] * center[j];
+}
+
 static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_center, const double* d_scale,
                            double* d_K, bool own_center) {
   const int64_t n = v->n, m = v->m;
@@ -766,14 +776,31 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   int rc = TPG_OK;
   hipError_t e = hipSuccess;
 #define GHIP(call) do { if (e == hipSuccess) { e = (call); if (e != hipSuccess) tpg_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e)); } } while (0)
-  GHIP(tpg_pmalloc((void**)&d_DG, (size_t)v->KG * 4 * 2 * T * 8 * sizeof(uint32_t)));
   GHIP(tpg_pmalloc((void**)&d_what, sizeof(double) * (size_t)m));
   GHIP(tpg_pmalloc((void**)&d_wc, sizeof(double) * (size_t)m));
   GHIP(tpg_pmalloc((void**)&d_r, sizeof(double) * (size_t)n));
   GHIP(tpg_pmalloc((void**)&d_part, sizeof(double) * 512));
+  // S' = G W G' by weight classes on the FP4 matrix cores when the weights take few distinct values (gramcls.hip:
+  // always so under the binomial scaling); the digit-split int8 kernel below otherwise
+  bool by_classes = false;
+  if (e == hipSuccess) {
+    double* d_w = nullptr;
+    GHIP(tpg_pmalloc((void**)&d_w, sizeof(double) * (size_t)m));
+    if (e == hipSuccess) {
+      TPG_LAUNCH(ctx, "pca_weights", tpg_pca_weights_kernel, dim3(1024), dim3(256), 0, d_scale, m, d_w);
+      rc = tpg_gram_classes(ctx, v, d_w, d_what, d_K, &by_classes);
+      if (rc == TPG_OK && by_classes)
+        TPG_LAUNCH(ctx, "pca_weights", tpg_pca_wc_kernel, dim3(1024), dim3(256), 0, (const double*)d_what, d_center, m, d_wc);
+    }
+    if (d_w) tpg_pfree(d_w);
+    if (rc != TPG_OK) { tpg_pfree(d_what); tpg_pfree(d_wc); tpg_pfree(d_r); tpg_pfree(d_part); return rc; }
+  }
+  if (!by_classes) {
+  GHIP(tpg_pmalloc((void**)&d_DG, (size_t)v->KG * 4 * 2 * T * 8 * sizeof(uint32_t)));
   GHIP(tpg_pmalloc((void**)&d_slabs, sizeof(long long) * (size_t)nun * PCA_SLAB_INTS));
   GHIP(hipMemsetAsync(d_slabs, 0, sizeof(long long) * (size_t)nun * PCA_SLAB_INTS, ctx->stream));
-  if (e == hipSuccess) {
+  }
+  if (e == hipSuccess && !by_classes) {
     TPG_LAUNCH(ctx, "pca_digits", tpg_pca_digits_kernel, dim3(1024), dim3(256), 0, d_scale, d_center, m, v->KG, F, T,
                d_DG, d_what, d_wc);
     GHIP(tpg_pmalloc((void**)&d_order, sizeof(int2) * (size_t)nun));
@@ -813,8 +840,9 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     GHIP(hipGetLastError());
   }
   if (e == hipSuccess && own_center) {
-    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, (const int32_t*)d_lut, nsbf,
-               (int)n, F, (const double*)nullptr, 0.0, d_K);
+    if (!by_classes)
+      TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, (const int32_t*)d_lut, nsbf,
+                 (int)n, F, (const double*)nullptr, 0.0, d_K);
     TPG_LAUNCH(ctx, "pca_colmean", tpg_colmean_kernel, dim3((unsigned)n), dim3(256), 0, (const double*)d_K, (int)n, d_r);
     TPG_LAUNCH(ctx, "pca_colmean", tpg_mean_kernel, dim3(1), dim3(256), 0, (const double*)d_r, (int)n, d_part);
     TPG_LAUNCH(ctx, "pca_double_center", tpg_double_center_kernel, dim3(2048), dim3(256), 0, d_K, (int)n,
@@ -837,8 +865,14 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     Cc = (double)s;
   }
   if (e == hipSuccess && rc == TPG_OK && !own_center) {
-    TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, (const int32_t*)d_lut, nsbf,
-               (int)n, F, (const double*)d_r, Cc, d_K);
+    if (!by_classes) {
+      TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, (const int32_t*)d_lut, nsbf,
+                 (int)n, F, (const double*)d_r, Cc, d_K);
+    } else {  // K = S' - r 1' - 1 r' + C on the matrix the class path left in d_K
+      GHIP(tpg_h2d_async(ctx, d_part, &Cc, sizeof(double)));
+      TPG_LAUNCH(ctx, "pca_double_center", tpg_double_center_kernel, dim3(2048), dim3(256), 0, d_K, (int)n,
+                 (const double*)d_r, (const double*)d_part);
+    }
     GHIP(hipGetLastError());
     GHIP(hipStreamSynchronize(ctx->stream));
   }
