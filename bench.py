@@ -534,6 +534,13 @@ def main():
                       peak=10000.0),
             mfma_roof("pca_gram_mfma", "tpg_pca_gram_kernel (v_mfma_i32_32x32x32_i8)", 4.0 * n * n * m_pca,
                       "PCA Gram: 4 weight digits x symmetric int8 product = 4 * N^2 M / 2 MACs"),
+            mfma_roof("pca_gram_classes", "tpg_gcls_gram_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 dosages)",
+                      1.0 * n * n * m_pca,
+                      "PCA Gram by weight classes: ONE unweighted symmetric product = N^2 M / 2 MACs on exact FP4 dosages, "
+                      "then 16 cvt + 16 FP64 fma per 32 x 32 tile and class; bound by that FP64 fold (VALU) and by the "
+                      "L2 -> CU operand path (0.83 KiB per MFMA), not by the MFMA pipe; the digit-split int8 kernel it "
+                      "replaces takes 1.8x as long for 4x the MFMA work",
+                      peak=10000.0),
         ]
         roofs = [r for r in roofs if r]
         roofs.sort(key=lambda r: -r["avg_launch_ms"])
@@ -564,6 +571,8 @@ def main():
                      "FBM bytes -> the raw AND the imputed view from one read: N M read + 2 x N M / 2 written"),
             hbm_roof("t4_expand", "tpg_t4_expand_kernel", 0.75 * n * m,
                      "2-bit T layout -> FP4 operand nibbles of the pairwise kernel: N M / 4 read + N M / 2 written"),
+            hbm_roof("gcls_gather", "tpg_gcls_gather_kernel", 0.75 * n * m_pca,
+                     "class-sorted FP4 operand layout of the PCA Gram: N M / 4 read (16-byte pieces of the L layout) + N M / 2 written"),
             hbm_roof("loci_counts", "tpg_loci_counts_kernel", 0.25 * n * m + 16.0 * m,
                      "per-locus genotype counts: N M / 4 read + 16 B per locus written"),
             hbm_roof("grouped_counts", "tpg_grouped_counts_kernel (int8 MFMA one-hot contraction)",
@@ -594,7 +603,7 @@ def main():
             "unit": "SNP-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "fp4-e2m1 planes (exact, f32/int32 accumulate) for the cross-products, int8 (int32 accumulate) for counts and the PCA Gram, f64 for statistics",
+            "dtype": "fp4-e2m1 operands (exact integers, f32 accumulate) for the cross-products and the PCA Gram, int8 (int32 accumulate) for counts, f64 for statistics",
             "data": "synthetic",
             "config": {"workload": wl, "analyses": analyses, "pca_included": bool(st.has_pca),
                        "collectives": "library-owned RCCL: reduce-scatter of int32 pairwise slabs, all-reduce of Fst sums and of the FP64 Gram"

@@ -864,3 +864,89 @@ def test_gt_pca_randomSVD_tolerance(tpg):
         assert r["square_frobenius"] == exact["square_frobenius"]
     with pytest.raises(ValueError):
         tpg.gt_pca_randomSVD(X, None, cols, k=k, tol=0.0)
+
+
+# ---------------------------------------------------------------- PCA Gram: weight-class path against the digit path
+def _np_gram(g, center, scale):
+    Z = (g.astype(np.float64) - center[None, :]) / scale[None, :]
+    return Z @ Z.T
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *a):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("n,m", [(37, 700), (100, 5000), (333, 20011), (700, 3001)])
+def test_pca_gram_weight_classes_equal_digits_and_numpy(tpg, n, m):
+    """S' = sum over weight classes of w_c G_c on the FP4 matrix cores (gramcls.hip) against the digit-split int8
+    kernel on the same view and against a float64 numpy Gram; both paths forced, whatever the cost model would pick."""
+    g = orc.synth_fbm(11, n, m, npop=5, miss=0.0)
+    g = g[:, (g.sum(0) > 0) & (g.sum(0) < 2 * n)]
+    X = _X(tpg, g)
+    v = tpg.View(X)
+    center, scale = tpg.pca_center_scale(v)
+    ref = _np_gram(g, center, scale)
+    with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None):
+        Kc = tpg.pca_gram(v, center, scale)
+    with _env(TPG_GRAM_DIGITS="1", TPG_GRAM_CLASSES=None):
+        Kd = tpg.pca_gram(v, center, scale)
+    sc = np.abs(ref).max()
+    assert np.array_equal(Kc, Kc.T)
+    assert np.abs(Kc - ref).max() <= 1e-11 * sc   # exact class Gram matrices, double weights, FP64 sums
+    assert np.abs(Kd - ref).max() <= 1e-6 * sc    # 2^-24 weight rounding
+    with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None):
+        assert np.array_equal(tpg.pca_gram(v, center, scale), Kc)  # run-to-run identical (ordered slab sums)
+
+
+def test_pca_gram_weight_classes_general_center_and_scale(tpg):
+    """center is not the column mean, the scale takes a handful of values (few classes) or one value per locus (every
+    locus its own class: the path still has to be right when it is forced)."""
+    n, m = 150, 2000
+    g = orc.synth_fbm(12, n, m, npop=3, miss=0.0)
+    X = _X(tpg, g)
+    v = tpg.View(X)
+    rng = np.random.default_rng(4)
+    center = rng.uniform(0.1, 1.9, m)
+    for scale in (rng.choice([0.5, 0.75, 1.0, 1.25, 3.0], m), rng.uniform(0.3, 2.0, m)):
+        ref = _np_gram(g, center, scale)
+        with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None):
+            Kc = tpg.pca_gram(v, center, scale)
+        assert np.abs(Kc - ref).max() <= 1e-11 * np.abs(ref).max()
+        Ka = tpg.pca_gram(v, center, scale)  # whatever the cost model picks
+        assert np.abs(Ka - ref).max() <= 1e-6 * np.abs(ref).max()
+
+
+def test_pca_gram_one_class_longer_than_an_exact_fp32_sum(tpg):
+    """Every locus the same genotype column: ONE weight class of 4.2 million loci, i.e. more 64-locus blocks than FP32
+    accumulators can take (4 x 2^22 = 2^24): the class is folded every 2^16 blocks."""
+    n, m = 40, 64 * 65536 + 64 * 100 + 3
+    col = np.array([2, 2, 0, 1, 2, 0, 1, 2, 2, 1] * 4, dtype=np.uint8)[:n]
+    Xb = np.empty((n, m), dtype=np.uint8, order="F")
+    Xb[:] = col[:, None]
+    X = tpg.FBM.from_numpy(Xb)
+    del Xb
+    v = tpg.View(X)
+    center, scale = tpg.pca_center_scale(v)
+    with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None):
+        K = tpg.pca_gram(v, center, scale)
+    z = (col.astype(np.float64) - center[0]) / scale[0]
+    ref = m * np.outer(z, z)
+    assert np.abs(K - ref).max() <= 1e-12 * np.abs(ref).max()

@@ -99,12 +99,13 @@ __global__ void tpg_gcls_place_kernel(const uint32_t* __restrict__ sorted_idx, c
 
 __global__ void tpg_gcls_block_table_kernel(const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ blk_start,
                                             const uint32_t* __restrict__ nblk, int nr, int64_t nblocks,
-                                            double* __restrict__ wblk, uint32_t* __restrict__ lastb) {
+                                            unsigned long long* __restrict__ wblk) {
   for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < nblocks; b += (int64_t)gridDim.x * blockDim.x) {
     const int r = tpg_gcls_find_run(blk_start, nr, (uint32_t)b);
     const uint32_t o = (uint32_t)b - blk_start[r];
-    wblk[b] = __longlong_as_double((long long)ukeys[r]);
-    lastb[b] = (o + 1 == nblk[r] || (o % GCLS_MAX_RUN) == GCLS_MAX_RUN - 1) ? 1 : 0;
+    // the keys end in five zero bits: the last one carries the "fold after this block" flag
+    const unsigned long long fl = (o + 1 == nblk[r] || (o % GCLS_MAX_RUN) == GCLS_MAX_RUN - 1) ? 1ull : 0ull;
+    wblk[b] = ukeys[r] | fl;
   }
 }
 
@@ -186,10 +187,9 @@ __device__ __forceinline__ void tpg_static_for(F&& f) {
 }
 
 __global__ __launch_bounds__(256, 1) void tpg_gcls_gram_kernel(const uint4* __restrict__ T4g, int64_t nblocks, int nrtv,
-                                                                  const double* __restrict__ wblk,
-                                                                  const uint32_t* __restrict__ lastb,
+                                                                  const unsigned long long* __restrict__ wblk,
                                                                   const int2* __restrict__ order, int64_t nun, int S,
-                                                                  double* __restrict__ slabs, int dbg) {
+                                                                  double* __restrict__ slabs) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
@@ -224,11 +224,14 @@ __global__ __launch_bounds__(256, 1) void tpg_gcls_gram_kernel(const uint4* __re
       // blocks past the range re-fetch the last one
       tpg_static_for<GCLS_D - 1>([&](auto dd) {
         constexpr int d = decltype(dd)::value;
-        const int64_t bc = (dbg & 2) ? b0 : (b0 + d < b1 ? b0 + d : bl);
+        const int64_t bc = b0 + d < b1 ? b0 + d : bl;
 #pragma unroll
         for (int t = 0; t < GA + GB; t++) R[d][t] = LD(pt[t] + bc * 64);
       });
       bool first = true;
+      // weight of the block with the fold flag in its last bit, fetched one block ahead (a scalar load on the
+      // path of every block would cost its latency every 6 MFMAs)
+      unsigned long long wf_next = wblk[b0];
       for (int64_t bb = b0; bb < b1; bb += GCLS_D) {
         tpg_static_for<GCLS_D>([&](auto cc) {
           constexpr int C = decltype(cc)::value, M = (C + GCLS_D - 1) % GCLS_D;
@@ -237,10 +240,12 @@ __global__ __launch_bounds__(256, 1) void tpg_gcls_gram_kernel(const uint4* __re
           // bookkeeping merges control-flow paths pessimistically, and a path without them turns the counted waits
           // of the whole loop into vmcnt(0)
           const int64_t bn = b + GCLS_D - 1;
-          const int64_t bc = (dbg & 2) ? b0 : (bn < b1 ? bn : bl);
+          const int64_t bc = bn < b1 ? bn : bl;
 #pragma unroll
           for (int t = 0; t < GA + GB; t++) R[M][t] = LD(pt[t] + bc * 64);
           if (b < b1) {
+            const unsigned long long wf = wf_next;
+            wf_next = wblk[b < bl ? b + 1 : bl];
             if (first) {  // a new class: the accumulators start from zero (an inline constant, no register writes)
               const v16f z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -250,8 +255,8 @@ __global__ __launch_bounds__(256, 1) void tpg_gcls_gram_kernel(const uint4* __re
               for (int p = 0; p < GP; p++) acc[p] = MFMA_G4(R[C][p / GB], R[C][GA + p % GB], acc[p]);
             }
             first = false;
-            if (((dbg & 1) ? false : (bool)lastb[b]) || b == bl) {  // end of the class (or of the range): fold
-              const double w = wblk[b];
+            if ((wf & 1ull) || b == bl) {  // end of the class (or of the range): fold
+              const double w = __longlong_as_double((long long)(wf & ~1ull));
 #pragma unroll
               for (int p = 0; p < GP; p++)
 #pragma unroll
@@ -384,13 +389,12 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
   if (cost_cls > cost_dig && !getenv("TPG_GRAM_CLASSES")) return TPG_OK;
 
   int32_t* d_src = nullptr;
-  double *d_wblk = nullptr, *d_slabs = nullptr;
-  uint32_t* d_last = nullptr;
+  double* d_slabs = nullptr;
+  unsigned long long* d_wblk = nullptr;
   uint4* d_T4g = nullptr;
   int2* d_order = nullptr;
   TPG_HIP(B.get(&d_src, (size_t)nblocks * 64));
   TPG_HIP(B.get(&d_wblk, (size_t)nblocks));
-  TPG_HIP(B.get(&d_last, (size_t)nblocks));
   TPG_HIP(B.get(&d_T4g, (size_t)(4 * v->Q) * (size_t)nblocks * 64));
   TPG_HIP(B.get(&d_order, (size_t)nun));
   TPG_HIP(B.get(&d_slabs, (size_t)S * (size_t)nun * GCLS_SLAB));
@@ -402,7 +406,7 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
                        (const unsigned long long*)d_ukeys, (const uint32_t*)d_estart, (const uint32_t*)d_bstart, (int)nruns, m,
                        d_src, d_what);
     hipLaunchKernelGGL(tpg_gcls_block_table_kernel, dim3(256), dim3(256), 0, ctx->stream, (const unsigned long long*)d_ukeys,
-                       (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks, d_wblk, d_last);
+                       (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks, d_wblk);
   }
   {
     const int64_t tasks = v->Q * nblocks;
@@ -411,8 +415,7 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
                (const int32_t*)d_src, nblocks, d_T4g);
   }
   TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T4g,
-             nblocks, nrtv, (const double*)d_wblk, (const uint32_t*)d_last, (const int2*)d_order, nun, S, d_slabs,
-             getenv("TPG_GCLS_DEBUG") ? atoi(getenv("TPG_GCLS_DEBUG")) : 0);
+             nblocks, nrtv, (const unsigned long long*)d_wblk, (const int2*)d_order, nun, S, d_slabs);
   TPG_LAUNCH(ctx, "gcls_assemble", tpg_gcls_assemble_kernel, dim3((unsigned)std::min<int64_t>(nun, 4096)), dim3(256), 0,
              (const double*)d_slabs, (const int2*)d_order, nun, S, (int)n, d_K);
   TPG_CHECK_LAUNCH();
