@@ -1565,6 +1565,23 @@ extern "C" int tpg_pca_random_svd(tpg_ctx* ctx, const tpg_view* v, int k, double
   return pca_svd_impl(ctx, nullptr, v, k, tol < 1e-12 ? 1e-12 : tol, d, u, vload, center, scale, square_frobenius);
 }
 
+// upper triangle (column k holds rows 0 .. k at k (k + 1) / 2) <-> full symmetric matrix
+__global__ void tpg_tri_pack_kernel(const double* __restrict__ K, int n, double* __restrict__ tri) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx % n, k = idx / n;
+    if (i <= k) tri[k * (k + 1) / 2 + i] = K[idx];
+  }
+}
+__global__ void tpg_tri_unpack_kernel(const double* __restrict__ tri, int n, double* __restrict__ K) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx % n, k = idx / n;
+    const int64_t lo = i < k ? i : k, hi = i < k ? k : i;
+    K[idx] = tri[hi * (hi + 1) / 2 + lo];
+  }
+}
+
 static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, double tol, double* d, double* u,
                         double* vload, double* center, double* scale, double* square_frobenius) {
   TPG_REQUIRE(ctx && v && d && u && vload && center && scale, TPG_EINVAL, "null argument");
@@ -1592,8 +1609,19 @@ static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, 
   TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true));
   st.mark("gram");
   if (comm && (comm->nranks > 1 || comm->nccl)) {  // K = sum over the ranks' loci of z_j z_j'
-    ProfScope ps(ctx, "pca_gram_allreduce");
-    TPG_TRY(tpg_comm_allreduce(comm, d_K, (int64_t)n * n, 1));
+    // only the upper triangle travels: n (n + 1) / 2 doubles instead of n^2 (K is symmetric bit for bit on every rank)
+    const int64_t ntri = n * (n + 1) / 2;
+    double* d_tri = nullptr;
+    TPG_HIP(tpg_pmalloc((void**)&d_tri, sizeof(double) * (size_t)ntri));
+    TPG_LAUNCH(ctx, "pca_gram_tri", tpg_tri_pack_kernel, dim3(2048), dim3(256), 0, (const double*)d_K, (int)n, d_tri);
+    int rc;
+    {
+      ProfScope ps(ctx, "pca_gram_allreduce");
+      rc = tpg_comm_allreduce(comm, d_tri, ntri, 1);
+    }
+    if (rc == TPG_OK) TPG_LAUNCH(ctx, "pca_gram_tri", tpg_tri_unpack_kernel, dim3(2048), dim3(256), 0, (const double*)d_tri, (int)n, d_K);
+    tpg_pfree(d_tri);
+    TPG_TRY(rc);
   }
   std::vector<double> lam((size_t)k);
   TPG_TRY(eig_topk(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>(), tol));
