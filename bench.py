@@ -66,7 +66,30 @@ class Step:
 
             self.comm = api.Comm.host(self.ctx, world, rank, sharding.all_reduce_numpy)
         else:
-            self.comm = api.Comm.from_torch_distributed(self.ctx)  # RCCL; a single rank exchanges nothing
+            # RCCL; a single rank exchanges nothing.  If the communicator cannot be made on some rank (no librccl.so, a
+            # refused peer mapping ...) every rank falls back to the host transport over gloo together -- correct, and
+            # slow: the line says which transport ran (config.collectives)
+            self.transport = "rccl"
+            comm, err = None, ""
+            try:
+                comm = api.Comm.from_torch_distributed(self.ctx)
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            if world > 1:
+                from tidypopgen_amd import sharding
+
+                bad = float(sharding.all_reduce_numpy(np.array([0.0 if comm is not None else 1.0]))[0])
+                if bad > 0:
+                    if comm is not None:
+                        comm.close()
+                    if rank == 0:
+                        print(f"[bench] RCCL communicator failed on {int(bad)} rank(s) ({err}); host transport over gloo",
+                              file=sys.stderr)
+                    comm = api.Comm.host(self.ctx, world, rank, sharding.all_reduce_numpy)
+                    self.transport = "host (gloo) fallback"
+            elif comm is None:
+                raise RuntimeError(err)
+            self.comm = comm
         n, G = args.n, args.pops
         if args.scaling == "strong":
             self.m_total = args.m
@@ -606,7 +629,8 @@ def main():
             "dtype": "fp4-e2m1 operands (exact integers, f32 accumulate) for the cross-products and the PCA Gram, int8 (int32 accumulate) for counts, f64 for statistics",
             "data": "synthetic",
             "config": {"workload": wl, "analyses": analyses, "pca_included": bool(st.has_pca),
-                       "collectives": "library-owned RCCL: reduce-scatter of int32 pairwise slabs, all-reduce of Fst sums and of the FP64 Gram"
+                       "collectives": (f"library-owned, transport {getattr(st, 'transport', 'host (gloo) rehearsal')}: reduce-scatter of int32 pairwise "
+                                       "slabs, all-reduce of Fst sums and of the FP64 Gram (upper triangle)")
                        if world > 1 else "none (one rank)"},
             "roofline": roof,
             "roofline_other_kernels": roofs[1:] + [r for r in others if r],
