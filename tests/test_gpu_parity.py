@@ -894,7 +894,8 @@ class _env:
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("n,m", [(37, 700), (100, 5000), (333, 20011), (700, 3001)])
+@pytest.mark.parametrize("n,m", [(2, 40), (31, 64), (33, 65), (37, 700), (96, 129), (100, 5000), (129, 1000), (333, 20011),
+                                 (700, 3001)])
 def test_pca_gram_weight_classes_equal_digits_and_numpy(tpg, n, m):
     """S' = sum over weight classes of w_c G_c on the FP4 matrix cores (gramcls.hip) against the digit-split int8
     kernel on the same view and against a float64 numpy Gram; both paths forced, whatever the cost model would pick."""
