@@ -6,10 +6,12 @@
 // scale_j = sqrt(2 p (1-p)), K = sum_j z_j z_j', eigen(K), d = sqrt(lambda), v = Z'u/d),
 // R/square_frobenius.R:19-35 and fbm256_prod_and_rowSumsSq (src/fbm_prod_and_rowSumSq.cpp:10-47).
 //
-// Gram matrix on int8 MFMA.  z_ij = (g_ij - c_j)/s_j with g in {0,1,2} (no missing values), so
+// Gram matrix.  z_ij = (g_ij - c_j)/s_j with g in {0,1,2} (no missing values), so
 //     K_ik = sum_j w_j g_ij g_kj  -  r_i  -  r_k  +  C,      w_j = 1/s_j^2,
 //     r_i  = sum_j w_j c_j g_ij,   C = sum_j w_j c_j^2.
-// The weights are rounded to fixed point, W_j = round(w_j 2^F), and written in balanced base-128
+// S' = sum_j w_j g_i g_k' comes from gramcls.hip (weight classes on the FP4 matrix cores) whenever the weights take few
+// enough distinct values for that to pay -- always so under the binomial scaling on a long panel -- and from the
+// digit-split int8 MFMA kernel of this file otherwise.  For the latter the weights are rounded to fixed point, W_j = round(w_j 2^F), and written in balanced base-128
 // digits W_j = sum_t D_t[j] 128^t, D_t in [-64, 63].  Then sum_j W_j g_ij g_kj is a sum of T exact
 // int8 x int8 -> int32 MFMA contractions with A = D_t[j] * g_ij (|.| <= 128) and B = g_kj.  The only
 // approximation is the rounding of w_j (relative error <= 2^-(F+1)/w_min <= 2^-(F+2)): K-hat is the
@@ -24,7 +26,7 @@
 //
 // Eigen step: Chebyshev-filtered subspace iteration (Zhou & Saad) on the N x N matrix in HBM; all
 // N-sized work (K Q products, projections, residuals) runs in FP64 kernels here, only b x b
-// (b = k + 12) factorizations run on the host.
+// (b = 2k + 12) factorizations run on the host.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
