@@ -308,13 +308,14 @@ struct GclsBufs {
   }
 };
 
-// cost models (microseconds per wave), fitted on tools/ubench_fold.hip and the digit kernel of pca.hip
+// cost models (microseconds per wave), fitted on the two kernels at 5 000 x 1 000 000: per tile 0.095 us per class (fold)
+// + 0.043 us per block (operand streaming, not the 0.0175 us of the MFMA itself); digit kernel 1.0 us per 128 loci
 static double gcls_cost_classes(int64_t nunits, int64_t nruns, int64_t nblocks, int nwaves, int* bestS) {
   double best = -1;
   for (int S = 1; S <= 32; S++) {
     if (nblocks / S < 4 && S > 1) break;
     const int64_t rounds = ceil_div(nunits * S, (int64_t)nwaves);
-    const double per = ((double)nruns / S + 1.0) * GP * 0.135 + (double)ceil_div(nblocks, (int64_t)S) * GP * 0.0175 + 6.0;
+    const double per = ((double)nruns / S + 1.0) * GP * 0.095 + (double)ceil_div(nblocks, (int64_t)S) * GP * 0.043 + 6.0;
     const double cost = (double)rounds * per;
     if (best < 0 || cost < best * 0.995) { best = cost; *bestS = S; }
   }
@@ -379,10 +380,11 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
   if (nblk_grid < 8) nblk_grid = 8;
   const int nwaves = 4 * nblk_grid;
   int S = 1;
-  const double cost_cls = gcls_cost_classes(nun, nruns, nblocks, nwaves, &S);
-  // the digit kernel: 32 x 128 wave tiles, 64 int8 MFMAs (~1.17 us) per 128 loci, 4 row tiles x super-tiles of 4
+  // + the sort, the gather (2.3 us per 1000 loci at n = 5 000: it scales with n m) and the assemble pass
+  const double cost_cls = gcls_cost_classes(nun, nruns, nblocks, nwaves, &S) + 650.0 + 2.3e-3 * (double)m * ((double)n / 5000.0);
+  // the digit kernel: 32 x 128 wave tiles, 64 int8 MFMAs (~1.0 us) per 128 loci, 4 row tiles x super-tiles of 4
   const int64_t nun_dig = (int64_t)nrtv * ceil_div((int64_t)nrtv, 4) / 2 + nrtv;
-  const double cost_dig = (double)ceil_div(nun_dig, (int64_t)nwaves) * ((double)ceil_div(m, 128) * 1.17) + 65.0;
+  const double cost_dig = (double)ceil_div(nun_dig, (int64_t)nwaves) * ((double)ceil_div(m, 128) * 1.0) + 65.0;
   if (getenv("TPG_DEBUG"))
     fprintf(stderr, "[tpg] gram classes: %lld classes, %lld blocks for %lld loci, S = %d, model %.0f us (digits %.0f us)\n",
             (long long)nruns, (long long)nblocks, (long long)m, S, cost_cls, cost_dig);
