@@ -951,3 +951,34 @@ def test_pca_gram_one_class_longer_than_an_exact_fp32_sum(tpg):
     z = (col.astype(np.float64) - center[0]) / scale[0]
     ref = m * np.outer(z, z)
     assert np.abs(K - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n,m,subset", [(300, 1000, False), (1000, 2500, False), (256, 1024, True)])
+def test_view_pair_layouts_serve_every_consumer(tpg, n, m, subset):
+    """A pair is packed as (L + the FP4 layout of the pairwise kernel, L): whatever contracts over loci on the 2-bit T
+    layout (individual counts, the digit Gram, the sweeps) gets T made from L, and a pair that goes through the generic
+    pack kernel (row subset) gets T and has its FP4 layout made on first use.  Everything must equal what the two views
+    created one by one give."""
+    fbi = orc.synth_fbm(21, n, m, npop=4, miss=0.05, imputed_bytes=True)
+    X = tpg.FBM.from_numpy(fbi)
+    rng = np.random.default_rng(3)
+    rows = (np.sort(rng.permutation(n)[: n - 7]) + 1).astype(np.int32) if subset else None
+    va, vb = tpg.View.pair(X, rows)
+    sa, sb = tpg.View(X, rows, code256=None), tpg.View(X, rows, code256=tpg.CODE_IMPUTE_PRED)
+    nn = va.n
+    pa, ps = tpg.Pairwise(X.ctx, nn), tpg.Pairwise(X.ctx, nn)
+    pa.accumulate(va)
+    ps.accumulate(sa)
+    ca, cs = pa.counts(), ps.counts()
+    for k in ca:
+        assert np.array_equal(ca[k], cs[k]), k
+    assert np.array_equal(tpg.indiv_counts(va), tpg.indiv_counts(sa))
+    assert np.array_equal(tpg.indiv_counts(vb), tpg.indiv_counts(sb))
+    cnt = tpg.loci_counts(vb)
+    alt = cnt[:, 1] + 2 * cnt[:, 2]
+    keep = (np.where((alt > 0) & (alt < 2 * nn))[0] + 1).astype(np.int32)
+    vb2, sb2 = tpg.View.pair(X, rows, keep)[1], tpg.View(X, rows, keep, code256=tpg.CODE_IMPUTE_PRED)
+    center, scale = tpg.pca_center_scale(sb2)
+    with _env(TPG_GRAM_DIGITS="1", TPG_GRAM_CLASSES=None):
+        assert np.array_equal(tpg.pca_gram(vb2, center, scale), tpg.pca_gram(sb2, center, scale))
+    assert np.array_equal(va.unpack(), sa.unpack()) and np.array_equal(vb.unpack(), sb.unpack())

@@ -122,11 +122,12 @@ struct tpg_view {
   tpg_ctx* ctx;
   int64_t n, m;    // kept individuals / loci
   int64_t Q, KG;   // ceil(n/128), ceil(m/128)
-  uint4* T;        // (4Q) row tiles x KG blocks
+  mutable uint4* T;  // (4Q) row tiles x KG blocks; NULL in the views of tpg_view_create_pair until somebody needs it
+                     // (tpg_view_need_T builds it from L)
   uint4* L;        // (4KG) locus tiles x Q blocks
   size_t bytes_each;
-  // T re-coded as FP4 (E2M1) operand nibbles for the pairwise kernel (pairwise.hip: tpg_t4_expand_kernel); made on
-  // the first tpg_pairwise_accumulate of the view, 2 x bytes_each
+  // T re-coded as FP4 (E2M1) operand nibbles for the pairwise kernel (pairwise.hip); written by the pack kernel for
+  // the first view of tpg_view_create_pair, otherwise made from T on the first tpg_pairwise_accumulate; 2 x bytes_each
   mutable uint4* T4 = nullptr;
   // the last per-class counts computed on this view (grouped_alt_freq, grouped_summaries and the Fst
   // methods of one analysis all use the same grouping): reused while the class vector is unchanged
@@ -237,6 +238,8 @@ int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype);  
 int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,
                     const uint8_t* d_lut, tpg_view* v, tpg_view* v2);
 int tpg_launch_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* d_codes, int from_L);
+// the T layout of a view that was packed without it (from L; a no-op when it is there)
+int tpg_view_need_T(tpg_ctx* ctx, const tpg_view* v);
 int tpg_launch_synth(tpg_ctx* ctx, uint8_t* d_bytes, uint64_t seed, int64_t nrow, int64_t ncol, int64_t j0,
                      int npop, uint32_t miss_thresh, int imputed_bytes);
 

@@ -21,6 +21,18 @@ __device__ __forceinline__ int tpg_lut(uint32_t lut, uint32_t codes) {
   return (int)__builtin_amdgcn_perm(0u, lut, codes);
 }
 
+// FP4 operand nibble of the pairwise kernel (pairwise.hip): bit 0 heterozygous, bit 1 typed, bit 2 homozygous, bit 3
+// dosage 0.  2-bit code -> nibble: dosage 0 -> 0xE, 1 -> 0x3, 2 -> 0x6, missing -> 0
+#define TPG_NIB_LUT 0x0006030Eu
+// one T dword (16 codes) -> two T4 dwords (16 nibbles)
+__device__ __forceinline__ void tpg_t4_words(uint32_t w, uint32_t& lo, uint32_t& hi) {
+  uint32_t nb[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) nb[k] = (uint32_t)tpg_lut(TPG_NIB_LUT, tpg_codes(w, k));
+  lo = nb[0] | (nb[1] << 4);
+  hi = nb[2] | (nb[3] << 4);
+}
+
 // bit position of element e (0..15) inside a packed dword
 __host__ __device__ __forceinline__ int tpg_elem_shift(int e) { return 8 * (e & 3) + 2 * (e >> 2); }
 

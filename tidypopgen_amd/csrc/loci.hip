@@ -79,6 +79,7 @@ extern "C" int tpg_indiv_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* out) {
   TPG_REQUIRE(ctx && v && out, TPG_EINVAL, "null argument");
   OutBuf o;
   TPG_TRY(o.init(out, sizeof(int32_t) * 4 * (size_t)v->n));
+  TPG_TRY(tpg_view_need_T(ctx, v));
   const int64_t n_rt = v->Q * 4;
   TPG_LAUNCH(ctx, "indiv_counts", tpg_loci_counts_kernel, dim3((unsigned)ceil_div(n_rt, 4)), dim3(256), 0,
              (const uint4*)v->T, n_rt, v->KG, v->m, v->n, o.dev<int4>());

@@ -113,12 +113,16 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
 // NV = 2: the same bytes decoded through TWO code tables into two views from one read of the FBM (the raw view of the
 // pairwise statistics and the imputed view of the PCA: R/gt_has_imputed.R:101-106 switches between exactly these two
 // tables on one FBM) -- 10 GB of traffic instead of 15 GB at 5 000 x 1 000 000.
+// T0 / T1 may be NULL (the view gets no T layout: tpg_view_need_T makes it from L if it is ever wanted); T4 (may be
+// NULL) = the FP4 operand layout of view 0 for the pairwise kernel (pairwise.hip), written instead of being expanded
+// from T later: every T word goes out as the two T4 words of the same lane.
 template <int NV>
 __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __restrict__ fbm, int64_t nrow,
                                                             const int32_t* __restrict__ cols, uint8_t* lut_and_flag,
                                                             int64_t n, int64_t m, int64_t Q, int64_t KG,
                                                             uint32_t* __restrict__ T0, uint32_t* __restrict__ L0,
-                                                            uint32_t* __restrict__ T1, uint32_t* __restrict__ L1) {
+                                                            uint32_t* __restrict__ T1, uint32_t* __restrict__ L1,
+                                                            uint32_t* __restrict__ T4) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[NV * (256 + 16) + NV * TILE * TILE];
   // lut_and_flag: NV tables of 256 bytes, each followed by its 16-byte flag area
   uint8_t* codes_all = smem + NV * (256 + 16);  // codes[view][locus][(individual + 32 * (locus >> 4)) & 127]
@@ -208,6 +212,8 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
     for (int vw = 0; vw < NV; vw++) {
     const uint8_t* codes = codes_all + vw * TILE * TILE;
     uint32_t* T = vw ? T1 : T0;
+    uint32_t* T4v = vw ? nullptr : T4;
+    if (!T && !T4v) continue;
     uint32_t d[16];
 #pragma unroll
     for (int e = 0; e < 16; e++)
@@ -224,9 +230,21 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
       W[3] |= __builtin_amdgcn_perm(t3, t1, 0x07060302u) << (2 * k);
     }
     const int64_t rt = bi * 4 + wv;
-    uint32_t* dst = T + ((rt * KG + bj) * 64 + 4 * iqq + 32 * (g & 1)) * 4 + (g >> 1);
+    if (T) {
+      uint32_t* dst = T + ((rt * KG + bj) * 64 + 4 * iqq + 32 * (g & 1)) * 4 + (g >> 1);
 #pragma unroll
-    for (int b = 0; b < 4; b++) dst[b * 4] = W[b];
+      for (int b = 0; b < 4; b++) dst[b * 4] = W[b];
+    }
+    if (T4v) {  // T word s = g >> 1 of lane l -> words 2 (s & 1), 2 (s & 1) + 1 of lane l in T4 block 2 kg + (s >> 1)
+      const int sT = g >> 1;
+      uint32_t* dst4 = T4v + (((rt * KG + bj) * 2 + (sT >> 1)) * 64 + 4 * iqq + 32 * (g & 1)) * 4 + 2 * (sT & 1);
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        uint32_t lo, hi;
+        tpg_t4_words(W[b], lo, hi);
+        *reinterpret_cast<uint2*>(dst4 + b * 4) = make_uint2(lo, hi);
+      }
+    }
     }  // view
   }
   }  // sub
@@ -246,12 +264,21 @@ int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, con
     const dim3 g1((unsigned)(v->KG * ((v->Q + 1) / 2)));
     if (v2)
       TPG_LAUNCH(ctx, "pack2", tpg_pack_fast_kernel<2>, g1, dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
-                 v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)v2->T, (uint32_t*)v2->L);
+                 v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)v2->T, (uint32_t*)v2->L,
+                 (uint32_t*)v->T4);
     else
       TPG_LAUNCH(ctx, "pack", tpg_pack_fast_kernel<1>, g1, dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
-                 v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                 v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                 (uint32_t*)v->T4);
     TPG_CHECK_LAUNCH();
     return TPG_OK;
+  }
+  // the generic kernel writes T and L only: a view created without T gets it here, and a T4 it was given is dropped
+  // (tpg_pairwise_accumulate makes it from T when it is needed)
+  for (tpg_view* w : {v, v2}) {
+    if (!w) continue;
+    if (!w->T) TPG_HIP(tpg_pmalloc((void**)&w->T, w->bytes_each));
+    if (w->T4) { tpg_pfree(w->T4); w->T4 = nullptr; }
   }
   TPG_LAUNCH(ctx, "pack", tpg_pack_kernel, grid, dim3(256), 0, fbm->d_bytes, fbm->nrow, fbm->bed_bpl, d_rows, d_cols,
              (uint8_t*)d_lut, v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L);
@@ -288,7 +315,51 @@ __global__ void tpg_unpack_kernel(const uint32_t* __restrict__ T, const uint32_t
   }
 }
 
+// T from L: one workgroup per 128 x 128 tile, the four L blocks of the tile unpacked into LDS code bytes and emitted as
+// its four T blocks (the second half of the generic pack kernel).  Only runs for a view that was packed without T
+// (tpg_view_create_pair) and is then handed to something that contracts over loci on the 2-bit layout.
+__global__ __launch_bounds__(256) void tpg_l2t_kernel(const uint32_t* __restrict__ L, int64_t Q, int64_t KG,
+                                                      uint32_t* __restrict__ T) {
+  __shared__ __attribute__((aligned(16))) uint8_t codes[TILE * LDS_STRIDE];  // codes[locus][individual]
+  const int tid = threadIdx.x;
+  const int64_t bj = blockIdx.x, bi = blockIdx.y;
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int idx = tid + 256 * it;
+    const int s = idx & 3, lane = (idx >> 2) & 63, tl = idx >> 8;
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t w = L[(((bj * 4 + tl) * Q + bi) * 64 + lane) * 4 + s];  // locus 32 tl + r, individuals 32 s + 16 h + e
+#pragma unroll
+    for (int e = 0; e < 16; e++) codes[(32 * tl + r) * LDS_STRIDE + 32 * s + 16 * h + e] = (uint8_t)((w >> tpg_elem_shift(e)) & 3u);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int idx = tid + 256 * it;
+    const int s = idx & 3, lane = (idx >> 2) & 63, tl = idx >> 8;
+    const int r = lane & 31, h = lane >> 5;
+    const int ind = 32 * tl + r;  // T: individual 32 tl + r, loci 32 s + 16 h + e
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) w |= (uint32_t)codes[(32 * s + 16 * h + e) * LDS_STRIDE + ind] << tpg_elem_shift(e);
+    T[(((bi * 4 + tl) * KG + bj) * 64 + lane) * 4 + s] = w;
+  }
+}
+
+int tpg_view_need_T(tpg_ctx* ctx, const tpg_view* v) {
+  if (v->T) return TPG_OK;
+  TPG_REQUIRE(v->KG < 2147483647ll && v->Q <= 65535, TPG_EINVAL, "view too large for the pack grid");
+  uint4* t = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&t, v->bytes_each));
+  TPG_LAUNCH(ctx, "l2t", tpg_l2t_kernel, dim3((unsigned)v->KG, (unsigned)v->Q), dim3(256), 0, (const uint32_t*)v->L, v->Q,
+             v->KG, (uint32_t*)t);
+  v->T = t;
+  TPG_CHECK_LAUNCH();
+  return TPG_OK;
+}
+
 int tpg_launch_unpack(tpg_ctx* ctx, const tpg_view* v, uint8_t* d_codes, int from_L) {
+  if (!from_L) TPG_TRY(tpg_view_need_T(ctx, v));
   TPG_LAUNCH(ctx, "unpack", tpg_unpack_kernel, dim3(2048), dim3(256), 0, (const uint32_t*)v->T,
              (const uint32_t*)v->L, from_L, v->n, v->m, v->Q, v->KG, d_codes);
   TPG_CHECK_LAUNCH();

@@ -52,7 +52,6 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-#define TPG_NIB_LUT 0x0006030Eu  // 2-bit code -> nibble: dosage 0 -> 0xE, 1 -> 0x3, 2 -> 0x6, missing -> 0
 #define TPG_NIB_V 0x22222222u
 #define TPG_NIB_H 0x11111111u
 #define TPG_NIB_D 0xCCCCCCCCu
@@ -79,13 +78,7 @@ __global__ __launch_bounds__(256) void tpg_t4_expand_kernel(const uint4* __restr
     const uint32_t in[4] = {w.x, w.y, w.z, w.w};
     uint32_t out[8];
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      uint32_t nb[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) nb[k] = (uint32_t)tpg_lut(TPG_NIB_LUT, tpg_codes(in[s], k));
-      out[2 * s] = nb[0] | (nb[1] << 4);
-      out[2 * s + 1] = nb[2] | (nb[3] << 4);
-    }
+    for (int s = 0; s < 4; s++) tpg_t4_words(in[s], out[2 * s], out[2 * s + 1]);
     T4[(blk * 2) * 64 + lane] = make_uint4(out[0], out[1], out[2], out[3]);
     T4[(blk * 2 + 1) * 64 + lane] = make_uint4(out[4], out[5], out[6], out[7]);
   }
@@ -481,8 +474,9 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
               "%lld loci accumulated + %lld more would overflow the int32 pair counts (limit %lld)", (long long)pw->loci,
               (long long)(col_end - col_begin), (long long)TPG_PW_MAX_LOCI);
   pw->loci += col_end - col_begin;
-  // the FP4 operand form of the view, made on first use
+  // the FP4 operand form of the view: written by the pack kernel (tpg_view_create_pair) or made here on first use
   if (!v->T4) {
+    TPG_TRY(tpg_view_need_T(ctx, v));
     uint4* t4 = nullptr;
     TPG_HIP(tpg_pmalloc((void**)&t4, 2 * v->bytes_each));
     const int64_t nblocks = 4 * v->Q * v->KG;

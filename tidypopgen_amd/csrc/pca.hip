@@ -320,6 +320,7 @@ extern "C" int tpg_fbm256_prod_and_rowSumsSq(tpg_ctx* ctx, const tpg_view* v, co
   double* d_inv = nullptr;
   TPG_HIP(tpg_pmalloc((void**)&d_inv, sizeof(double) * (size_t)v->m));
   TPG_LAUNCH(ctx, "inv_scale", tpg_inv_kernel, dim3(1024), dim3(256), 0, is.dev<double>(), v->m, d_inv);
+  TPG_TRY(tpg_view_need_T(ctx, v));
   int rc = run_sweep(ctx, SW_COLSCALE, v->T, v->Q * 4, v->KG, v->n, v->m, ic.dev<double>(), d_inv, iv.dev<double>(),
                      v->m, K, oxv.dev<double>(), nullptr, orss.dev<double>());
   tpg_pfree(d_inv);
@@ -340,6 +341,7 @@ extern "C" int tpg_fbm256_valid_prod(tpg_ctx* ctx, const tpg_view* v, const doub
   TPG_TRY(it.init(ctx, Tab, sizeof(double) * (size_t)v->m * (size_t)K));
   OutBuf oo;
   TPG_TRY(oo.init(out, sizeof(double) * (size_t)v->n * (size_t)K));
+  TPG_TRY(tpg_view_need_T(ctx, v));
   TPG_TRY(run_sweep(ctx, SW_VALID, v->T, v->Q * 4, v->KG, v->n, v->m, nullptr, nullptr, it.dev<double>(), v->m, K,
                     oo.dev<double>(), nullptr, nullptr));
   return oo.commit(ctx);
@@ -798,6 +800,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     if (rc != TPG_OK) { tpg_pfree(d_what); tpg_pfree(d_wc); tpg_pfree(d_r); tpg_pfree(d_part); return rc; }
   }
   if (!by_classes) {
+  if (e == hipSuccess && tpg_view_need_T(ctx, v) != TPG_OK) { tpg_pfree(d_what); tpg_pfree(d_wc); tpg_pfree(d_r); tpg_pfree(d_part); return TPG_EHIP; }
   GHIP(tpg_pmalloc((void**)&d_DG, (size_t)v->KG * 4 * 2 * T * 8 * sizeof(uint32_t)));
   GHIP(tpg_pmalloc((void**)&d_slabs, sizeof(long long) * (size_t)nun * PCA_SLAB_INTS));
   GHIP(hipMemsetAsync(d_slabs, 0, sizeof(long long) * (size_t)nun * PCA_SLAB_INTS, ctx->stream));
@@ -854,7 +857,8 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   }
   if (e == hipSuccess && !own_center) {
     // r_i = sum_j what_j c_j g_ij  (RAW sweep with a one-column table), C = sum_j what_j c_j^2
-    rc = run_sweep(ctx, SW_RAW, v->T, v->Q * 4, v->KG, n, m, nullptr, nullptr, d_wc, m, 1, d_r, nullptr, nullptr);
+    rc = tpg_view_need_T(ctx, v);
+    if (rc == TPG_OK) rc = run_sweep(ctx, SW_RAW, v->T, v->Q * 4, v->KG, n, m, nullptr, nullptr, d_wc, m, 1, d_r, nullptr, nullptr);
   }
   double Cc = 0;
   if (e == hipSuccess && rc == TPG_OK && !own_center) {

@@ -621,7 +621,11 @@ static int view_create_impl(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* row
   for (int k = 0; k < nv; k++) {
     v[k] = new tpg_view{ctx, n, m, ceil_div(n, 128), ceil_div(m, 128), nullptr, nullptr, 0};
     v[k]->bytes_each = (size_t)v[k]->Q * (size_t)v[k]->KG * 4096;
-    VHIP(tpg_pmalloc((void**)&v[k]->T, v[k]->bytes_each));
+    // A pair is "the raw view of the pairwise statistics + the imputed view of the PCA": neither reads the 2-bit T
+    // layout (the pairwise kernel reads T4, the class Gram its own sorted layout), so the pair is packed as L + T4 and
+    // L; whoever does want T gets it from L (tpg_view_need_T).
+    if (!two) VHIP(tpg_pmalloc((void**)&v[k]->T, v[k]->bytes_each));
+    else if (k == 0) VHIP(tpg_pmalloc((void**)&v[k]->T4, 2 * v[k]->bytes_each));
     VHIP(tpg_pmalloc((void**)&v[k]->L, v[k]->bytes_each));
   }
   VHIP(tpg_pmalloc((void**)&d_lut, sizeof(lut)));
