@@ -60,7 +60,15 @@ class Step:
         self.tpg, self.api, self.lib = tpg, api, tpg._lib.lib
         self.args, self.rank, self.world = args, rank, world
         share_gpu = os.environ.get("TPG_BENCH_SHARE_GPU") == "1"  # rehearsal: several ranks on one GPU, gloo transport
-        self.ctx = tpg.Context(0 if share_gpu else local_rank)
+        # a launcher may hand every rank ONE visible device (HIP_VISIBLE_DEVICES narrowed per rank) or all of them
+        ndev = tpg.device_count()
+        if share_gpu or (ndev == 1 and world > 1):
+            device = 0
+        elif local_rank < ndev:
+            device = local_rank
+        else:
+            raise RuntimeError(f"rank {rank}: local rank {local_rank} but only {ndev} HIP device(s) visible")
+        self.ctx = tpg.Context(device)
         if share_gpu:
             from tidypopgen_amd import sharding
 
@@ -482,8 +490,41 @@ def cpu_baseline(args):
                       f"(OpenMP), PCA Gram via BLAS; {dt:.1f} s; eigen step excluded"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes through
+    torch.distributed.run (one per GPU) and hand on rank 0's JSON line and the children's exit code.  This process never
+    touches the GPU (counting devices does not initialise HIP); the ranks are new processes, not a re-exec."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    if os.environ.get("TPG_BENCH_SHARE_GPU") != "1":  # rehearsal mode puts every rank on device 0
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"[bench] --gpus {n} asked for, {have} HIP device(s) visible: refusing to report a "
+                             f"{n}-GPU line from fewer GPUs (TPG_BENCH_SHARE_GPU=1 rehearses the sharded path on one)\n")
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks\n")
+        sys.exit(2)
     # stdout carries exactly one JSON line: libraries that print to fd 1 (RCCL's version banner on communicator
     # creation, for one) are sent to stderr for the whole run, the result goes to the saved descriptor
     sys.stdout.flush()

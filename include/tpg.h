@@ -53,6 +53,8 @@ const char* tpg_last_error(void);
 const char* tpg_version(void);
 
 /* ---- context ---------------------------------------------------------- */
+/* HIP devices visible to this process (0 when there is none or the runtime fails: tpg_ctx_create then says why) */
+int tpg_device_count(int* count);
 int tpg_ctx_create(int device, tpg_ctx** out);
 void tpg_ctx_destroy(tpg_ctx* ctx);
 /* use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream */
@@ -326,6 +328,25 @@ tpg_comm* tpg_multi_comm(tpg_multi* mg, int i);
 int tpg_multi_pairwise(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1,
                        int64_t n, const int32_t* colInd1, int64_t m, int ibs_type, double* ibs, double* king,
                        double* allele_sharing, double* grm);
+/* The other analyses of one HOST FBM on all devices of `mg`, for a caller that is ONE process (an R session): every
+ * device uploads and packs its share of colInd (through code256; NULL = raw bytes) and the results land in the
+ * caller's arrays (host or device memory).
+ *   tpg_multi_grouped_alt_freq: loci_alt_freq of a grouped gen_tibble (R/loci_alt_freq.R:174-197), out m x 2G; with
+ *     groupIds0 == NULL the ungrouped form (R/loci_alt_freq.R:328-379), out m x 2.  Per-locus outputs: no exchange.
+ *   tpg_multi_pop_fst: pairwise_pop_fst (R/pairwise_pop_fst.R:116-161), arguments as tpg_pairwise_pop_fst; by-locus
+ *     rows come from the device that owns the locus, totals from the numerator / denominator sums of all devices.
+ *   tpg_multi_pca_partial_svd: gt_pca_partialSVD (R/gt_pca_partialSVD.R:67-108), arguments as tpg_pca_partial_svd;
+ *     the Gram matrix is summed over the devices by one all-reduce (RCCL). */
+int tpg_multi_grouped_alt_freq(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1,
+                               int64_t n, const int32_t* colInd1, int64_t m, const double* code256,
+                               const int32_t* groupIds0, int ngroups, const double* ploidy, int as_counts, double* out);
+int tpg_multi_pop_fst(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
+                      const int32_t* colInd1, int64_t m, const double* code256, const int32_t* groupIds0, int ngroups,
+                      const double* ploidy, int method, const int32_t* pairs1, int P, int by_locus, int return_num_dem,
+                      double* fst_tot, double* out_a, double* out_b);
+int tpg_multi_pca_partial_svd(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1,
+                              int64_t n, const int32_t* colInd1, int64_t m, const double* code256, int k, double* d,
+                              double* u, double* vload, double* center, double* scale, double* square_frobenius);
 
 /* ---- PCA (gt_pca_partialSVD) ---------------------------------------------- */
 /* center / scale of bigsnpr::snp_scaleBinom; TPG_ENUMERIC on a missing value or zero scale */

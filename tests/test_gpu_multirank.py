@@ -172,3 +172,88 @@ def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
                                                             api._ptr(vl), api._ptr(ce), api._ptr(sc), C.byref(fro)))
     assert np.array_equal(d, exact["d"]) and np.array_equal(u, exact["u"]) and fro.value == exact["square_frobenius"]
     comm.close()
+
+
+def _align_sign(a, b):
+    s = np.sign((a * b).sum(axis=0))
+    s[s == 0] = 1
+    return a * s
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 3])
+def test_multi_fst_freq_pca_against_oracle(ndev):
+    """tpg_multi_pop_fst / tpg_multi_grouped_alt_freq / tpg_multi_pca_partial_svd: what ONE R process calls for
+    BASELINE configs 4 and 5.  ndev = 1 is the plain single-device path; ndev = 2, 3 list device 0 several times, so the
+    device threads exchange through the in-process host transport (RCCL refuses one GPU twice): thread teams, phases,
+    status agreement and the row-range writes into the caller's matrices are the code an 8-GPU run executes."""
+    import tidypopgen_amd as tpg
+    from oracle import oracle as orc
+
+    n, m, G, k = 180, 2900, 5, 6
+    fbm = orc.synth_fbm(29, n, m, npop=G, miss=0.04, imputed_bytes=True)
+    gid = (np.arange(n) % G).astype(np.int32)
+    mg = tpg.Multi(ndev, devices=[0] * ndev)
+    rows = (np.random.default_rng(3).permutation(n)[:150] + 1).astype(np.int32)
+    cols = (np.sort(np.random.default_rng(4).permutation(m)[:2500]) + 1).astype(np.int32)
+    for r, c in ((None, None), (rows, cols)):
+        g = gid if r is None else gid[r - 1]
+        # grouped and ungrouped allele frequencies: bit exact
+        assert np.array_equal(mg.loci_alt_freq(fbm, r, c, g, G),
+                              orc.grouped_alt_freq_dip_pseudo_cpp(fbm, r, c, g, G, np.full(len(g), 2.0)))
+        assert np.array_equal(mg.loci_alt_freq(fbm, r, c, as_counts=True), orc.loci_alt_freq(fbm, r, c, as_counts=True))
+        for method in ("Hudson", "WC84", "Nei87"):
+            o = orc.pairwise_pop_fst(fbm, r, c, g, G, method=method, by_locus=True)
+            t = mg.pairwise_pop_fst(fbm, r, c, g, G, method=method, by_locus=True)
+            assert np.array_equal(t["fst_locus"], o["fst_locus"], equal_nan=True), method  # per locus: bit identical
+            assert np.allclose(t["fst_tot"], o["fst_tot"], rtol=1e-12, atol=0), method
+            t2 = mg.pairwise_pop_fst(fbm, r, c, g, G, method=method)
+            assert np.allclose(t2["fst_tot"], o["fst_tot"], rtol=1e-12, atol=0), method
+        o = orc.pairwise_pop_fst(fbm, r, c, g, G, method="Hudson", return_num_dem=True)
+        t = mg.pairwise_pop_fst(fbm, r, c, g, G, method="Hudson", return_num_dem=True)
+        for key in ("Fst_by_locus_num", "Fst_by_locus_den"):
+            assert np.array_equal(t[key], o[key], equal_nan=True), key
+    # PCA on the polymorphic loci (big_SVD stops on a zero scale)
+    dec = np.where(fbm > 3, fbm - 4, fbm)
+    pc = (np.where((dec.sum(axis=0) > 0) & (dec.sum(axis=0) < 2 * n))[0] + 1).astype(np.int32)
+    o = orc.gt_pca_partialSVD(fbm, None, pc, k=k)
+    t = mg.gt_pca_partialSVD(fbm, None, pc, k=k)
+    assert np.array_equal(t["center"], o["center"]) and np.array_equal(t["scale"], o["scale"])
+    assert t["square_frobenius"] == pytest.approx(o["square_frobenius"], rel=1e-12)
+    assert np.allclose(t["d"], o["d"], rtol=1e-6, atol=0)
+    so, st = o["u"] * o["d"], _align_sign(t["u"] * t["d"], o["u"] * o["d"])
+    assert np.max(np.abs(st - so)) <= 1e-6 * np.max(np.abs(so))
+    assert np.max(np.abs(_align_sign(t["v"], o["v"]) - o["v"])) <= 1e-6 * np.max(np.abs(o["v"]))
+    # a shard with a zero scale fails on ONE device thread only: every device gives up together (no thread is left in
+    # the Gram all-reduce), and the error is big_SVD's
+    mono = fbm.copy()
+    mono[:, m - 5] = 0
+    with pytest.raises(tpg._lib.TpgError) as e:
+        mg.gt_pca_partialSVD(mono, None, None, k=k)
+    assert e.value.code == 4
+    # a panel too short for every device to hold k loci runs on one device
+    short = mg.gt_pca_partialSVD(fbm, None, pc[:100], k=k)
+    assert np.allclose(short["d"], orc.gt_pca_partialSVD(fbm, None, pc[:100], k=k)["d"], rtol=1e-6)
+    mg.close()
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_n_launches_n_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it starts two ranks itself (torch.distributed.run children) and
+    reports n_gpus = 2 and the transport; asking for more GPUs than there are is refused instead of reported as N."""
+    common = ["--steps", "1", "--warmup", "0", "--indiv", "500", "--snps", "40000", "--pops", "7", "--k", "6",
+              "--no-cpu-baseline", "--no-end-to-end"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + common, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600, env=dict(env, TPG_BENCH_SHARE_GPU="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and "transport" in out["config"]["collectives"]
+    import tidypopgen_amd as tpg
+
+    have = tpg.device_count()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(have + 1)] + common, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "refusing" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

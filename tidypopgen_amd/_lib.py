@@ -73,7 +73,7 @@ for _name in ("tpg_ctx_destroy", "tpg_fbm_free", "tpg_view_free", "tpg_pairwise_
 
 # every symbol include/tpg.h declares (checked by tests/test_abi.py against the header)
 SYMBOLS = [
-    "tpg_last_error", "tpg_version", "tpg_ctx_create", "tpg_ctx_destroy", "tpg_ctx_set_stream", "tpg_ctx_sync",
+    "tpg_last_error", "tpg_version", "tpg_device_count", "tpg_ctx_create", "tpg_ctx_destroy", "tpg_ctx_set_stream", "tpg_ctx_sync",
     "tpg_prof_enable", "tpg_prof_reset", "tpg_prof_get", "tpg_prof_dump", "tpg_dev_alloc", "tpg_dev_free",
     "tpg_dev_to_host", "tpg_dev_from_host", "tpg_sym_eig_topk", "tpg_pca_loadings", "tpg_pairwise_pop_fst_sums", "tpg_fbm_from_host", "tpg_fbm_open_bk",
     "tpg_fbm_synth", "tpg_fbm_alloc", "tpg_fbm_upload_cols", "tpg_pca_gram_add", "tpg_fbm_open_bed", "tpg_fbm_from_bed_host", "tpg_fbm_to_host", "tpg_fbm_free", "tpg_view_create", "tpg_view_create_pair", "tpg_view_free", "tpg_view_n",
@@ -91,6 +91,7 @@ SYMBOLS = [
     "tpg_comm_rank", "tpg_comm_size", "tpg_shard_loci", "tpg_comm_allreduce_f64", "tpg_pairwise_buffer_bytes_sharded",
     "tpg_pairwise_create_sharded", "tpg_pairwise_reduce", "tpg_pairwise_band", "tpg_pairwise_band_of", "tpg_pairwise_epilogues_sharded",
     "tpg_pca_partial_svd_sharded", "tpg_multi_create", "tpg_multi_destroy", "tpg_multi_ndev", "tpg_multi_ctx", "tpg_multi_comm", "tpg_multi_pairwise",
+    "tpg_multi_grouped_alt_freq", "tpg_multi_pop_fst", "tpg_multi_pca_partial_svd",
 ]
 
 

@@ -114,6 +114,13 @@ class Context:
 _default_ctx: Optional[Context] = None
 
 
+def device_count() -> int:
+    """HIP devices visible to this process"""
+    c = C.c_int()
+    check(lib.tpg_device_count(C.byref(c)))
+    return c.value
+
+
 def default_context() -> Context:
     global _default_ctx
     if _default_ctx is None:
@@ -348,8 +355,17 @@ class Comm:
 
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return cls.init_rank(ctx, 1, 0, None)
-        box = [cls.unique_id() if dist.get_rank() == 0 else None]
+        # rank 0 always reaches the broadcast: a failure to make the id (no librccl.so ...) travels as a marker, so that
+        # no rank is left waiting in the broadcast and every rank raises together
+        box = [None]
+        if dist.get_rank() == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as e:  # noqa: BLE001
+                box[0] = f"{type(e).__name__}: {e}"
         dist.broadcast_object_list(box, src=0)
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError(f"rank 0 could not create the RCCL id: {box[0]}")
         return cls.init_rank(ctx, dist.get_world_size(), dist.get_rank(), box[0])
 
     @classmethod
@@ -444,6 +460,62 @@ class Multi:
                                      _ptr(r), C.c_int64(n), _ptr(c), C.c_int64(m), C.c_int(0 if ibs_type == "proportion" else 1),
                                      *[_ptr(outs.get(k)) for k in names]))
         return outs
+
+    @staticmethod
+    def _fbm_args(X_bytes, ind_row, ind_col):
+        X_bytes = np.asarray(X_bytes)
+        assert X_bytes.dtype == np.uint8 and X_bytes.flags.f_contiguous
+        r, c = _i32(ind_row), _i32(ind_col)
+        n = X_bytes.shape[0] if r is None else len(r)
+        m = X_bytes.shape[1] if c is None else len(c)
+        args = (_ptr(X_bytes), C.c_int64(X_bytes.shape[0]), C.c_int64(X_bytes.shape[1]), _ptr(r), C.c_int64(n), _ptr(c),
+                C.c_int64(m))
+        return args, n, m, (X_bytes, r, c)
+
+    def loci_alt_freq(self, X_bytes, ind_row=None, ind_col=None, groupIds=None, ngroups: int = 0, ploidy=None,
+                      as_counts: bool = False, code256=CODE_012) -> np.ndarray:
+        """loci_alt_freq of a host FBM on all devices: m x 2G (grouped) or m x 2 ({n_alt | freq, n_valid})"""
+        args, n, m, _keep = self._fbm_args(X_bytes, ind_row, ind_col)
+        gid, code = _i32(groupIds), _f64(code256)
+        pl = np.full(n, 2.0) if ploidy is None else _f64(ploidy)
+        out = np.zeros((m, 2 * ngroups if gid is not None else 2), order="F")
+        check(lib.tpg_multi_grouped_alt_freq(self.h, *args, _ptr(code), _ptr(gid), C.c_int(ngroups), _ptr(pl),
+                                             C.c_int(int(as_counts)), _ptr(out)))
+        return out
+
+    def pairwise_pop_fst(self, X_bytes, ind_row, ind_col, groupIds, ngroups: int, ploidy=None, method: str = "Hudson",
+                         by_locus: bool = False, return_num_dem: bool = False, pairwise_combn=None, code256=CODE_012):
+        """pairwise_pop_fst of a host FBM on all devices (same result layout as api.pairwise_pop_fst)"""
+        args, n, m, _keep = self._fbm_args(X_bytes, ind_row, ind_col)
+        if return_num_dem:
+            by_locus = True
+        pairs = combn2(ngroups) if pairwise_combn is None else np.asarray(pairwise_combn, dtype=np.int32)
+        pairs_c = np.ascontiguousarray(pairs.T)
+        P = pairs_c.shape[0]
+        gid, code = _i32(groupIds), _f64(code256)
+        pl = np.full(n, 2.0) if ploidy is None else _f64(ploidy)
+        tot, a, b = _fst_outputs(m, P, by_locus, return_num_dem)
+        check(lib.tpg_multi_pop_fst(self.h, *args, _ptr(code), _ptr(gid), C.c_int(ngroups), _ptr(pl),
+                                    C.c_int(FST_METHODS[method]), _ptr(pairs_c), C.c_int(P), C.c_int(int(by_locus)),
+                                    C.c_int(int(return_num_dem)), _ptr(tot), _ptr(a), _ptr(b)))
+        return _fst_result(tot, a, b, by_locus, return_num_dem)
+
+    def gt_pca_partialSVD(self, X_bytes, ind_row=None, ind_col=None, k: int = 10, total_var: bool = True,
+                          code256=CODE_IMPUTE_PRED) -> dict:
+        """gt_pca_partialSVD of a host FBM on all devices (same result as api.gt_pca_partialSVD)"""
+        args, n, m, _keep = self._fbm_args(X_bytes, ind_row, ind_col)
+        code = _f64(code256)
+        d = np.zeros(k)
+        u = np.zeros((n, k), order="F")
+        vl = np.zeros((m, k), order="F")
+        center, scale = np.zeros(m), np.zeros(m)
+        fro = C.c_double()
+        check(lib.tpg_multi_pca_partial_svd(self.h, *args, _ptr(code), C.c_int(k), _ptr(d), _ptr(u), _ptr(vl), _ptr(center),
+                                            _ptr(scale), C.byref(fro) if total_var else None))
+        out = dict(d=d, u=u, v=vl, center=center, scale=scale, method="partialSVD")
+        if total_var:
+            out["square_frobenius"] = fro.value
+        return out
 
     def close(self):
         if self.h:

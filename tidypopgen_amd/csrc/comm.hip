@@ -20,6 +20,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -36,24 +39,34 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllToAll)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-static RcclApi* rccl() {
-  static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.handle ? &api : nullptr;
-  tried = true;
+static RcclApi g_rccl;
+static std::string g_rccl_why;  // why the load failed (dlerror() text, read once: a second dlerror() returns NULL)
+static std::once_flag g_rccl_once;
+
+static void rccl_load() {
+  RcclApi& api = g_rccl;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* nm : names) {
     api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
     if (api.handle) break;
+    const char* why = dlerror();
+    g_rccl_why = why ? why : "not found";
   }
-  if (!api.handle) return nullptr;
-#define RSYM(field, sym)                                                   \
-  do {                                                                     \
-    *(void**)(&api.field) = dlsym(api.handle, sym);                        \
-    if (!api.field) { dlclose(api.handle); api.handle = nullptr; return nullptr; } \
+  if (!api.handle) return;
+#define RSYM(field, sym)                                                                          \
+  do {                                                                                            \
+    *(void**)(&api.field) = dlsym(api.handle, sym);                                               \
+    if (!api.field) {                                                                             \
+      g_rccl_why = std::string("librccl.so lacks ") + sym;                                        \
+      dlclose(api.handle);                                                                        \
+      api.handle = nullptr;                                                                       \
+      return;                                                                                     \
+    }                                                                                             \
   } while (0)
   RSYM(GetUniqueId, "ncclGetUniqueId");
   RSYM(CommInitRank, "ncclCommInitRank");
@@ -61,9 +74,16 @@ static RcclApi* rccl() {
   RSYM(CommDestroy, "ncclCommDestroy");
   RSYM(AllReduce, "ncclAllReduce");
   RSYM(ReduceScatter, "ncclReduceScatter");
+  RSYM(AllToAll, "ncclAllToAll");
+  RSYM(AllGather, "ncclAllGather");
   RSYM(GetErrorString, "ncclGetErrorString");
 #undef RSYM
-  return &api;
+}
+
+// several host threads (one context each) may ask at once: the loader runs once, the others wait for it
+static RcclApi* rccl() {
+  std::call_once(g_rccl_once, rccl_load);
+  return g_rccl.handle ? &g_rccl : nullptr;
 }
 
 #define TPG_RCCL(api, call)                                                                              \
@@ -80,38 +100,59 @@ static_assert(sizeof(ncclUniqueId) == 128, "tpg_comm_unique_id hands out 128 byt
 extern "C" int tpg_comm_unique_id(uint8_t* id128) {
   TPG_REQUIRE(id128, TPG_EINVAL, "null argument");
   RcclApi* api = rccl();
-  TPG_REQUIRE(api, TPG_EHIP, "RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "not found");
+  TPG_REQUIRE(api, TPG_EHIP, "RCCL (librccl.so) could not be loaded: %s", g_rccl_why.c_str());
   ncclUniqueId id;
   TPG_RCCL(api, api->GetUniqueId(&id));
   memcpy(id128, &id, 128);
   return TPG_OK;
 }
 
-extern "C" int tpg_comm_init_rank(tpg_ctx* ctx, int nranks, int rank, const uint8_t* id128, tpg_comm** out) {
-  TpgEnter _enter(ctx);
-  TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
-  TPG_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, TPG_EINVAL, "bad rank %d of %d", rank, nranks);
+// the status word of tpg_comm_agree lives in device memory reserved HERE: a rank that has just run out of memory must
+// still be able to tell the others
+static void comm_delete(tpg_comm* c) {
+  if (!c) return;
+  if (c->d_status) (void)hipFree(c->d_status);
+  delete c;
+}
+
+static tpg_comm* comm_new(tpg_ctx* ctx, int nranks, int rank) {
   tpg_comm* c = new tpg_comm();
   c->ctx = ctx;
   c->nranks = nranks;
   c->rank = rank;
+  if (hipMalloc((void**)&c->d_status, sizeof(int32_t) * TPG_COMM_STATUS_INTS) != hipSuccess) {
+    (void)hipGetLastError();
+    delete c;
+    tpg_set_error("hipMalloc of the communicator's status word failed");
+    return nullptr;
+  }
+  return c;
+}
+
+extern "C" int tpg_comm_init_rank(tpg_ctx* ctx, int nranks, int rank, const uint8_t* id128, tpg_comm** out) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, TPG_EINVAL, "bad rank %d of %d", rank, nranks);
+  tpg_comm* c = comm_new(ctx, nranks, rank);
+  if (!c) return TPG_EHIP;
   // a single rank exchanges nothing: no communicator, every collective is the identity (TPG_COMM_FORCE_RCCL=1 builds
   // a real one-rank RCCL communicator all the same: the rehearsal of the RCCL calls a one-GPU box allows)
   const bool force = getenv("TPG_COMM_FORCE_RCCL") && getenv("TPG_COMM_FORCE_RCCL")[0] == '1';
   if (nranks > 1 || force) {
     RcclApi* api = rccl();
     if (!api || (!id128 && nranks > 1)) {
-      delete c;
-      tpg_set_error(api ? "null unique id" : "RCCL (librccl.so) could not be loaded");
+      comm_delete(c);
+      if (api) tpg_set_error("null unique id");
+      else tpg_set_error("RCCL (librccl.so) could not be loaded: %s", g_rccl_why.c_str());
       return api ? TPG_EINVAL : TPG_EHIP;
     }
     ncclUniqueId id;
     if (id128) memcpy(&id, id128, 128);
-    else if (api->GetUniqueId(&id) != ncclSuccess) { delete c; tpg_set_error("ncclGetUniqueId failed"); return TPG_EHIP; }
+    else if (api->GetUniqueId(&id) != ncclSuccess) { comm_delete(c); tpg_set_error("ncclGetUniqueId failed"); return TPG_EHIP; }
     ncclComm_t nc = nullptr;
     ncclResult_t r = api->CommInitRank(&nc, nranks, id, rank);  // the context's device is current (TpgEnter)
     if (r != ncclSuccess) {
-      delete c;
+      comm_delete(c);
       tpg_set_error("ncclCommInitRank(rank %d of %d): %s", rank, nranks, api->GetErrorString(r));
       return TPG_EHIP;
     }
@@ -127,10 +168,8 @@ extern "C" int tpg_comm_init_host(tpg_ctx* ctx, int nranks, int rank,
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && out && (allreduce || nranks == 1), TPG_EINVAL, "null argument");
   TPG_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, TPG_EINVAL, "bad rank %d of %d", rank, nranks);
-  tpg_comm* c = new tpg_comm();
-  c->ctx = ctx;
-  c->nranks = nranks;
-  c->rank = rank;
+  tpg_comm* c = comm_new(ctx, nranks, rank);
+  if (!c) return TPG_EHIP;
   c->host_fn = allreduce;
   c->host_user = user;
   *out = c;
@@ -139,15 +178,15 @@ extern "C" int tpg_comm_init_host(tpg_ctx* ctx, int nranks, int rank,
 
 extern "C" void tpg_comm_destroy(tpg_comm* comm) {
   if (!comm) return;
+  TpgEnter _enter(comm->ctx);
   if (comm->nccl) {
     RcclApi* api = rccl();
     if (api) {
-      TpgEnter _enter(comm->ctx);
       (void)hipStreamSynchronize(comm->ctx->stream);
       (void)api->CommDestroy((ncclComm_t)comm->nccl);
     }
   }
-  delete comm;
+  comm_delete(comm);
 }
 
 extern "C" int tpg_comm_rank(const tpg_comm* comm) { return comm ? comm->rank : 0; }
@@ -181,6 +220,39 @@ int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype) {
   TPG_RCCL(api, api->AllReduce(d_buf, d_buf, (size_t)count, dtype == 0 ? ncclInt32 : ncclFloat64, ncclSum,
                                (ncclComm_t)comm->nccl, comm->ctx->stream));
   return TPG_OK;
+}
+
+// Every rank passes the status of the rank-local steps it has just done (allocations, a shard with a zero scale ...) and
+// all of them get the same answer: TPG_OK only if every rank said so, else the highest error code any rank reported.  Called
+// before a data collective, so that a rank that failed does not leave the others waiting in it for ever (RCCL has no
+// timeout).  A tiny all-reduce of one counter per error code; the identity on a single rank.
+int tpg_comm_agree(tpg_comm* comm, int rc) {
+  if (!comm || (comm->nranks == 1 && !comm->nccl)) return rc;
+  const std::string own = rc != TPG_OK ? tpg_last_error() : "";
+  int32_t h[TPG_COMM_STATUS_INTS] = {};
+  h[rc >= 0 && rc < TPG_COMM_STATUS_INTS ? rc : TPG_EHIP] = 1;
+  int xrc = TPG_OK;
+  if (comm->host_fn) {
+    if (comm->host_fn(comm->host_user, h, TPG_COMM_STATUS_INTS, 0) != 0) { tpg_set_error("the host all-reduce callback failed"); xrc = TPG_EHIP; }
+  } else {
+    RcclApi* api = rccl();
+    hipStream_t s = comm->ctx->stream;
+    hipError_t e = api && comm->nccl ? hipMemcpyAsync(comm->d_status, h, sizeof(h), hipMemcpyHostToDevice, s) : hipErrorNotInitialized;
+    if (e == hipSuccess && api->AllReduce(comm->d_status, comm->d_status, TPG_COMM_STATUS_INTS, ncclInt32, ncclSum,
+                                          (ncclComm_t)comm->nccl, s) != ncclSuccess)
+      e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipMemcpyAsync(h, comm->d_status, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { tpg_set_error("status exchange between the ranks failed: %s", hipGetErrorString(e)); xrc = TPG_EHIP; }
+  }
+  if (xrc != TPG_OK) return xrc;
+  if (rc != TPG_OK) { tpg_set_error("%s", own.c_str()); return rc; }
+  int failed = 0, worst = TPG_OK;
+  for (int c = 1; c < TPG_COMM_STATUS_INTS; c++)
+    if (h[c] > 0) { failed += h[c]; worst = c; }
+  if (!failed) return TPG_OK;
+  tpg_set_error("%d of %d ranks failed before the exchange (error code %d there): every rank gives up", failed, comm->nranks, worst);
+  return worst;
 }
 
 // d_buf holds nranks chunks of chunk_count int32; afterwards chunk `rank` holds the sum over the ranks of that chunk
@@ -237,10 +309,53 @@ extern "C" int tpg_shard_loci(int64_t m_total, int nranks, int rank, int64_t* be
 
 // ---------------------------------------------------------------------------
 // One process, several GPUs.
+//
+// Rehearsal transport between the device threads of ONE process (a device listed twice in tpg_multi_create, which RCCL
+// refuses, or TPG_MULTI_HOST_TRANSPORT=1): an all-reduce through host memory -- the last thread to arrive adds the
+// ranks' buffers in rank order (the same sums on every run), everybody copies the result.  It lets the tpg_multi_* paths
+// (thread teams, phases, status agreement, band and row-range writes) run with several ranks on a one-GPU box; tests only.
+struct InprocGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int n = 0, arrived = 0, left = 0;
+  uint64_t gen = 0;
+  std::vector<void*> slot;
+  std::vector<uint8_t> acc;
+};
+struct InprocRank { InprocGroup* g; int rank; };
+
+static int inproc_allreduce(void* user, void* buf, int64_t count, int dtype) {
+  InprocRank* me = (InprocRank*)user;
+  InprocGroup* g = me->g;
+  std::unique_lock<std::mutex> lk(g->mu);
+  g->cv.wait(lk, [&] { return g->left == 0; });  // the previous exchange has been read by everybody
+  const uint64_t my_gen = g->gen;
+  g->slot[(size_t)me->rank] = buf;
+  if (++g->arrived == g->n) {
+    const size_t es = dtype == 0 ? sizeof(int32_t) : sizeof(double);
+    g->acc.assign((size_t)count * es, 0);
+    for (int r = 0; r < g->n; r++) {
+      if (dtype == 0) { int32_t* a = (int32_t*)g->acc.data(); const int32_t* b = (const int32_t*)g->slot[(size_t)r]; for (int64_t i = 0; i < count; i++) a[i] += b[i]; }
+      else { double* a = (double*)g->acc.data(); const double* b = (const double*)g->slot[(size_t)r]; for (int64_t i = 0; i < count; i++) a[i] += b[i]; }
+    }
+    g->arrived = 0;
+    g->left = g->n;
+    g->gen++;
+    g->cv.notify_all();
+  } else {
+    g->cv.wait(lk, [&] { return g->gen != my_gen; });
+  }
+  memcpy(buf, g->acc.data(), g->acc.size());
+  if (--g->left == 0) g->cv.notify_all();
+  return 0;
+}
+
 struct tpg_multi {
   int ndev = 0;
   std::vector<tpg_ctx*> ctx;
   std::vector<tpg_comm*> comm;
+  InprocGroup inproc;
+  std::vector<InprocRank> inproc_rank;
 };
 
 extern "C" void tpg_multi_destroy(tpg_multi* mg) {
@@ -264,9 +379,17 @@ extern "C" int tpg_multi_create(int ndev, const int* devices, tpg_multi** out) {
     mg->ctx.push_back(c);
   }
   std::vector<ncclComm_t> nc((size_t)ndev, nullptr);
-  if (ndev > 1) {
+  bool host_transport = getenv("TPG_MULTI_HOST_TRANSPORT") && getenv("TPG_MULTI_HOST_TRANSPORT")[0] == '1';
+  for (int i = 0; i < ndev; i++)
+    for (int j = 0; j < i; j++)
+      if (devs[(size_t)i] == devs[(size_t)j]) host_transport = true;
+  if (ndev > 1 && host_transport) {
+    mg->inproc.n = ndev;
+    mg->inproc.slot.assign((size_t)ndev, nullptr);
+    mg->inproc_rank.resize((size_t)ndev);
+  } else if (ndev > 1) {
     RcclApi* api = rccl();
-    if (!api) { tpg_multi_destroy(mg); tpg_set_error("RCCL (librccl.so) could not be loaded"); return TPG_EHIP; }
+    if (!api) { tpg_multi_destroy(mg); tpg_set_error("RCCL (librccl.so) could not be loaded: %s", g_rccl_why.c_str()); return TPG_EHIP; }
     ncclResult_t r = api->CommInitAll(nc.data(), ndev, devs.data());
     if (r != ncclSuccess) {
       tpg_multi_destroy(mg);
@@ -275,11 +398,21 @@ extern "C" int tpg_multi_create(int ndev, const int* devices, tpg_multi** out) {
     }
   }
   for (int i = 0; i < ndev; i++) {
-    tpg_comm* c = new tpg_comm();
-    c->ctx = mg->ctx[(size_t)i];
-    c->nranks = ndev;
-    c->rank = i;
+    TpgEnter _enter(mg->ctx[(size_t)i]);
+    tpg_comm* c = comm_new(mg->ctx[(size_t)i], ndev, i);
+    if (!c) {
+      RcclApi* api = rccl();
+      for (int j = i; j < ndev; j++)
+        if (nc[(size_t)j] && api) (void)api->CommDestroy(nc[(size_t)j]);
+      tpg_multi_destroy(mg);
+      return TPG_EHIP;
+    }
     c->nccl = nc[(size_t)i];
+    if (mg->inproc.n) {
+      mg->inproc_rank[(size_t)i] = InprocRank{&mg->inproc, i};
+      c->host_fn = inproc_allreduce;
+      c->host_user = &mg->inproc_rank[(size_t)i];
+    }
     mg->comm.push_back(c);
   }
   *out = mg;
@@ -315,6 +448,75 @@ static int multi_run(tpg_multi* mg, F fn) {
   return TPG_OK;
 }
 
+// This device's share of the view (rowInd, colInd, code256) of a HOST FBM: the contiguous range [j0, j1) of colInd
+// (tpg_shard_loci), only the FBM columns that range touches uploaded, packed.  An empty share (more devices than
+// 128-locus groups) leaves f and v NULL: the device still takes part in the exchanges.
+struct MultiShard {
+  tpg_fbm* f = nullptr;
+  tpg_view* v = nullptr;
+  int64_t j0 = 0, j1 = 0;
+};
+
+static int multi_shard_view(tpg_multi* mg, int r, const uint8_t* fbm_bytes, int64_t nrow, const int32_t* rowInd1, int64_t n,
+                            const int32_t* colInd1, int64_t m, const double* code256, MultiShard* me) {
+  tpg_ctx* ctx = mg->ctx[(size_t)r];
+  TPG_TRY(tpg_shard_loci(m, mg->ndev, r, &me->j0, &me->j1));
+  const int64_t j0 = me->j0, j1 = me->j1;
+  if (j1 <= j0) return TPG_OK;
+  // a contiguous byte range of the column-major FBM when colInd is the identity, else the covering range of this
+  // device's share of colInd with the indices rebased onto it
+  int64_t c0 = j0, c1 = j1;  // 0-based FBM columns [c0, c1)
+  std::vector<int32_t> cols;
+  if (colInd1) {
+    int32_t lo = colInd1[j0], hi = colInd1[j0];
+    for (int64_t j = j0; j < j1; j++) { lo = std::min(lo, colInd1[j]); hi = std::max(hi, colInd1[j]); }
+    c0 = lo - 1;
+    c1 = hi;
+    cols.resize((size_t)(j1 - j0));
+    for (int64_t j = j0; j < j1; j++) cols[(size_t)(j - j0)] = colInd1[j] - (int32_t)c0;
+  }
+  TPG_TRY(tpg_fbm_from_host(ctx, fbm_bytes + (size_t)c0 * (size_t)nrow, nrow, c1 - c0, &me->f));
+  return tpg_view_create(ctx, me->f, rowInd1, n, colInd1 ? cols.data() : nullptr, j1 - j0, code256, &me->v);
+}
+
+static void multi_shard_free(tpg_multi* mg, std::vector<MultiShard>& st) {
+  for (int r = 0; r < mg->ndev; r++) {
+    TpgEnter _enter(mg->ctx[(size_t)r]);
+    tpg_view_free(st[(size_t)r].v);
+    tpg_fbm_free(st[(size_t)r].f);
+  }
+}
+
+static int multi_check_args(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1,
+                            int64_t* n, const int32_t* colInd1, int64_t* m) {
+  TPG_REQUIRE(mg && fbm_bytes, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(nrow > 0 && ncol > 0, TPG_EINVAL, "empty FBM");
+  if (!rowInd1) *n = nrow;
+  if (!colInd1) *m = ncol;
+  TPG_REQUIRE(*n > 0 && *m > 0, TPG_EINVAL, "empty view");
+  if (colInd1)
+    for (int64_t j = 0; j < *m; j++)
+      TPG_REQUIRE(colInd1[j] >= 1 && colInd1[j] <= ncol, TPG_EINVAL, "colInd[%lld] = %d out of [1,%lld]", (long long)j,
+                  colInd1[j], (long long)ncol);
+  return TPG_OK;
+}
+
+// rows [j0, j0 + ml) of the caller's m x ncols column-major host (or device) matrix <- a device's ml x ncols block
+static int multi_rows_to_caller(tpg_ctx* ctx, double* dst, int64_t m, int64_t j0, const double* d_src, int64_t ml, int64_t ncols) {
+  if (ml <= 0 || ncols <= 0) return TPG_OK;
+  TPG_HIP(hipMemcpy2DAsync(dst + j0, sizeof(double) * (size_t)m, d_src, sizeof(double) * (size_t)ml, sizeof(double) * (size_t)ml,
+                           (size_t)ncols, hipMemcpyDefault, ctx->stream));
+  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  return TPG_OK;
+}
+
+struct PoolBuf {  // device scratch of one device thread, back to its pool on scope exit
+  void* p = nullptr;
+  int alloc(size_t bytes) { TPG_HIP(tpg_pmalloc(&p, bytes ? bytes : 16)); return TPG_OK; }
+  ~PoolBuf() { tpg_pfree(p); }
+  template <typename T> T* as() { return (T*)p; }
+};
+
 // snp_ibs / snp_king / snp_allele_sharing / pairwise_grm of one host FBM on all the devices of `mg`
 // (R/snp_ibs.R:42-104, R/snp_king.R:32-103, R/snp_allele_sharing.R:33-82, R/pairwise_grm.R:30-51 -- their block loops
 // become: every device takes a contiguous share of colInd, uploads just those columns, packs, accumulates; one
@@ -322,43 +524,19 @@ static int multi_run(tpg_multi* mg, F fn) {
 extern "C" int tpg_multi_pairwise(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol,
                                   const int32_t* rowInd1, int64_t n, const int32_t* colInd1, int64_t m, int ibs_type,
                                   double* ibs, double* king, double* allele_sharing, double* grm) {
-  TPG_REQUIRE(mg && fbm_bytes, TPG_EINVAL, "null argument");
-  TPG_REQUIRE(nrow > 0 && ncol > 0, TPG_EINVAL, "empty FBM");
-  if (!rowInd1) n = nrow;
-  if (!colInd1) m = ncol;
-  TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty view");
-  if (colInd1)
-    for (int64_t j = 0; j < m; j++)
-      TPG_REQUIRE(colInd1[j] >= 1 && colInd1[j] <= ncol, TPG_EINVAL, "colInd[%lld] = %d out of [1,%lld]", (long long)j,
-                  colInd1[j], (long long)ncol);
-  struct Rank { tpg_fbm* f = nullptr; tpg_view* v = nullptr; tpg_pairwise* pw = nullptr; };
-  std::vector<Rank> st((size_t)mg->ndev);
+  TPG_TRY(multi_check_args(mg, fbm_bytes, nrow, ncol, rowInd1, &n, colInd1, &m));
+  std::vector<MultiShard> st((size_t)mg->ndev);
+  std::vector<tpg_pairwise*> pw((size_t)mg->ndev, nullptr);
   // phase 1, no exchange: upload, pack and accumulate this device's loci.  The phases are separate thread teams so
   // that a failure on one device (out of memory, a bad index) is known to all before anyone enters a collective --
   // a rank that skipped the reduce-scatter would leave the others waiting in it for ever.
   int rc = multi_run(mg, [&](int r) -> int {
     tpg_ctx* ctx = mg->ctx[(size_t)r];
     TpgEnter _enter(ctx);
-    Rank& me = st[(size_t)r];
-    int64_t j0, j1;
-    TPG_TRY(tpg_shard_loci(m, mg->ndev, r, &j0, &j1));
-    TPG_TRY(tpg_pairwise_create_sharded(ctx, mg->comm[(size_t)r], n, &me.pw));
-    if (j1 <= j0) return TPG_OK;  // more devices than 128-locus groups: nothing of its own, still takes part below
-    // this device's loci: a contiguous byte range of the column-major FBM when colInd is the identity, else the
-    // covering range of its share of colInd with the indices rebased onto it
-    int64_t c0 = j0, c1 = j1;  // 0-based FBM columns [c0, c1)
-    std::vector<int32_t> cols;
-    if (colInd1) {
-      int32_t lo = colInd1[j0], hi = colInd1[j0];
-      for (int64_t j = j0; j < j1; j++) { lo = std::min(lo, colInd1[j]); hi = std::max(hi, colInd1[j]); }
-      c0 = lo - 1;
-      c1 = hi;
-      cols.resize((size_t)(j1 - j0));
-      for (int64_t j = j0; j < j1; j++) cols[(size_t)(j - j0)] = colInd1[j] - (int32_t)c0;
-    }
-    TPG_TRY(tpg_fbm_from_host(ctx, fbm_bytes + (size_t)c0 * (size_t)nrow, nrow, c1 - c0, &me.f));
-    TPG_TRY(tpg_view_create(ctx, me.f, rowInd1, n, colInd1 ? cols.data() : nullptr, j1 - j0, nullptr /* raw bytes */, &me.v));
-    return tpg_pairwise_accumulate(ctx, me.pw, me.v, 0, -1);
+    TPG_TRY(tpg_pairwise_create_sharded(ctx, mg->comm[(size_t)r], n, &pw[(size_t)r]));
+    TPG_TRY(multi_shard_view(mg, r, fbm_bytes, nrow, rowInd1, n, colInd1, m, nullptr /* raw bytes */, &st[(size_t)r]));
+    if (!st[(size_t)r].v) return TPG_OK;  // nothing of its own, still takes part below
+    return tpg_pairwise_accumulate(ctx, pw[(size_t)r], st[(size_t)r].v, 0, -1);
   });
   // phase 2: one reduce-scatter, then every device finishes its band and writes it into the caller's matrices
   if (rc == TPG_OK)
@@ -366,16 +544,180 @@ extern "C" int tpg_multi_pairwise(tpg_multi* mg, const uint8_t* fbm_bytes, int64
       tpg_ctx* ctx = mg->ctx[(size_t)r];
       tpg_comm* comm = mg->comm[(size_t)r];
       TpgEnter _enter(ctx);
-      TPG_TRY(tpg_pairwise_reduce(ctx, comm, st[(size_t)r].pw));
-      return tpg_pairwise_epilogues_sharded(ctx, comm, st[(size_t)r].pw, ibs_type, m, ibs, king, allele_sharing, grm);
+      TPG_TRY(tpg_pairwise_reduce(ctx, comm, pw[(size_t)r]));
+      return tpg_pairwise_epilogues_sharded(ctx, comm, pw[(size_t)r], ibs_type, m, ibs, king, allele_sharing, grm);
     });
   std::string err = rc == TPG_OK ? "" : tpg_last_error();
   for (int r = 0; r < mg->ndev; r++) {
     TpgEnter _enter(mg->ctx[(size_t)r]);
-    tpg_pairwise_free(st[(size_t)r].pw);
-    tpg_view_free(st[(size_t)r].v);
-    tpg_fbm_free(st[(size_t)r].f);
+    tpg_pairwise_free(pw[(size_t)r]);
   }
+  multi_shard_free(mg, st);
+  if (rc != TPG_OK) tpg_set_error("%s", err.c_str());
+  return rc;
+}
+
+// loci_alt_freq (grouped: R/loci_alt_freq.R:174-197 around grouped_alt_freq_dip_pseudo_cpp; ungrouped when groupIds0
+// is NULL: R/loci_alt_freq.R:328-379 around alt_freq_dip_pseudo_cpp) of one host FBM on all devices.  The outputs are
+// per locus, so the devices' shares are disjoint row ranges of `out` (m x 2G, or m x 2): no exchange at all.
+extern "C" int tpg_multi_grouped_alt_freq(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol,
+                                          const int32_t* rowInd1, int64_t n, const int32_t* colInd1, int64_t m,
+                                          const double* code256, const int32_t* groupIds0, int ngroups,
+                                          const double* ploidy, int as_counts, double* out) {
+  TPG_TRY(multi_check_args(mg, fbm_bytes, nrow, ncol, rowInd1, &n, colInd1, &m));
+  TPG_REQUIRE(out, TPG_EINVAL, "null output");
+  TPG_REQUIRE(!groupIds0 || ngroups > 0, TPG_EINVAL, "ngroups must be positive");
+  const int64_t ncols = groupIds0 ? 2 * (int64_t)ngroups : 2;
+  std::vector<MultiShard> st((size_t)mg->ndev);
+  int rc = multi_run(mg, [&](int r) -> int {
+    tpg_ctx* ctx = mg->ctx[(size_t)r];
+    TpgEnter _enter(ctx);
+    MultiShard& me = st[(size_t)r];
+    TPG_TRY(multi_shard_view(mg, r, fbm_bytes, nrow, rowInd1, n, colInd1, m, code256, &me));
+    if (!me.v) return TPG_OK;
+    const int64_t ml = me.j1 - me.j0;
+    PoolBuf d_out;
+    TPG_TRY(d_out.alloc(sizeof(double) * (size_t)ml * (size_t)ncols));
+    if (groupIds0) TPG_TRY(tpg_grouped_alt_freq_dip_pseudo(ctx, me.v, groupIds0, ngroups, ploidy, as_counts, d_out.as<double>()));
+    else TPG_TRY(tpg_alt_freq_dip_pseudo(ctx, me.v, ploidy, as_counts, d_out.as<double>()));
+    return multi_rows_to_caller(ctx, out, m, me.j0, d_out.as<double>(), ml, ncols);
+  });
+  std::string err = rc == TPG_OK ? "" : tpg_last_error();
+  multi_shard_free(mg, st);
+  if (rc != TPG_OK) tpg_set_error("%s", err.c_str());
+  return rc;
+}
+
+// pairwise_pop_fst (R/pairwise_pop_fst.R:116-161: grouped_summaries_dip_pseudo_cpp + one of the three loop functions)
+// of one host FBM on all devices.  By-locus outputs are disjoint row ranges of the m x P matrices; the totals are
+// ratios of sums over loci, so every device returns the numerator / denominator sums of its loci
+// (tpg_pairwise_pop_fst_sums) and they are added here on the host, in device order (2 P doubles per device: the same
+// answer on every run; one process needs no collective for that).
+extern "C" int tpg_multi_pop_fst(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1,
+                                 int64_t n, const int32_t* colInd1, int64_t m, const double* code256,
+                                 const int32_t* groupIds0, int ngroups, const double* ploidy, int method,
+                                 const int32_t* pairs1, int P, int by_locus, int return_num_dem, double* fst_tot,
+                                 double* out_a, double* out_b) {
+  TPG_TRY(multi_check_args(mg, fbm_bytes, nrow, ncol, rowInd1, &n, colInd1, &m));
+  TPG_REQUIRE(groupIds0 && pairs1 && P > 0 && ngroups > 0, TPG_EINVAL, "null or empty argument");
+  if (return_num_dem) by_locus = 1;  // R/pairwise_pop_fst.R:103-106
+  TPG_REQUIRE(!by_locus || out_a, TPG_EINVAL, "by_locus output requested but out_a is NULL");
+  TPG_REQUIRE(!return_num_dem || out_b, TPG_EINVAL, "return_num_dem requested but out_b is NULL");
+  TPG_REQUIRE(return_num_dem || fst_tot, TPG_EINVAL, "fst_tot is NULL");
+  std::vector<MultiShard> st((size_t)mg->ndev);
+  std::vector<std::vector<double>> sums((size_t)mg->ndev, std::vector<double>(2 * (size_t)P, 0.0));
+  int rc = multi_run(mg, [&](int r) -> int {
+    tpg_ctx* ctx = mg->ctx[(size_t)r];
+    TpgEnter _enter(ctx);
+    MultiShard& me = st[(size_t)r];
+    TPG_TRY(multi_shard_view(mg, r, fbm_bytes, nrow, rowInd1, n, colInd1, m, code256, &me));
+    if (!me.v) return TPG_OK;
+    const int64_t ml = me.j1 - me.j0;
+    double* sn = sums[(size_t)r].data();
+    if (!return_num_dem) TPG_TRY(tpg_pairwise_pop_fst_sums(ctx, me.v, groupIds0, ngroups, ploidy, method, pairs1, P, sn, sn + P));
+    if (!by_locus) return TPG_OK;
+    PoolBuf da, db;
+    TPG_TRY(da.alloc(sizeof(double) * (size_t)ml * (size_t)P));
+    if (return_num_dem) TPG_TRY(db.alloc(sizeof(double) * (size_t)ml * (size_t)P));
+    std::vector<double> tot((size_t)P);  // this shard's own ratios: not what the caller asked for
+    TPG_TRY(tpg_pairwise_pop_fst(ctx, me.v, groupIds0, ngroups, ploidy, method, pairs1, P, 1, return_num_dem, tot.data(),
+                                 da.as<double>(), db.as<double>()));
+    TPG_TRY(multi_rows_to_caller(ctx, out_a, m, me.j0, da.as<double>(), ml, P));
+    if (return_num_dem) TPG_TRY(multi_rows_to_caller(ctx, out_b, m, me.j0, db.as<double>(), ml, P));
+    return TPG_OK;
+  });
+  if (rc == TPG_OK && fst_tot && !return_num_dem) {
+    std::vector<double> tot(2 * (size_t)P, 0.0);
+    for (int r = 0; r < mg->ndev; r++)
+      for (size_t q = 0; q < 2 * (size_t)P; q++) tot[q] += sums[(size_t)r][q];
+    std::vector<double> ratio((size_t)P);
+    for (int q = 0; q < P; q++) ratio[(size_t)q] = tot[(size_t)q] / tot[(size_t)(P + q)];
+    if (tpg_is_device_ptr(fst_tot)) {
+      tpg_ctx* ctx = mg->ctx[0];
+      TpgEnter _enter(ctx);
+      hipError_t e = hipMemcpyAsync(fst_tot, ratio.data(), sizeof(double) * (size_t)P, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) { tpg_set_error("fst_tot: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+    } else {
+      memcpy(fst_tot, ratio.data(), sizeof(double) * (size_t)P);
+    }
+  }
+  std::string err = rc == TPG_OK ? "" : tpg_last_error();
+  multi_shard_free(mg, st);
+  if (rc != TPG_OK) tpg_set_error("%s", err.c_str());
+  return rc;
+}
+
+// gt_pca_partialSVD (R/gt_pca_partialSVD.R:67-108 around bigstatsr::big_SVD) of one host FBM on all devices: every
+// device packs its share of colInd and runs tpg_pca_partial_svd_sharded (Gram matrix of its loci, one all-reduce over
+// RCCL, replicated eigen step, the loadings of its loci); center / scale / loadings land in the devices' row ranges of
+// the caller's arrays, d / u come from device 0 (identical everywhere).  A panel too short to give every device k
+// loci runs on device 0 alone.
+extern "C" int tpg_multi_pca_partial_svd(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol,
+                                         const int32_t* rowInd1, int64_t n, const int32_t* colInd1, int64_t m,
+                                         const double* code256, int k, double* d, double* u, double* vload, double* center,
+                                         double* scale, double* square_frobenius) {
+  TPG_TRY(multi_check_args(mg, fbm_bytes, nrow, ncol, rowInd1, &n, colInd1, &m));
+  TPG_REQUIRE(d && u && vload && center && scale, TPG_EINVAL, "null output");
+  TPG_REQUIRE(k >= 1 && k <= n && k <= m, TPG_EINVAL, "k = %d out of range", k);
+  bool spread = mg->ndev > 1;
+  for (int r = 0; r < mg->ndev && spread; r++) {
+    int64_t j0, j1;
+    TPG_TRY(tpg_shard_loci(m, mg->ndev, r, &j0, &j1));
+    if (j1 - j0 < k) spread = false;
+  }
+  if (!spread) {  // one device, no exchange
+    tpg_ctx* ctx = mg->ctx[0];
+    TpgEnter _enter(ctx);
+    tpg_fbm* f = nullptr;
+    tpg_view* v = nullptr;
+    int rc = tpg_fbm_from_host(ctx, fbm_bytes, nrow, ncol, &f);
+    if (rc == TPG_OK) rc = tpg_view_create(ctx, f, rowInd1, n, colInd1, m, code256, &v);
+    if (rc == TPG_OK) rc = tpg_pca_partial_svd(ctx, v, k, d, u, vload, center, scale, square_frobenius);
+    std::string err = rc == TPG_OK ? "" : tpg_last_error();
+    tpg_view_free(v);
+    tpg_fbm_free(f);
+    if (rc != TPG_OK) tpg_set_error("%s", err.c_str());
+    return rc;
+  }
+  std::vector<MultiShard> st((size_t)mg->ndev);
+  // phase 1 (no exchange): upload + pack; a failure here is known to all before anyone enters the Gram all-reduce
+  int rc = multi_run(mg, [&](int r) -> int {
+    TpgEnter _enter(mg->ctx[(size_t)r]);
+    return multi_shard_view(mg, r, fbm_bytes, nrow, rowInd1, n, colInd1, m, code256, &st[(size_t)r]);
+  });
+  std::vector<double> fro((size_t)mg->ndev, 0.0);
+  if (rc == TPG_OK)
+    rc = multi_run(mg, [&](int r) -> int {
+      tpg_ctx* ctx = mg->ctx[(size_t)r];
+      TpgEnter _enter(ctx);
+      MultiShard& me = st[(size_t)r];
+      const int64_t ml = me.j1 - me.j0;
+      PoolBuf dv, dc, ds, du, dd;
+      // rank-local steps that can fail sit inside tpg_pca_partial_svd_sharded BEFORE its first exchange, where the ranks
+      // agree on a status (tpg_comm_agree): nobody is left waiting in a collective
+      int lrc = dv.alloc(sizeof(double) * (size_t)ml * (size_t)k);
+      if (lrc == TPG_OK) lrc = dc.alloc(sizeof(double) * (size_t)ml);
+      if (lrc == TPG_OK) lrc = ds.alloc(sizeof(double) * (size_t)ml);
+      if (lrc == TPG_OK) lrc = du.alloc(sizeof(double) * (size_t)n * (size_t)k);
+      if (lrc == TPG_OK) lrc = dd.alloc(sizeof(double) * (size_t)k);
+      lrc = tpg_comm_agree(mg->comm[(size_t)r], lrc);
+      TPG_TRY(lrc);
+      TPG_TRY(tpg_pca_partial_svd_sharded(ctx, mg->comm[(size_t)r], me.v, k, dd.as<double>(), du.as<double>(), dv.as<double>(),
+                                          dc.as<double>(), ds.as<double>(), square_frobenius ? &fro[(size_t)r] : nullptr));
+      TPG_TRY(multi_rows_to_caller(ctx, vload, m, me.j0, dv.as<double>(), ml, k));
+      TPG_TRY(multi_rows_to_caller(ctx, center, m, me.j0, dc.as<double>(), ml, 1));
+      TPG_TRY(multi_rows_to_caller(ctx, scale, m, me.j0, ds.as<double>(), ml, 1));
+      if (r == 0) {
+        TPG_HIP(hipMemcpyAsync(u, du.as<double>(), sizeof(double) * (size_t)n * (size_t)k, hipMemcpyDefault, ctx->stream));
+        TPG_HIP(hipMemcpyAsync(d, dd.as<double>(), sizeof(double) * (size_t)k, hipMemcpyDefault, ctx->stream));
+        TPG_HIP(hipStreamSynchronize(ctx->stream));
+      }
+      return TPG_OK;
+    });
+  if (rc == TPG_OK && square_frobenius) *square_frobenius = fro[0];
+  std::string err = rc == TPG_OK ? "" : tpg_last_error();
+  multi_shard_free(mg, st);
   if (rc != TPG_OK) tpg_set_error("%s", err.c_str());
   return rc;
 }

@@ -230,7 +230,10 @@ struct tpg_comm {
   void* nccl = nullptr;  // ncclComm_t
   int (*host_fn)(void* user, void* buf, int64_t count, int dtype) = nullptr;  // in-place sum; dtype 0 int32, 1 float64
   void* host_user = nullptr;
+  int32_t* d_status = nullptr;  // device int32[TPG_COMM_STATUS_INTS]: the status word of tpg_comm_agree
 };
+#define TPG_COMM_STATUS_INTS 8
+int tpg_comm_agree(tpg_comm* comm, int rc);  // all ranks get the same status (the worst any of them passed in)
 int tpg_comm_reduce_scatter_i32(tpg_comm* comm, int32_t* d_buf, int64_t chunk_count);  // in place, chunk r -> rank r
 int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype);          // in place, device memory
 

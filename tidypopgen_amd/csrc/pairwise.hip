@@ -361,26 +361,15 @@ extern "C" int tpg_pairwise_reduce(tpg_ctx* ctx, tpg_comm* comm, tpg_pairwise* p
               "accumulators were created for rank %d of %d, the communicator is rank %d of %d", pw->rank, pw->nranks,
               comm->rank, comm->nranks);
   TPG_REQUIRE(!pw->reduced, TPG_EINVAL, "already reduced: zero the accumulators first");
+  // the locus count behind the overflow guard is the total over the ranks: known BEFORE the sums are exchanged, so that
+  // a panel that is too long is refused with the accumulators intact instead of after they have wrapped
+  double loci = (double)pw->loci;
+  if (comm->nranks > 1 || comm->nccl) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, &loci, 1));
+  TPG_REQUIRE(loci <= (double)TPG_PW_MAX_LOCI, TPG_EUNSUPPORTED, "%.0f loci over all ranks overflow the int32 pair counts", loci);
   {
     ProfScope ps(ctx, "pairwise_reduce_scatter");
     TPG_TRY(tpg_comm_reduce_scatter_i32(comm, pw->acc, pw->chunk_units * TPG_PW_TILE_INTS));
   }
-  // the locus count behind the overflow guard is the total over the ranks
-  double loci = (double)pw->loci;
-  if (comm->nranks > 1 || comm->nccl) {
-    double* d_l = nullptr;
-    TPG_HIP(tpg_pmalloc((void**)&d_l, sizeof(double)));
-    hipError_t e = hipMemcpyAsync(d_l, &loci, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    int rc = e == hipSuccess ? tpg_comm_allreduce(comm, d_l, 1, 1) : TPG_EHIP;
-    if (rc == TPG_OK) {
-      e = hipMemcpyAsync(&loci, d_l, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    }
-    tpg_pfree(d_l);
-    TPG_HIP(e);
-    TPG_TRY(rc);
-  }
-  TPG_REQUIRE(loci <= (double)TPG_PW_MAX_LOCI, TPG_EUNSUPPORTED, "%.0f loci over all ranks overflow the int32 pair counts", loci);
   pw->loci = (int64_t)loci;
   pw->reduced = true;
   return TPG_OK;
@@ -712,10 +701,21 @@ static int epilogues_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_pairwise* pw, 
               "use tpg_pairwise_epilogues_sharded");
   const size_t bytes = sizeof(double) * (size_t)n * (size_t)n;
   OutBuf bi, bk, ba, bg;
-  if (ibs) TPG_TRY(bi.init(ibs, bytes));
-  if (king) TPG_TRY(bk.init(king, bytes));
-  if (allele_sharing) TPG_TRY(ba.init(allele_sharing, bytes));
-  if (grm) TPG_TRY(bg.init(grm, bytes));
+  auto staging = [&]() -> int {
+    if (ibs) TPG_TRY(bi.init(ibs, bytes));
+    if (king) TPG_TRY(bk.init(king, bytes));
+    if (allele_sharing) TPG_TRY(ba.init(allele_sharing, bytes));
+    if (grm) TPG_TRY(bg.init(grm, bytes));
+    return TPG_OK;
+  };
+  int lrc = staging();
+  // Host outputs are staged in device buffers whose allocation can fail on one rank alone; the GRM then exchanges its
+  // mean over the ranks, so they agree on a status first (every rank passes the same kind of pointers: all callers of the
+  // sharded entry point do).  Device outputs allocate nothing: no exchange of a status either.
+  const bool staged = (ibs && !tpg_is_device_ptr(ibs)) || (king && !tpg_is_device_ptr(king)) ||
+                      (allele_sharing && !tpg_is_device_ptr(allele_sharing)) || (grm && !tpg_is_device_ptr(grm));
+  if (grm && comm && !band.whole && staged) lrc = tpg_comm_agree(comm, lrc);
+  TPG_TRY(lrc);
   // GRM needs the allele-sharing matrix: write it into the GRM buffer when the caller does not want both
   double* as_dst = allele_sharing ? ba.dev<double>() : bg.dev<double>();
   const unsigned nt = (unsigned)ceil_div(pw->n, 32);

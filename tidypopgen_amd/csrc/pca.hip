@@ -1591,51 +1591,61 @@ __global__ void tpg_tri_unpack_kernel(const double* __restrict__ tri, int n, dou
 static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, double tol, double* d, double* u,
                         double* vload, double* center, double* scale, double* square_frobenius) {
   TPG_REQUIRE(ctx && v && d && u && vload && center && scale, TPG_EINVAL, "null argument");
-  TPG_REQUIRE(k >= 1 && k <= 52 && k <= v->n && k <= v->m, TPG_EINVAL, "k = %d out of range", k);
+  TPG_REQUIRE(k >= 1 && k <= 52 && k <= v->n, TPG_EINVAL, "k = %d out of range", k);
   const int64_t n = v->n, m = v->m;
   OutBuf oc, os, ou, ov;
-  TPG_TRY(oc.init(center, sizeof(double) * (size_t)m));
-  TPG_TRY(os.init(scale, sizeof(double) * (size_t)m));
-  TPG_TRY(ou.init(u, sizeof(double) * (size_t)n * (size_t)k));
-  TPG_TRY(ov.init(vload, sizeof(double) * (size_t)m * (size_t)k));
   int32_t* d_counts = nullptr;
-  double *d_K = nullptr, *d_dk = nullptr;
-  TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)m));
-  struct Free { void *a, *b, *c, *d; ~Free() { tpg_pfree(a); tpg_pfree(b); tpg_pfree(c); tpg_pfree(d); } } fr{d_counts, nullptr, nullptr, nullptr};
+  double *d_K = nullptr, *d_dk = nullptr, *d_tri = nullptr;
+  struct Free { void *a, *b, *c, *d; ~Free() { tpg_pfree(a); tpg_pfree(b); tpg_pfree(c); tpg_pfree(d); } } fr{nullptr, nullptr, nullptr, nullptr};
   StageTimer st(ctx, "svd");
-  TPG_TRY(pca_counts_center_scale(ctx, v, d_counts, oc.dev<double>(), os.dev<double>()));
-  st.mark("counts, center, scale");
-  if (square_frobenius) {
-    TPG_TRY(frobenius_from_counts(ctx, v, d_counts, oc.dev<double>(), os.dev<double>(), square_frobenius));
-    if (comm) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, square_frobenius, 1));  // identity on a single rank
-  }
-  TPG_HIP(tpg_pmalloc((void**)&d_K, sizeof(double) * (size_t)n * (size_t)n));
-  fr.b = d_K;
+  const bool exchange = comm && (comm->nranks > 1 || comm->nccl);
+  const int64_t ntri = n * (n + 1) / 2;
+  // Everything that can fail on THIS rank alone (allocations; a missing value or a zero scale among this shard's loci)
+  // comes first, then the ranks agree on a status: a rank that gave up here would otherwise leave the others waiting in
+  // the all-reduces below for ever.
+  auto local_steps = [&]() -> int {
+    TPG_REQUIRE(k <= m, TPG_EINVAL, "k = %d but this view has %lld loci", k, (long long)m);
+    TPG_TRY(oc.init(center, sizeof(double) * (size_t)m));
+    TPG_TRY(os.init(scale, sizeof(double) * (size_t)m));
+    TPG_TRY(ou.init(u, sizeof(double) * (size_t)n * (size_t)k));
+    TPG_TRY(ov.init(vload, sizeof(double) * (size_t)m * (size_t)k));
+    TPG_HIP(tpg_pmalloc((void**)&d_counts, sizeof(int32_t) * 4 * (size_t)m));
+    fr.a = d_counts;
+    TPG_HIP(tpg_pmalloc((void**)&d_K, sizeof(double) * (size_t)n * (size_t)n));
+    fr.b = d_K;
+    TPG_HIP(tpg_pmalloc((void**)&d_dk, sizeof(double) * (size_t)k));
+    fr.d = d_dk;
+    if (exchange) {
+      TPG_HIP(tpg_pmalloc((void**)&d_tri, sizeof(double) * (size_t)ntri));
+      fr.c = d_tri;
+    }
+    TPG_TRY(pca_counts_center_scale(ctx, v, d_counts, oc.dev<double>(), os.dev<double>()));
+    st.mark("counts, center, scale");
+    if (square_frobenius) TPG_TRY(frobenius_from_counts(ctx, v, d_counts, oc.dev<double>(), os.dev<double>(), square_frobenius));
+    return TPG_OK;
+  };
+  int lrc = local_steps();
+  if (exchange) lrc = tpg_comm_agree(comm, lrc);
+  TPG_TRY(lrc);
+  if (square_frobenius && exchange) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, square_frobenius, 1));
   st.mark("frobenius + alloc K");
+  // a failure of the Gram kernels themselves (launch error) is not rank-local in practice: same code, same shapes
   TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true));
   st.mark("gram");
-  if (comm && (comm->nranks > 1 || comm->nccl)) {  // K = sum over the ranks' loci of z_j z_j'
+  if (exchange) {  // K = sum over the ranks' loci of z_j z_j'
     // only the upper triangle travels: n (n + 1) / 2 doubles instead of n^2 (K is symmetric bit for bit on every rank)
-    const int64_t ntri = n * (n + 1) / 2;
-    double* d_tri = nullptr;
-    TPG_HIP(tpg_pmalloc((void**)&d_tri, sizeof(double) * (size_t)ntri));
     TPG_LAUNCH(ctx, "pca_gram_tri", tpg_tri_pack_kernel, dim3(2048), dim3(256), 0, (const double*)d_K, (int)n, d_tri);
-    int rc;
     {
       ProfScope ps(ctx, "pca_gram_allreduce");
-      rc = tpg_comm_allreduce(comm, d_tri, ntri, 1);
+      TPG_TRY(tpg_comm_allreduce(comm, d_tri, ntri, 1));
     }
-    if (rc == TPG_OK) TPG_LAUNCH(ctx, "pca_gram_tri", tpg_tri_unpack_kernel, dim3(2048), dim3(256), 0, (const double*)d_tri, (int)n, d_K);
-    tpg_pfree(d_tri);
-    TPG_TRY(rc);
+    TPG_LAUNCH(ctx, "pca_gram_tri", tpg_tri_unpack_kernel, dim3(2048), dim3(256), 0, (const double*)d_tri, (int)n, d_K);
   }
   std::vector<double> lam((size_t)k);
   TPG_TRY(eig_topk(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>(), tol));
   st.mark("eig_topk");
   std::vector<double> dh((size_t)k);
   for (int j = 0; j < k; j++) dh[(size_t)j] = sqrt(lam[(size_t)j] > 0 ? lam[(size_t)j] : 0.0);
-  TPG_HIP(tpg_pmalloc((void**)&d_dk, sizeof(double) * (size_t)k));
-  fr.d = d_dk;
   TPG_HIP(hipMemcpyAsync(d_dk, dh.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
   // v = Z'u / d  (no missing values: checked by pca_counts_center_scale above)
   TPG_TRY(pca_loadings_device(ctx, v, oc.dev<double>(), os.dev<double>(), ou.dev<double>(), d_dk, k, ov.dev<double>()));

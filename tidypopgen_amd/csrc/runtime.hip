@@ -214,6 +214,14 @@ extern "C" int tpg_prof_dump(tpg_ctx* ctx, char* buf, size_t cap) {
 }
 
 // ---------------------------------------------------------------------------
+extern "C" int tpg_device_count(int* count) {
+  TPG_REQUIRE(count, TPG_EINVAL, "null argument");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  *count = e == hipSuccess ? c : 0;
+  return TPG_OK;
+}
+
 extern "C" int tpg_ctx_create(int device, tpg_ctx** out) {
   TPG_REQUIRE(out, TPG_EINVAL, "null out");
   int count = 0;
