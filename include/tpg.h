@@ -250,12 +250,15 @@ int tpg_filter_high_relatedness(tpg_ctx* ctx, const double* matrix, int64_t n, d
 
 /* Literal per-block mirrors of the three increment_* entry points
  * (src/snp_ibs.cpp:22-74, src/snp_king.cpp:21-74, src/snp_as.cpp:22-67); the scratch matrices of the reference
- * are not needed.  fbm_bytes is the host (mmapped) FBM.  RESIDENT and DEFERRED: the FBM is uploaded the first time
- * its address is seen and stays in HBM (tpg_resident_drop forgets it -- call that if the FBM's bytes change); every
- * (K, K2) pair gets device accumulators that live across the calls of the R block loop (R/snp_ibs.R:69-82), so a
- * block moves nothing over PCIe.  The caller's n x n doubles are incremented when tpg_increment_flush is called (once,
- * after the loop: one line added to the R driver) -- not at every block, which would cost two
- * N x N downloads per block.  All blocks that accumulate into the same (K, K2) must pass the same rowInd. */
+ * are not needed.  fbm_bytes is the host (mmapped) FBM.  DEFAULT = the reference's semantics: the caller's n x n
+ * doubles are incremented when the call returns (an unmodified R driver reads them right after its loop,
+ * R/snp_ibs.R:84-95).  Every call uploads the columns of its own block; no copy of the caller's FBM outlives the
+ * call, so an FBM that is rewritten in place between analyses (R/gt_impute_simple.R:86) is never read stale.
+ * OPT-IN, tpg_increment_defer(ctx, 1): every (K, K2) pair gets device accumulators that live across the calls of the
+ * R block loop (R/snp_ibs.R:69-82) and the caller's matrices are incremented by tpg_increment_flush (one line added
+ * to the R driver after its loop): one N x N download per analysis instead of per block.  All
+ * blocks that accumulate into the same (K, K2) must then pass the same rowInd. */
+int tpg_increment_defer(tpg_ctx* ctx, int on);
 int tpg_increment_ibs_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes,
                              int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
                              const int32_t* colInd1, int64_t m);
@@ -266,13 +269,15 @@ int tpg_increment_as_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* 
                             int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
                             const int32_t* colInd1, int64_t m);
 
-/* K += accumulated sums for every pending (K, K2) pair; the device accumulators are released */
+/* K += accumulated sums for every pending (K, K2) pair; the device accumulators are released (a no-op unless
+ * tpg_increment_defer is on) */
 int tpg_increment_flush(tpg_ctx* ctx);
-/* forget the FBMs uploaded by the increment_* mirrors (an error while increments are pending) */
+/* release the device scratch the increment_* mirrors keep between calls (an error while increments are pending) */
 int tpg_resident_drop(tpg_ctx* ctx);
-/* quirk Q1 through the literal mirror (opt-in): note that the block just passed to tpg_increment_as_counts for
- * matrix K was one column narrower than the R driver's scratch matrices */
-int tpg_increment_as_note_narrow_block(tpg_ctx* ctx, const double* K);
+/* quirk Q1 through the literal mirror (opt-in): the block just passed to tpg_increment_as_counts for the n x n
+ * matrix K was one column narrower than the R driver's scratch matrices: +1 on every element, at the flush when K is
+ * pending, at once otherwise */
+int tpg_increment_as_note_narrow_block(tpg_ctx* ctx, double* K, int64_t n);
 
 /* ---- SNP-block shards over the GPUs of one node -------------------------------------------------
  * The locus axis is the reference's own block axis (R/snp_ibs.R:59-82): a shard is a contiguous range of loci.

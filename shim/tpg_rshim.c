@@ -5,13 +5,18 @@
  * reference's C++ takes from `BM` through bigstatsr's accessors is taken here from the FBM's plain R fields
  * (`backingfile`, `nrow`, `ncol`, `code256`) and the backing file itself.
  *
- * STATUS: written against R's documented C API, NOT compiled in the build image (R is not installed there; see
- * INTEGRATION.md).  The C ABI underneath is exercised through ctypes by tests/ on the GPU.
+ * STATUS: written against R's documented C API.  R is not installed in the build image, so what is checked there is:
+ * (1) the file compiles with -Wall -Wextra -Werror against tests/rmock/ (declarations of the ~35 R API functions it
+ * uses, written from R's documentation -- a syntax and signature guard, NOT R), and (2) linked against the small mock
+ * runtime of tests/rmock/rmock.c it is driven on the GPU by tests/test_gpu_rshim.py exactly as the R drivers drive it
+ * (block loop of R/snp_ibs.R:69-82 on FBM objects whose fields are read through Rf_eval).  See INTEGRATION.md.
  *
  * Where it goes: tidypopgen/src/tpg_rshim.c, replacing the `[[Rcpp::export]]` bodies of the functions listed in
- * tpg_rshim_entries[] (INTEGRATION.md section 2 says how the registration tables are merged).  R code is unchanged,
- * except that the three pairwise drivers gain ONE line after their block loop (`tpg_flush()`, see
- * _tidypopgen_tpg_flush below); without that line set TPG_RSHIM_EAGER=1 and every block call flushes itself.
+ * tpg_rshim_entries[] (INTEGRATION.md section 2 says how the registration tables are merged), or the package
+ * shim/tpgshim beside an unmodified tidypopgen.  R code is UNCHANGED and correct by default: every increment_* call
+ * adds its block's sums to k / k2 before it returns, as the reference does.  Opt-in fast path: TPG_RSHIM_DEFERRED=1
+ * keeps the sums in HBM across the block loop; the three pairwise drivers then need ONE line after their loop
+ * (`tpg_flush()`, see _tidypopgen_tpg_flush below).
  *
  * Threading: R calls these from its main thread only; the shim holds one tpg_ctx per R session.
  */
@@ -34,10 +39,18 @@
 
 static tpg_ctx* g_ctx = NULL;
 
+/* TPG_RSHIM_DEFERRED=1: the increment_* functions keep their sums in HBM until tpg_flush() (the R drivers must then
+ * call it after their block loop).  Default: off -- an unmodified driver gets the reference's semantics. */
+static int deferred(void) {
+  const char* e = getenv("TPG_RSHIM_DEFERRED");
+  return e && e[0] == '1';
+}
+
 static tpg_ctx* ctx(void) {
   if (!g_ctx) {
     const char* dev = getenv("TPG_DEVICE");
     if (tpg_ctx_create(dev ? atoi(dev) : 0, &g_ctx) != TPG_OK) Rf_error("tidypopgen (GPU): %s", tpg_last_error());
+    if (deferred() && tpg_increment_defer(g_ctx, 1) != TPG_OK) Rf_error("tidypopgen (GPU): %s", tpg_last_error());
   }
   return g_ctx;
 }
@@ -65,8 +78,11 @@ static const char* field_path(SEXP env, const char* name) {
   return R_ExpandFileName(CHAR(STRING_ELT(v, 0)));
 }
 
-/* A backing file mapped into this process, and (for genotype FBMs) its copy in HBM.  Keyed by path: the 5 GB upload
- * happens once per data set and session, not once per call or per block (SURVEY.md 8b "Ownership"). */
+/* A backing file mapped into this process, and (for genotype FBMs) its copy in HBM.  The 5 GB upload happens once per
+ * data set, not once per call -- but bigsnpr::snp_fastImputeSimple (R/gt_impute_simple.R:86) and gt_set_imputed-style
+ * writes change the backing file IN PLACE, so the HBM copy is only trusted while the file's size, modification time
+ * and a fingerprint of 4 096 pages spread over it are what they were at upload; anything else re-uploads.
+ * TPG_RSHIM_NO_CACHE=1 uploads at every call. */
 typedef struct {
   char* path;
   void* map;
@@ -74,10 +90,42 @@ typedef struct {
   int writable;
   int64_t nrow, ncol;
   tpg_fbm* dev; /* NULL for the double N x N accumulators */
+  int64_t mtime_ns;
+  uint64_t fingerprint;
 } mapped_file;
 
 static mapped_file* g_files = NULL;
 static int g_nfiles = 0;
+
+static uint64_t fingerprint_of(const uint8_t* p, size_t bytes) { /* FNV-1a over up to 4 096 whole 4-KiB pages */
+  const size_t page = 4096, npages = (bytes + page - 1) / page, want = npages < 4096 ? npages : 4096;
+  uint64_t h = 1469598103934665603ull;
+  for (size_t k = 0; k < want; k++) {
+    const size_t pg = want > 1 ? k * (npages - 1) / (want - 1) : 0, off = pg * page;
+    const size_t len = bytes - off < page ? bytes - off : page;
+    for (size_t t = 0; t < len; t += 8) {
+      uint64_t w = 0;
+      memcpy(&w, p + off + t, len - t < 8 ? len - t : 8);
+      h = (h ^ w) * 1099511628211ull;
+    }
+  }
+  return h;
+}
+
+static int64_t mtime_of(const char* path, size_t* size) {
+  struct stat st;
+  if (stat(path, &st) != 0) Rf_error("cannot stat backing file '%s'", path);
+  *size = (size_t)st.st_size;
+  return (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+}
+
+static void forget_file(int k) { /* unmap, free the HBM copy, close the gap in g_files */
+  if (g_files[k].dev) tpg_fbm_free(g_files[k].dev);
+  munmap(g_files[k].map, g_files[k].bytes);
+  free(g_files[k].path);
+  g_files[k] = g_files[g_nfiles - 1];
+  g_nfiles--;
+}
 
 static mapped_file* map_file(const char* path, size_t bytes, int writable, int64_t nrow, int64_t ncol) {
   for (int k = 0; k < g_nfiles; k++)
@@ -108,6 +156,8 @@ static mapped_file* map_file(const char* path, size_t bytes, int writable, int64
   f->nrow = nrow;
   f->ncol = ncol;
   f->dev = NULL;
+  f->mtime_ns = 0;
+  f->fingerprint = 0;
   return f;
 }
 
@@ -119,8 +169,21 @@ static mapped_file* genotype_fbm(SEXP BM) {
 
 static tpg_fbm* genotype_fbm_dev(SEXP BM) {
   mapped_file* f = genotype_fbm(BM);
+  size_t size = 0;
+  const int64_t mt = mtime_of(f->path, &size);
+  if (size < f->bytes) Rf_error("backing file '%s' shrank below the FBM it should hold", f->path);
+  const uint64_t fp = fingerprint_of((const uint8_t*)f->map, f->bytes);
+  const char* nc = getenv("TPG_RSHIM_NO_CACHE");
+  if (f->dev && ((nc && nc[0] == '1') || mt != f->mtime_ns || fp != f->fingerprint)) { /* the bytes changed under us */
+    tpg_fbm_free(f->dev);
+    f->dev = NULL;
+  }
   /* the library maps the file, touches its pages with a team of threads and uploads it with one copy */
-  if (!f->dev) TPG_R(tpg_fbm_open_bk(ctx(), f->path, f->nrow, f->ncol, &f->dev));
+  if (!f->dev) {
+    TPG_R(tpg_fbm_open_bk(ctx(), f->path, f->nrow, f->ncol, &f->dev));
+    f->mtime_ns = mt;
+    f->fingerprint = fp;
+  }
   return f->dev;
 }
 
@@ -130,12 +193,24 @@ static const double* code256_of(SEXP BM) {
   return REAL(c);
 }
 
-/* a double FBM (the N x N accumulators the R drivers allocate with bigstatsr::FBM(n, n, init = 0)) */
+/* a double FBM (the N x N accumulators the R drivers allocate with bigstatsr::FBM(n, n, init = 0)): mapped for the
+ * time the library may write to it -- this call by default, until the flush under TPG_RSHIM_DEFERRED=1 -- and unmapped
+ * then (release_accumulators), so that a session does not pile up mappings of R's deleted temp files */
 static double* double_fbm(SEXP K, int64_t n) {
   const int64_t nrow = field_i64(K, "nrow"), ncol = field_i64(K, "ncol");
   if (nrow != n || ncol != n) Rf_error("accumulator FBM is %lld x %lld, expected %lld x %lld", (long long)nrow,
                                        (long long)ncol, (long long)n, (long long)n);
   return (double*)map_file(field_path(K, "backingfile"), sizeof(double) * (size_t)n * (size_t)n, 1, n, n)->map;
+}
+
+static void release_accumulators(void) {
+  for (int k = g_nfiles - 1; k >= 0; k--)
+    if (g_files[k].writable) forget_file(k);
+}
+
+/* after an increment_* call: by default its sums are already in k / k2 and their mappings can go */
+static void after_increment(void) {
+  if (!deferred()) release_accumulators();
 }
 
 static tpg_view* view_of(SEXP BM, SEXP rowInd, SEXP colInd, int raw_bytes) {
@@ -332,13 +407,9 @@ SEXP _tidypopgen_pairwise_fst_nei87_loop(SEXP pairwise_combn, SEXP n, SEXP het_o
 /* ---- pairwise individual matrices: the per-block increment functions ----------------------------------------------
  * The R drivers (R/snp_ibs.R:59-82, R/snp_king.R:51-77, R/snp_allele_sharing.R:49-70) call these once per locus block
  * with the same FBM and the same two N x N double FBMs.  The library keeps the genotype FBM and the accumulators in
- * HBM across the calls; the sums reach k / k2 when _tidypopgen_tpg_flush is called (or at every call under
- * TPG_RSHIM_EAGER=1).  The scratch matrices the reference fills are not touched. */
-
-static int eager(void) {
-  const char* e = getenv("TPG_RSHIM_EAGER");
-  return e && e[0] == '1';
-}
+ * Default: every call uploads the columns of its block, accumulates, and adds the sums to k / k2 before it returns.
+ * TPG_RSHIM_DEFERRED=1: the accumulators stay in HBM across the calls and the sums reach k / k2 when
+ * _tidypopgen_tpg_flush is called.  The scratch matrices the reference fills are not touched. */
 
 /* increment_ibs_counts(k, k2, genotype0, genotype1, genotype2, BM, rowInd, colInd)   src/snp_ibs.cpp:22-74 */
 SEXP _tidypopgen_increment_ibs_counts(SEXP k, SEXP k2, SEXP g0, SEXP g1, SEXP g2, SEXP BM, SEXP rowInd, SEXP colInd) {
@@ -347,7 +418,7 @@ SEXP _tidypopgen_increment_ibs_counts(SEXP k, SEXP k2, SEXP g0, SEXP g1, SEXP g2
   const int64_t n = (int64_t)XLENGTH(rowInd);
   TPG_R(tpg_increment_ibs_counts(ctx(), double_fbm(k, n), double_fbm(k2, n), (const uint8_t*)f->map, f->nrow, f->ncol,
                                  INTEGER(rowInd), n, INTEGER(colInd), (int64_t)XLENGTH(colInd)));
-  if (eager()) TPG_R(tpg_increment_flush(ctx()));
+  after_increment();
   return R_NilValue;
 }
 
@@ -360,7 +431,7 @@ SEXP _tidypopgen_increment_king_numerator(SEXP k, SEXP n_Aa_i, SEXP g0, SEXP g1,
   const int64_t n = (int64_t)XLENGTH(rowInd);
   TPG_R(tpg_increment_king_numerator(ctx(), double_fbm(k, n), double_fbm(n_Aa_i, n), (const uint8_t*)f->map, f->nrow,
                                      f->ncol, INTEGER(rowInd), n, INTEGER(colInd), (int64_t)XLENGTH(colInd)));
-  if (eager()) TPG_R(tpg_increment_flush(ctx()));
+  after_increment();
   return R_NilValue;
 }
 
@@ -378,16 +449,18 @@ SEXP _tidypopgen_increment_as_counts(SEXP k, SEXP k2, SEXP na_mat, SEXP dos_mat,
   const char* q = getenv("TPG_EMULATE_AS_PAD_QUIRK");
   if (q && q[0] == '1') {
     SEXP dim = Rf_getAttrib(dos_mat, R_DimSymbol);
-    if (Rf_length(dim) == 2 && (int64_t)INTEGER(dim)[1] == m + 1) TPG_R(tpg_increment_as_note_narrow_block(ctx(), K));
+    if (Rf_length(dim) == 2 && (int64_t)INTEGER(dim)[1] == m + 1) TPG_R(tpg_increment_as_note_narrow_block(ctx(), K, n));
   }
-  if (eager()) TPG_R(tpg_increment_flush(ctx()));
+  after_increment();
   return R_NilValue;
 }
 
-/* tpg_flush(): the one line the three pairwise drivers gain after their block loop -- writes the sums held in HBM
- * into the k / k2 FBMs (one download of two N x N matrices per analysis).  Not a reference symbol. */
+/* tpg_flush(): under TPG_RSHIM_DEFERRED=1 the one line the three pairwise drivers gain after their block loop -- writes
+ * the sums held in HBM into the k / k2 FBMs (one download of two N x N matrices per analysis); a no-op otherwise.  Not a
+ * reference symbol. */
 SEXP _tidypopgen_tpg_flush(void) {
   if (g_ctx) TPG_R(tpg_increment_flush(g_ctx));
+  release_accumulators();
   return R_NilValue;
 }
 
@@ -397,11 +470,7 @@ SEXP _tidypopgen_tpg_release(void) {
     TPG_R(tpg_increment_flush(g_ctx));
     TPG_R(tpg_resident_drop(g_ctx));
   }
-  for (int k = 0; k < g_nfiles; k++) {
-    if (g_files[k].dev) tpg_fbm_free(g_files[k].dev);
-    munmap(g_files[k].map, g_files[k].bytes);
-    free(g_files[k].path);
-  }
+  while (g_nfiles > 0) forget_file(g_nfiles - 1);
   free(g_files);
   g_files = NULL;
   g_nfiles = 0;
@@ -430,6 +499,118 @@ SEXP _tidypopgen_fbm256_prod_and_rowSumsSq(SEXP BM, SEXP ind_row, SEXP ind_col, 
   return out;
 }
 
+/* ---- whole analyses on all the GPUs of the node (additions; not reference symbols) ---------------------------------
+ * The per-block entry points above are literal drop-ins and run on one GPU.  An R session is ONE process, so the way to
+ * the other GPUs is one call per analysis: the library gives every device a share of colInd (its own upload, pack and
+ * sweep on a host thread per device) and exchanges what is additive over loci itself (RCCL).  These replace the BODY of
+ * the R drivers -- snp_ibs / snp_king / snp_allele_sharing / pairwise_grm (R/snp_ibs.R:42-104 ...), pairwise_pop_fst's
+ * numeric part (R/pairwise_pop_fst.R:116-161), loci_alt_freq on a grouped tibble (R/loci_alt_freq.R:174-197),
+ * gt_pca_partialSVD's big_SVD call (R/gt_pca_partialSVD.R:82-89) -- INTEGRATION.md 2c shows the R side.
+ * Devices: TPG_DEVICES (a count; default = all visible). */
+static tpg_multi* g_multi = NULL;
+
+static tpg_multi* multi(void) {
+  if (!g_multi) {
+    int ndev = 0;
+    const char* e = getenv("TPG_DEVICES");
+    if (e) ndev = atoi(e);
+    else TPG_R(tpg_device_count(&ndev));
+    if (ndev < 1) Rf_error("tidypopgen (GPU): no HIP device");
+    TPG_R(tpg_multi_create(ndev, NULL, &g_multi));
+  }
+  return g_multi;
+}
+
+static void check_ind(SEXP rowInd, SEXP colInd) {
+  if (TYPEOF(rowInd) != INTSXP || TYPEOF(colInd) != INTSXP) Rf_error("rowInd / colInd must be integer vectors");
+}
+
+/* tpg_snp_pairwise(BM, rowInd, colInd, adjusted_counts) -> list(ibs, king, allele_sharing, grm), each n x n */
+SEXP _tidypopgen_tpg_snp_pairwise(SEXP BM, SEXP rowInd, SEXP colInd, SEXP adjusted_counts) {
+  check_ind(rowInd, colInd);
+  mapped_file* f = genotype_fbm(BM);
+  const int n = (int)XLENGTH(rowInd);
+  SEXP mats[4];
+  for (int k = 0; k < 4; k++) mats[k] = PROTECT(Rf_allocMatrix(REALSXP, n, n));
+  TPG_R(tpg_multi_pairwise(multi(), (const uint8_t*)f->map, f->nrow, f->ncol, INTEGER(rowInd), n, INTEGER(colInd),
+                           (int64_t)XLENGTH(colInd), Rf_asLogical(adjusted_counts) ? TPG_IBS_ADJUSTED_COUNTS : TPG_IBS_PROPORTION,
+                           REAL(mats[0]), REAL(mats[1]), REAL(mats[2]), REAL(mats[3])));
+  static const char* names[4] = {"ibs", "king", "allele_sharing", "grm"};
+  SEXP out = named_list(4, names, mats);
+  UNPROTECT(4);
+  return out;
+}
+
+/* tpg_grouped_alt_freq(BM, rowInd, colInd, groupIds, ngroups, ploidy, as_counts) -> m x 2G (groupIds NULL: m x 2) */
+SEXP _tidypopgen_tpg_grouped_alt_freq(SEXP BM, SEXP rowInd, SEXP colInd, SEXP groupIds, SEXP ngroups, SEXP ploidy,
+                                      SEXP as_counts) {
+  check_ind(rowInd, colInd);
+  mapped_file* f = genotype_fbm(BM);
+  const int grouped = groupIds != R_NilValue;
+  const int G = grouped ? Rf_asInteger(ngroups) : 0;
+  SEXP pl = PROTECT(Rf_coerceVector(ploidy, REALSXP));
+  SEXP gid = PROTECT(grouped ? Rf_coerceVector(groupIds, INTSXP) : R_NilValue);
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)XLENGTH(colInd), grouped ? 2 * G : 2));
+  TPG_R(tpg_multi_grouped_alt_freq(multi(), (const uint8_t*)f->map, f->nrow, f->ncol, INTEGER(rowInd), (int64_t)XLENGTH(rowInd),
+                                   INTEGER(colInd), (int64_t)XLENGTH(colInd), code256_of(BM), grouped ? INTEGER(gid) : NULL, G,
+                                   REAL(pl), Rf_asLogical(as_counts), REAL(out)));
+  UNPROTECT(3);
+  return out;
+}
+
+/* tpg_pairwise_pop_fst(BM, rowInd, colInd, groupIds, ngroups, ploidy, method, pairwise_combn, by_locus, return_num_dem)
+ * method: 0 Hudson, 1 Nei87, 2 WC84.  Same list as the three loop functions return. */
+SEXP _tidypopgen_tpg_pairwise_pop_fst(SEXP BM, SEXP rowInd, SEXP colInd, SEXP groupIds, SEXP ngroups, SEXP ploidy, SEXP method,
+                                      SEXP pairwise_combn, SEXP by_locus, SEXP return_num_dem) {
+  check_ind(rowInd, colInd);
+  mapped_file* f = genotype_fbm(BM);
+  const int G = Rf_asInteger(ngroups), m = (int)XLENGTH(colInd);
+  SEXP pl = PROTECT(Rf_coerceVector(ploidy, REALSXP));
+  SEXP gid = PROTECT(Rf_coerceVector(groupIds, INTSXP));
+  SEXP pc = PROTECT(Rf_coerceVector(pairwise_combn, INTSXP));
+  const int P = (int)(XLENGTH(pc) / 2), rnd = Rf_asLogical(return_num_dem), want_a = Rf_asLogical(by_locus) || rnd;
+  SEXP tot = PROTECT(Rf_allocVector(REALSXP, P));
+  SEXP a = PROTECT(Rf_allocMatrix(REALSXP, want_a ? m : 0, want_a ? P : 0));
+  SEXP b = PROTECT(Rf_allocMatrix(REALSXP, rnd ? m : 0, rnd ? P : 0));
+  TPG_R(tpg_multi_pop_fst(multi(), (const uint8_t*)f->map, f->nrow, f->ncol, INTEGER(rowInd), (int64_t)XLENGTH(rowInd),
+                          INTEGER(colInd), m, code256_of(BM), INTEGER(gid), G, REAL(pl), Rf_asInteger(method), INTEGER(pc), P,
+                          want_a, rnd, REAL(tot), want_a ? REAL(a) : NULL, rnd ? REAL(b) : NULL));
+  SEXP out;
+  if (!rnd) {
+    static const char* names[2] = {"fst_locus", "fst_tot"};
+    SEXP vals[2] = {a, tot};
+    out = named_list(2, names, vals);
+  } else {
+    static const char* names[2] = {"Fst_by_locus_num", "Fst_by_locus_den"};
+    SEXP vals[2] = {a, b};
+    out = named_list(2, names, vals);
+  }
+  UNPROTECT(6);
+  return out;
+}
+
+/* tpg_pca_partial_svd(BM, rowInd, colInd, k) -> list(d, u, v, center, scale, square_frobenius): what big_SVD returns to
+ * gt_pca_partialSVD (R/gt_pca_partialSVD.R:82-105) plus the squared Frobenius norm of R/square_frobenius.R */
+SEXP _tidypopgen_tpg_pca_partial_svd(SEXP BM, SEXP rowInd, SEXP colInd, SEXP k) {
+  check_ind(rowInd, colInd);
+  mapped_file* f = genotype_fbm(BM);
+  const int n = (int)XLENGTH(rowInd), m = (int)XLENGTH(colInd), K = Rf_asInteger(k);
+  SEXP vals[6];
+  vals[0] = PROTECT(Rf_allocVector(REALSXP, K));
+  vals[1] = PROTECT(Rf_allocMatrix(REALSXP, n, K));
+  vals[2] = PROTECT(Rf_allocMatrix(REALSXP, m, K));
+  vals[3] = PROTECT(Rf_allocVector(REALSXP, m));
+  vals[4] = PROTECT(Rf_allocVector(REALSXP, m));
+  vals[5] = PROTECT(Rf_allocVector(REALSXP, 1));
+  TPG_R(tpg_multi_pca_partial_svd(multi(), (const uint8_t*)f->map, f->nrow, f->ncol, INTEGER(rowInd), n, INTEGER(colInd), m,
+                                  code256_of(BM), K, REAL(vals[0]), REAL(vals[1]), REAL(vals[2]), REAL(vals[3]), REAL(vals[4]),
+                                  REAL(vals[5])));
+  static const char* names[6] = {"d", "u", "v", "center", "scale", "square_frobenius"};
+  SEXP out = named_list(6, names, vals);
+  UNPROTECT(6);
+  return out;
+}
+
 /* ---- registration ------------------------------------------------------------------------------------------------
  * Same names and arities as the reference's table (src/RcppExports.cpp:348-371).  These rows replace the rows of the
  * same name there; the other rows of that table (compute_np_mn, the HWE functions, the VCF / packedancestry readers,
@@ -452,6 +633,10 @@ const R_CallMethodDef tpg_rshim_entries[] = {
     /* additions (not in the reference): */
     {"_tidypopgen_tpg_flush", (DL_FUNC)&_tidypopgen_tpg_flush, 0},
     {"_tidypopgen_tpg_release", (DL_FUNC)&_tidypopgen_tpg_release, 0},
+    {"_tidypopgen_tpg_snp_pairwise", (DL_FUNC)&_tidypopgen_tpg_snp_pairwise, 4},
+    {"_tidypopgen_tpg_grouped_alt_freq", (DL_FUNC)&_tidypopgen_tpg_grouped_alt_freq, 7},
+    {"_tidypopgen_tpg_pairwise_pop_fst", (DL_FUNC)&_tidypopgen_tpg_pairwise_pop_fst, 10},
+    {"_tidypopgen_tpg_pca_partial_svd", (DL_FUNC)&_tidypopgen_tpg_pca_partial_svd, 4},
     {NULL, NULL, 0}};
 
 #ifdef TPG_RSHIM_STANDALONE
@@ -466,6 +651,10 @@ void R_init_tpgshim(DllInfo* dll) {
 void R_unload_tpgshim(DllInfo* dll) {
   (void)dll;
   _tidypopgen_tpg_release();
+  if (g_multi) {
+    tpg_multi_destroy(g_multi);
+    g_multi = NULL;
+  }
   if (g_ctx) {
     tpg_ctx_destroy(g_ctx);
     g_ctx = NULL;

@@ -225,7 +225,7 @@ def test_multi_fst_freq_pca_against_oracle(ndev):
     assert np.max(np.abs(_align_sign(t["v"], o["v"]) - o["v"])) <= 1e-6 * np.max(np.abs(o["v"]))
     # a shard with a zero scale fails on ONE device thread only: every device gives up together (no thread is left in
     # the Gram all-reduce), and the error is big_SVD's
-    mono = fbm.copy()
+    mono = fbm.copy(order="F")
     mono[:, m - 5] = 0
     with pytest.raises(tpg._lib.TpgError) as e:
         mg.gt_pca_partialSVD(mono, None, None, k=k)

@@ -85,7 +85,7 @@ SYMBOLS = [
     "tpg_pairwise_king", "tpg_pairwise_allele_sharing", "tpg_pairwise_grm", "tpg_pairwise_epilogues", "tpg_block_means", "tpg_increment_ibs_counts",
     "tpg_increment_king_numerator", "tpg_increment_as_counts", "tpg_pca_center_scale", "tpg_pca_gram",
     "tpg_pca_partial_svd", "tpg_fbm256_prod_and_rowSumsSq", "tpg_square_frobenius",
-    "tpg_pairwise_set_as_pad_quirk", "tpg_as_pad_quirk_blocks", "tpg_increment_flush", "tpg_resident_drop",
+    "tpg_pairwise_set_as_pad_quirk", "tpg_as_pad_quirk_blocks", "tpg_increment_defer", "tpg_increment_flush", "tpg_resident_drop",
     "tpg_increment_as_note_narrow_block", "tpg_filter_high_relatedness", "tpg_pca_random_svd",
     "tpg_fbm256_valid_prod", "tpg_comm_unique_id", "tpg_comm_init_rank", "tpg_comm_init_host", "tpg_comm_destroy",
     "tpg_comm_rank", "tpg_comm_size", "tpg_shard_loci", "tpg_comm_allreduce_f64", "tpg_pairwise_buffer_bytes_sharded",

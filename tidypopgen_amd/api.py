@@ -668,9 +668,10 @@ def filter_high_relatedness(matrix, kings_threshold, ids=None, ctx: Optional[Con
 
 
 def increment_ibs_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] = None, flush: bool = True):
-    """Literal mirror of src/snp_ibs.cpp:22-74 (X_bytes is the host FBM).  The FBM and the accumulators stay resident
-    on the device between calls; with flush = True (default) k, k2 are incremented when the call returns, as in the
-    reference; a block loop passes flush = False and calls increment_flush() once after the loop."""
+    """Literal mirror of src/snp_ibs.cpp:22-74 (X_bytes is the host FBM; every call uploads the columns of its own
+    block, nothing of the FBM is kept).  flush = True (default): k, k2 are incremented when the call returns, as in the
+    reference.  flush = False (tpg_increment_defer): the sums stay in device accumulators across the calls of a block loop
+    and reach k, k2 at increment_flush()."""
     return _increment(lib.tpg_increment_ibs_counts, k, k2, X_bytes, rowInd, colInd, ctx, flush)
 
 
@@ -684,11 +685,9 @@ def increment_as_counts(k, k2, X_bytes, rowInd, colInd, ctx: Optional[Context] =
     """Literal mirror of src/snp_as.cpp:22-67.  scratch_cols = number of columns of the scratch matrices the R driver
     passes; with emulate_as_pad_quirk a block one column narrower than that adds +1 to every numerator (quirk Q1)."""
     ctx = ctx or default_context()
-    _increment(lib.tpg_increment_as_counts, k, k2, X_bytes, rowInd, colInd, ctx, False)
+    _increment(lib.tpg_increment_as_counts, k, k2, X_bytes, rowInd, colInd, ctx, flush)
     if emulate_as_pad_quirk and scratch_cols is not None and scratch_cols == len(colInd) + 1:
-        check(lib.tpg_increment_as_note_narrow_block(ctx.h, _ptr(k)))
-    if flush:
-        increment_flush(ctx)
+        check(lib.tpg_increment_as_note_narrow_block(ctx.h, _ptr(k), C.c_int64(k.shape[0])))
 
 
 def increment_flush(ctx: Optional[Context] = None):
@@ -698,7 +697,7 @@ def increment_flush(ctx: Optional[Context] = None):
 
 
 def resident_drop(ctx: Optional[Context] = None):
-    """forget the FBMs the increment_* mirrors uploaded (needed if the host bytes change)"""
+    """release the device scratch the increment_* mirrors keep between calls"""
     ctx = ctx or default_context()
     check(lib.tpg_resident_drop(ctx.h))
 
@@ -709,10 +708,9 @@ def _increment(fn, a, b, X_bytes, rowInd, colInd, ctx, flush):
     assert X_bytes.dtype == np.uint8 and X_bytes.flags.f_contiguous
     assert a.flags.f_contiguous and b.flags.f_contiguous and a.dtype == np.float64 and b.dtype == np.float64
     r, c = _i32(rowInd), _i32(colInd)
+    check(lib.tpg_increment_defer(ctx.h, C.c_int(int(not flush))))  # switching it off flushes what is pending
     check(fn(ctx.h, _ptr(a), _ptr(b), _ptr(X_bytes), C.c_int64(X_bytes.shape[0]), C.c_int64(X_bytes.shape[1]),
              _ptr(r), C.c_int64(len(r)), _ptr(c), C.c_int64(len(c))))
-    if flush:
-        increment_flush(ctx)
 
 
 def _ploidy(v: View, ploidy):

@@ -1065,17 +1065,17 @@ extern "C" int tpg_filter_high_relatedness(tpg_ctx* ctx, const double* matrix, i
 }
 
 // ---------------------------------------------------------------------------
-// Literal per-block mirrors of increment_{ibs,king,as}_counts, RESIDENT: the R drivers call these once per locus
-// block (38 times at 5 000 x 1 000 000 with the default block size) on the same FBM and the same pair of N x N
-// accumulators.  The FBM is uploaded on first sight (cache keyed by its host address and shape) and every (K, K2)
-// pair gets device accumulators that live across the calls, so a block costs one pack + one MFMA pass and moves
-// nothing over PCIe; the sums are added to the caller's matrices when it asks (tpg_increment_flush -- one D2H of
-// two N x N matrices per analysis instead of per block).
-struct ResidentFbm {
-  const uint8_t* host;
-  int64_t nrow, ncol;
-  tpg_fbm* fbm;
-};
+// Literal per-block mirrors of increment_{ibs,king,as}_counts.  The R drivers call these once per locus block (38 times
+// at 5 000 x 1 000 000 with the default block size) on the same FBM and the same pair of N x N accumulators.
+//
+// Nothing of the caller's FBM is kept between calls: every call uploads the columns of ITS block (the blocks of a driver
+// loop cover the FBM once, so the loop moves the same bytes a whole upload would) -- an FBM whose bytes change between two
+// analyses (bigsnpr::snp_fastImputeSimple rewrites the backing file in place, R/gt_impute_simple.R:86), or another array
+// at a reused address, can therefore never be served from a stale HBM copy.
+// Default: literal semantics, K and K2 are incremented when the call returns (src/snp_ibs.cpp:67-72).  After
+// tpg_increment_defer(ctx, 1) every (K, K2) pair gets device accumulators that live across the calls of the block loop and
+// the sums reach the caller's matrices at tpg_increment_flush: one download of two N x N matrices per analysis instead of
+// per block.
 struct ResidentAcc {
   int which;  // 0 IBS, 1 KING, 2 allele sharing
   double *A, *B;
@@ -1083,8 +1083,9 @@ struct ResidentAcc {
   tpg_pairwise* pw;
 };
 struct Resident {
-  std::vector<ResidentFbm> fbms;
+  bool defer = false;
   std::vector<ResidentAcc> accs;
+  tpg_pairwise* spare = nullptr;  // the accumulators of the last immediate call, reused while n stays the same
 };
 
 static Resident* resident_of(tpg_ctx* ctx) {
@@ -1095,41 +1096,87 @@ static Resident* resident_of(tpg_ctx* ctx) {
 void tpg_resident_release(tpg_ctx* ctx) {  // called by tpg_ctx_destroy and tpg_resident_drop
   Resident* r = (Resident*)ctx->resident;
   if (!r) return;
-  for (auto& f : r->fbms) tpg_fbm_free(f.fbm);
   for (auto& a : r->accs) tpg_pairwise_free(a.pw);
+  tpg_pairwise_free(r->spare);
   delete r;
   ctx->resident = nullptr;
+}
+
+// K += sums, K2 += sums: exact (integer-valued doubles), so the order of the blocks does not matter
+static int add_counts_to_caller(tpg_ctx* ctx, int which, const tpg_pairwise* pw, double* A, double* B) {
+  const size_t nn = (size_t)pw->n * (size_t)pw->n;
+  std::vector<double> ta(nn), tb(nn);
+  if (which == 0) TPG_TRY(tpg_pairwise_counts(ctx, pw, ta.data(), tb.data(), nullptr, nullptr, nullptr, nullptr));
+  else if (which == 1) TPG_TRY(tpg_pairwise_counts(ctx, pw, nullptr, nullptr, ta.data(), tb.data(), nullptr, nullptr));
+  else TPG_TRY(tpg_pairwise_counts(ctx, pw, nullptr, nullptr, nullptr, nullptr, ta.data(), tb.data()));
+  const int NT = nn >= (1u << 20) ? 8 : 1;
+  std::vector<std::thread> th;
+  auto body = [&](int t) {
+    for (size_t k = nn * (size_t)t / (size_t)NT; k < nn * (size_t)(t + 1) / (size_t)NT; k++) { A[k] += ta[k]; B[k] += tb[k]; }
+  };
+  for (int t = 1; t < NT; t++) th.emplace_back(body, t);
+  body(0);
+  for (auto& t : th) t.join();
+  return TPG_OK;
+}
+
+// the columns colInd names, in HBM: the covering column range of the FBM when the block is (nearly) contiguous, as the
+// blocks of the R drivers are; the m columns gathered on the host when colInd is scattered (an LD-pruned subset ...)
+static int upload_block_columns(tpg_ctx* ctx, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, const int32_t* colInd1,
+                                int64_t m, tpg_fbm** f, std::vector<int32_t>& cols) {
+  int32_t lo = colInd1[0], hi = colInd1[0];
+  for (int64_t j = 0; j < m; j++) {
+    TPG_REQUIRE(colInd1[j] >= 1 && colInd1[j] <= ncol, TPG_EINVAL, "colInd[%lld] = %d out of [1,%lld]", (long long)j,
+                colInd1[j], (long long)ncol);
+    lo = std::min(lo, colInd1[j]);
+    hi = std::max(hi, colInd1[j]);
+  }
+  const int64_t span = (int64_t)hi - lo + 1;
+  cols.resize((size_t)m);
+  if (span <= 2 * m + 64) {
+    for (int64_t j = 0; j < m; j++) cols[(size_t)j] = colInd1[j] - (lo - 1);
+    return tpg_fbm_from_host(ctx, fbm_bytes + (size_t)(lo - 1) * (size_t)nrow, nrow, span, f);
+  }
+  std::vector<uint8_t> stage((size_t)nrow * (size_t)m);
+  for (int64_t j = 0; j < m; j++) {
+    memcpy(stage.data() + (size_t)j * (size_t)nrow, fbm_bytes + (size_t)(colInd1[j] - 1) * (size_t)nrow, (size_t)nrow);
+    cols[(size_t)j] = (int32_t)(j + 1);
+  }
+  return tpg_fbm_from_host(ctx, stage.data(), nrow, m, f);  // waited for: the staging buffer may go
 }
 
 static int increment_common(tpg_ctx* ctx, int which, double* A, double* B, const uint8_t* fbm_bytes, int64_t nrow,
                             int64_t ncol, const int32_t* rowInd1, int64_t n, const int32_t* colInd1, int64_t m) {
   TPG_REQUIRE(ctx && A && B && fbm_bytes && rowInd1 && colInd1, TPG_EINVAL, "null argument");
-  TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty block");
+  TPG_REQUIRE(n > 0 && m > 0 && nrow > 0 && ncol > 0, TPG_EINVAL, "empty block");
   Resident* r = resident_of(ctx);
-  tpg_fbm* f = nullptr;
-  for (auto& e : r->fbms)
-    if (e.host == fbm_bytes && e.nrow == nrow && e.ncol == ncol) f = e.fbm;
-  if (!f) {
-    TPG_TRY(tpg_fbm_from_host(ctx, fbm_bytes, nrow, ncol, &f));
-    r->fbms.push_back(ResidentFbm{fbm_bytes, nrow, ncol, f});
-  }
   ResidentAcc* acc = nullptr;
   for (auto& e : r->accs)
     if (e.A == A && e.B == B) acc = &e;
+  tpg_pairwise* pw = nullptr;
   if (acc) {
     TPG_REQUIRE(acc->which == which, TPG_EINVAL, "these accumulators are pending for another increment_* function; flush first");
     TPG_REQUIRE((int64_t)acc->rows.size() == n && memcmp(acc->rows.data(), rowInd1, sizeof(int32_t) * (size_t)n) == 0,
                 TPG_EINVAL, "rowInd changed between blocks that accumulate into the same matrices; flush first");
-  } else {
-    tpg_pairwise* pw = nullptr;
+    pw = acc->pw;
+  } else if (r->defer) {
     TPG_TRY(tpg_pairwise_create(ctx, n, nullptr, &pw));
     r->accs.push_back(ResidentAcc{which, A, B, std::vector<int32_t>(rowInd1, rowInd1 + n), pw});
-    acc = &r->accs.back();
+  } else {
+    if (r->spare && r->spare->n != n) { tpg_pairwise_free(r->spare); r->spare = nullptr; }
+    if (r->spare) TPG_TRY(tpg_pairwise_zero(ctx, r->spare));
+    else TPG_TRY(tpg_pairwise_create(ctx, n, nullptr, &r->spare));
+    pw = r->spare;
   }
+  tpg_fbm* f = nullptr;
   tpg_view* v = nullptr;
-  TPG_TRY(tpg_view_create(ctx, f, rowInd1, n, colInd1, m, nullptr /* raw bytes, src/snp_ibs.cpp:47-54 */, &v));
-  int rc = tpg_pairwise_accumulate(ctx, acc->pw, v, 0, -1);
-  tpg_view_free(v);  // stream-ordered: the block returns to this context's pool
+  std::vector<int32_t> cols;
+  int rc = upload_block_columns(ctx, fbm_bytes, nrow, ncol, colInd1, m, &f, cols);
+  if (rc == TPG_OK) rc = tpg_view_create(ctx, f, rowInd1, n, cols.data(), m, nullptr /* raw bytes, src/snp_ibs.cpp:47-54 */, &v);
+  if (rc == TPG_OK) rc = tpg_pairwise_accumulate(ctx, pw, v, 0, -1);
+  if (rc == TPG_OK && pw == r->spare) rc = add_counts_to_caller(ctx, which, pw, A, B);  // immediate: as the reference
+  tpg_view_free(v);  // stream-ordered: the blocks return to this context's pool
+  tpg_fbm_free(f);
   return rc;
 }
 
@@ -1140,48 +1187,53 @@ extern "C" int tpg_increment_flush(tpg_ctx* ctx) {
   if (!r) return TPG_OK;
   int rc = TPG_OK;
   for (auto& a : r->accs) {
-    if (rc == TPG_OK) {
-      const size_t nn = (size_t)a.pw->n * (size_t)a.pw->n;
-      std::vector<double> ta(nn), tb(nn);
-      if (a.which == 0) rc = tpg_pairwise_counts(ctx, a.pw, ta.data(), tb.data(), nullptr, nullptr, nullptr, nullptr);
-      else if (a.which == 1) rc = tpg_pairwise_counts(ctx, a.pw, nullptr, nullptr, ta.data(), tb.data(), nullptr, nullptr);
-      else rc = tpg_pairwise_counts(ctx, a.pw, nullptr, nullptr, nullptr, nullptr, ta.data(), tb.data());
-      if (rc == TPG_OK) {  // K += sums: exact (integer-valued doubles), the order of the blocks does not matter
-        const int NT = 8;
-        std::thread th[NT];
-        for (int t = 0; t < NT; t++)
-          th[t] = std::thread([&, t]() {
-            for (size_t k = nn * t / NT; k < nn * (t + 1) / NT; k++) { a.A[k] += ta[k]; a.B[k] += tb[k]; }
-          });
-        for (int t = 0; t < NT; t++) th[t].join();
-      }
-    }
+    if (rc == TPG_OK) rc = add_counts_to_caller(ctx, a.which, a.pw, a.A, a.B);
     tpg_pairwise_free(a.pw);
   }
   r->accs.clear();
   return rc;
 }
 
+// on != 0: the increment_* mirrors keep their sums in HBM until tpg_increment_flush; 0 (the default): every call
+// increments the caller's matrices before it returns.  Switching it off flushes what is pending.
+extern "C" int tpg_increment_defer(tpg_ctx* ctx, int on) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
+  Resident* r = resident_of(ctx);
+  if (!on && !r->accs.empty()) TPG_TRY(tpg_increment_flush(ctx));
+  r->defer = on != 0;
+  return TPG_OK;
+}
+
+// releases the device memory the increment_* mirrors hold between calls (an error while increments are pending).  No
+// copy of a caller's FBM is ever kept, so there is nothing to invalidate when its bytes change.
 extern "C" int tpg_resident_drop(tpg_ctx* ctx) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
   Resident* r = (Resident*)ctx->resident;
   TPG_REQUIRE(!r || r->accs.empty(), TPG_EINVAL, "increments are pending: call tpg_increment_flush first");
+  const bool defer = r && r->defer;
   tpg_resident_release(ctx);
+  if (defer) resident_of(ctx)->defer = true;
   return TPG_OK;
 }
 
 // quirk Q1 for the literal mirror: the shim calls this for a block whose scratch matrices are one column wider than
-// the block (src/snp_as.cpp:57-63) when the emulation is wanted
-extern "C" int tpg_increment_as_note_narrow_block(tpg_ctx* ctx, const double* K) {
+// the block (src/snp_as.cpp:57-63) when the emulation is wanted: +1 on every element of the numerator K (n x n) --
+// noted on the pending device accumulators, or added to K right away when nothing is pending for it
+extern "C" int tpg_increment_as_note_narrow_block(tpg_ctx* ctx, double* K, int64_t n) {
   TpgEnter _enter(ctx);
-  TPG_REQUIRE(ctx && K, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(ctx && K && n > 0, TPG_EINVAL, "bad argument");
   Resident* r = (Resident*)ctx->resident;
   if (r)
     for (auto& a : r->accs)
-      if (a.A == K && a.which == 2) { a.pw->as_pad_quirk += 1; return TPG_OK; }
-  tpg_set_error("no pending allele-sharing increment for this matrix");
-  return TPG_EINVAL;
+      if (a.A == K) {
+        TPG_REQUIRE(a.which == 2 && a.pw->n == n, TPG_EINVAL, "K is pending for another increment_* function or another n");
+        a.pw->as_pad_quirk += 1;
+        return TPG_OK;
+      }
+  for (size_t k = 0; k < (size_t)n * (size_t)n; k++) K[k] += 1.0;
+  return TPG_OK;
 }
 
 extern "C" int tpg_increment_ibs_counts(tpg_ctx* ctx, double* K, double* K2, const uint8_t* fbm_bytes, int64_t nrow,
