@@ -217,4 +217,4 @@ def test_whole_analysis_entry_points(shim, tmp_path, monkeypatch):
     assert shim.list_elt(pca, 5)[0] == pytest.approx(op["square_frobenius"], rel=1e-12)
     # errors of the library arrive as R errors (Rf_error), as BEGIN_RCPP / END_RCPP deliver C++ exceptions
     with pytest.raises(RuntimeError, match="tidypopgen"):
-        shim.call("tpg_pca_partial_svd", BM, shim.int(rows), shim.int(np.arange(1, m + 1)), shim.int([k]))
+        shim.call("tpg_pca_partial_svd", BM, shim.int(rows), shim.int(cols), shim.int([n + 1]))  # k > n

@@ -21,11 +21,11 @@
 //      run-length encoding -> classes; every class is padded to whole 64-locus blocks (zero dosage contributes
 //      nothing); per block its weight and an "accumulators must be folded after this block" flag (end of class, or
 //      2^16 blocks = 2^22 loci since the last fold: 4 x 2^22 is the largest FP32 sum that is still exact).
-//   2. tpg_gcls_gather_kernel: the class-sorted operand layout T4g -- block (rt, b) = 32 individuals x the 64 loci
-//      of sorted block b, one FP4 nibble per dosage (0, 1.0, 2.0) -- gathered from the view's L layout.
-//   3. tpg_gcls_gram_kernel: one wave = a 64 x 96 tile of pairs (2 x 3 accumulator tiles) over a range of blocks.
-//      Operands go from the loads (six blocks ahead) straight into the MFMAs: no decode instructions at all.
-//      K split S: each (unit, split) writes its own FP64 slab with plain stores.
+//   2. tpg_gcls_gather_kernel: the class-sorted operand layout T2g -- block (rt, b) = 32 individuals x the 64 loci
+//      of sorted block b, the 2-bit dosage codes (missing -> 0) -- gathered from the view's L layout.
+//   3. tpg_gcls_gram_kernel: one wave = a 64 x 64 tile of pairs (2 x 2 accumulator tiles) over a range of blocks, two
+//      waves per SIMD.  A 16-byte load per lane carries the operand of two blocks; one v_and_b32 (+ one shift) per
+//      operand word makes the FP4 nibbles in registers.  K split S: each (unit, split) writes its own FP64 slab.
 //   4. tpg_gcls_assemble_kernel: the S slabs of a unit are added in a fixed order (run-to-run identical results)
 //      and written to both triangles of the n x n matrix.
 #include <math.h>
@@ -43,7 +43,10 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-constexpr int GA = 2, GB = 3, GP = GA * GB;  // row tiles of the A side, of the B side, accumulator tiles per wave
+// This file is compiled with -mllvm -amdgpu-mfma-vgpr-form (csrc/Makefile): the MFMAs of the Gram kernel write their
+// sums to VGPRs and the kernel uses no AGPR at all, so that hipcc gives a two-waves-per-SIMD kernel its whole budget as
+// VGPRs (256 instead of 128 + 128) and a fold is v_cvt_f64_f32 + v_fma_f64 per element, without a v_accvgpr_read.
+constexpr int GA = 2, GB = 2, GP = GA * GB;  // wave tile = 2 x 2 accumulator tiles of 32 x 32 pairs
 #define GCLS_SLAB (GP * 16 * 64)             // doubles per (unit, split)
 #define GCLS_MAX_RUN 65536                   // blocks between two folds: 4 * 64 * 65536 = 2^24
 
@@ -110,72 +113,71 @@ __global__ void tpg_gcls_block_table_kernel(const unsigned long long* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// 2. gather.  One wave = sorted block b x the four row tiles 4q .. 4q+3 (one 16-byte column of an L block per locus and
-// lane half): lane l fetches the two 16-byte pieces of locus src[64 b + l] (individuals 128 q + 32 s + 16 h + e), the
-// wave transposes them through LDS, and lane (r, ho) of output block s ends up with the 32 dosages of individual
-// 32 (4q + s) + r at the loci 32 ho .. 32 ho + 31 of the block, one FP4 nibble each: 0 -> 0, 1 -> 0x2 (1.0),
-// 2 -> 0x4 (2.0), missing or padding -> 0.  (Which locus sits on which nibble is immaterial: both MFMA operands come
-// from this layout.)
+// 2. gather into the class-sorted 2-BIT operand layout T2g of the Gram kernel.  One wave = a PAIR of sorted blocks
+// (2 bp, 2 bp + 1) x the four row tiles 4q .. 4q+3 (one 16-byte column of an L block per locus and lane half): lane l
+// fetches the two 16-byte pieces of locus src[64 b + l] (individuals 128 q + 32 s + 16 h + e), the wave transposes them
+// through LDS, and lane (r, ho) of output row tile s ends up with the 32 dosages of individual 32 (4q + s) + r at the
+// loci 32 ho .. 32 ho + 31 of each block: one uint4 = {P0, P1 of block 2 bp, P0, P1 of block 2 bp + 1}, a source dword
+// P packing 16 codes as nibbles [c_odd | c_even], so that P & 0x33333333 and (P >> 2) & 0x33333333 are FP4 operand
+// words of value dosage / 2.  Missing / padding -> 0.  (Which locus sits on which nibble is immaterial: both MFMA
+// operands come from this layout.)
 __global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(const uint4* __restrict__ L, int64_t Q,
-                                                              const int32_t* __restrict__ src, int64_t nblocks,
-                                                              uint4* __restrict__ T4g) {
+                                                               const int32_t* __restrict__ src, int64_t nblocks,
+                                                               int64_t rs2, uint4* __restrict__ T2g) {
   __shared__ __attribute__((aligned(16))) uint32_t sh[4][2][4][64];  // [wave][source half][s][locus]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 31, ho = lane >> 5, hs = r >> 4, shf = tpg_elem_shift(r & 15);
-  for (int64_t task = (int64_t)blockIdx.x * 4 + wv; task < Q * nblocks; task += (int64_t)gridDim.x * 4) {
-    const int64_t q = task % Q, b = task / Q;
-    const int32_t j = src[b * 64 + lane];
-    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
-    if (j >= 0) {
-      const uint4* p = L + (((int64_t)(j >> 5)) * Q + q) * 64 + (j & 31);
-      w0 = p[0];
-      w1 = p[32];
-    }
-    sh[wv][0][0][lane] = w0.x; sh[wv][0][1][lane] = w0.y; sh[wv][0][2][lane] = w0.z; sh[wv][0][3][lane] = w0.w;
-    sh[wv][1][0][lane] = w1.x; sh[wv][1][1][lane] = w1.y; sh[wv][1][2][lane] = w1.z; sh[wv][1][3][lane] = w1.w;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int64_t npairs = (nblocks + 1) >> 1;
+  for (int64_t task = (int64_t)blockIdx.x * 4 + wv; task < Q * npairs; task += (int64_t)gridDim.x * 4) {
+    const int64_t q = task % Q, bp = task / Q;
+    uint32_t out[4][4];  // [s][word]
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const uint4* rd = (const uint4*)&sh[wv][hs][s][32 * ho];
-      uint32_t out[4];
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        const uint4 a = rd[2 * d], c = rd[2 * d + 1];
-        const uint32_t ws[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-        uint32_t acc = 0;
-#pragma unroll
-        for (int e = 0; e < 8; e++) acc = (acc << 4) | ((ws[e] >> shf) & 3u);
-        const uint32_t m3 = acc & (acc >> 1) & 0x11111111u;  // code 3
-        out[d] = ((acc << 1) & 0x66666666u) & ~((m3 << 1) | (m3 << 2));
+    for (int hb = 0; hb < 2; hb++) {
+      const int64_t b = 2 * bp + hb;
+      const int32_t j = b < nblocks ? src[b * 64 + lane] : -1;
+      uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
+      if (j >= 0) {
+        const uint4* p = L + (((int64_t)(j >> 5)) * Q + q) * 64 + (j & 31);
+        w0 = p[0];
+        w1 = p[32];
       }
-      T4g[((4 * q + s) * nblocks + b) * 64 + lane] = make_uint4(out[0], out[1], out[2], out[3]);
+      sh[wv][0][0][lane] = w0.x; sh[wv][0][1][lane] = w0.y; sh[wv][0][2][lane] = w0.z; sh[wv][0][3][lane] = w0.w;
+      sh[wv][1][0][lane] = w1.x; sh[wv][1][1][lane] = w1.y; sh[wv][1][2][lane] = w1.z; sh[wv][1][3][lane] = w1.w;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const uint4* rd = (const uint4*)&sh[wv][hs][s][32 * ho];
+        uint32_t nib[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const uint4 a = rd[2 * d], c = rd[2 * d + 1];
+          const uint32_t ws[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+          uint32_t acc = 0;
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc = (acc << 4) | ((ws[e] >> shf) & 3u);
+          const uint32_t m3 = acc & (acc >> 1) & 0x11111111u;  // code 3 -> 0
+          nib[d] = acc & ~(m3 | (m3 << 1));
+        }
+        out[s][2 * hb] = nib[0] | (nib[1] << 2);
+        out[s][2 * hb + 1] = nib[2] | (nib[3] << 2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+      T2g[((4 * q + s) * rs2 + bp) * 64 + lane] = make_uint4(out[s][0], out[s][1], out[s][2], out[s][3]);
   }
 }
 
 // ---------------------------------------------------------------------------
-// 3. class Gram.  Unit (I, J): A row tiles 2I, 2I+1 against B row tiles 3J .. 3J+2 (a tile past the data reads the
-// last tile instead; the assemble kernel never looks at its products).
-#define MFMA_G4(a, b, c) \
-  __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tpg_g8(a), tpg_g8(b), (c), 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f)
 __device__ __forceinline__ v8i tpg_g8(v4u a) { return v8i{(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0}; }
 
-// Operand blocks go from the loads straight into the MFMAs (no decode, no LDS): GCLS_D rotating register slots of
-// GA + GB fragments, each filled GCLS_D - 1 blocks (~0.6 us of MFMAs, more with the folds) ahead of its use; the K
-// loop is unrolled by GCLS_D so that no slot is ever copied.
-// (Tried and dropped: a wave-private LDS ring filled by LDS-DMA, 20.3 ms at 5 000 x 1 000 000; a ring shared by the four
-// waves of a workgroup -- half the L2 traffic, one s_barrier per two blocks -- 32 ms.)
-#define GCLS_D 6
-// the accumulators live in AGPRs; a volatile read keeps hipcc from hoisting the 96 v_accvgpr_read of a fold out of
-// the "class ends here" branch into every block of the K loop (it does, behind an s_nop for the MFMA results)
-__device__ __forceinline__ float tpg_acc_read(float a) {
-  float v;
-  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
-  return v;
+__device__ __forceinline__ int64_t tpg_uniform64(int64_t x) {  // a wave-uniform value the compiler keeps in SGPRs
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 template <int C, class F>
@@ -186,25 +188,59 @@ __device__ __forceinline__ void tpg_static_for(F&& f) {
   }
 }
 
-__global__ __launch_bounds__(256, 1) void tpg_gcls_gram_kernel(const uint4* __restrict__ T4g, int64_t nblocks, int nrtv,
-                                                                  const unsigned long long* __restrict__ wblk,
-                                                                  const int2* __restrict__ order, int64_t nun, int S,
-                                                                  double* __restrict__ slabs) {
+// ---------------------------------------------------------------------------
+// 3. class Gram.  Unit (I, J): row tiles 2I, 2I+1 against row tiles 2J, 2J+1 (a tile past the data reads the last
+// tile instead; the assemble kernel never looks at its products); one wave = a 64 x 64 tile of pairs over a range of
+// blocks, TWO waves per SIMD (the grid is 2 x one workgroup per CU).
+//
+// What bounds it, measured (tools/gram_only.py, rocprofv3 --pmc): (1) the L2 -> CU path, 19 - 20 TB/s over
+// the chip = 1 KiB per XCD and clock, the same with every load an L2 hit -- so a genotype crosses it as its 2-BIT code,
+// not as an FP4 nibble: one 16-byte load per lane holds the operand of TWO 64-locus blocks, and two VALU instructions per
+// source dword turn it into FP4 operand words in registers.  The code itself IS an FP4 value (nibble 0001 = 0.5,
+// 0010 = 1.0), so X = P & 0x33333333 and X' = (P >> 2) & 0x33333333 are operand words of value dosage / 2, and the E8M0
+// block scales of the MFMA (2 on both sides) give the products back as 0 / 1 / 2 / 4: exact integers in FP32 below 2^24.
+// (2) VALU issue: 6 instructions per MFMA for that expansion beside the 8.5 of the folds (out64 += w_c * (double)acc at
+// the end of every class: v_cvt_f64_f32 + v_fma_f64 per element).  The second wave of a SIMD is what lets MFMAs, loads
+// and folds overlap at all: with one wave per SIMD (64 x 96 tiles, FP4 operands) the same work took 16.4 ms against 12.2.
+// The first MFMA of a class takes the inline constant 0 as C, so nothing is ever zeroed.
+// K split S: each (unit, split) writes its own FP64 slab with plain stores.
+#define MFMA_G4S2(a, b, c) \
+  __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tpg_g8(a), tpg_g8(b), (c), 4, 4, 0, (int)0x80808080, 0, (int)0x80808080)
+
+// GCLS_D rotating register slots of GA + GB source fragments (two blocks each), filled GCLS_D - 1 pairs ahead of their use;
+// the K loop is unrolled by GCLS_D so that no slot is ever copied.  (Tried and dropped: three slots -- hipcc spills;
+// FP4 operands in HBM -- 13.4 ms, L2 -> CU bound; the two waves of a SIMD on the same block range -- same time; 512-thread
+// workgroups -- 16 ms; a wave-private LDS ring filled by LDS-DMA; a ring shared by the waves of a workgroup.)
+#define GCLS_D 2
+__global__ __launch_bounds__(256, 2) void tpg_gcls_gram_kernel(const uint4* __restrict__ T2g, int64_t nblocks, int64_t rs2, int nrtv,
+                                                               const unsigned long long* __restrict__ wblk,
+                                                               const int2* __restrict__ order, int64_t nun, int S,
+                                                               double* __restrict__ slabs) {
+  constexpr int WPE = 2;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+  // Workgroups b and b + gridDim.x / 2 share a CU (dispatch is round-robin over the XCDs, then over the CUs:
+  // tools/xcc_probe.hip), i.e. every SIMD holds one wave of each HALF of the grid.  The halves take different halves of the
+  // K range (split indices [0, S/2) and [S/2, S)), so the two waves of a SIMD meet their class boundaries at different
+  // times.  XCD x takes in every round a run of consecutive units of one K range, whose re-reads hit its own L2.
+  const int hgrid = gridDim.x / WPE, half = (int)blockIdx.x / hgrid, bx = (int)blockIdx.x % hgrid;
+  const int xcd = bx & 7, cidx = bx >> 3, cpx = hgrid >> 3;
+  const int SH = S / WPE;  // splits per half (the host makes S even)
+  const int64_t npairs = (nblocks + 1) >> 1;
   for (int64_t round = 0;; round++) {
     const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
-    if (un >= nun * S) break;
-    const int ks = (int)(un / nun);
+    if (un >= nun * SH) break;
+    const int ks = half * SH + (int)(un / nun);
     const int64_t u = un % nun;
-    const int2 ij = order[u];
-    const int64_t b0 = (nblocks * ks) / S, b1 = (nblocks * (ks + 1)) / S;
+    const int2 ijv = order[u];
+    const int2 ij = make_int2(__builtin_amdgcn_readfirstlane(ijv.x), __builtin_amdgcn_readfirstlane(ijv.y));
+    const int64_t p0 = tpg_uniform64((npairs * ks) / S), p1 = tpg_uniform64((npairs * (ks + 1)) / S);  // block pairs
+    const int64_t bend = 2 * p1 < nblocks ? 2 * p1 : nblocks;                                          // blocks [2 p0, bend)
     const uint4* pt[GA + GB];
 #pragma unroll
-    for (int t = 0; t < GA; t++) pt[t] = T4g + ((int64_t)min(GA * ij.x + t, nrtv - 1) * nblocks) * 64 + lane;
+    for (int t = 0; t < GA; t++) pt[t] = T2g + ((int64_t)min(GA * ij.x + t, nrtv - 1) * rs2) * 64;
 #pragma unroll
-    for (int t = 0; t < GB; t++) pt[GA + t] = T4g + ((int64_t)min(GB * ij.y + t, nrtv - 1) * nblocks) * 64 + lane;
+    for (int t = 0; t < GB; t++) pt[GA + t] = T2g + ((int64_t)min(GB * ij.y + t, nrtv - 1) * rs2) * 64;
 
     double o[GP][16];
 #pragma unroll
@@ -217,51 +253,66 @@ __global__ __launch_bounds__(256, 1) void tpg_gcls_gram_kernel(const uint4* __re
 #pragma unroll
       for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
 
-    if (b0 < b1) {
-      const int64_t bl = b1 - 1;
+    if (p0 < p1) {
+      const int64_t pl = p1 - 1, bl = bend - 1;
       v4u R[GCLS_D][GA + GB];
-      auto LD = [&](const uint4* p) { return *(const v4u*)p; };
-      // blocks past the range re-fetch the last one
+      // uniform base + one 32-bit lane offset (global_load_dwordx4 v, v_off, s[base]); the empty asm keeps hipcc from
+      // folding the lane into four loop-invariant 64-bit VGPR pointers (8 registers and a v_lshl_add_u64 per load)
+      auto LD = [&](const uint4* p) {
+        uint32_t off = (uint32_t)lane * 16u;
+        asm("" : "+v"(off));
+        return *(const v4u*)((const char*)p + off);
+      };
+      // pairs past the range re-fetch the last one: the loads are issued on every path, because hipcc's s_waitcnt
+      // bookkeeping merges control-flow paths pessimistically and a path without them turns the counted waits of the
+      // whole loop into vmcnt(0)
       tpg_static_for<GCLS_D - 1>([&](auto dd) {
         constexpr int d = decltype(dd)::value;
-        const int64_t bc = b0 + d < b1 ? b0 + d : bl;
+        const int64_t pc = p0 + d < p1 ? p0 + d : pl;
 #pragma unroll
-        for (int t = 0; t < GA + GB; t++) R[d][t] = LD(pt[t] + bc * 64);
+        for (int t = 0; t < GA + GB; t++) R[d][t] = LD(pt[t] + pc * 64);
       });
       bool first = true;
-      // weight of the block with the fold flag in its last bit, fetched one block ahead (a scalar load on the
-      // path of every block would cost its latency every 6 MFMAs)
-      unsigned long long wf_next = wblk[b0];
-      for (int64_t bb = b0; bb < b1; bb += GCLS_D) {
+      unsigned long long wf_next = wblk[2 * p0];
+      for (int64_t pp = p0; pp < p1; pp += GCLS_D) {
         tpg_static_for<GCLS_D>([&](auto cc) {
           constexpr int C = decltype(cc)::value, M = (C + GCLS_D - 1) % GCLS_D;
-          const int64_t b = bb + C;
-          // the loads are issued on every path (a block past the range re-fetches the last one): hipcc's s_waitcnt
-          // bookkeeping merges control-flow paths pessimistically, and a path without them turns the counted waits
-          // of the whole loop into vmcnt(0)
-          const int64_t bn = b + GCLS_D - 1;
-          const int64_t bc = bn < b1 ? bn : bl;
+          const int64_t pr = pp + C;
+          const int64_t pn = pr + GCLS_D - 1;
+          const int64_t pc = pn < p1 ? pn : pl;
 #pragma unroll
-          for (int t = 0; t < GA + GB; t++) R[M][t] = LD(pt[t] + bc * 64);
-          if (b < b1) {
-            const unsigned long long wf = wf_next;
-            wf_next = wblk[b < bl ? b + 1 : bl];
-            if (first) {  // a new class: the accumulators start from zero (an inline constant, no register writes)
-              const v16f z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int t = 0; t < GA + GB; t++) R[M][t] = LD(pt[t] + pc * 64);
+          if (pr < p1) {
 #pragma unroll
-              for (int p = 0; p < GP; p++) acc[p] = MFMA_G4(R[C][p / GB], R[C][GA + p % GB], z);
-            } else {
+            for (int hb = 0; hb < 2; hb++) {
+              const int64_t b = 2 * pr + hb;
+              if (b < bend) {
+                const unsigned long long wf = wf_next;
+                wf_next = wblk[b < bl ? b + 1 : bl];
+                v4u X[GA + GB];
 #pragma unroll
-              for (int p = 0; p < GP; p++) acc[p] = MFMA_G4(R[C][p / GB], R[C][GA + p % GB], acc[p]);
-            }
-            first = false;
-            if ((wf & 1ull) || b == bl) {  // end of the class (or of the range): fold
-              const double w = __longlong_as_double((long long)(wf & ~1ull));
+                for (int t = 0; t < GA + GB; t++) {
+                  const uint32_t w0 = R[C][t][2 * hb], w1 = R[C][t][2 * hb + 1];
+                  X[t] = v4u{w0 & 0x33333333u, (w0 >> 2) & 0x33333333u, w1 & 0x33333333u, (w1 >> 2) & 0x33333333u};
+                }
+                if (first) {
+                  const v16f z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-              for (int p = 0; p < GP; p++)
+                  for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2(X[p / GB], X[GA + p % GB], z);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 16; i++) o[p][i] = __builtin_fma((double)tpg_acc_read(acc[p][i]), w, o[p][i]);
-              first = true;
+                  for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2(X[p / GB], X[GA + p % GB], acc[p]);
+                }
+                first = false;
+                if ((wf & 1ull) || b == bl) {
+                  const double w = __longlong_as_double((long long)(wf & ~1ull));
+#pragma unroll
+                  for (int p = 0; p < GP; p++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) o[p][i] = __builtin_fma((double)acc[p][i], w, o[p][i]);
+                  first = true;
+                }
+              }
             }
           }
         });
@@ -308,14 +359,15 @@ struct GclsBufs {
   }
 };
 
-// cost models (microseconds per wave), fitted on the two kernels at 5 000 x 1 000 000: per tile 0.095 us per class (fold)
-// + 0.043 us per block (operand streaming, not the 0.0175 us of the MFMA itself); digit kernel 1.0 us per 128 loci
+// cost models (microseconds per wave), fitted on the two kernels at n = 5 000 (12.2 ms at 1 000 000 loci, 6.0 ms on a
+// shard of 125 000 loci that holds as many classes): per tile 0.136 us per class (fold) + 0.079 us per block (expansion,
+// MFMA, operand streaming); digit kernel 1.0 us per 128 loci.  S is even: the two halves of the grid take S / 2 splits each.
 static double gcls_cost_classes(int64_t nunits, int64_t nruns, int64_t nblocks, int nwaves, int* bestS) {
   double best = -1;
-  for (int S = 1; S <= 32; S++) {
-    if (nblocks / S < 4 && S > 1) break;
+  for (int S = 2; S <= 32; S += 2) {
+    if (nblocks / S < 4 && S > 2) break;
     const int64_t rounds = ceil_div(nunits * S, (int64_t)nwaves);
-    const double per = ((double)nruns / S + 1.0) * GP * 0.095 + (double)ceil_div(nblocks, (int64_t)S) * GP * 0.043 + 6.0;
+    const double per = ((double)nruns / S + 1.0) * GP * 0.136 + (double)ceil_div(nblocks, (int64_t)S) * GP * 0.079 + 6.0;
     const double cost = (double)rounds * per;
     if (best < 0 || cost < best * 0.995) { best = cost; *bestS = S; }
   }
@@ -365,26 +417,29 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
   const int64_t nruns = totals[0], nblocks = totals[1];
   TPG_REQUIRE(nruns > 0 && nblocks > 0, TPG_EHIP, "class table is empty");
 
-  // units (I, J) that hold at least one wanted pair of row tiles (B tile >= A tile), in patch order
+  // units (I, J) that hold at least one wanted pair of row tiles (J tile >= I tile), in patch order: blocks of 8 J,
+  // inside a block row after row, so that the run of units an XCD takes in one round shares its row tiles
   const int nrtv = (int)ceil_div(n, 32);
   const int nI = (int)ceil_div(nrtv, GA), nJ = (int)ceil_div(nrtv, GB);
   std::vector<int2> order;
-  for (int pj = 0; pj * 8 < nJ; pj++) {
-    const int j1 = std::min(nJ, pj * 8 + 8);
+  const int PJ = 8;
+  for (int pj = 0; pj * PJ < nJ; pj++) {
+    const int j1 = std::min(nJ, pj * PJ + PJ);
     for (int I = 0; I < nI; I++)
-      for (int J = pj * 8; J < j1; J++)
+      for (int J = pj * PJ; J < j1; J++)
         if (GB * J + GB - 1 >= GA * I) order.push_back(make_int2(I, J));
   }
   const int64_t nun = (int64_t)order.size();
-  int nblk_grid = ctx->num_cu / 8 * 8;
-  if (nblk_grid < 8) nblk_grid = 8;
+  int ncu8 = ctx->num_cu / 8 * 8;
+  if (ncu8 < 8) ncu8 = 8;
+  const int nblk_grid = 2 * ncu8;  // two workgroups per CU = two waves per SIMD
   const int nwaves = 4 * nblk_grid;
-  int S = 1;
-  // + the sort, the gather (2.3 us per 1000 loci at n = 5 000: it scales with n m) and the assemble pass
-  const double cost_cls = gcls_cost_classes(nun, nruns, nblocks, nwaves, &S) + 650.0 + 2.3e-3 * (double)m * ((double)n / 5000.0);
+  int S = 2;
+  // + the sort, the gather (2.0 us per 1000 loci at n = 5 000: it scales with n m) and the assemble pass
+  const double cost_cls = gcls_cost_classes(nun, nruns, nblocks, nwaves, &S) + 650.0 + 2.0e-3 * (double)m * ((double)n / 5000.0);
   // the digit kernel: 32 x 128 wave tiles, 64 int8 MFMAs (~1.0 us) per 128 loci, 4 row tiles x super-tiles of 4
   const int64_t nun_dig = (int64_t)nrtv * ceil_div((int64_t)nrtv, 4) / 2 + nrtv;
-  const double cost_dig = (double)ceil_div(nun_dig, (int64_t)nwaves) * ((double)ceil_div(m, 128) * 1.0) + 65.0;
+  const double cost_dig = (double)ceil_div(nun_dig, (int64_t)(4 * ncu8)) * ((double)ceil_div(m, 128) * 1.0) + 65.0;
   if (getenv("TPG_DEBUG"))
     fprintf(stderr, "[tpg] gram classes: %lld classes, %lld blocks for %lld loci, S = %d, model %.0f us (digits %.0f us)\n",
             (long long)nruns, (long long)nblocks, (long long)m, S, cost_cls, cost_dig);
@@ -393,11 +448,12 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
   int32_t* d_src = nullptr;
   double* d_slabs = nullptr;
   unsigned long long* d_wblk = nullptr;
-  uint4* d_T4g = nullptr;
+  uint4* d_T2g = nullptr;
   int2* d_order = nullptr;
   TPG_HIP(B.get(&d_src, (size_t)nblocks * 64));
   TPG_HIP(B.get(&d_wblk, (size_t)nblocks));
-  TPG_HIP(B.get(&d_T4g, (size_t)(4 * v->Q) * (size_t)nblocks * 64));
+  const int64_t rs2 = (nblocks + 1) / 2;  // row-tile stride of T2g: a uint4 per lane and PAIR of blocks
+  TPG_HIP(B.get(&d_T2g, (size_t)(4 * v->Q) * (size_t)rs2 * 64));
   TPG_HIP(B.get(&d_order, (size_t)nun));
   TPG_HIP(B.get(&d_slabs, (size_t)S * (size_t)nun * GCLS_SLAB));
   TPG_HIP(tpg_h2d_async(ctx, d_order, order.data(), sizeof(int2) * (size_t)nun));
@@ -411,13 +467,13 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
                        (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks, d_wblk);
   }
   {
-    const int64_t tasks = v->Q * nblocks;
+    const int64_t tasks = v->Q * rs2;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(tasks, 4), (int64_t)ctx->num_cu * 16);
     TPG_LAUNCH(ctx, "gcls_gather", tpg_gcls_gather_kernel, dim3(grid), dim3(256), 0, (const uint4*)v->L, v->Q,
-               (const int32_t*)d_src, nblocks, d_T4g);
+               (const int32_t*)d_src, nblocks, rs2, d_T2g);
   }
-  TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T4g,
-             nblocks, nrtv, (const unsigned long long*)d_wblk, (const int2*)d_order, nun, S, d_slabs);
+  TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T2g, nblocks,
+             rs2, nrtv, (const unsigned long long*)d_wblk, (const int2*)d_order, nun, S, d_slabs);
   TPG_LAUNCH(ctx, "gcls_assemble", tpg_gcls_assemble_kernel, dim3((unsigned)std::min<int64_t>(nun, 4096)), dim3(256), 0,
              (const double*)d_slabs, (const int2*)d_order, nun, S, (int)n, d_K);
   TPG_CHECK_LAUNCH();
