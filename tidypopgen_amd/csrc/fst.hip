@@ -17,7 +17,10 @@
 // Hudson / WC84 / Nei87), not HBM bound: the counts it reads are 12 B per locus-population.
 #include <math.h>
 
+#include <algorithm>
+
 #include "common.h"
+#include "devfrag.h"
 
 #define FST_NAN __longlong_as_double(0x7FF8000000000000ll)
 
@@ -126,6 +129,32 @@ struct FstSrc {
   const double* h;
 };
 
+// n (valid alleles), freq_alt and het_obs of population g at locus j, as grouped_summaries_dip_pseudo_cpp forms them
+// (src/grouped_summaries_dip_pseudo_cpp.cpp:40-56), from the class counts of the fused path or from the caller's matrices
+__device__ __forceinline__ void fst_stage(const FstSrc& src, int64_t m, int64_t j, int g, double& vn, double& vp, double& vh) {
+  if (src.cnt) {
+    const int64_t plane = src.Mpad * src.Cpad;
+    if (!src.has_hap) {
+      const int64_t o = j * src.Cpad + g;
+      const int n1 = src.cnt[o], n2 = src.cnt[plane + o], nv = src.cnt[2 * plane + o];
+      vn = (double)(2 * nv);
+      vp = (double)(n1 + 2 * n2) / vn;
+      vh = (double)(2 * n1) / vn;
+    } else {
+      const int64_t o = j * src.Cpad + 2 * g;
+      const int n1d = src.cnt[o], n2d = src.cnt[plane + o], nvd = src.cnt[2 * plane + o];
+      const int n1h = src.cnt[o + 1], n2h = src.cnt[plane + o + 1], nvh = src.cnt[2 * plane + o + 1];
+      vn = (double)(2 * nvd + nvh);
+      vp = ((double)(n1d + 2 * n2d) + 0.5 * (double)(n1h + 2 * n2h)) / vn;
+      vh = (double)(2 * (n1d + n1h)) / vn;
+    }
+  } else {
+    vn = src.n[j + (int64_t)g * m];
+    vp = src.p[j + (int64_t)g * m];
+    vh = src.h ? src.h[j + (int64_t)g * m] : 0.0;
+  }
+}
+
 // PPT population pairs per thread (1 or 8): with P > 256 pairs the (n, p, h) staging of a locus chunk is done
 // once per workgroup instead of once per 256 pairs.
 template <int METHOD, bool FAST, int PPT>
@@ -155,29 +184,7 @@ __global__ __launch_bounds__(256) void tpg_fst_kernel(FstSrc src, int64_t m, int
       const int l = idx / G, g = idx % G;
       const int64_t j = j0 + l;
       double vn = FST_NAN, vp = FST_NAN, vh = FST_NAN;
-      if (j < m) {
-        if (src.cnt) {
-          const int64_t plane = src.Mpad * src.Cpad;
-          if (!src.has_hap) {
-            const int64_t o = j * src.Cpad + g;
-            const int n1 = src.cnt[o], n2 = src.cnt[plane + o], nv = src.cnt[2 * plane + o];
-            vn = (double)(2 * nv);
-            vp = (double)(n1 + 2 * n2) / vn;
-            vh = (double)(2 * n1) / vn;
-          } else {
-            const int64_t o = j * src.Cpad + 2 * g;
-            const int n1d = src.cnt[o], n2d = src.cnt[plane + o], nvd = src.cnt[2 * plane + o];
-            const int n1h = src.cnt[o + 1], n2h = src.cnt[plane + o + 1], nvh = src.cnt[2 * plane + o + 1];
-            vn = (double)(2 * nvd + nvh);
-            vp = ((double)(n1d + 2 * n2d) + 0.5 * (double)(n1h + 2 * n2h)) / vn;
-            vh = (double)(2 * (n1d + n1h)) / vn;
-          }
-        } else {
-          vn = src.n[j + (int64_t)g * m];
-          vp = src.p[j + (int64_t)g * m];
-          vh = src.h ? src.h[j + (int64_t)g * m] : 0.0;
-        }
-      }
+      if (j < m) fst_stage(src, m, j, g, vn, vp, vh);
       sh_n[idx] = vn; sh_p[idx] = vp; sh_h[idx] = vh;
       if (METHOD == TPG_FST_HUDSON) sh_e[idx] = (vp * (1 - vp)) / (vn - 1);  // (p q) / (n - 1), once per population
       if (METHOD == TPG_FST_WC84 && FAST) {  // individuals, het_obs * individuals, 1 / individuals
@@ -235,6 +242,193 @@ __global__ __launch_bounds__(256) void tpg_fst_reduce_kernel(const double* __res
   }
 }
 
+// ---------------------------------------------------------------------------
+// Hudson, totals only (no per-locus output), as three masked matrix products over the loci.  With m_g = 1 where the
+// reference keeps the locus for population g (freq and p q / (n - 1) not NaN, src/pairwise_fst_hudson_loop.cpp:43-52 drops a
+// locus for a pair when its numerator or denominator is NaN) and a_g = m_g (p_g^2 - e_g), b_g = m_g, c_g = m_g p_g:
+//     sum_j num = sum_j m_1 m_2 [(p_1 - p_2)^2 - e_1 - e_2] = (A B')[g1,g2] + (A B')[g2,g1] - 2 (C C')[g1,g2]
+//     sum_j den = sum_j m_1 m_2 [p_1 q_2 + p_2 q_1]         = (C B')[g1,g2] + (C B')[g2,g1] - 2 (C C')[g1,g2]
+// i.e. 3 x 2 G^2 flops per locus instead of ~12 per population pair and locus with 8 LDS reads each: 64 x 64 populations per
+// workgroup, a 4 x 4 block of (g1, g2) and 48 FP64 sums per thread, operands staged once per chunk of loci in LDS.  The
+// sums are formed in another order than the reference's (and than the by-locus path's, which stays statement for
+// statement): the totals agree to ~1e-14 relative.
+#define FSTG_T 64   // populations per tile side
+#define FSTG_LB 32  // loci per staged chunk
+__global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_kernel(FstSrc src, int64_t m, int G, int ntile,
+                                                                  double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* ra = sh;                          // [l][64] a of the row populations
+  double* rc = sh + FSTG_LB * FSTG_T;       // c of the row populations
+  double* cb = sh + 2 * FSTG_LB * FSTG_T;   // b of the column populations
+  const int tR = blockIdx.y / ntile, tC = blockIdx.y % ntile;
+  const bool diag = tR == tC;
+  double* cc = diag ? rc : sh + 3 * FSTG_LB * FSTG_T;  // c of the column populations
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  double AB[4][4], CB[4][4], CC[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) { AB[r][c] = 0.0; CB[r][c] = 0.0; CC[r][c] = 0.0; }
+  const int64_t nchunks = (m + FSTG_LB - 1) / FSTG_LB;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t j0 = ch * FSTG_LB;
+    __syncthreads();
+    // a tile on the diagonal (always, up to 64 populations) stages its populations once: rows and columns are the same
+    for (int idx = threadIdx.x; idx < (diag ? 1 : 2) * FSTG_LB * FSTG_T; idx += 256) {
+      const int side = idx / (FSTG_LB * FSTG_T), rem = idx % (FSTG_LB * FSTG_T);
+      const int l = rem / FSTG_T, gl = rem % FSTG_T;
+      const int g = (side ? tC : tR) * FSTG_T + gl;
+      const int64_t j = j0 + l;
+      double a = 0.0, b = 0.0, c = 0.0;
+      if (j < m && g < G) {
+        double vn, vp, vh;
+        fst_stage(src, m, j, g, vn, vp, vh);
+        const double e = (vp * (1 - vp)) / (vn - 1);  // src/pairwise_fst_hudson_loop.cpp:28-29
+        if (vp == vp && e == e) { a = vp * vp - e; b = 1.0; c = vp; }
+      }
+      if (side) { cb[rem] = b; cc[rem] = c; }
+      else {
+        ra[rem] = a; rc[rem] = c;
+        if (diag) cb[rem] = b;
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int l = 0; l < FSTG_LB; l++) {
+      const v4d a4 = *(const v4d*)&ra[l * FSTG_T + 4 * ty], c4 = *(const v4d*)&rc[l * FSTG_T + 4 * ty];
+      const v4d b4 = *(const v4d*)&cb[l * FSTG_T + 4 * tx], d4 = *(const v4d*)&cc[l * FSTG_T + 4 * tx];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          AB[r][c] = fma(a4[r], b4[c], AB[r][c]);
+          CB[r][c] = fma(c4[r], b4[c], CB[r][c]);
+          CC[r][c] = fma(c4[r], d4[c], CC[r][c]);
+        }
+    }
+  }
+  // partial sums of this workgroup: [block x][tile][product][row][col]
+  double* o = part + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 3) * FSTG_T * FSTG_T;
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int q = (4 * ty + r) * FSTG_T + 4 * tx + c;
+      o[q] = AB[r][c];
+      o[FSTG_T * FSTG_T + q] = CB[r][c];
+      o[2 * FSTG_T * FSTG_T + q] = CC[r][c];
+    }
+}
+
+// full[tile][product][row][col] = sum over the workgroups' partials, in workgroup order (the same sums on every run)
+__global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_reduce_kernel(const double* __restrict__ part, int nbx, int64_t cells,
+                                                                         double* __restrict__ full) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= cells) return;
+  double s = 0.0;
+  for (int b = 0; b < nbx; b++) s += part[(int64_t)b * cells + q];
+  full[q] = s;
+}
+
+__global__ void tpg_fst_hudson_gemm_final_kernel(const double* __restrict__ full, int ntile, const int32_t* __restrict__ pairs0, int P,
+                                                 double* __restrict__ fst_tot, double* __restrict__ sum_num,
+                                                 double* __restrict__ sum_den) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= P) return;
+  const int g1 = pairs0[2 * pi], g2 = pairs0[2 * pi + 1];
+  auto at = [&](int prod, int r, int c) {
+    const int t = (r / FSTG_T) * ntile + c / FSTG_T;
+    return full[(((int64_t)t * 3 + prod) * FSTG_T + r % FSTG_T) * FSTG_T + c % FSTG_T];
+  };
+  const double cc2 = 2 * at(2, g1, g2);
+  const double sn = at(0, g1, g2) + at(0, g2, g1) - cc2, sd = at(1, g1, g2) + at(1, g2, g1) - cc2;
+  if (fst_tot) fst_tot[pi] = sn / sd;
+  if (sum_num) { sum_num[pi] = sn; sum_den[pi] = sd; }
+}
+
+// ---------------------------------------------------------------------------
+// WC84, totals only, on the class counts of the fused path.  The estimator is the FAST form of fst_terms above; what
+// is new is where the reciprocals come from.  Everything in it that depends on the sample sizes ALONE depends on the
+// number of valid alleles of the pair, A = A_1 + A_2 -- a small integer (at most four times the largest group) -- so
+// 1 / nt, 1 / nt^2, (nt - 1) / (2 nt), nt / (2 (nt / 2 - 1)) and nt^2 / (4 (nt / 2 - 1)) (nt = A / 2 individuals) are
+// tabulated once per workgroup by IEEE divisions (closer to the reference than v_rcp_f64 + Newton steps) and a pair
+// and locus costs ~27 FP64 instructions and three 16-byte table reads instead of ~60 instructions.
+// Staged per (locus, population) as four doubles {individuals, freq_alt, het_obs * individuals, 1 / individuals}.
+#define FSTW_TAB 6  // doubles per table entry
+template <int PPT>
+__global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64_t m, int G, int LB, int kmax,
+                                                               const int32_t* __restrict__ pairs0, int P,
+                                                               double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* st = sh;                                   // [l][g][4]
+  double* tab = sh + (size_t)LB * G * 4;             // [A][FSTW_TAB]
+  int* shA = (int*)(tab + (size_t)(kmax + 1) * FSTW_TAB);  // [l][g] valid alleles
+  for (int A = threadIdx.x; A <= kmax; A += 256) {
+    const double nt = 0.5 * (double)A, nb1 = 0.5 * nt - 1.0;
+    const double r = 1.0 / nt, sv = 1.0 / nb1;  // nb1 = 0 (one individual per population): +inf, as the reference's 1 / 0
+    double* t = tab + (size_t)A * FSTW_TAB;
+    t[0] = r;
+    t[1] = r * r;
+    t[2] = (0.5 * (nt - 1.0)) * r;
+    t[3] = (0.5 * nt) * sv;
+    t[4] = (0.25 * (nt * nt)) * sv;
+    t[5] = 0.0;
+  }
+  int pidx[PPT], g1[PPT], g2[PPT];
+  double sum_num[PPT], sum_den[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; k++) {
+    pidx[k] = (blockIdx.y * PPT + k) * 256 + threadIdx.x;
+    g1[k] = 0; g2[k] = 0;
+    if (pidx[k] < P) { g1[k] = pairs0[2 * pidx[k]]; g2[k] = pairs0[2 * pidx[k] + 1]; }
+    sum_num[k] = 0.0; sum_den[k] = 0.0;
+  }
+  const int64_t nchunks = (m + LB - 1) / LB;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t j0 = ch * LB;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < LB * G; idx += 256) {
+      const int l = idx / G, g = idx % G;
+      const int64_t j = j0 + l;
+      double vn = 0.0, vp = FST_NAN, vh = FST_NAN;
+      if (j < m) fst_stage(src, m, j, g, vn, vp, vh);
+      const double ni = 0.5 * vn;
+      *(v4d*)&st[4 * idx] = v4d{ni, vp, vh * ni, 1.0 / ni};
+      shA[idx] = (int)vn;
+    }
+    __syncthreads();
+    const int lmax = (int)((m - j0) < LB ? (m - j0) : LB);
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      if (pidx[k] >= P) continue;
+#pragma unroll 2
+      for (int l = 0; l < lmax; l++) {
+        const int o1 = l * G + g1[k], o2 = l * G + g2[k];
+        const v4d s1 = *(const v4d*)&st[4 * o1], s2 = *(const v4d*)&st[4 * o2];  // {n, p, H, e}
+        const int A = min(shA[o1] + shA[o2], kmax);
+        const double* t = tab + (size_t)A * FSTW_TAB;
+        const double2 t01 = *(const double2*)t, t23 = *(const double2*)(t + 2);
+        const double t4 = t[4];
+        const double p_bar = fma(s2[1], s2[0], s1[1] * s1[0]) * t01.x, h_bar = (s1[2] + s2[2]) * t01.x;
+        const double d = s1[1] - s2[1], d2 = d * d;
+        const double half_s2 = (d2 * (s1[0] * s2[0])) * t01.y;
+        const double core = fma(-p_bar, p_bar, p_bar) - half_s2;
+        const double X = t4 * (s1[3] * s2[3]);
+        const double a = fma(-X, fma(-0.25, h_bar, core), 0.5 * d2);
+        const double b = t23.y * fma(-t23.x, h_bar, core);
+        const double den = fma(0.5, h_bar, a + b);
+        if (den == den) { sum_num[k] += a; sum_den[k] += den; }  // a NaN numerator makes the denominator NaN too
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PPT; k++)
+    if (pidx[k] < P) {
+      part[((int64_t)blockIdx.x * P + pidx[k]) * 2] = sum_num[k];
+      part[((int64_t)blockIdx.x * P + pidx[k]) * 2 + 1] = sum_den[k];
+    }
+}
+
 // flag[0] = 1 if some freq_ref entry is not exactly 1 - freq_alt (NaN matches NaN)
 __global__ void tpg_freq_ref_check_kernel(const double* __restrict__ p, const double* __restrict__ q, int64_t total,
                                           int* __restrict__ flag) {
@@ -246,7 +440,7 @@ __global__ void tpg_freq_ref_check_kernel(const double* __restrict__ p, const do
 
 static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const int32_t* pairs1, int P, int by_locus,
                    int return_num_dem, double* fst_tot, double* out_a, double* out_b, double* sum_num = nullptr,
-                   double* sum_den = nullptr) {
+                   double* sum_den = nullptr, int kmax = 0 /* valid alleles of a pair at most (0: unknown) */) {
   TPG_REQUIRE(method == TPG_FST_HUDSON || method == TPG_FST_NEI87 || method == TPG_FST_WC84, TPG_EINVAL,
               "unknown Fst method %d", method);
   TPG_REQUIRE(P > 0 && pairs1, TPG_EINVAL, "no population pairs");
@@ -267,6 +461,32 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   TPG_REQUIRE((size_t)LB * G * 4 * sizeof(double) <= 150 * 1024, TPG_EUNSUPPORTED, "too many populations (%d)", G);
   const size_t shmem = (size_t)LB * G * 4 * sizeof(double);
   const bool fast = !by_locus;  // exact statement order whenever per-locus values are returned
+  if (fast && method == TPG_FST_HUDSON) {  // totals only: three masked matrix products over the loci
+    const int ntile = (int)ceil_div(G, FSTG_T);
+    const int64_t cells = (int64_t)ntile * ntile * 3 * FSTG_T * FSTG_T;
+    const int64_t nch = ceil_div(m, FSTG_LB);
+    int nbx = (int)std::min<int64_t>(nch, std::max(1, 2 * ctx->num_cu / (ntile * ntile)));
+    OutBuf ot, osn, osd;
+    if (fst_tot) TPG_TRY(ot.init(fst_tot, sizeof(double) * (size_t)P));
+    if (sum_num) { TPG_TRY(osn.init(sum_num, sizeof(double) * (size_t)P)); TPG_TRY(osd.init(sum_den, sizeof(double) * (size_t)P)); }
+    double* d_gp = nullptr;
+    TPG_HIP(tpg_pmalloc((void**)&d_gp, sizeof(double) * (size_t)cells * (size_t)(nbx + 1)));
+    double* d_full = d_gp + (size_t)cells * (size_t)nbx;
+    const size_t shg = sizeof(double) * 4 * FSTG_LB * FSTG_T;
+    (void)hipFuncSetAttribute((const void*)tpg_fst_hudson_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shg);
+    TPG_LAUNCH(ctx, "fst_hudson", tpg_fst_hudson_gemm_kernel, dim3((unsigned)nbx, (unsigned)(ntile * ntile)), dim3(256), shg, src, m, G,
+               ntile, d_gp);
+    TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_hudson_gemm_reduce_kernel, dim3((unsigned)ceil_div(cells, 256)), dim3(256), 0,
+               (const double*)d_gp, nbx, cells, d_full);
+    TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_hudson_gemm_final_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, (const double*)d_full,
+               ntile, pb.dev<int32_t>(), P, ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
+    hipError_t e = hipGetLastError();
+    tpg_pfree(d_gp);  // stream-ordered
+    if (e != hipSuccess) { tpg_set_error("fst kernels: %s", hipGetErrorString(e)); return TPG_EHIP; }
+    if (fst_tot) TPG_TRY(ot.commit(ctx));
+    if (sum_num) { TPG_TRY(osn.commit(ctx)); TPG_TRY(osd.commit(ctx)); }
+    return TPG_OK;
+  }
   const int64_t nchunks = ceil_div(m, LB);
   const int ppt = P > 256 ? 8 : 1;
   const int ypass = (int)ceil_div(P, 256 * ppt);
@@ -281,7 +501,22 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   if (rc == TPG_OK && fst_tot) rc = ot.init(fst_tot, sizeof(double) * (size_t)P);
   if (rc == TPG_OK && by_locus) rc = oa.init(out_a, mp);
   if (rc == TPG_OK && return_num_dem) rc = ob.init(out_b, mp);
-  if (rc == TPG_OK) {
+  const size_t sh_tab = sizeof(double) * ((size_t)LB * G * 4 + (size_t)(kmax + 1) * FSTW_TAB) + sizeof(int) * (size_t)LB * G;
+  const bool wc84_tab = fast && method == TPG_FST_WC84 && src.cnt && !src.has_hap && kmax > 0 && sh_tab <= 150 * 1024;
+  if (rc == TPG_OK && wc84_tab) {  // reciprocals by table: see tpg_fst_wc84_tab_kernel
+    dim3 grid((unsigned)nblocks, (unsigned)ypass);
+    if (ppt == 8) {
+      (void)hipFuncSetAttribute((const void*)tpg_fst_wc84_tab_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_tab);
+      TPG_LAUNCH(ctx, "fst_wc84", (tpg_fst_wc84_tab_kernel<8>), grid, dim3(256), sh_tab, src, m, G, LB, kmax, pb.dev<int32_t>(), P, d_part);
+    } else {
+      (void)hipFuncSetAttribute((const void*)tpg_fst_wc84_tab_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_tab);
+      TPG_LAUNCH(ctx, "fst_wc84", (tpg_fst_wc84_tab_kernel<1>), grid, dim3(256), sh_tab, src, m, G, LB, kmax, pb.dev<int32_t>(), P, d_part);
+    }
+    TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 16)), dim3(256), 0, d_part, nblocks, P,
+               ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { tpg_set_error("fst kernels: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
+  } else if (rc == TPG_OK) {
     dim3 grid((unsigned)nblocks, (unsigned)ypass);
 #define FST_LAUNCH1(M, F, PP, NAME)                                                                              \
   do {                                                                                                           \
@@ -375,8 +610,12 @@ static int fused_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, 
   GroupedCounts gc;
   TPG_TRY(tpg_grouped_counts(ctx, v, cls.data(), ngroups * (has_hap ? 2 : 1), &gc));
   FstSrc src{gc.cnt, gc.Mpad, gc.Cpad, has_hap, nullptr, nullptr, nullptr, nullptr};
+  // the valid alleles of a pair of populations never exceed four times the largest group
+  std::vector<int64_t> gsize((size_t)ngroups, 0);
+  for (int64_t i = 0; i < v->n; i++) gsize[(size_t)groupIds0[i]]++;
+  const int64_t kmax = 4 * *std::max_element(gsize.begin(), gsize.end());
   return run_fst(ctx, method, src, v->m, ngroups, pairs1, P, by_locus, return_num_dem, fst_tot, out_a, out_b, sum_num,
-                 sum_den);
+                 sum_den, kmax < (1 << 20) ? (int)kmax : 0);
 }
 
 extern "C" int tpg_pairwise_pop_fst(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupIds0, int ngroups,
