@@ -12,8 +12,11 @@ the device generator, tests/test_gpu_parity.py::test_synth_matches_host) and res
   * Hudson / WC84 by locus for 5 population pairs x ALL loci bit-identical, totals <= 1e-12;
   * alt_freq, missingness and grouped_alt_freq (all 51 groups) on 30 000 sampled loci bit-exact, read out of the
     whole-panel device result;
-  * PCA: numpy.linalg.eigvalsh of the device Gram matrix vs d^2 (<= 1e-9), the Gram sub-block of the 64 individuals
-    vs an FP64 numpy Gram over all loci (<= 1e-6 of its scale), center / scale vs the counts.
+  * PCA: numpy.linalg.eigh (LAPACK) of the device Gram matrix vs d^2 (<= 1e-9) and vs u (sign-aligned, 1e-6 where the
+    spectral gap allows), four 64 x 64 sub-blocks of the Gram matrix (spread sample, the partial last row tile, a middle
+    tile, the first tile edges) vs an FP64 numpy Gram over all loci (<= 1e-6 of its scale), center / scale vs the counts,
+    the loadings v on 30 000 sampled loci vs FP64 Z'u / d from oracle-generated columns (<= 1e-9), and
+    fbm256_prod_and_rowSumsSq at full size vs a numpy restatement for the 64 sampled individuals over all loci (<= 1e-9).
 """
 import math
 
@@ -131,6 +134,16 @@ def _check_fst_sample(tpg, orc, X, seed, n, m):
             assert np.allclose(s["fst_tot"], exact, rtol=1e-11, atol=0), (method, s["fst_tot"] / exact - 1)
 
 
+def _fp64_gram_of_rows(orc, seed, rows, m, keep, center, scale):
+    """Z Z' of a few individuals over all kept loci in FP64 numpy, from oracle-generated rows"""
+    sub = orc.CODE_IMPUTE_PRED[orc.synth_rows(seed, rows, m, npop=G, miss=0.02, imputed_bytes=True)][:, keep]
+    Ks = np.zeros((len(rows), len(rows)))
+    for a in range(0, sub.shape[1], 65536):
+        Z = (sub[:, a:a + 65536] - center[a:a + 65536]) / scale[a:a + 65536]
+        Ks += Z @ Z.T
+    return Ks, sub
+
+
 def _check_pca_sample(tpg, orc, X, seed, n, m, k):
     rows = _sample_rows(n)
     vi = tpg.View(X, code256=tpg.CODE_IMPUTE_PRED)
@@ -148,19 +161,59 @@ def _check_pca_sample(tpg, orc, X, seed, n, m, k):
     assert np.allclose(r["scale"], scale, rtol=1e-15, atol=0)
     vv = tpg.View(X, None, cols, code256=tpg.CODE_IMPUTE_PRED)
     K = tpg.pca_gram(vv, r["center"], r["scale"])
-    lam = np.linalg.eigvalsh(K)[::-1][:k]
+    # eigenvalues AND eigenvectors of the device Gram matrix by LAPACK (numpy.linalg.eigh) against d^2 and u
+    lam_all, U_all = np.linalg.eigh(K)
+    lam, U = lam_all[::-1][:k], U_all[:, ::-1][:, :k]
     assert np.allclose(r["d"] ** 2, lam, rtol=1e-9, atol=0)
-    # FP64 Gram of the 64 sampled individuals over all kept loci
-    sub = orc.CODE_IMPUTE_PRED[orc.synth_rows(seed, rows, m, npop=G, miss=0.02, imputed_bytes=True)][:, keep]
-    Ks = np.zeros((64, 64))
-    for a in range(0, sub.shape[1], 65536):
-        Z = (sub[:, a:a + 65536] - center[a:a + 65536]) / scale[a:a + 65536]
-        Ks += Z @ Z.T
-    Kd = K[np.ix_(rows, rows)]
-    assert np.abs(Kd - Ks).max() <= 1e-6 * np.abs(Ks).max()
-    assert np.allclose(np.diag(Kd), np.diag(Ks), rtol=1e-6)
-    # scores: u d = Z v through the independent FP64 sweep, and u spans eigenvectors of K
+    gaps = np.minimum(np.abs(np.diff(lam_all[::-1][:k + 1])), np.abs(np.diff(np.concatenate([[np.inf], lam]))))
+    sign = np.sign((U * r["u"]).sum(axis=0))
+    du = np.abs(r["u"] - U * sign).max(axis=0)
+    # an eigenvector is determined up to (residual) / (gap to its neighbours): 1e-6 wherever the gap allows it
+    tol_u = np.maximum(1e-6, 1e-10 * lam[0] / gaps)
+    assert np.all(du <= tol_u), (du, tol_u)
+    # the Gram matrix itself against FP64 numpy over ALL kept loci on four 64 x 64 sub-blocks: the spread sample, the
+    # last 64 rows (the partial last row tile), a tile-aligned run in the middle, and rows around the first tile edges
+    mid = (n // 2) // 64 * 64
+    row_sets = [rows, np.arange(n - 64, n), np.arange(mid, mid + 64), np.arange(17, 17 + 64)]
+    sub0 = None
+    for rs in row_sets:
+        rs = np.asarray(rs, dtype=np.int64)
+        Ks, sub = _fp64_gram_of_rows(orc, seed, rs, m, keep, center, scale)
+        if sub0 is None:
+            sub0 = sub
+        Kd = K[np.ix_(rs, rs)]
+        assert np.abs(Kd - Ks).max() <= 1e-6 * np.abs(Ks).max()
+        assert np.allclose(np.diag(Kd), np.diag(Ks), rtol=1e-6)
+    # u spans eigenvectors of K
     assert np.abs(K @ r["u"] - r["u"] * r["d"] ** 2).max() <= 1e-9 * r["d"][0] ** 2
+    del K, U_all
+    # loadings v = Z'u / d (R/gt_pca_partialSVD.R:82-89 via big_SVD) on 30 blocks of 1 000 loci, from oracle-generated
+    # columns in FP64 numpy with the (LAPACK-checked) device u
+    kept_index = np.cumsum(keep) - 1  # locus -> row of v
+    width = 1000
+    starts = np.linspace(0, m - width, 30).astype(np.int64)
+    starts[1:-1] += 37
+    vmax = np.abs(r["v"]).max()
+    for j0 in starts:
+        blk = orc.CODE_IMPUTE_PRED[orc.synth_fbm(seed, n, width, j0=int(j0), npop=G, miss=0.02, imputed_bytes=True)]
+        kb = keep[j0:j0 + width]
+        ji = kept_index[j0:j0 + width][kb]
+        Z = (blk[:, kb] - center[ji]) / scale[ji]
+        v_ref = (Z.T @ r["u"]) / r["d"]
+        assert np.abs(r["v"][ji] - v_ref).max() <= 1e-9 * vmax, int(j0)
+    # fbm256_prod_and_rowSumsSq at full size (src/fbm_prod_and_rowSumSq.cpp:30-44: XV[i,k] = sum_j z_ij V[j,k],
+    # rss[i] = sum_j z_ij^2, missing -> 0) against numpy on the 64 sampled individuals over ALL kept loci
+    XV, rss = tpg.fbm256_prod_and_rowSumsSq(X, None, cols, center, scale, r["v"], code256=tpg.CODE_IMPUTE_PRED)
+    XV_ref = np.zeros((64, k))
+    rss_ref = np.zeros(64)
+    for a in range(0, sub0.shape[1], 65536):
+        Z = (sub0[:, a:a + 65536] - center[a:a + 65536]) / scale[a:a + 65536]
+        XV_ref += Z @ r["v"][a:a + 65536]
+        rss_ref += (Z * Z).sum(axis=1)
+    assert np.abs(XV[rows] - XV_ref).max() <= 1e-9 * np.abs(XV_ref).max()
+    assert np.allclose(rss[rows], rss_ref, rtol=1e-10)
+    # and X V = u d (the SVD relation) for everybody
+    assert np.abs(XV - r["u"] * r["d"]).max() <= 1e-8 * r["d"][0]
     return r
 
 
