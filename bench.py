@@ -239,6 +239,57 @@ def _e2e_file(st):
     return None
 
 
+def _e2e_bed_file(st, dirname):
+    """the resident panel as a PLINK .bed payload (SNP-major, 2 bits per genotype, 3-byte magic): imputed genotypes where
+    the panel has them -- a .bed cannot mark a genotype as imputed, so this is the file the imputed data set would be
+    exported as (no missing genotypes; R/gen_tibble_bed.R:101-125 reads such a file into an FBM through bigsnpr)"""
+    n, m = st.args.n, st.m
+    lut = np.array([3, 2, 0, 1], dtype=np.uint8)  # dosage 0, 1, 2, missing -> .bed code (11, 10, 00, 01)
+    path = os.path.join(dirname, f"tpg_bench_{os.getpid()}.bed")
+    host = st.X.to_numpy()
+    with open(path, "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]))
+        pad = (-n) % 4
+        for c0 in range(0, m, 65536):
+            blk = host[:, c0:c0 + 65536]
+            code = lut[np.where(blk > 3, blk - 4, blk)].T  # loci x individuals
+            if pad:
+                code = np.concatenate([code, np.zeros((code.shape[0], pad), dtype=np.uint8)], axis=1)
+            q = code.reshape(code.shape[0], -1, 4)
+            f.write((q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8).tobytes())
+    return path
+
+
+def _e2e_bed(st, path):
+    """.bed file -> HBM as it is (n m / 4 bytes, 4x fewer than the .bk route) -> the step -> every result in host memory"""
+    tpg, api, lib, ctx, a = st.tpg, st.api, st.lib, st.ctx, st.args
+    chk = tpg._lib.check
+    n, m, k = a.n, st.m, a.k
+    resident = st.X
+    try:
+        t0 = time.perf_counter()
+        st.X = tpg.FBM.open_bed(path, n, m, ctx=ctx, code256=tpg.CODE_012)
+        ctx.sync()
+        t_up = time.perf_counter()
+        st.run()
+        t_run = time.perf_counter()
+        host = {}
+        down = _e2e_download(st, ctx, st.d_nn, [st.d_freq], [st.d_gfreq], [m], host)
+        u = np.empty((n, k), order="F")
+        chk(lib.tpg_dev_to_host(ctx.h, api._ptr(u), st.d_pca["u"], C.c_size_t(u.nbytes)))
+        vl = np.empty((st.m_pca, k), order="F")
+        chk(lib.tpg_dev_to_host(ctx.h, api._ptr(vl), st.d_pca["v"], C.c_size_t(vl.nbytes)))
+        t1 = time.perf_counter()
+        down += u.nbytes + vl.nbytes
+        up = os.path.getsize(path)
+        return {"value": n * m / (t1 - t0), "seconds": t1 - t0, "upload_s": t_up - t0, "step_s": t_run - t_up,
+                "download_s": t1 - t_run, "upload_GBps": up / (t_up - t0) / 1e9, "bytes_up": up, "bytes_down": down,
+                "pca_d_max_rel_diff_vs_bk_route": None}
+    finally:
+        st.X.free()
+        st.X = resident
+
+
 def _e2e_download(st, ctx, d_nn, d_freq_blocks, d_gfreq_blocks, mbs, host):
     """results -> host memory (IBS / KING / GRM, per-locus and grouped frequencies)"""
     api, lib, chk = st.api, st.lib, st.tpg._lib.check
@@ -421,18 +472,35 @@ def end_to_end(st):
     path = _e2e_file(st)
     if path is None:
         return {"skipped": "no room for the backing file"}
+    bed_path = None
     try:
         ser = _e2e_serial(st, path)
+        d_bk = st.pca_d.copy()
         ovl = _e2e_overlapped(st, path)
-        return {"value": ovl["value"], "unit": "SNP-genotypes/s", "seconds": ovl["seconds"],
-                "route": "bigstatsr .bk (1 byte per genotype, warm page cache) -> HBM in 8 locus blocks uploaded by a second "
-                         "thread / stream beside pack + accumulate -> all results in host memory",
-                "overlapped": ovl, "serial": ser}
-    finally:
+        out = {"value": ovl["value"], "unit": "SNP-genotypes/s", "seconds": ovl["seconds"],
+               "route": "bigstatsr .bk (1 byte per genotype, warm page cache) -> HBM in 8 locus blocks uploaded by a second "
+                        "thread / stream beside pack + accumulate -> all results in host memory",
+               "overlapped": ovl, "serial": ser}
+        os.remove(path)  # room for the .bed
         try:
-            os.remove(path)
-        except OSError:
-            pass
+            bed_path = _e2e_bed_file(st, os.path.dirname(path))
+            bed = _e2e_bed(st, bed_path)
+            # the .bed holds the imputed genotypes, so its PCA is the PCA of the .bk route (the pairwise statistics see
+            # no missing genotype there, which is a different input: not compared)
+            bed["pca_d_max_rel_diff_vs_bk_route"] = float(np.max(np.abs(st.pca_d / d_bk - 1))) if st.has_pca else None
+            bed["route"] = ("PLINK .bed of the imputed panel (2 bits per genotype, warm page cache) -> HBM as it is -> "
+                            "pack from the .bed bytes -> the step -> all results in host memory (serial)")
+            out["bed"] = bed
+        except (OSError, MemoryError) as e:
+            out["bed"] = {"skipped": f"{type(e).__name__}: {e}"}
+        return out
+    finally:
+        for p_ in (path, bed_path):
+            try:
+                if p_:
+                    os.remove(p_)
+            except OSError:
+                pass
 
 
 def cpu_baseline(args):

@@ -363,10 +363,11 @@ int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* center, const do
  * the genotypes in blocks of loci; tpg_sym_eig_topk and tpg_pca_loadings finish the SVD */
 int tpg_pca_gram_add(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale, double* K);
 /* full partial SVD: d[k], u n x k, v m x k, center[m], scale[m]; square_frobenius may be NULL
- * (R/square_frobenius.R:19-35).  k <= 52 (the eigen solver works on a block of 2k + 12 <= 64 vectors). */
+ * (R/square_frobenius.R:19-35).  Any k <= n (the eigen solver works on a block of at most 64 vectors: beyond 52
+ * components the spectrum is taken in batches of 26 with explicit deflation in between). */
 int tpg_pca_partial_svd(tpg_ctx* ctx, const tpg_view* v, int k, double* d, double* u, double* vload,
                         double* center, double* scale, double* square_frobenius);
-/* gt_pca_randomSVD (R/gt_pca_randomSVD.R:77-135; k <= 52 as above): the same truncated SVD accepted at the
+/* gt_pca_randomSVD (R/gt_pca_randomSVD.R:77-135): the same truncated SVD accepted at the
  * relative residual `tol` of the reference's big_randomSVD / RSpectra path (default there 1e-4):
  * |K u_j - d_j^2 u_j| <= tol * d_1^2 for every returned pair. */
 int tpg_pca_random_svd(tpg_ctx* ctx, const tpg_view* v, int k, double tol, double* d, double* u, double* vload,

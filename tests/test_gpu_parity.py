@@ -982,3 +982,55 @@ def test_view_pair_layouts_serve_every_consumer(tpg, n, m, subset):
     with _env(TPG_GRAM_DIGITS="1", TPG_GRAM_CLASSES=None):
         assert np.array_equal(tpg.pca_gram(vb2, center, scale), tpg.pca_gram(sb2, center, scale))
     assert np.array_equal(va.unpack(), sa.unpack()) and np.array_equal(vb.unpack(), sb.unpack())
+
+
+def test_pca_more_than_52_components(tpg):
+    """k is free in the reference (R/gt_pca_partialSVD.R:70-89).  Beyond 52 components the eigen step runs in batches of
+    26 with explicit deflation: d against LAPACK, u orthonormal and an eigenbasis of the device Gram, v = Z'u / d."""
+    n, m, k = 300, 4000, 100
+    fbm = orc.synth_fbm(73, n, m, npop=6, miss=0.02, imputed_bytes=True)
+    dec = np.where(fbm > 3, fbm - 4, fbm)
+    cols = (np.where((dec.sum(axis=0) > 0) & (dec.sum(axis=0) < 2 * n))[0] + 1).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    o = orc.gt_pca_partialSVD(fbm, None, cols, k=k)
+    r = tpg.gt_pca_partialSVD(X, None, cols, k=k)
+    assert np.allclose(r["d"], o["d"], rtol=1e-6, atol=0)
+    assert np.all(np.diff(r["d"]) <= 0)
+    assert np.abs(r["u"].T @ r["u"] - np.eye(k)).max() <= 1e-9
+    v = tpg.View(X, None, cols, code256=tpg.CODE_IMPUTE_PRED)
+    K = tpg.pca_gram(v, r["center"], r["scale"])
+    assert np.abs(K @ r["u"] - r["u"] * r["d"] ** 2).max() <= 1e-9 * r["d"][0] ** 2
+    Z = (dec[:, cols - 1] - r["center"]) / r["scale"]
+    assert np.abs(r["v"] - (Z.T @ r["u"]) / r["d"]).max() <= 1e-9 * np.abs(r["v"]).max()
+    # the leading scores are the oracle's (the trailing ones sit in the bulk of the spectrum, where vectors of close
+    # eigenvalues mix: compared as a subspace)
+    so, sr = o["u"][:, :20] * o["d"][:20], _align_sign(r["u"][:, :20] * r["d"][:20], o["u"][:, :20] * o["d"][:20])
+    assert np.max(np.abs(sr - so)) <= 1e-6 * np.max(np.abs(so))
+    P_o, P_r = o["u"] @ o["u"].T, r["u"] @ r["u"].T
+    gap = (o["d"][k - 1] ** 2 - np.linalg.eigvalsh(K)[::-1][k]) / o["d"][0] ** 2
+    assert np.abs(P_o - P_r).max() <= 1e-9 / gap
+    lam, U = tpg.sym_eig_topk(K, 60)  # the stand-alone entry point takes the batched route too
+    assert np.allclose(lam, o["d"][:60] ** 2, rtol=1e-9)
+
+
+def test_code_dosage_table_is_accepted_when_no_dosage_byte_occurs(tpg):
+    """bigsnpr's CODE_DOSAGE (bytes 7 .. 207 = 0.00 .. 2.00) is one of the two tables gt_uses_imputed accepts
+    (R/gt_has_imputed.R:54-55).  tidypopgen's own imputations only ever write bytes 4 .. 6, for which it decodes like
+    CODE_IMPUTE_PRED: same results; an FBM that does hold a fractional dosage is refused, not rounded."""
+    code_dosage = np.full(256, np.nan)
+    code_dosage[:3] = [0, 1, 2]
+    code_dosage[4:7] = [0, 1, 2]
+    code_dosage[7:208] = np.round(np.arange(201) * 0.01, 2)
+    n, m = 120, 1500
+    fbm = orc.synth_fbm(74, n, m, npop=3, miss=0.05, imputed_bytes=True)
+    X = tpg.FBM.from_numpy(fbm)
+    a = tpg.loci_alt_freq(tpg.FBM.from_numpy(fbm, code256=code_dosage))
+    b = tpg.loci_alt_freq(tpg.FBM.from_numpy(fbm, code256=tpg.CODE_IMPUTE_PRED))
+    assert np.array_equal(a, b)
+    va, vb = tpg.View(X, code256=code_dosage), tpg.View(X, code256=tpg.CODE_IMPUTE_PRED)
+    assert np.array_equal(va.unpack(), vb.unpack())
+    bad = fbm.copy(order="F")
+    bad[5, 7] = 57  # dosage 0.50
+    with pytest.raises(tpg._lib.TpgError) as e:
+        tpg.View(tpg.FBM.from_numpy(bad), code256=code_dosage)
+    assert e.value.code == 3

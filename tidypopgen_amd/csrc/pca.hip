@@ -1539,6 +1539,54 @@ static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_
                                const double* d_U, const double* d_dk, int k, double* d_V);
 
 // ---------------------------------------------------------------------------
+// More than 52 components (the reference's k is free, R/gt_pca_partialSVD.R:70-89): the block of the subspace iteration
+// is at most 64 columns wide (LDS tiles of its kernels), so the spectrum is taken in batches of 26 pairs (block 2 * 26 +
+// 12 = 64) with EXPLICIT deflation in between: K <- K - U_b diag(lambda_b) U_b' on a scratch copy of the matrix moves the
+// converged eigenvalues to 0 +- eps * lambda_1 and leaves the other pairs alone, so the next batch converges to the next
+// 26.  Later batches meet a stricter absolute tolerance (it is relative to THEIR largest eigenvalue).
+__global__ __launch_bounds__(256) void tpg_deflate_kernel(double* __restrict__ K, int n, const double* __restrict__ U,
+                                                          const double* __restrict__ lam, int kb) {
+  __shared__ double ui[16][33], uj[16][33];  // [row in tile][component], kb <= 32
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+  for (int q = threadIdx.x; q < 16 * kb; q += 256) {
+    const int r = q & 15, c = q >> 4;
+    ui[r][c] = i0 + r < n ? U[(int64_t)(i0 + r) + (int64_t)c * n] * lam[c] : 0.0;
+    uj[r][c] = j0 + r < n ? U[(int64_t)(j0 + r) + (int64_t)c * n] : 0.0;
+  }
+  __syncthreads();
+  const int i = i0 + tx, j = j0 + ty;
+  if (i >= n || j >= n) return;
+  double s = 0.0;
+  for (int c = 0; c < kb; c++) s = fma(ui[tx][c], uj[ty][c], s);
+  K[(int64_t)i + (int64_t)j * n] -= s;
+}
+
+static int eig_topk_any(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambda_host, double* d_U, double tol) {
+  if (k <= 52) return eig_topk(ctx, d_K, n, k, lambda_host, d_U, tol);
+  double *Kw = nullptr, *d_lam = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&Kw, sizeof(double) * (size_t)n * (size_t)n));
+  struct Free { void *a, *b; ~Free() { tpg_pfree(a); tpg_pfree(b); } } fr{Kw, nullptr};
+  TPG_HIP(tpg_pmalloc((void**)&d_lam, sizeof(double) * 32));
+  fr.b = d_lam;
+  TPG_HIP(hipMemcpyAsync(Kw, d_K, sizeof(double) * (size_t)n * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+  const int KB = 26;
+  for (int done = 0; done < k;) {
+    const int kb = std::min(KB, k - done);
+    double* Ub = d_U + (size_t)done * (size_t)n;
+    TPG_TRY(eig_topk(ctx, Kw, n, kb, lambda_host + done, Ub, tol));
+    done += kb;
+    if (done < k) {
+      TPG_HIP(tpg_h2d_async(ctx, d_lam, lambda_host + done - kb, sizeof(double) * (size_t)kb));
+      TPG_LAUNCH(ctx, "eig_deflate", tpg_deflate_kernel, dim3((unsigned)((n + 15) / 16), (unsigned)((n + 15) / 16)), dim3(256), 0, Kw, n,
+                 (const double*)Ub, (const double*)d_lam, kb);
+      TPG_CHECK_LAUNCH();
+    }
+  }
+  return TPG_OK;
+}
+
+// ---------------------------------------------------------------------------
 static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, double tol, double* d, double* u,
                         double* vload, double* center, double* scale, double* square_frobenius);
 
@@ -1591,7 +1639,7 @@ __global__ void tpg_tri_unpack_kernel(const double* __restrict__ tri, int n, dou
 static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, double tol, double* d, double* u,
                         double* vload, double* center, double* scale, double* square_frobenius) {
   TPG_REQUIRE(ctx && v && d && u && vload && center && scale, TPG_EINVAL, "null argument");
-  TPG_REQUIRE(k >= 1 && k <= 52 && k <= v->n, TPG_EINVAL, "k = %d out of range", k);
+  TPG_REQUIRE(k >= 1 && k <= v->n, TPG_EINVAL, "k = %d out of range", k);
   const int64_t n = v->n, m = v->m;
   OutBuf oc, os, ou, ov;
   int32_t* d_counts = nullptr;
@@ -1642,7 +1690,7 @@ static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, 
     TPG_LAUNCH(ctx, "pca_gram_tri", tpg_tri_unpack_kernel, dim3(2048), dim3(256), 0, (const double*)d_tri, (int)n, d_K);
   }
   std::vector<double> lam((size_t)k);
-  TPG_TRY(eig_topk(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>(), tol));
+  TPG_TRY(eig_topk_any(ctx, d_K, (int)n, k, lam.data(), ou.dev<double>(), tol));
   st.mark("eig_topk");
   std::vector<double> dh((size_t)k);
   for (int j = 0; j < k; j++) dh[(size_t)j] = sqrt(lam[(size_t)j] > 0 ? lam[(size_t)j] : 0.0);
@@ -1867,13 +1915,13 @@ static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_
 extern "C" int tpg_sym_eig_topk(tpg_ctx* ctx, const double* K, int64_t n, int k, double* lambda, double* U) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && K && lambda && U, TPG_EINVAL, "null argument");
-  TPG_REQUIRE(n > 0 && k >= 1 && k <= 52 && k <= n, TPG_EINVAL, "bad n = %lld / k = %d", (long long)n, k);
+  TPG_REQUIRE(n > 0 && k >= 1 && k <= n, TPG_EINVAL, "bad n = %lld / k = %d", (long long)n, k);
   InBuf ik;
   TPG_TRY(ik.init(ctx, K, sizeof(double) * (size_t)n * (size_t)n));
   OutBuf ou;
   TPG_TRY(ou.init(U, sizeof(double) * (size_t)n * (size_t)k));
   std::vector<double> lam((size_t)k);
-  TPG_TRY(eig_topk(ctx, ik.dev<double>(), (int)n, k, lam.data(), ou.dev<double>()));
+  TPG_TRY(eig_topk_any(ctx, ik.dev<double>(), (int)n, k, lam.data(), ou.dev<double>(), 1e-12));
   if (tpg_is_device_ptr(lambda)) TPG_HIP(hipMemcpyAsync(lambda, lam.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
   else memcpy(lambda, lam.data(), sizeof(double) * (size_t)k);
   TPG_HIP(hipStreamSynchronize(ctx->stream));
