@@ -27,15 +27,18 @@ def _run(cmd, env_extra):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("scaling", ["strong", "weak"])
-def test_two_shards_equal_one(tmp_path, scaling):
+@pytest.mark.parametrize("scaling,exchange", [("strong", False), ("weak", False), ("strong", True)])
+def test_two_shards_equal_one(tmp_path, scaling, exchange):
+    """exchange: the PCA Gram with whole weight classes per rank (the packed columns go round by an all-to-all,
+    gramcls.hip) instead of every rank's own loci -- forced here, the cost model keeps it for long panels"""
     d1, d2 = str(tmp_path / "one.json"), str(tmp_path / "two.json")
     common = ["--steps", "1", "--warmup", "0", "--indiv", "700", "--pops", "9", "--k", "8", "--no-cpu-baseline",
               "--no-end-to-end", "--scaling", scaling]
     _run([sys.executable, "bench.py", "--gpus", "1", "--snps", "60000", "--digest", d1] + common, {})
     _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-          "127.0.0.1", "--master-port", "29533" if scaling == "strong" else "29535", "bench.py", "--gpus", "2", "--snps",
-          "60000" if scaling == "strong" else "30000", "--digest", d2] + common, {"TPG_BENCH_SHARE_GPU": "1"})
+          "127.0.0.1", "--master-port", "29537" if exchange else ("29533" if scaling == "strong" else "29535"), "bench.py", "--gpus", "2", "--snps",
+          "60000" if scaling == "strong" else "30000", "--digest", d2] + common,
+         {"TPG_BENCH_SHARE_GPU": "1", **({"TPG_GRAM_EXCHANGE": "1"} if exchange else {})})
     a, b = json.load(open(d1)), json.load(open(d2))
     # integer cross-products are exact, so every epilogue value is identical (the bands of the two ranks tile the
     # matrices: the digest sums what each rank wrote); the GRM mean is summed in another order
@@ -47,7 +50,8 @@ def test_two_shards_equal_one(tmp_path, scaling):
         assert a[name + "_sum"] == pytest.approx(b[name + "_sum"], rel=1e-12)
     for name in ("fst_hudson", "fst_wc84"):
         assert np.allclose(a[name], b[name], rtol=1e-12, atol=0)
-    assert np.allclose(a["pca_d"], b["pca_d"], rtol=1e-7)  # Gram partials use per-shard weight scaling
+    # the digit Gram of a shard rounds its weights per shard (1e-7); exchanged classes are exact integer matrices
+    assert np.allclose(a["pca_d"], b["pca_d"], rtol=1e-9 if exchange else 1e-7)
     assert a["pca_fro"] == pytest.approx(b["pca_fro"], rel=1e-12)
     assert np.allclose(a["pca_u_abs_colsum"], b["pca_u_abs_colsum"], rtol=1e-5)
 
@@ -257,3 +261,35 @@ def test_bench_gpus_n_launches_n_ranks(tmp_path):
                        text=True, timeout=600, env=env)
     assert r.returncode != 0 and "refusing" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("ndev", [2, 8])
+def test_pca_with_whole_classes_per_rank(ndev, monkeypatch):
+    """tpg_gram_classes_exchanged among the device threads of one process (in-process host transport, one GPU listed ndev
+    times): key histogram all-reduce, equal-cost key ranges, records packed by destination, the all-to-all, the class Gram
+    of the records received, double centering per rank, the triangle all-reduce.  Against one device and the oracle; with 8
+    ranks some own only a few classes (and on a tiny panel none)."""
+    import tidypopgen_amd as tpg
+    from oracle import oracle as orc
+
+    monkeypatch.setenv("TPG_GRAM_EXCHANGE", "1")
+    n, m, k = 230, 9000, 7
+    fbm = orc.synth_fbm(31, n, m, npop=4, miss=0.03, imputed_bytes=True)
+    dec = np.where(fbm > 3, fbm - 4, fbm)
+    pc = (np.where((dec.sum(axis=0) > 0) & (dec.sum(axis=0) < 2 * n))[0] + 1).astype(np.int32)
+    one = tpg.gt_pca_partialSVD(tpg.FBM.from_numpy(fbm), None, pc, k=k)
+    o = orc.gt_pca_partialSVD(fbm, None, pc, k=k)
+    mg = tpg.Multi(ndev, devices=[0] * ndev)
+    t = mg.gt_pca_partialSVD(fbm, None, pc, k=k)
+    assert np.array_equal(t["center"], one["center"]) and np.array_equal(t["scale"], one["scale"])
+    assert np.allclose(t["d"], one["d"], rtol=1e-10, atol=0)  # exact class matrices, double weights: only the sum order differs
+    assert np.allclose(t["d"], o["d"], rtol=1e-6, atol=0)
+    assert np.max(np.abs(_align_sign(t["u"], one["u"]) - one["u"])) <= 1e-8
+    assert np.max(np.abs(_align_sign(t["v"], one["v"]) - one["v"])) <= 1e-8 * np.abs(one["v"]).max()
+    assert t["square_frobenius"] == pytest.approx(one["square_frobenius"], rel=1e-12)
+    # a short panel: fewer classes than ranks can own, some ranks receive nothing
+    few = pc[:max(8 * ndev, 2 * k * ndev)]
+    t2 = mg.gt_pca_partialSVD(fbm, None, few, k=k)
+    o2 = orc.gt_pca_partialSVD(fbm, None, few, k=k)
+    assert np.allclose(t2["d"], o2["d"], rtol=1e-6, atol=0)
+    mg.close()

@@ -39,7 +39,8 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*AllToAll)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllToAllv)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -74,7 +75,7 @@ static void rccl_load() {
   RSYM(CommDestroy, "ncclCommDestroy");
   RSYM(AllReduce, "ncclAllReduce");
   RSYM(ReduceScatter, "ncclReduceScatter");
-  RSYM(AllToAll, "ncclAllToAll");
+  RSYM(AllToAllv, "ncclAllToAllv");
   RSYM(AllGather, "ncclAllGather");
   RSYM(GetErrorString, "ncclGetErrorString");
 #undef RSYM
@@ -253,6 +254,59 @@ int tpg_comm_agree(tpg_comm* comm, int rc) {
   if (!failed) return TPG_OK;
   tpg_set_error("%d of %d ranks failed before the exchange (error code %d there): every rank gives up", failed, comm->nranks, worst);
   return worst;
+}
+
+// All-to-all of 8-byte words between the ranks (device memory, stream-ordered): rank r sends scnt[d] words at soff[d] of
+// d_send to rank d and receives rcnt[s] words from rank s at roff[s] of d_recv (what ncclAllToAllv does).  Used by the
+// PCA Gram to give every rank whole weight classes (gramcls.hip: the packed genotype columns travel, 1 280 bytes per
+// locus at n = 5 000).  On the rehearsal transport the exchange is emulated by an all-reduce of a buffer in which every
+// rank fills only the slots it sends (tests: small panels).
+int tpg_comm_alltoallv64(tpg_comm* comm, const void* d_send, const size_t* scnt, const size_t* soff, void* d_recv,
+                         const size_t* rcnt, const size_t* roff) {
+  TPG_REQUIRE(comm && scnt && soff && rcnt && roff, TPG_EINVAL, "bad all-to-all arguments");
+  const int R = comm->nranks, me = comm->rank;
+  hipStream_t s = comm->ctx->stream;
+  if (R == 1 && !comm->nccl) {
+    TPG_REQUIRE(scnt[0] == rcnt[0], TPG_EINVAL, "all-to-all counts do not match");
+    if (scnt[0]) TPG_HIP(hipMemcpyAsync((uint64_t*)d_recv + roff[0], (const uint64_t*)d_send + soff[0], 8 * scnt[0], hipMemcpyDeviceToDevice, s));
+    return TPG_OK;
+  }
+  if (comm->host_fn) {
+    std::vector<int32_t> cm((size_t)R * R, 0);
+    for (int d = 0; d < R; d++) {
+      TPG_REQUIRE(scnt[d] < (1ull << 30), TPG_EUNSUPPORTED, "rehearsal all-to-all too large");
+      cm[(size_t)me * R + d] = (int32_t)scnt[d];
+    }
+    TPG_REQUIRE(comm->host_fn(comm->host_user, cm.data(), (int64_t)R * R, 0) == 0, TPG_EHIP, "the host all-reduce callback failed");
+    std::vector<size_t> base((size_t)R + 1, 0);
+    for (int d = 0; d < R; d++) {
+      size_t in = 0;
+      for (int r = 0; r < R; r++) in += (size_t)cm[(size_t)r * R + d];
+      base[(size_t)d + 1] = base[(size_t)d] + in;
+    }
+    for (int r = 0; r < R; r++) TPG_REQUIRE((size_t)cm[(size_t)r * R + me] == rcnt[r], TPG_EINVAL, "all-to-all counts do not match");
+    const size_t total = base[(size_t)R];
+    TPG_REQUIRE(total < (1ull << 28), TPG_EUNSUPPORTED, "rehearsal all-to-all too large");
+    std::vector<uint64_t> H(total ? total : 1, 0);
+    for (int d = 0; d < R; d++) {
+      size_t o = base[(size_t)d];
+      for (int r = 0; r < me; r++) o += (size_t)cm[(size_t)r * R + d];
+      if (scnt[d]) TPG_HIP(hipMemcpyAsync(H.data() + o, (const uint64_t*)d_send + soff[d], 8 * scnt[d], hipMemcpyDeviceToHost, s));
+    }
+    TPG_HIP(hipStreamSynchronize(s));
+    TPG_REQUIRE(comm->host_fn(comm->host_user, H.data(), (int64_t)(2 * total), 0) == 0, TPG_EHIP, "the host all-reduce callback failed");
+    size_t o = base[(size_t)me];
+    for (int r = 0; r < R; r++) {
+      if (rcnt[r]) TPG_HIP(hipMemcpyAsync((uint64_t*)d_recv + roff[r], H.data() + o, 8 * rcnt[r], hipMemcpyHostToDevice, s));
+      o += rcnt[r];
+    }
+    TPG_HIP(hipStreamSynchronize(s));
+    return TPG_OK;
+  }
+  RcclApi* api = rccl();
+  TPG_REQUIRE(api && comm->nccl, TPG_EHIP, "communicator has no transport");
+  TPG_RCCL(api, api->AllToAllv(d_send, scnt, soff, d_recv, rcnt, roff, ncclUint64, (ncclComm_t)comm->nccl, s));
+  return TPG_OK;
 }
 
 // d_buf holds nranks chunks of chunk_count int32; afterwards chunk `rank` holds the sum over the ranks of that chunk

@@ -74,6 +74,12 @@ int tpg_prof_resolve(tpg_ctx* ctx);
 // (nothing written) when the weights take too many distinct values for that to pay.  d_what (may be NULL): the weight
 // actually used for every locus (its class representative, within 2^-47 of w_j)
 int tpg_gram_classes(tpg_ctx* ctx, const struct tpg_view* v, const double* d_w, double* d_what, double* d_K, bool* done);
+// The same over the ranks of a communicator, with whole weight classes per rank: `v` holds this rank's loci (counts: its
+// m x 4 genotype counts, scale: its binomial scales), the packed columns are exchanged so that rank r ends up with ALL loci
+// of the allele-count range it owns, and d_K receives S' of those classes (the sum over the ranks is S' of the panel).
+// *done = false (on every rank alike, nothing exchanged) when that would not pay.
+int tpg_gram_classes_exchanged(tpg_ctx* ctx, struct tpg_comm* comm, const struct tpg_view* v, const int32_t* d_counts,
+                               const double* d_scale, double* d_K, bool* done);
 
 // Launch a kernel on the context's stream, bracketed by HIP events when profiling is on.
 #define TPG_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                          \
@@ -236,6 +242,9 @@ struct tpg_comm {
 int tpg_comm_agree(tpg_comm* comm, int rc);  // all ranks get the same status (the worst any of them passed in)
 int tpg_comm_reduce_scatter_i32(tpg_comm* comm, int32_t* d_buf, int64_t chunk_count);  // in place, chunk r -> rank r
 int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype);          // in place, device memory
+// 8-byte words: rank r sends scnt[d] words at soff[d] to rank d, receives rcnt[s] words from rank s at roff[s]
+int tpg_comm_alltoallv64(tpg_comm* comm, const void* d_send, const size_t* scnt, const size_t* soff, void* d_recv,
+                         const size_t* rcnt, const size_t* roff);
 
 // ---- cross-TU entry points (one per .hip file) -----------------------------
 int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, const int32_t* d_cols,

@@ -121,7 +121,18 @@ __global__ void tpg_gcls_block_table_kernel(const unsigned long long* __restrict
 // P packing 16 codes as nibbles [c_odd | c_even], so that P & 0x33333333 and (P >> 2) & 0x33333333 are FP4 operand
 // words of value dosage / 2.  Missing / padding -> 0.  (Which locus sits on which nibble is immaterial: both MFMA
 // operands come from this layout.)
-__global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(const uint4* __restrict__ L, int64_t Q,
+// Where the 16-byte pieces of a locus live (uint4 units): piece (j, q, h) at base + (j >> sh) * sa + (j & msk) * sb +
+// q * sq + h * sh1.  A view's L layout: 32 loci per 1-KiB block, {5, Q * 64, 31, 1, 64, 32}; records received from other
+// ranks (tpg_gram_classes_exchanged): one locus after the other, {0, record size / 16, 0, 0, 2, 1}.
+struct GclsSrc {
+  const uint4* base;
+  int sh;
+  int64_t sa;
+  int msk;
+  int64_t sb, sq, sh1;
+};
+
+__global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(GclsSrc S, int64_t Q,
                                                                const int32_t* __restrict__ src, int64_t nblocks,
                                                                int64_t rs2, uint4* __restrict__ T2g) {
   __shared__ __attribute__((aligned(16))) uint32_t sh[4][2][4][64];  // [wave][source half][s][locus]
@@ -137,9 +148,9 @@ __global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(const uint4* __res
       const int32_t j = b < nblocks ? src[b * 64 + lane] : -1;
       uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
       if (j >= 0) {
-        const uint4* p = L + (((int64_t)(j >> 5)) * Q + q) * 64 + (j & 31);
+        const uint4* p = S.base + (int64_t)(j >> S.sh) * S.sa + (int64_t)(j & S.msk) * S.sb + q * S.sq;
         w0 = p[0];
-        w1 = p[32];
+        w1 = p[S.sh1];
       }
       sh[wv][0][0][lane] = w0.x; sh[wv][0][1][lane] = w0.y; sh[wv][0][2][lane] = w0.z; sh[wv][0][3][lane] = w0.w;
       sh[wv][1][0][lane] = w1.x; sh[wv][1][1][lane] = w1.y; sh[wv][1][2][lane] = w1.z; sh[wv][1][3][lane] = w1.w;
@@ -374,10 +385,10 @@ static double gcls_cost_classes(int64_t nunits, int64_t nruns, int64_t nblocks, 
   return best;
 }
 
-int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double* d_what, double* d_K, bool* done) {
+static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, const GclsSrc& src, const double* d_w, double* d_what,
+                             double* d_K, bool force, bool* done) {
   *done = false;
-  const int64_t n = v->n, m = v->m;
-  if (m >= (1ll << 31) - 64 || getenv("TPG_GRAM_DIGITS")) return TPG_OK;
+  if (m >= (1ll << 31) - 64 || (getenv("TPG_GRAM_DIGITS") && !force)) return TPG_OK;
   GclsBufs B;
   unsigned long long *d_key = nullptr, *d_key2 = nullptr, *d_ukeys = nullptr;
   uint32_t *d_idx = nullptr, *d_idx2 = nullptr, *d_counts = nullptr, *d_cnt = nullptr, *d_nblk = nullptr, *d_estart = nullptr,
@@ -443,7 +454,7 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
   if (getenv("TPG_DEBUG"))
     fprintf(stderr, "[tpg] gram classes: %lld classes, %lld blocks for %lld loci, S = %d, model %.0f us (digits %.0f us)\n",
             (long long)nruns, (long long)nblocks, (long long)m, S, cost_cls, cost_dig);
-  if (cost_cls > cost_dig && !getenv("TPG_GRAM_CLASSES")) return TPG_OK;
+  if (cost_cls > cost_dig && !force && !getenv("TPG_GRAM_CLASSES")) return TPG_OK;
 
   int32_t* d_src = nullptr;
   double* d_slabs = nullptr;
@@ -453,7 +464,7 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
   TPG_HIP(B.get(&d_src, (size_t)nblocks * 64));
   TPG_HIP(B.get(&d_wblk, (size_t)nblocks));
   const int64_t rs2 = (nblocks + 1) / 2;  // row-tile stride of T2g: a uint4 per lane and PAIR of blocks
-  TPG_HIP(B.get(&d_T2g, (size_t)(4 * v->Q) * (size_t)rs2 * 64));
+  TPG_HIP(B.get(&d_T2g, (size_t)(4 * Q) * (size_t)rs2 * 64));
   TPG_HIP(B.get(&d_order, (size_t)nun));
   TPG_HIP(B.get(&d_slabs, (size_t)S * (size_t)nun * GCLS_SLAB));
   TPG_HIP(tpg_h2d_async(ctx, d_order, order.data(), sizeof(int2) * (size_t)nun));
@@ -467,10 +478,10 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
                        (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks, d_wblk);
   }
   {
-    const int64_t tasks = v->Q * rs2;
+    const int64_t tasks = Q * rs2;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(tasks, 4), (int64_t)ctx->num_cu * 16);
-    TPG_LAUNCH(ctx, "gcls_gather", tpg_gcls_gather_kernel, dim3(grid), dim3(256), 0, (const uint4*)v->L, v->Q,
-               (const int32_t*)d_src, nblocks, rs2, d_T2g);
+    TPG_LAUNCH(ctx, "gcls_gather", tpg_gcls_gather_kernel, dim3(grid), dim3(256), 0, src, Q, (const int32_t*)d_src, nblocks, rs2,
+               d_T2g);
   }
   TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T2g, nblocks,
              rs2, nrtv, (const unsigned long long*)d_wblk, (const int2*)d_order, nun, S, d_slabs);
@@ -479,4 +490,214 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
   TPG_CHECK_LAUNCH();
   *done = true;
   return TPG_OK;  // the scratch blocks go back to the pool in stream order (GclsBufs)
+}
+
+int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double* d_what, double* d_K, bool* done) {
+  const GclsSrc src{v->L, 5, v->Q * 64, 31, 1, 64, 32};
+  return gram_classes_core(ctx, v->n, v->Q, v->m, src, d_w, d_what, d_K, false, done);
+}
+
+// ---------------------------------------------------------------------------
+// Whole weight classes per rank (SNP-block shards over several GPUs).
+//
+// A rank's shard of the loci holds a slice of EVERY weight class, so the fold cost of the class path (one fold per
+// class and tile) does not shrink with the shard: 6.0 ms on a 125 000-locus shard of the 5 000 x 1 000 000 panel against
+// 12.2 ms for the whole panel.  But S' = sum_c w_c G_c is a sum over classes as much as over loci: if rank r holds ALL
+// loci of the classes it owns, it pays 1 / R of the folds AND 1 / R of the blocks.  So the packed genotype columns travel
+// once (32 Q + 16 bytes per locus = 1 296 B at n = 5 000; 140 MB per rank at 8 ranks) by one all-to-all:
+//   1. key_j = min(c_j, 2n - c_j) of the locus' allele count c_j (the binomial weight is a function of it); histogram of
+//      the keys over all ranks (one int32 all-reduce of n + 1 bins);
+//   2. the keys are cut into R contiguous ranges of equal modelled cost (the same cut on every rank);
+//   3. every rank sorts its loci by destination and packs a record per locus: the 2 Q 16-byte pieces of its column of the
+//      L layout, then its weight;  the counts go round (R x R int32), then the records (tpg_comm_alltoallv64);
+//   4. the class Gram of the records received (gram_classes_core with the records as the source of the gather).
+// The caller sums the S' of the ranks (the all-reduce it does anyway).  The decision to go this way is taken from the
+// global histogram, i.e. alike on every rank.
+#define GCLX_REC_WORDS(Q) (4 * (Q) + 2)  // 8-byte words per record: 32 Q bytes of column + weight + pad
+
+__global__ void tpg_gclx_keys_kernel(const int32_t* __restrict__ counts, int64_t m, int n, int32_t* __restrict__ key,
+                                     int32_t* __restrict__ hist) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    const int c = counts[4 * j + 1] + 2 * counts[4 * j + 2];
+    const int k = min(c, 2 * n - c);
+    key[j] = k;
+    atomicAdd(&hist[k], 1);
+  }
+}
+
+__global__ void tpg_gclx_dest_kernel(const int32_t* __restrict__ key, int64_t m, const uint8_t* __restrict__ owner,
+                                     uint32_t* __restrict__ dest, uint32_t* __restrict__ idx, int32_t* __restrict__ per_dest) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t d = owner[key[j]];
+    dest[j] = d;
+    idx[j] = (uint32_t)j;
+    atomicAdd(&per_dest[d], 1);
+  }
+}
+
+// record i <- locus order[i]: one wave copies the 2 Q pieces of the column (L layout) and the weight
+__global__ __launch_bounds__(256) void tpg_gclx_pack_kernel(const uint4* __restrict__ L, int64_t Q, const uint32_t* __restrict__ order,
+                                                            const double* __restrict__ scale, int64_t m,
+                                                            uint4* __restrict__ rec) {
+  const int lane = threadIdx.x & 63;
+  const int64_t recq = 2 * Q + 1;  // uint4 per record
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < m; i += (int64_t)gridDim.x * 4) {
+    const uint32_t j = order[i];
+    const uint4* p = L + ((int64_t)(j >> 5) * Q) * 64 + (j & 31);
+    for (int64_t t = lane; t < 2 * Q; t += 64) rec[i * recq + t] = p[(t >> 1) * 64 + (t & 1) * 32];
+    if (lane == 0) {
+      const double sc = scale[j], w = 1.0 / (sc * sc);
+      rec[i * recq + 2 * Q] = make_uint4((uint32_t)__double_as_longlong(w), (uint32_t)(__double_as_longlong(w) >> 32), 0u, 0u);
+    }
+  }
+}
+
+__global__ void tpg_gclx_weights_kernel(const uint4* __restrict__ rec, int64_t Q, int64_t m, double* __restrict__ w) {
+  const int64_t recq = 2 * Q + 1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 t = rec[i * recq + 2 * Q];
+    w[i] = __longlong_as_double((long long)(((unsigned long long)t.y << 32) | t.x));
+  }
+}
+
+int tpg_gram_classes_exchanged(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, const int32_t* d_counts, const double* d_scale,
+                               double* d_K, bool* done) {
+  *done = false;
+  const int R = comm->nranks, me = comm->rank;
+  const int64_t n = v->n, m = v->m, Q = v->Q;
+  if (R < 2 || R > 255 || n >= (1 << 30) || getenv("TPG_GRAM_NO_EXCHANGE")) return TPG_OK;
+  GclsBufs B;
+  int32_t *d_key = nullptr, *d_hist = nullptr, *d_perdest = nullptr;
+  uint8_t* d_owner = nullptr;
+  uint32_t *d_dest = nullptr, *d_dest2 = nullptr, *d_idx = nullptr, *d_idx2 = nullptr;
+  void* d_tmp = nullptr;
+  size_t t_sort = 0;
+  std::vector<int32_t> hist((size_t)n + 1, 0);
+  // rank-local steps first, then the ranks agree on a status before the first exchange (nobody is left waiting in it)
+  auto local = [&]() -> int {
+    TPG_HIP(B.get(&d_key, (size_t)std::max<int64_t>(m, 1)));
+    TPG_HIP(B.get(&d_hist, (size_t)n + 1));
+    TPG_HIP(B.get(&d_perdest, (size_t)R));
+    TPG_HIP(B.get(&d_owner, (size_t)n + 1));
+    TPG_HIP(B.get(&d_dest, (size_t)std::max<int64_t>(m, 1)));
+    TPG_HIP(B.get(&d_dest2, (size_t)std::max<int64_t>(m, 1)));
+    TPG_HIP(B.get(&d_idx, (size_t)std::max<int64_t>(m, 1)));
+    TPG_HIP(B.get(&d_idx2, (size_t)std::max<int64_t>(m, 1)));
+    TPG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, d_dest, d_dest2, d_idx, d_idx2, (int)m, 0, 8, ctx->stream));
+    TPG_HIP(B.get((uint8_t**)&d_tmp, t_sort));
+    TPG_HIP(hipMemsetAsync(d_hist, 0, sizeof(int32_t) * ((size_t)n + 1), ctx->stream));
+    TPG_HIP(hipMemsetAsync(d_perdest, 0, sizeof(int32_t) * (size_t)R, ctx->stream));
+    if (m > 0)
+      hipLaunchKernelGGL(tpg_gclx_keys_kernel, dim3(512), dim3(256), 0, ctx->stream, d_counts, m, (int)n, d_key, d_hist);
+    TPG_HIP(hipGetLastError());
+    return TPG_OK;
+  };
+  TPG_TRY(tpg_comm_agree(comm, local()));
+  {
+    ProfScope ps(ctx, "gclx_histogram");
+    TPG_TRY(tpg_comm_allreduce(comm, d_hist, n + 1, 0));
+    TPG_HIP(hipMemcpyAsync(hist.data(), d_hist, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->stream));
+    TPG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  // cost of a key = its class's blocks and fold; the same arithmetic on every rank
+  int64_t m_all = 0, runs_all = 0, blocks_all = 0;
+  for (int64_t k = 0; k <= n; k++)
+    if (hist[(size_t)k] > 0) { m_all += hist[(size_t)k]; runs_all++; blocks_all += ((int64_t)hist[(size_t)k] + 63) / 64; }
+  if (m_all == 0) return TPG_OK;
+  const double cost_all = (double)runs_all * 0.136 + (double)blocks_all * 0.079;
+  // does it pay?  modelled time of this rank's share of whole classes + the exchange (records at ~40 GB/s, a few
+  // launches) against the cheaper of the two local paths on a shard (digits: 1.0 us per 128 loci and 4 row tiles)
+  const int nrtv = (int)ceil_div(n, 32);
+  const double units = (double)nrtv * (double)nrtv / 8.0, waves = 8.0 * (double)(ctx->num_cu > 8 ? ctx->num_cu : 8);
+  const double t_exch = units / waves * 4.0 * cost_all / R + 700.0 + (double)m_all / R * (double)(32 * Q + 16) / 40e3;
+  const double shard_blocks = (double)blocks_all / R + (double)runs_all;  // a shard pads every class to a block of its own
+  const double t_cls_local = units / waves * 4.0 * ((double)runs_all * 0.136 + shard_blocks * 0.079) + 650.0;
+  const double t_dig_local = ((double)nrtv * nrtv / 8.0 + nrtv) / (waves / 2.0) * ((double)m_all / R / 128.0) + 65.0;
+  if (getenv("TPG_DEBUG") && me == 0)
+    fprintf(stderr, "[tpg] gram exchange: %lld loci, %lld classes, %lld blocks over %d ranks: model %.0f us (local classes %.0f, digits %.0f)\n",
+            (long long)m_all, (long long)runs_all, (long long)blocks_all, R, t_exch, t_cls_local, t_dig_local);
+  if (t_exch > std::min(t_cls_local, t_dig_local) && !getenv("TPG_GRAM_EXCHANGE")) return TPG_OK;
+
+  // contiguous key ranges of (nearly) equal cost
+  std::vector<uint8_t> owner((size_t)n + 1, (uint8_t)(R - 1));
+  {
+    double acc = 0;
+    int r = 0;
+    for (int64_t k = 0; k <= n; k++) {
+      owner[(size_t)k] = (uint8_t)r;
+      if (hist[(size_t)k] > 0) acc += 0.136 + 0.079 * (double)(((int64_t)hist[(size_t)k] + 63) / 64);
+      while (r < R - 1 && acc >= cost_all * (double)(r + 1) / R) r++;
+    }
+  }
+  std::vector<int32_t> per_dest((size_t)R, 0);
+  uint4 *d_send = nullptr, *d_recv = nullptr;
+  double* d_w = nullptr;
+  const int64_t recq = 2 * Q + 1;  // uint4 per record
+  std::vector<size_t> scnt((size_t)R), soff((size_t)R), rcnt((size_t)R), roff((size_t)R);
+  std::vector<int32_t> cm((size_t)R * R, 0);
+  int64_t m_in = 0;
+  auto pack = [&]() -> int {
+    TPG_HIP(tpg_h2d_async(ctx, d_owner, owner.data(), (size_t)n + 1));
+    if (m > 0) {
+      ProfScope ps(ctx, "gclx_sort");
+      hipLaunchKernelGGL(tpg_gclx_dest_kernel, dim3(512), dim3(256), 0, ctx->stream, (const int32_t*)d_key, m, (const uint8_t*)d_owner,
+                         d_dest, d_idx, d_perdest);
+      size_t t = t_sort;
+      TPG_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, t, d_dest, d_dest2, d_idx, d_idx2, (int)m, 0, 8, ctx->stream));
+    }
+    TPG_HIP(hipMemcpyAsync(per_dest.data(), d_perdest, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, ctx->stream));
+    TPG_HIP(hipStreamSynchronize(ctx->stream));
+    TPG_HIP(B.get(&d_send, (size_t)std::max<int64_t>(m, 1) * (size_t)recq));
+    if (m > 0)
+      TPG_LAUNCH(ctx, "gclx_pack", tpg_gclx_pack_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(m, 4), (int64_t)ctx->num_cu * 16)),
+                 dim3(256), 0, (const uint4*)v->L, Q, (const uint32_t*)d_idx2, d_scale, m, d_send);
+    TPG_HIP(hipGetLastError());
+    return TPG_OK;
+  };
+  TPG_TRY(tpg_comm_agree(comm, pack()));
+  // who sends how many loci to whom: row `me` of an R x R table, summed over the ranks
+  {
+    int32_t* d_cm = nullptr;
+    TPG_HIP(B.get(&d_cm, (size_t)R * R));
+    for (int d = 0; d < R; d++) cm[(size_t)me * R + d] = per_dest[(size_t)d];
+    TPG_HIP(tpg_h2d_async(ctx, d_cm, cm.data(), sizeof(int32_t) * (size_t)R * R));
+    TPG_TRY(tpg_comm_allreduce(comm, d_cm, (int64_t)R * R, 0));
+    TPG_HIP(hipMemcpyAsync(cm.data(), d_cm, sizeof(int32_t) * (size_t)R * R, hipMemcpyDeviceToHost, ctx->stream));
+    TPG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  {
+    size_t so = 0, ro = 0;
+    for (int r = 0; r < R; r++) {
+      scnt[(size_t)r] = (size_t)cm[(size_t)me * R + r] * (size_t)recq * 2;  // 8-byte words
+      soff[(size_t)r] = so;
+      so += scnt[(size_t)r];
+      rcnt[(size_t)r] = (size_t)cm[(size_t)r * R + me] * (size_t)recq * 2;
+      roff[(size_t)r] = ro;
+      ro += rcnt[(size_t)r];
+      m_in += cm[(size_t)r * R + me];
+    }
+  }
+  auto recv_alloc = [&]() -> int {
+    TPG_HIP(B.get(&d_recv, (size_t)std::max<int64_t>(m_in, 1) * (size_t)recq));
+    TPG_HIP(B.get(&d_w, (size_t)std::max<int64_t>(m_in, 1)));
+    return TPG_OK;
+  };
+  TPG_TRY(tpg_comm_agree(comm, recv_alloc()));
+  {
+    ProfScope ps(ctx, "gclx_alltoall");
+    TPG_TRY(tpg_comm_alltoallv64(comm, d_send, scnt.data(), soff.data(), d_recv, rcnt.data(), roff.data()));
+  }
+  // the class Gram of the loci this rank owns now (none: a zero matrix)
+  if (m_in == 0) {
+    TPG_HIP(hipMemsetAsync(d_K, 0, sizeof(double) * (size_t)n * (size_t)n, ctx->stream));
+    *done = true;
+    return TPG_OK;
+  }
+  hipLaunchKernelGGL(tpg_gclx_weights_kernel, dim3(512), dim3(256), 0, ctx->stream, (const uint4*)d_recv, Q, m_in, d_w);
+  const GclsSrc src{d_recv, 0, recq, 0, 0, 2, 1};
+  bool ok = false;
+  TPG_TRY(gram_classes_core(ctx, n, Q, m_in, src, d_w, nullptr, d_K, true, &ok));
+  TPG_REQUIRE(ok, TPG_EHIP, "class Gram of the exchanged loci was not computed");
+  *done = true;
+  return TPG_OK;
 }

@@ -891,6 +891,25 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   return rc;
 }
 
+// K = H S' H for S' in d_K (the double centering pca_gram_device applies when `center` is the column mean): linear in
+// S', so every rank applies it to the S' of the classes it owns before the partial matrices are summed
+static int pca_double_center_inplace(tpg_ctx* ctx, double* d_K, int64_t n) {
+  double *d_r = nullptr, *d_part = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_r, sizeof(double) * (size_t)n));
+  hipError_t e = tpg_pmalloc((void**)&d_part, sizeof(double) * 512);
+  if (e == hipSuccess) {
+    TPG_LAUNCH(ctx, "pca_colmean", tpg_colmean_kernel, dim3((unsigned)n), dim3(256), 0, (const double*)d_K, (int)n, d_r);
+    TPG_LAUNCH(ctx, "pca_colmean", tpg_mean_kernel, dim3(1), dim3(256), 0, (const double*)d_r, (int)n, d_part);
+    TPG_LAUNCH(ctx, "pca_double_center", tpg_double_center_kernel, dim3(2048), dim3(256), 0, d_K, (int)n, (const double*)d_r,
+               (const double*)d_part);
+    e = hipGetLastError();
+  }
+  tpg_pfree(d_r);
+  tpg_pfree(d_part);
+  TPG_HIP(e);
+  return TPG_OK;
+}
+
 extern "C" int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale, double* K) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && v && center && scale && K, TPG_EINVAL, "null argument");
@@ -1677,8 +1696,13 @@ static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, 
   TPG_TRY(lrc);
   if (square_frobenius && exchange) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, square_frobenius, 1));
   st.mark("frobenius + alloc K");
+  // Several ranks: every rank takes whole weight classes (the packed columns are exchanged once, gramcls.hip) when that
+  // pays -- decided alike on every rank --, otherwise the Gram matrix of its own loci.
+  bool exchanged = false;
+  if (exchange) TPG_TRY(tpg_gram_classes_exchanged(ctx, comm, v, d_counts, os.dev<double>(), d_K, &exchanged));
+  if (exchanged) TPG_TRY(pca_double_center_inplace(ctx, d_K, n));
   // a failure of the Gram kernels themselves (launch error) is not rank-local in practice: same code, same shapes
-  TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true));
+  else TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true));
   st.mark("gram");
   if (exchange) {  // K = sum over the ranks' loci of z_j z_j'
     // only the upper triangle travels: n (n + 1) / 2 doubles instead of n^2 (K is symmetric bit for bit on every rank)
