@@ -666,12 +666,12 @@ def main():
                       peak=10000.0),
             mfma_roof("pca_gram_mfma", "tpg_pca_gram_kernel (v_mfma_i32_32x32x32_i8)", 4.0 * n * n * m_pca,
                       "PCA Gram: 4 weight digits x symmetric int8 product = 4 * N^2 M / 2 MACs"),
-            mfma_roof("pca_gram_classes", "tpg_gcls_gram_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 dosages)",
+            mfma_roof("pca_gram_classes", "tpg_gcls_gram_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 dosages from 2-bit codes)",
                       1.0 * n * n * m_pca,
-                      "PCA Gram by weight classes: ONE unweighted symmetric product = N^2 M / 2 MACs on exact FP4 dosages, "
-                      "then 16 cvt + 16 FP64 fma per 32 x 32 tile and class; bound by that FP64 fold (VALU) and by the "
-                      "L2 -> CU operand path (0.83 KiB per MFMA), not by the MFMA pipe; the digit-split int8 kernel it "
-                      "replaces takes 1.8x as long for 4x the MFMA work",
+                      "PCA Gram by weight classes: ONE unweighted symmetric product = N^2 M / 2 MACs on exact FP4 dosages "
+                      "(2-bit codes over the L2 -> CU path, expanded to FP4 nibbles in registers: 6 VALU per MFMA), then "
+                      "16 cvt + 16 FP64 fma per 32 x 32 tile and class (8.5 VALU per MFMA); 64 x 64 wave tiles, two waves per "
+                      "SIMD; bound by VALU issue (16 per MFMA) with the MFMA pipe 27 % busy",
                       peak=10000.0),
         ]
         roofs = [r for r in roofs if r]
@@ -704,8 +704,9 @@ def main():
                      "N M / 4 each, + the FP4 operand layout T4 of the raw view, N M / 2)"),
             hbm_roof("t4_expand", "tpg_t4_expand_kernel", 0.75 * n * m,
                      "2-bit T layout -> FP4 operand nibbles of the pairwise kernel: N M / 4 read + N M / 2 written"),
-            hbm_roof("gcls_gather", "tpg_gcls_gather_kernel", 0.75 * n * m_pca,
-                     "class-sorted FP4 operand layout of the PCA Gram: N M / 4 read (16-byte pieces of the L layout) + N M / 2 written"),
+            hbm_roof("gcls_gather", "tpg_gcls_gather_kernel", 0.5 * n * m_pca,
+                     "class-sorted 2-bit operand layout of the PCA Gram: N M / 4 read (16-byte pieces of the L layout, i.e. a "
+                     "quarter of every 64-byte sector fetched) + N M / 4 written"),
             hbm_roof("loci_counts", "tpg_loci_counts_kernel", 0.25 * n * m + 16.0 * m,
                      "per-locus genotype counts: N M / 4 read + 16 B per locus written"),
             hbm_roof("grouped_counts", "tpg_grouped_counts_kernel (int8 MFMA one-hot contraction)",
@@ -714,8 +715,10 @@ def main():
                      "(also 3*2*N*Cpad int8 ops per locus on the MFMA pipe: bound by neither)"),
             hbm_roof("grouped_finalize", "tpg_grouped_finalize_kernel", (12.0 * Cpad + 16.0 * G) * m,
                      "counts -> the m x 2G doubles grouped_alt_freq returns: 12 Cpad B read + 16 G B written per locus"),
-            valu_roof("fst_hudson", "tpg_fst_kernel<Hudson, sums>", 12.0 * P * m, "about 12 flop per pair-locus (SURVEY.md 8d)"),
-            valu_roof("fst_wc84", "tpg_fst_kernel<WC84, sums>", 45.0 * P * m, "about 45 flop per pair-locus (SURVEY.md 8d)"),
+            valu_roof("fst_hudson", "tpg_fst_hudson_gemm_kernel (totals as three masked G x M x G products)", 12.0 * P * m,
+                      "priced at SURVEY.md 8d's ~12 flop per pair-locus; the kernel itself does 3 * 2 * 64^2 flop per locus"),
+            valu_roof("fst_wc84", "tpg_fst_wc84_tab_kernel<8> (totals, reciprocals tabulated by valid-allele count)", 45.0 * P * m,
+                      "priced at SURVEY.md 8d's ~45 flop per pair-locus; the kernel issues ~27 FP64 instructions per pair-locus"),
             mfma_roof("loadings_mfma", "tpg_loadings_mfma_kernel (v = Z'u/d)", 2.0 * n * m_pca * 6 * k,
                       "u split into 6 int8 digits: 2 N M 6k ops; HBM side N M / 4 + 4 * 32 ceil(6k/32) B per locus"),
             hbm_roof("pairwise_epilogue", "tpg_pairwise_epilogue_kernel", (20.0 * n * (n + 64) / 2 + 24.0 * n * n) / max(1, world),

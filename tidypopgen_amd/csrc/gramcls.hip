@@ -492,9 +492,39 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   return TPG_OK;  // the scratch blocks go back to the pool in stream order (GclsBufs)
 }
 
+// The gather wants a locus' 2 Q pieces next to each other: in the L layout they are 1 KiB apart, every 16-byte piece the
+// quarter of a 64-byte sector whose other three quarters belong to other loci (5 GB fetched for 1.25 GB used at
+// 5 000 x 1 000 000).  So the view is first copied LOCUS-MAJOR (LM: locus j = 2 Q consecutive pieces, q-major, then h) by a
+// streaming transpose -- a workgroup takes the blocks (lt, q0 .. q0 + 3), 4 KiB, and writes 128 contiguous bytes per
+// locus -- and the gather reads 32 contiguous bytes per (locus, q) whose sector neighbours are the next q of the same
+// locus, wanted by the next task: 0.5 + 0.7 ms instead of 2.1.
+__global__ __launch_bounds__(256) void tpg_gcls_l2lm_kernel(const uint4* __restrict__ L, int64_t Q, int64_t n_lt,
+                                                            uint4* __restrict__ LM) {
+  __shared__ uint4 sh[32][8];  // [locus in tile][2 (q - q0) + h]
+  const int64_t QG = (Q + 3) / 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int64_t task = blockIdx.x; task < n_lt * QG; task += gridDim.x) {
+    const int64_t lt = task / QG, q0 = (task % QG) * 4;
+    if (q0 + wv < Q) sh[lane & 31][2 * wv + (lane >> 5)] = L[(lt * Q + q0 + wv) * 64 + lane];
+    __syncthreads();
+    const int r = threadIdx.x >> 3, p = threadIdx.x & 7;
+    if (q0 + (p >> 1) < Q) LM[((lt * 32 + r) * Q + q0) * 2 + p] = sh[r][p];
+    __syncthreads();
+  }
+}
+
 int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double* d_what, double* d_K, bool* done) {
-  const GclsSrc src{v->L, 5, v->Q * 64, 31, 1, 64, 32};
-  return gram_classes_core(ctx, v->n, v->Q, v->m, src, d_w, d_what, d_K, false, done);
+  *done = false;
+  if (getenv("TPG_GRAM_DIGITS")) return TPG_OK;
+  const int64_t n_lt = 4 * v->KG;
+  uint4* d_LM = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_LM, sizeof(uint4) * (size_t)n_lt * 32 * (size_t)v->Q * 2));
+  TPG_LAUNCH(ctx, "gcls_l2lm", tpg_gcls_l2lm_kernel, dim3((unsigned)std::min<int64_t>(n_lt * ((v->Q + 3) / 4), (int64_t)ctx->num_cu * 32)),
+             dim3(256), 0, (const uint4*)v->L, v->Q, n_lt, d_LM);
+  const GclsSrc src{d_LM, 0, 2 * v->Q, 0, 0, 2, 1};
+  const int rc = gram_classes_core(ctx, v->n, v->Q, v->m, src, d_w, d_what, d_K, false, done);
+  tpg_pfree(d_LM);  // stream-ordered
+  return rc;
 }
 
 // ---------------------------------------------------------------------------
