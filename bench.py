@@ -136,7 +136,8 @@ class Step:
                       "center": self._dalloc(8 * self.m_pca), "scale": self._dalloc(8 * self.m_pca)}
         self.pca_d = np.zeros(k)
         self.pca_fro = C.c_double()
-        self.fst_sums = np.zeros((4, self.P))  # Hudson num, den; WC84 num, den
+        self.fst_sums = np.zeros((4, self.P))  # Hudson num, den; WC84 num, den: read back only by fst_results()
+        self.d_fst = self._dalloc(8 * 4 * self.P)  # the same, resident: the step leaves them in HBM like every other output
 
     def _dalloc(self, nbytes):
         return self.ctx.dev_alloc(max(int(nbytes), 16))
@@ -162,18 +163,16 @@ class Step:
         chk(lib.tpg_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(self.ploidy), C.c_int(0), self.d_freq))
         chk(lib.tpg_grouped_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(self.gid), C.c_int(G), api._ptr(self.ploidy),
                                                 C.c_int(0), self.d_gfreq))
-        for row, code in ((0, 0), (2, 2)):  # Hudson, WC84: sums over this rank's loci
+        for row, code in ((0, 0), (2, 2)):  # Hudson, WC84: sums over this rank's loci, left in HBM (no host round trip)
             chk(lib.tpg_pairwise_pop_fst_sums(ctx.h, v.h, api._ptr(self.gid), C.c_int(G), api._ptr(self.ploidy),
                                               C.c_int(code), api._ptr(self.pairs), C.c_int(P),
-                                              api._ptr(self.fst_sums[row]), api._ptr(self.fst_sums[row + 1])))
+                                              C.c_void_p(self.d_fst.value + 8 * P * row),
+                                              C.c_void_p(self.d_fst.value + 8 * P * (row + 1))))
         self.pw.zero()
         self.pw.accumulate(v)
         # data-path exchanges (identities on one rank): integer N x N partials, one reduce-scatter; 4 P doubles
         self.pw.reduce()
-        self.comm.allreduce_f64(self.fst_sums)
-        with np.errstate(invalid="ignore", divide="ignore"):
-            self.fst["Hudson"] = self.fst_sums[0] / self.fst_sums[1]
-            self.fst["WC84"] = self.fst_sums[2] / self.fst_sums[3]
+        self.comm.allreduce_f64(self.d_fst.value, 4 * P)
         chk(lib.tpg_pairwise_epilogues_sharded(ctx.h, self.comm.h, self.pw.h, C.c_int(0), C.c_int64(self.m_total),
                                                self.d_nn[0], self.d_nn[1], C.c_void_p(None), self.d_nn[2]))
         v.free()
@@ -194,6 +193,14 @@ class Step:
         ctx.sync()
 
 
+def fst_results(st):
+    """the Fst ratios from the numerator / denominator sums the step left in HBM"""
+    st.tpg._lib.check(st.lib.tpg_dev_to_host(st.ctx.h, st.api._ptr(st.fst_sums), st.d_fst, C.c_size_t(st.fst_sums.nbytes)))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        st.fst["Hudson"] = st.fst_sums[0] / st.fst_sums[1]
+        st.fst["WC84"] = st.fst_sums[2] / st.fst_sums[3]
+
+
 def digest(st):
     """A few numbers that pin every output of the step (used to compare sharded and unsharded runs).  The N x N
     outputs are sharded by bands: every rank contributes the elements it wrote, summed over the ranks."""
@@ -201,6 +208,7 @@ def digest(st):
 
     n, k = st.args.n, st.args.k
     chk = st.tpg._lib.check
+    fst_results(st)
     out = {"fst_hudson": st.fst["Hudson"].tolist(), "fst_wc84": st.fst["WC84"].tolist(),
            "pca_d": st.pca_d.tolist(), "pca_fro": st.pca_fro.value}
     mask = sharding.band_mask(n, st.world, st.rank)
@@ -469,6 +477,7 @@ def end_to_end(st):
     """Host backing file -> HBM -> every result of the step back in host memory, on rank 0's panel at N = 1: what an R
     caller holding a bigstatsr .bk file pays, PCIe included (never `value`).  Two ways: serial (upload, step,
     download) and the block pipeline of _e2e_overlapped."""
+    fst_results(st)  # of the resident step: what the pipelines are compared with
     path = _e2e_file(st)
     if path is None:
         return {"skipped": "no room for the backing file"}
