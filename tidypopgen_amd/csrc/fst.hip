@@ -350,37 +350,39 @@ __global__ void tpg_fst_hudson_gemm_final_kernel(const double* __restrict__ full
 // WC84, totals only, on the class counts of the fused path.  The estimator is the FAST form of fst_terms above; what
 // is new is where the reciprocals come from.  Everything in it that depends on the sample sizes ALONE depends on the
 // number of valid alleles of the pair, A = A_1 + A_2 -- a small integer (at most four times the largest group) -- so
-// 1 / nt, 1 / nt^2, (nt - 1) / (2 nt), nt / (2 (nt / 2 - 1)) and nt^2 / (4 (nt / 2 - 1)) (nt = A / 2 individuals) are
-// tabulated once per workgroup by IEEE divisions (closer to the reference than v_rcp_f64 + Newton steps) and a pair
-// and locus costs ~27 FP64 instructions and three 16-byte table reads instead of ~60 instructions.
+// 1 / nt, (nt - 1) / (2 nt), nt / (2 (nt / 2 - 1)) and nt^2 / (4 (nt / 2 - 1)) (nt = A / 2 individuals) are tabulated
+// once per workgroup by IEEE divisions (closer to the reference than v_rcp_f64 + Newton steps) and a pair and locus
+// costs ~30 FP64 instructions and one 32-byte table read instead of ~60 instructions.
 // Staged per (locus, population) as four doubles {individuals, freq_alt, het_obs * individuals, 1 / individuals}.
-#define FSTW_TAB 6  // doubles per table entry
-template <int PPT>
+#define FSTW_TAB 4  // doubles per table entry: {1 / nt, (nt - 1) / (2 nt), nt / (2 nb1), nt^2 / (4 nb1)}
+// GS = stride of the staged arrays in populations: 64 (a compile-time constant: every LDS address of the pair loop is
+// then a per-pair base register + an immediate offset, no integer arithmetic inside it) when G <= 64, else 0 = G itself.
+template <int PPT, int GS>
 __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64_t m, int G, int LB, int kmax,
                                                                const int32_t* __restrict__ pairs0, int P,
                                                                double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* st = sh;                                   // [l][g][4]
-  double* tab = sh + (size_t)LB * G * 4;             // [A][FSTW_TAB]
-  int* shA = (int*)(tab + (size_t)(kmax + 1) * FSTW_TAB);  // [l][g] valid alleles
+  const int gs = GS ? GS : G;
+  // byte offsets inside the dynamic LDS block: staged {n, p, H, e} [l][g], then the table [A]
+  const uint32_t tab_b = (uint32_t)LB * gs * 32u;
+  char* shb = (char*)sh;
   for (int A = threadIdx.x; A <= kmax; A += 256) {
     const double nt = 0.5 * (double)A, nb1 = 0.5 * nt - 1.0;
     const double r = 1.0 / nt, sv = 1.0 / nb1;  // nb1 = 0 (one individual per population): +inf, as the reference's 1 / 0
-    double* t = tab + (size_t)A * FSTW_TAB;
+    double* t = (double*)(shb + tab_b) + (size_t)A * FSTW_TAB;
     t[0] = r;
-    t[1] = r * r;
-    t[2] = (0.5 * (nt - 1.0)) * r;
-    t[3] = (0.5 * nt) * sv;
-    t[4] = (0.25 * (nt * nt)) * sv;
-    t[5] = 0.0;
+    t[1] = (0.5 * (nt - 1.0)) * r;
+    t[2] = (0.5 * nt) * sv;
+    t[3] = (0.25 * (nt * nt)) * sv;
   }
-  int pidx[PPT], g1[PPT], g2[PPT];
+  int pidx[PPT];
+  uint32_t o1[PPT], o2[PPT];  // the pair's two populations
   double sum_num[PPT], sum_den[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; k++) {
     pidx[k] = (blockIdx.y * PPT + k) * 256 + threadIdx.x;
-    g1[k] = 0; g2[k] = 0;
-    if (pidx[k] < P) { g1[k] = pairs0[2 * pidx[k]]; g2[k] = pairs0[2 * pidx[k] + 1]; }
+    o1[k] = 0; o2[k] = 0;
+    if (pidx[k] < P) { o1[k] = (uint32_t)pairs0[2 * pidx[k]]; o2[k] = (uint32_t)pairs0[2 * pidx[k] + 1]; }
     sum_num[k] = 0.0; sum_den[k] = 0.0;
   }
   const int64_t nchunks = (m + LB - 1) / LB;
@@ -393,32 +395,34 @@ __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64
       double vn = 0.0, vp = FST_NAN, vh = FST_NAN;
       if (j < m) fst_stage(src, m, j, g, vn, vp, vh);
       const double ni = 0.5 * vn;
-      *(v4d*)&st[4 * idx] = v4d{ni, vp, vh * ni, 1.0 / ni};
-      shA[idx] = (int)vn;
+      const uint32_t q = (uint32_t)(l * gs + g);
+      *(v4d*)(shb + q * 32u) = v4d{ni, vp, vh * ni, 1.0 / ni};
     }
     __syncthreads();
     const int lmax = (int)((m - j0) < LB ? (m - j0) : LB);
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
       if (pidx[k] >= P) continue;
-#pragma unroll 2
+      const uint32_t a1 = o1[k] * 32u, a2 = o2[k] * 32u;
+      double sn = sum_num[k], sd = sum_den[k];
+#pragma unroll 4
       for (int l = 0; l < lmax; l++) {
-        const int o1 = l * G + g1[k], o2 = l * G + g2[k];
-        const v4d s1 = *(const v4d*)&st[4 * o1], s2 = *(const v4d*)&st[4 * o2];  // {n, p, H, e}
-        const int A = min(shA[o1] + shA[o2], kmax);
-        const double* t = tab + (size_t)A * FSTW_TAB;
-        const double2 t01 = *(const double2*)t, t23 = *(const double2*)(t + 2);
-        const double t4 = t[4];
-        const double p_bar = fma(s2[1], s2[0], s1[1] * s1[0]) * t01.x, h_bar = (s1[2] + s2[2]) * t01.x;
+        const uint32_t lo = (uint32_t)l * (uint32_t)gs;
+        const v4d s1 = *(const v4d*)(shb + a1 + lo * 32u), s2 = *(const v4d*)(shb + a2 + lo * 32u);  // {n, p, H, e}
+        // valid alleles of the pair = 2 (n1 + n2): an exact small integer in FP64 (an empty population has n = 0)
+        const int A = min(__double2int_rz(2.0 * (s1[0] + s2[0])), kmax);
+        const v4d t = *(const v4d*)(shb + tab_b + (uint32_t)A * (FSTW_TAB * 8u));
+        const double p_bar = fma(s2[1], s2[0], s1[1] * s1[0]) * t[0], h_bar = (s1[2] + s2[2]) * t[0];
         const double d = s1[1] - s2[1], d2 = d * d;
-        const double half_s2 = (d2 * (s1[0] * s2[0])) * t01.y;
+        const double half_s2 = (d2 * (s1[0] * s2[0])) * (t[0] * t[0]);
         const double core = fma(-p_bar, p_bar, p_bar) - half_s2;
-        const double X = t4 * (s1[3] * s2[3]);
+        const double X = t[3] * (s1[3] * s2[3]);
         const double a = fma(-X, fma(-0.25, h_bar, core), 0.5 * d2);
-        const double b = t23.y * fma(-t23.x, h_bar, core);
+        const double b = t[2] * fma(-t[1], h_bar, core);
         const double den = fma(0.5, h_bar, a + b);
-        if (den == den) { sum_num[k] += a; sum_den[k] += den; }  // a NaN numerator makes the denominator NaN too
+        if (den == den) { sn += a; sd += den; }  // a NaN numerator makes the denominator NaN too
       }
+      sum_num[k] = sn; sum_den[k] = sd;
     }
   }
 #pragma unroll
@@ -501,18 +505,26 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   if (rc == TPG_OK && fst_tot) rc = ot.init(fst_tot, sizeof(double) * (size_t)P);
   if (rc == TPG_OK && by_locus) rc = oa.init(out_a, mp);
   if (rc == TPG_OK && return_num_dem) rc = ob.init(out_b, mp);
-  const size_t sh_tab = sizeof(double) * ((size_t)LB * G * 4 + (size_t)(kmax + 1) * FSTW_TAB) + sizeof(int) * (size_t)LB * G;
+  // the table kernel stages 32 bytes per (locus, population), at a stride of 64 populations when G <= 64
+  const int gs_tab = G <= 64 ? 64 : G, lb_tab = G <= 64 ? 16 : LB;
+  const size_t sh_tab = (size_t)lb_tab * gs_tab * 32 + (size_t)(kmax + 1) * FSTW_TAB * 8;
   const bool wc84_tab = fast && method == TPG_FST_WC84 && src.cnt && !src.has_hap && kmax > 0 && sh_tab <= 150 * 1024;
   if (rc == TPG_OK && wc84_tab) {  // reciprocals by table: see tpg_fst_wc84_tab_kernel
-    dim3 grid((unsigned)nblocks, (unsigned)ypass);
-    if (ppt == 8) {
-      (void)hipFuncSetAttribute((const void*)tpg_fst_wc84_tab_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_tab);
-      TPG_LAUNCH(ctx, "fst_wc84", (tpg_fst_wc84_tab_kernel<8>), grid, dim3(256), sh_tab, src, m, G, LB, kmax, pb.dev<int32_t>(), P, d_part);
-    } else {
-      (void)hipFuncSetAttribute((const void*)tpg_fst_wc84_tab_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_tab);
-      TPG_LAUNCH(ctx, "fst_wc84", (tpg_fst_wc84_tab_kernel<1>), grid, dim3(256), sh_tab, src, m, G, LB, kmax, pb.dev<int32_t>(), P, d_part);
-    }
-    TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 16)), dim3(256), 0, d_part, nblocks, P,
+    const int64_t nch = ceil_div(m, lb_tab);
+    const int nbt = (int)std::max<int64_t>(1, std::min<int64_t>(nch, (int64_t)nblocks));
+    dim3 grid((unsigned)nbt, (unsigned)ypass);
+#define FSTW_LAUNCH(PP, GSV)                                                                                                    \
+  do {                                                                                                                          \
+    (void)hipFuncSetAttribute((const void*)tpg_fst_wc84_tab_kernel<PP, GSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_tab); \
+    TPG_LAUNCH(ctx, "fst_wc84", (tpg_fst_wc84_tab_kernel<PP, GSV>), grid, dim3(256), sh_tab, src, m, G, lb_tab, kmax, pb.dev<int32_t>(), P, \
+               d_part);                                                                                                         \
+  } while (0)
+    if (ppt == 8 && G <= 64) FSTW_LAUNCH(8, 64);
+    else if (ppt == 8) FSTW_LAUNCH(8, 0);
+    else if (G <= 64) FSTW_LAUNCH(1, 64);
+    else FSTW_LAUNCH(1, 0);
+#undef FSTW_LAUNCH
+    TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 16)), dim3(256), 0, d_part, nbt, P,
                ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { tpg_set_error("fst kernels: %s", hipGetErrorString(e)); rc = TPG_EHIP; }

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
     if (un >= nun * S) break;
     const int ks = (int)(un / nun);
     const int2 ijt = order[un % nun];
-    const int I = ijt.x, jt = ijt.y;
+    const int I = __builtin_amdgcn_readfirstlane(ijt.x), jt = __builtin_amdgcn_readfirstlane(ijt.y);
     const int64_t tp0 = tpg_pw_unit_index(nst, I, jt) + rowpad[I];
     const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
 
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
 #pragma unroll
     for (int t = 0; t < TA; t++) {
       there[t] = TA * I + t < nct;
-      pa[t] = T4 + ((int64_t)(there[t] ? TA * I + t : 0) * KG * 2) * 64 + lane;
+      pa[t] = T4 + ((int64_t)(there[t] ? TA * I + t : 0) * KG * 2) * 64;
     }
-    const uint4* pb0 = T4 + ((int64_t)jt * KG * 2) * 64 + lane;
+    const uint4* pb0 = T4 + ((int64_t)jt * KG * 2) * 64;
 
     v16f cV[TA], cD[TA], cH[TA], cHV[TA], cVH[TA];
 #pragma unroll
@@ -171,7 +171,13 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       // native vectors, not HIP's uint4 struct: with the struct the register allocator splits the loaded tuple right
       // after the load (v_mov behind an s_waitcnt vmcnt: a full memory latency at the top of every group)
       v4u RA[3][TA][2], RB[3][2];
-      auto LD = [&](const uint4* p) { return *(const v4u*)p; };
+      // wave-uniform base (SGPRs) + one 32-bit lane offset: global_load_dwordx4 v, v_off, s[base]; the empty asm keeps
+      // hipcc from folding the lane into loop-invariant 64-bit VGPR pointers (a v_lshl_add_u64 per load)
+      auto LD = [&](const uint4* p) {
+        uint32_t off = (uint32_t)lane * 16u;
+        asm("" : "+v"(off));
+        return *(const v4u*)((const char*)p + off);
+      };
       const int64_t i1 = k0 + 1 < k1 ? k0 + 1 : kl;
 #pragma unroll
       for (int s = 0; s < 2; s++) {
