@@ -52,7 +52,8 @@ struct tpg_ctx {
   std::vector<hipEvent_t> event_pool;
   int num_cu = 256;
   int pool_id = 0;  // this context's device-memory pool (runtime.hip): blocks are reused in the order of ITS stream
-  void* resident = nullptr;  // pairwise.hip: FBM uploads and accumulators kept across increment_* calls
+  void* resident = nullptr;  // pairwise.hip: accumulators kept across increment_* calls
+  double* eig_pinned = nullptr;  // pca.hip: pinned staging slots of the eigen solver's small matrices
   // small host -> device copies without a stream synchronisation: a ring of pinned slots (runtime.hip: tpg_h2d_async)
   static constexpr int H2D_SLOTS = 8;
   static constexpr size_t H2D_SLOT_BYTES = 256u << 10;

@@ -1301,9 +1301,10 @@ struct EigWork {
     TPG_HIP(tpg_pmalloc((void**)&lam_dev, sizeof(double) * 64));
     TPG_HIP(tpg_pmalloc((void**)&cdev, sizeof(double) * 64 * 64));
     TPG_HIP(tpg_pmalloc((void**)&dtmp, sizeof(double) * (size_t)b * (size_t)n));
-    static double* pinned = nullptr;  // 512 KB, allocated once per process (pinning costs ~1 ms)
-    if (!pinned) TPG_HIP(hipHostMalloc((void**)&pinned, sizeof(double) * 64 * 64 * XSLOTS, hipHostMallocDefault));
-    xpin = pinned;
+    // 512 KB of pinned staging, allocated once per CONTEXT (pinning costs ~1 ms) and freed with it: several contexts
+    // may run the eigen step at the same time (the device threads of tpg_multi_*), each writes its own slots
+    if (!ctx->eig_pinned) TPG_HIP(hipHostMalloc((void**)&ctx->eig_pinned, sizeof(double) * 64 * 64 * XSLOTS, hipHostMallocDefault));
+    xpin = ctx->eig_pinned;
     TPG_HIP(tpg_pmalloc((void**)&xdev, sizeof(double) * 64 * 64 * XSLOTS));
     return TPG_OK;
   }

@@ -259,6 +259,7 @@ extern "C" void tpg_ctx_destroy(tpg_ctx* ctx) {
       (void)hipHostFree(ctx->h2d_pinned);
     }
     tpg_resident_release(ctx);
+    if (ctx->eig_pinned) (void)hipHostFree(ctx->eig_pinned);
     pool_close(ctx->pool_id);  // only this context's blocks
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }
