@@ -379,7 +379,8 @@ static double gcls_cost_classes(int64_t nunits, int64_t nruns, int64_t nblocks, 
     if (nblocks / S < 4 && S > 2) break;
     const int64_t rounds = ceil_div(nunits * S, (int64_t)nwaves);
     const double per = ((double)nruns / S + 1.0) * GP * 0.136 + (double)ceil_div(nblocks, (int64_t)S) * GP * 0.079 + 6.0;
-    const double cost = (double)rounds * per;
+    // + the assemble pass over the S slabs of every unit (0.48 ms at S = 18 and 3 160 units)
+    const double cost = (double)rounds * per + (double)S * (double)nunits * 8.5e-3;
     if (best < 0 || cost < best * 0.995) { best = cost; *bestS = S; }
   }
   return best;
