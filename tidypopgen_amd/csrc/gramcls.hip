@@ -138,6 +138,9 @@ __global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(GclsSrc S, int64_t
   __shared__ __attribute__((aligned(16))) uint32_t sh[4][2][4][64];  // [wave][source half][s][locus]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 31, ho = lane >> 5, hs = r >> 4, shf = tpg_elem_shift(r & 15);
+  uint32_t rot[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) rot[e] = (uint32_t)(shf - 4 * e) & 31u;
   const int64_t npairs = (nblocks + 1) >> 1;
   for (int64_t task = (int64_t)blockIdx.x * 4 + wv; task < Q * npairs; task += (int64_t)gridDim.x * 4) {
     const int64_t q = task % Q, bp = task / Q;
@@ -165,9 +168,11 @@ __global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(GclsSrc S, int64_t
         for (int d = 0; d < 4; d++) {
           const uint4 a = rd[2 * d], c = rd[2 * d + 1];
           const uint32_t ws[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+          // this lane's individual sits at bits [shf, shf + 1] of every word: a rotation brings them to nibble e
+          // (v_alignbit_b32), v_and_or_b32 drops them into place: two instructions per genotype
           uint32_t acc = 0;
 #pragma unroll
-          for (int e = 0; e < 8; e++) acc = (acc << 4) | ((ws[e] >> shf) & 3u);
+          for (int e = 0; e < 8; e++) acc = (__builtin_amdgcn_alignbit(ws[e], ws[e], rot[e]) & (3u << (4 * e))) | acc;
           const uint32_t m3 = acc & (acc >> 1) & 0x11111111u;  // code 3 -> 0
           nib[d] = acc & ~(m3 | (m3 << 1));
         }
