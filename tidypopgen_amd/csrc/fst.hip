@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256) void tpg_fst_reduce_kernel(const double* __res
 // sums are formed in another order than the reference's (and than the by-locus path's, which stays statement for
 // statement): the totals agree to ~1e-14 relative.
 #define FSTG_T 64   // populations per tile side
-#define FSTG_LB 32  // loci per staged chunk
-__global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_kernel(FstSrc src, int64_t m, int G, int ntile,
+#define FSTG_LB 16  // loci per staged chunk (32 KiB of LDS: four workgroups per CU hide one another's staging)
+__global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_kernel(FstSrc src, int64_t m, int G, int ntile, int kmax,
                                                                   double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* ra = sh;                          // [l][64] a of the row populations
@@ -263,51 +263,108 @@ __global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_kernel(FstSrc src, in
   const int tR = blockIdx.y / ntile, tC = blockIdx.y % ntile;
   const bool diag = tR == tC;
   double* cc = diag ? rc : sh + 3 * FSTG_LB * FSTG_T;  // c of the column populations
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  // 1 / A and 1 / (A - 1) for A valid alleles (class counts: A is a small integer), by IEEE divisions once per workgroup:
+  // the per-population staging then needs no division (freq = alt * (1 / A) differs from alt / A by at most an ulp; the
+  // by-locus path, which must be bit-identical to the reference, divides)
+  double* inv = sh + 4 * FSTG_LB * FSTG_T;
+  for (int A = threadIdx.x; A <= kmax; A += 256) { inv[2 * A] = 1.0 / (double)A; inv[2 * A + 1] = 1.0 / ((double)A - 1.0); }
+  // thread grid TG x TG of 4 x 4 blocks, TG = populations of this tile / 4 rounded up: with 51 populations 13 x 13 = 169
+  // threads work (three waves) instead of 256 on a padded 64 x 64 tile
+  const int gR = min(FSTG_T, G - tR * FSTG_T), gC = min(FSTG_T, G - tC * FSTG_T);
+  const int TGy = (gR + 3) / 4, TGx = (gC + 3) / 4;
+  const bool work = (int)threadIdx.x < TGy * TGx;
+  const int ty = work ? threadIdx.x / TGx : 0, tx = work ? threadIdx.x % TGx : 0;
   double AB[4][4], CB[4][4], CC[4][4];
 #pragma unroll
   for (int r = 0; r < 4; r++)
 #pragma unroll
     for (int c = 0; c < 4; c++) { AB[r][c] = 0.0; CB[r][c] = 0.0; CC[r][c] = 0.0; }
   const int64_t nchunks = (m + FSTG_LB - 1) / FSTG_LB;
+  // class counts of diploids (kmax > 0): the three counts of this thread's (locus, population) slots of the NEXT chunk are
+  // fetched into registers before the products of the current one, so that their latency hides behind the FMAs
+  constexpr int NSLOT = 2 * FSTG_LB * FSTG_T / 256;
+  const int nslot = (diag ? 1 : 2) * FSTG_LB * FSTG_T / 256;
+  int pn1[NSLOT], pn2[NSLOT], pnv[NSLOT];
+  auto fetch = [&](int64_t ch) {
+#pragma unroll
+    for (int i = 0; i < NSLOT; i++) {
+      pn1[i] = 0; pn2[i] = 0; pnv[i] = 0;
+      if (i < nslot && ch < nchunks) {
+        const int idx = threadIdx.x + 256 * i;
+        const int side = idx / (FSTG_LB * FSTG_T), rem = idx % (FSTG_LB * FSTG_T);
+        const int g = (side ? tC : tR) * FSTG_T + rem % FSTG_T;
+        const int64_t j = ch * FSTG_LB + rem / FSTG_T;
+        if (j < m && g < G) {
+          const int64_t plane = src.Mpad * src.Cpad, o = j * src.Cpad + g;
+          pn1[i] = src.cnt[o]; pn2[i] = src.cnt[plane + o]; pnv[i] = src.cnt[2 * plane + o];
+        }
+      }
+    }
+  };
+  if (kmax > 0) fetch(blockIdx.x);
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t j0 = ch * FSTG_LB;
     __syncthreads();
-    // a tile on the diagonal (always, up to 64 populations) stages its populations once: rows and columns are the same
-    for (int idx = threadIdx.x; idx < (diag ? 1 : 2) * FSTG_LB * FSTG_T; idx += 256) {
-      const int side = idx / (FSTG_LB * FSTG_T), rem = idx % (FSTG_LB * FSTG_T);
-      const int l = rem / FSTG_T, gl = rem % FSTG_T;
-      const int g = (side ? tC : tR) * FSTG_T + gl;
-      const int64_t j = j0 + l;
-      double a = 0.0, b = 0.0, c = 0.0;
-      if (j < m && g < G) {
-        double vn, vp, vh;
-        fst_stage(src, m, j, g, vn, vp, vh);
-        const double e = (vp * (1 - vp)) / (vn - 1);  // src/pairwise_fst_hudson_loop.cpp:28-29
-        if (vp == vp && e == e) { a = vp * vp - e; b = 1.0; c = vp; }
+    if (kmax > 0) {
+#pragma unroll
+      for (int i = 0; i < NSLOT; i++) {
+        if (i >= nslot) break;
+        const int idx = threadIdx.x + 256 * i;
+        const int side = idx / (FSTG_LB * FSTG_T), rem = idx % (FSTG_LB * FSTG_T);
+        double a = 0.0, b = 0.0, c = 0.0;
+        const int A = min(2 * pnv[i], kmax);
+        if (A > 0) {  // no valid genotype (or a slot past the data): freq is NaN, the population drops out
+          const double vp = (double)(pn1[i] + 2 * pn2[i]) * inv[2 * A];
+          const double e = (vp * (1 - vp)) * inv[2 * A + 1];
+          if (e == e) { a = vp * vp - e; b = 1.0; c = vp; }
+        }
+        if (side) { cb[rem] = b; cc[rem] = c; }
+        else {
+          ra[rem] = a; rc[rem] = c;
+          if (diag) cb[rem] = b;
+        }
       }
-      if (side) { cb[rem] = b; cc[rem] = c; }
-      else {
-        ra[rem] = a; rc[rem] = c;
-        if (diag) cb[rem] = b;
+    } else {
+      // a tile on the diagonal (always, up to 64 populations) stages its populations once: rows and columns are the same
+      for (int idx = threadIdx.x; idx < (diag ? 1 : 2) * FSTG_LB * FSTG_T; idx += 256) {
+        const int side = idx / (FSTG_LB * FSTG_T), rem = idx % (FSTG_LB * FSTG_T);
+        const int l = rem / FSTG_T, gl = rem % FSTG_T;
+        const int g = (side ? tC : tR) * FSTG_T + gl;
+        const int64_t j = j0 + l;
+        double a = 0.0, b = 0.0, c = 0.0;
+        if (j < m && g < G) {
+          double vn, vp, vh;
+          fst_stage(src, m, j, g, vn, vp, vh);
+          const double e = (vp * (1 - vp)) / (vn - 1);  // src/pairwise_fst_hudson_loop.cpp:28-29
+          if (vp == vp && e == e) { a = vp * vp - e; b = 1.0; c = vp; }
+        }
+        if (side) { cb[rem] = b; cc[rem] = c; }
+        else {
+          ra[rem] = a; rc[rem] = c;
+          if (diag) cb[rem] = b;
+        }
       }
     }
     __syncthreads();
+    if (kmax > 0) fetch(ch + gridDim.x);
+    if (work) {
 #pragma unroll 2
-    for (int l = 0; l < FSTG_LB; l++) {
-      const v4d a4 = *(const v4d*)&ra[l * FSTG_T + 4 * ty], c4 = *(const v4d*)&rc[l * FSTG_T + 4 * ty];
-      const v4d b4 = *(const v4d*)&cb[l * FSTG_T + 4 * tx], d4 = *(const v4d*)&cc[l * FSTG_T + 4 * tx];
+      for (int l = 0; l < FSTG_LB; l++) {
+        const v4d a4 = *(const v4d*)&ra[l * FSTG_T + 4 * ty], c4 = *(const v4d*)&rc[l * FSTG_T + 4 * ty];
+        const v4d b4 = *(const v4d*)&cb[l * FSTG_T + 4 * tx], d4 = *(const v4d*)&cc[l * FSTG_T + 4 * tx];
 #pragma unroll
-      for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          AB[r][c] = fma(a4[r], b4[c], AB[r][c]);
-          CB[r][c] = fma(c4[r], b4[c], CB[r][c]);
-          CC[r][c] = fma(c4[r], d4[c], CC[r][c]);
-        }
+          for (int c = 0; c < 4; c++) {
+            AB[r][c] = fma(a4[r], b4[c], AB[r][c]);
+            CB[r][c] = fma(c4[r], b4[c], CB[r][c]);
+            CC[r][c] = fma(c4[r], d4[c], CC[r][c]);
+          }
+      }
     }
   }
   // partial sums of this workgroup: [block x][tile][product][row][col]
+  if (!work) return;
   double* o = part + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 3) * FSTG_T * FSTG_T;
 #pragma unroll
   for (int r = 0; r < 4; r++)
@@ -320,25 +377,30 @@ __global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_kernel(FstSrc src, in
     }
 }
 
-// full[tile][product][row][col] = sum over the workgroups' partials, in workgroup order (the same sums on every run)
+// full[slice][tile][product][row][col] = sum over every FSTG_SL-th workgroup's partials, in workgroup order; the final
+// kernel adds the FSTG_SL slices in slice order (the same sums on every run)
+#define FSTG_SL 16
 __global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_reduce_kernel(const double* __restrict__ part, int nbx, int64_t cells,
                                                                          double* __restrict__ full) {
   const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (q >= cells) return;
   double s = 0.0;
-  for (int b = 0; b < nbx; b++) s += part[(int64_t)b * cells + q];
-  full[q] = s;
+  for (int b = blockIdx.y; b < nbx; b += FSTG_SL) s += part[(int64_t)b * cells + q];
+  full[(int64_t)blockIdx.y * cells + q] = s;
 }
 
-__global__ void tpg_fst_hudson_gemm_final_kernel(const double* __restrict__ full, int ntile, const int32_t* __restrict__ pairs0, int P,
-                                                 double* __restrict__ fst_tot, double* __restrict__ sum_num,
-                                                 double* __restrict__ sum_den) {
+__global__ void tpg_fst_hudson_gemm_final_kernel(const double* __restrict__ full, int64_t cells, int ntile,
+                                                 const int32_t* __restrict__ pairs0, int P, double* __restrict__ fst_tot,
+                                                 double* __restrict__ sum_num, double* __restrict__ sum_den) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= P) return;
   const int g1 = pairs0[2 * pi], g2 = pairs0[2 * pi + 1];
   auto at = [&](int prod, int r, int c) {
     const int t = (r / FSTG_T) * ntile + c / FSTG_T;
-    return full[(((int64_t)t * 3 + prod) * FSTG_T + r % FSTG_T) * FSTG_T + c % FSTG_T];
+    const int64_t q = (((int64_t)t * 3 + prod) * FSTG_T + r % FSTG_T) * FSTG_T + c % FSTG_T;
+    double v = 0.0;
+    for (int sl = 0; sl < FSTG_SL; sl++) v += full[(int64_t)sl * cells + q];
+    return v;
   };
   const double cc2 = 2 * at(2, g1, g2);
   const double sn = at(0, g1, g2) + at(0, g2, g1) - cc2, sd = at(1, g1, g2) + at(1, g2, g1) - cc2;
@@ -386,19 +448,43 @@ __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64
     sum_num[k] = 0.0; sum_den[k] = 0.0;
   }
   const int64_t nchunks = (m + LB - 1) / LB;
+  // the three class counts of this thread's (locus, population) slots of the NEXT chunk are fetched into registers before
+  // the pair loop of the current one (their latency hides behind it); FSTW_SLOTS x 256 >= LB * G
+  constexpr int FSTW_SLOTS = 8;
+  int pn1[FSTW_SLOTS], pn2[FSTW_SLOTS], pnv[FSTW_SLOTS];
+  auto fetch = [&](int64_t ch) {
+    const int64_t plane = src.Mpad * src.Cpad;
+#pragma unroll
+    for (int i = 0; i < FSTW_SLOTS; i++) {
+      pn1[i] = 0; pn2[i] = 0; pnv[i] = 0;
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < LB * G && ch < nchunks) {
+        const int64_t j = ch * LB + idx / G;
+        if (j < m) {
+          const int64_t o = j * src.Cpad + idx % G;
+          pn1[i] = src.cnt[o]; pn2[i] = src.cnt[plane + o]; pnv[i] = src.cnt[2 * plane + o];
+        }
+      }
+    }
+  };
+  fetch(blockIdx.x);
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t j0 = ch * LB;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < LB * G; idx += 256) {
-      const int l = idx / G, g = idx % G;
-      const int64_t j = j0 + l;
-      double vn = 0.0, vp = FST_NAN, vh = FST_NAN;
-      if (j < m) fst_stage(src, m, j, g, vn, vp, vh);
-      const double ni = 0.5 * vn;
-      const uint32_t q = (uint32_t)(l * gs + g);
-      *(v4d*)(shb + q * 32u) = v4d{ni, vp, vh * ni, 1.0 / ni};
+#pragma unroll
+    for (int i = 0; i < FSTW_SLOTS; i++) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < LB * G) {
+        // src/grouped_summaries_dip_pseudo_cpp.cpp:40-56 on the counts (diploids): n = 2 valid, freq, het_obs
+        const double vn = (double)(2 * pnv[i]);
+        const double vp = (double)(pn1[i] + 2 * pn2[i]) / vn, vh = (double)(2 * pn1[i]) / vn;  // 0 / 0 = NaN: no valid genotype
+        const double ni = 0.5 * vn;
+        const uint32_t q = (uint32_t)((idx / G) * gs + idx % G);
+        *(v4d*)(shb + q * 32u) = v4d{ni, vp, vh * ni, 1.0 / ni};
+      }
     }
     __syncthreads();
+    fetch(ch + gridDim.x);
     const int lmax = (int)((m - j0) < LB ? (m - j0) : LB);
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
@@ -469,21 +555,23 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
     const int ntile = (int)ceil_div(G, FSTG_T);
     const int64_t cells = (int64_t)ntile * ntile * 3 * FSTG_T * FSTG_T;
     const int64_t nch = ceil_div(m, FSTG_LB);
-    int nbx = (int)std::min<int64_t>(nch, std::max(1, 2 * ctx->num_cu / (ntile * ntile)));
+    int nbx = (int)std::min<int64_t>(nch, std::max(1, 4 * ctx->num_cu / (ntile * ntile)));
     OutBuf ot, osn, osd;
     if (fst_tot) TPG_TRY(ot.init(fst_tot, sizeof(double) * (size_t)P));
     if (sum_num) { TPG_TRY(osn.init(sum_num, sizeof(double) * (size_t)P)); TPG_TRY(osd.init(sum_den, sizeof(double) * (size_t)P)); }
     double* d_gp = nullptr;
-    TPG_HIP(tpg_pmalloc((void**)&d_gp, sizeof(double) * (size_t)cells * (size_t)(nbx + 1)));
+    TPG_HIP(tpg_pmalloc((void**)&d_gp, sizeof(double) * (size_t)cells * (size_t)(nbx + FSTG_SL)));
     double* d_full = d_gp + (size_t)cells * (size_t)nbx;
-    const size_t shg = sizeof(double) * 4 * FSTG_LB * FSTG_T;
+    // reciprocals by table when the source is the class counts of diploids and the table fits (kmax valid alleles at most)
+    const int kq = (src.cnt && !src.has_hap && kmax > 0 && kmax <= 4096) ? kmax : 0;
+    const size_t shg = sizeof(double) * (4 * FSTG_LB * FSTG_T + 2 * ((size_t)kq + 1));
     (void)hipFuncSetAttribute((const void*)tpg_fst_hudson_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shg);
     TPG_LAUNCH(ctx, "fst_hudson", tpg_fst_hudson_gemm_kernel, dim3((unsigned)nbx, (unsigned)(ntile * ntile)), dim3(256), shg, src, m, G,
-               ntile, d_gp);
-    TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_hudson_gemm_reduce_kernel, dim3((unsigned)ceil_div(cells, 256)), dim3(256), 0,
+               ntile, kq, d_gp);
+    TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_hudson_gemm_reduce_kernel, dim3((unsigned)ceil_div(cells, 256), FSTG_SL), dim3(256), 0,
                (const double*)d_gp, nbx, cells, d_full);
     TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_hudson_gemm_final_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, (const double*)d_full,
-               ntile, pb.dev<int32_t>(), P, ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
+               cells, ntile, pb.dev<int32_t>(), P, ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
     hipError_t e = hipGetLastError();
     tpg_pfree(d_gp);  // stream-ordered
     if (e != hipSuccess) { tpg_set_error("fst kernels: %s", hipGetErrorString(e)); return TPG_EHIP; }
@@ -508,7 +596,8 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
   // the table kernel stages 32 bytes per (locus, population), at a stride of 64 populations when G <= 64
   const int gs_tab = G <= 64 ? 64 : G, lb_tab = G <= 64 ? 16 : LB;
   const size_t sh_tab = (size_t)lb_tab * gs_tab * 32 + (size_t)(kmax + 1) * FSTW_TAB * 8;
-  const bool wc84_tab = fast && method == TPG_FST_WC84 && src.cnt && !src.has_hap && kmax > 0 && sh_tab <= 150 * 1024;
+  const bool wc84_tab = fast && method == TPG_FST_WC84 && src.cnt && !src.has_hap && kmax > 0 && sh_tab <= 150 * 1024 &&
+                        (int64_t)lb_tab * G <= 8 * 256;  // a thread prefetches at most 8 (locus, population) slots
   if (rc == TPG_OK && wc84_tab) {  // reciprocals by table: see tpg_fst_wc84_tab_kernel
     const int64_t nch = ceil_div(m, lb_tab);
     const int nbt = (int)std::max<int64_t>(1, std::min<int64_t>(nch, (int64_t)nblocks));
