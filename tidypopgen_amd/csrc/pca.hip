@@ -1320,10 +1320,7 @@ struct EigWork {
   int set_locked(const double* Lptr, int count, const double* lam_host) {
     L = Lptr;
     nl = count;
-    if (count > 0) {
-      TPG_HIP(hipMemcpyAsync(lam_dev, lam_host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
-      TPG_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    if (count > 0) TPG_HIP(tpg_h2d_async(ctx, lam_dev, lam_host, sizeof(double) * (size_t)count));  // pinned slot: no wait
     return TPG_OK;
   }
   // Y = alpha K' Q + beta Y1 + gamma Y0   with K' = K - L diag(lam) L'; no host synchronisation
