@@ -309,6 +309,48 @@ int tpg_comm_alltoallv64(tpg_comm* comm, const void* d_send, const size_t* scnt,
   return TPG_OK;
 }
 
+// The all-to-all is the one collective of this library that a run on one GPU cannot exercise over RCCL.  Before its first
+// real use every communicator sends a few known words round and checks what arrives; a transport error or a wrong word
+// on ANY rank switches the class exchange off on ALL of them (tpg_comm_agree), and the PCA falls back to the Gram matrix
+// of every rank's own loci, which needs all-reduces only.
+bool tpg_comm_alltoall_usable(tpg_comm* comm) {
+  if (!comm) return false;
+  if (comm->a2a_state != 0) return comm->a2a_state > 0;
+  const int R = comm->nranks, me = comm->rank, W = 4;
+  std::vector<uint64_t> hs((size_t)R * W), hr((size_t)R * W, 0);
+  std::vector<size_t> cnt((size_t)R, (size_t)W), off((size_t)R);
+  for (int d = 0; d < R; d++) {
+    off[(size_t)d] = (size_t)d * W;
+    for (int w = 0; w < W; w++) hs[(size_t)d * W + w] = 0x5450470000000000ull + (uint64_t)me * 65536 + (uint64_t)d * 256 + (uint64_t)w;
+  }
+  uint64_t *ds = nullptr, *dr = nullptr;
+  int rc = TPG_OK;
+  hipStream_t s = comm->ctx->stream;
+  if (tpg_pmalloc((void**)&ds, 8 * hs.size()) != hipSuccess || tpg_pmalloc((void**)&dr, 8 * hr.size()) != hipSuccess) rc = TPG_EHIP;
+  rc = tpg_comm_agree(comm, rc);
+  if (rc == TPG_OK) {
+    if (hipMemcpyAsync(ds, hs.data(), 8 * hs.size(), hipMemcpyHostToDevice, s) != hipSuccess) rc = TPG_EHIP;
+    if (hipMemsetAsync(dr, 0, 8 * hr.size(), s) != hipSuccess) rc = TPG_EHIP;
+    rc = tpg_comm_agree(comm, rc);
+  }
+  if (rc == TPG_OK) {
+    rc = tpg_comm_alltoallv64(comm, ds, cnt.data(), off.data(), dr, cnt.data(), off.data());
+    if (rc == TPG_OK && (hipMemcpyAsync(hr.data(), dr, 8 * hr.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                         hipStreamSynchronize(s) != hipSuccess))
+      rc = TPG_EHIP;
+    if (rc == TPG_OK)
+      for (int r = 0; r < R; r++)
+        for (int w = 0; w < W; w++)
+          if (hr[(size_t)r * W + w] != 0x5450470000000000ull + (uint64_t)r * 65536 + (uint64_t)me * 256 + (uint64_t)w) rc = TPG_EHIP;
+    rc = tpg_comm_agree(comm, rc);
+  }
+  tpg_pfree(ds);
+  tpg_pfree(dr);
+  comm->a2a_state = rc == TPG_OK ? 1 : -1;
+  if (rc != TPG_OK && getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] all-to-all self-test failed on this communicator: no class exchange\n");
+  return rc == TPG_OK;
+}
+
 // d_buf holds nranks chunks of chunk_count int32; afterwards chunk `rank` holds the sum over the ranks of that chunk
 // (the other chunks are left with this rank's own partial values)
 int tpg_comm_reduce_scatter_i32(tpg_comm* comm, int32_t* d_buf, int64_t chunk_count) {

@@ -238,12 +238,16 @@ struct tpg_comm {
   int (*host_fn)(void* user, void* buf, int64_t count, int dtype) = nullptr;  // in-place sum; dtype 0 int32, 1 float64
   void* host_user = nullptr;
   int32_t* d_status = nullptr;  // device int32[TPG_COMM_STATUS_INTS]: the status word of tpg_comm_agree
+  int a2a_state = 0;            // tpg_comm_alltoall_usable: 0 not tried yet, 1 works, -1 does not (on every rank alike)
 };
 #define TPG_COMM_STATUS_INTS 8
 int tpg_comm_agree(tpg_comm* comm, int rc);  // all ranks get the same status (the worst any of them passed in)
 int tpg_comm_reduce_scatter_i32(tpg_comm* comm, int32_t* d_buf, int64_t chunk_count);  // in place, chunk r -> rank r
 int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype);          // in place, device memory
 // 8-byte words: rank r sends scnt[d] words at soff[d] to rank d, receives rcnt[s] words from rank s at roff[s]
+// a tiny all-to-all with known contents, once per communicator: true on every rank or on none.  The class exchange of the
+// PCA Gram (gramcls.hip) is only taken when it is.
+bool tpg_comm_alltoall_usable(tpg_comm* comm);
 int tpg_comm_alltoallv64(tpg_comm* comm, const void* d_send, const size_t* scnt, const size_t* soff, void* d_recv,
                          const size_t* rcnt, const size_t* roff);
 

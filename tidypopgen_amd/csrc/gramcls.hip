@@ -629,6 +629,7 @@ int tpg_gram_classes_exchanged(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, 
     return TPG_OK;
   };
   TPG_TRY(tpg_comm_agree(comm, local()));
+  if (!tpg_comm_alltoall_usable(comm)) return TPG_OK;  // the same answer on every rank
   {
     ProfScope ps(ctx, "gclx_histogram");
     TPG_TRY(tpg_comm_allreduce(comm, d_hist, n + 1, 0));
@@ -641,11 +642,12 @@ int tpg_gram_classes_exchanged(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, 
     if (hist[(size_t)k] > 0) { m_all += hist[(size_t)k]; runs_all++; blocks_all += ((int64_t)hist[(size_t)k] + 63) / 64; }
   if (m_all == 0) return TPG_OK;
   const double cost_all = (double)runs_all * 0.136 + (double)blocks_all * 0.079;
-  // does it pay?  modelled time of this rank's share of whole classes + the exchange (records at ~40 GB/s, a few
-  // launches) against the cheaper of the two local paths on a shard (digits: 1.0 us per 128 loci and 4 row tiles)
+  // does it pay?  modelled time of this rank's share of whole classes + the exchange (a rank sends (R - 1) / R of its records
+  // over R - 1 xGMI links at once: ~300 GB/s per rank; a few launches) against the cheaper of the two local paths on a
+  // shard (digits: 1.0 us per 128 loci and 4 row tiles)
   const int nrtv = (int)ceil_div(n, 32);
   const double units = (double)nrtv * (double)nrtv / 8.0, waves = 8.0 * (double)(ctx->num_cu > 8 ? ctx->num_cu : 8);
-  const double t_exch = units / waves * 4.0 * cost_all / R + 700.0 + (double)m_all / R * (double)(32 * Q + 16) / 40e3;
+  const double t_exch = units / waves * 4.0 * cost_all / R + 700.0 + (double)m_all / R * (double)(32 * Q + 16) / 300e3;
   const double shard_blocks = (double)blocks_all / R + (double)runs_all;  // a shard pads every class to a block of its own
   const double t_cls_local = units / waves * 4.0 * ((double)runs_all * 0.136 + shard_blocks * 0.079) + 650.0;
   const double t_dig_local = ((double)nrtv * nrtv / 8.0 + nrtv) / (waves / 2.0) * ((double)m_all / R / 128.0) + 65.0;
