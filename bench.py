@@ -752,7 +752,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl, "analyses": analyses, "pca_included": bool(st.has_pca),
                        "collectives": (f"library-owned, transport {getattr(st, 'transport', 'host (gloo) rehearsal')}: reduce-scatter of int32 pairwise "
-                                       "slabs, all-reduce of Fst sums and of the FP64 Gram (upper triangle)")
+                                       "slabs, all-reduce of Fst sums and of the FP64 Gram (upper triangle), all-to-all of the packed columns "
+                                       "(whole weight classes per rank) when the PCA's cost model takes it")
                        if world > 1 else "none (one rank)"},
             "roofline": roof,
             "roofline_other_kernels": roofs[1:] + [r for r in others if r],
