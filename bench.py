@@ -751,6 +751,9 @@ def main():
             "dtype": "fp4-e2m1 operands (exact integers, f32 accumulate) for the cross-products and the PCA Gram, int8 (int32 accumulate) for counts, f64 for statistics",
             "data": "synthetic",
             "config": {"workload": wl, "analyses": analyses, "pca_included": bool(st.has_pca),
+                       "pca_gram_path": ("whole weight classes per rank (packed columns by one all-to-all)" if "gclx_alltoall" in prof
+                                         else "this rank's loci, weight classes" if "pca_gram_classes" in prof
+                                         else "this rank's loci, int8 weight digits"),
                        "collectives": (f"library-owned, transport {getattr(st, 'transport', 'host (gloo) rehearsal')}: reduce-scatter of int32 pairwise "
                                        "slabs, all-reduce of Fst sums and of the FP64 Gram (upper triangle), all-to-all of the packed columns "
                                        "(whole weight classes per rank) when the PCA's cost model takes it")
