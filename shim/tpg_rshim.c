@@ -81,7 +81,7 @@ static const char* field_path(SEXP env, const char* name) {
 /* A backing file mapped into this process, and (for genotype FBMs) its copy in HBM.  The 5 GB upload happens once per
  * data set, not once per call -- but bigsnpr::snp_fastImputeSimple (R/gt_impute_simple.R:86) and gt_set_imputed-style
  * writes change the backing file IN PLACE, so the HBM copy is only trusted while the file's size, modification time
- * and a fingerprint of 4 096 pages spread over it are what they were at upload; anything else re-uploads.
+ * and a fingerprint of 512 pages spread over it are what they were at upload; anything else re-uploads.
  * TPG_RSHIM_NO_CACHE=1 uploads at every call. */
 typedef struct {
   char* path;
@@ -97,8 +97,8 @@ typedef struct {
 static mapped_file* g_files = NULL;
 static int g_nfiles = 0;
 
-static uint64_t fingerprint_of(const uint8_t* p, size_t bytes) { /* FNV-1a over up to 4 096 whole 4-KiB pages */
-  const size_t page = 4096, npages = (bytes + page - 1) / page, want = npages < 4096 ? npages : 4096;
+static uint64_t fingerprint_of(const uint8_t* p, size_t bytes) { /* FNV-1a over up to 512 whole 4-KiB pages (2 MB read) */
+  const size_t page = 4096, npages = (bytes + page - 1) / page, want = npages < 512 ? npages : 512;
   uint64_t h = 1469598103934665603ull;
   for (size_t k = 0; k < want; k++) {
     const size_t pg = want > 1 ? k * (npages - 1) / (want - 1) : 0, off = pg * page;
