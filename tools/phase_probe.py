@@ -4,7 +4,6 @@ import sys, time
 import ctypes as C
 import numpy as np
 sys.path.insert(0, ".")
-sys.argv = [sys.argv[0]]
 import bench
 
 args = bench.parse()
