@@ -976,7 +976,9 @@ extern "C" int tpg_pca_gram_add(tpg_ctx* ctx, const tpg_view* v, const double* c
 __global__ __launch_bounds__(256) void tpg_symm_apply_kernel(const double* __restrict__ K, int n,
                                                              const double* __restrict__ Q, int b, int S,
                                                              double* __restrict__ part) {
-  __shared__ double qs[64][65];
+  // two buffers of the 64-deep slice of Q: the slice and the K values of chunk c + 1 are fetched (into registers) before
+  // the MFMAs of chunk c and written to the other buffer after them, one barrier per chunk
+  __shared__ double qs[2][64][65];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   const int row0 = (blockIdx.x * 4 + wv) * 16;
@@ -988,25 +990,38 @@ __global__ __launch_bounds__(256) void tpg_symm_apply_kernel(const double* __res
   v4d acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0, 0, 0, 0};
-  for (int ch = cbeg; ch < cend; ch++) {
+  double av[16], qv[16];
+  auto fetch = [&](int ch) {  // K values of this lane and this thread's 16 entries of the Q slice, chunk ch
     const int k0 = ch * 64;
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
-      const int kk = idx & 63, c = idx >> 6;
-      qs[kk][c] = (k0 + kk < n && c < b) ? Q[(k0 + kk) + (int64_t)c * n] : 0.0;
-    }
-    __syncthreads();
-    double av[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) {
       const int k = k0 + 4 * u + kq;
       av[u] = (row < n && k < n) ? K[row + (int64_t)k * n] : 0.0;
+      const int idx = threadIdx.x + 256 * u, kk = idx & 63, c = idx >> 6;
+      qv[u] = (k0 + kk < n && c < b) ? Q[(k0 + kk) + (int64_t)c * n] : 0.0;
     }
+  };
+  if (cbeg < cend) {
+    fetch(cbeg);
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int idx = threadIdx.x + 256 * u; qs[0][idx & 63][idx >> 6] = qv[u]; }
+  }
+  for (int ch = cbeg; ch < cend; ch++) {
+    const int cur = (ch - cbeg) & 1;
+    __syncthreads();  // qs[cur] is complete, qs[cur ^ 1] has been read by everybody
+    double a0[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) a0[u] = av[u];
+    if (ch + 1 < cend) fetch(ch + 1);
 #pragma unroll
     for (int u = 0; u < 16; u++) {
 #pragma unroll
       for (int ct = 0; ct < 4; ct++)
-        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], qs[4 * u + kq][ct * 16 + r16], acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], qs[cur][4 * u + kq][ct * 16 + r16], acc[ct], 0, 0, 0);
+    }
+    if (ch + 1 < cend) {
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const int idx = threadIdx.x + 256 * u; qs[cur ^ 1][idx & 63][idx >> 6] = qv[u]; }
     }
   }
 #pragma unroll
