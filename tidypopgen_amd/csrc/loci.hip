@@ -409,7 +409,10 @@ __global__ __launch_bounds__(256) void tpg_grouped_finalize_kernel(const int32_t
                                                                    const int32_t* __restrict__ group_size,
                                                                    double* __restrict__ o0, double* __restrict__ o1,
                                                                    double* __restrict__ o2, double* __restrict__ o3) {
-  __shared__ double tile[4][32][65];  // [output][group chunk][locus]
+  // [output][group chunk][locus]; only as many outputs as the mode writes (2 / 1 / 4): 33 KiB instead of 66 for the
+  // allele frequencies, i.e. four workgroups per CU instead of two
+  extern __shared__ double tile_raw[];
+  double (*tile)[32][65] = (double (*)[32][65])tile_raw;
   const int64_t j0 = (int64_t)blockIdx.x * 64;
   for (int g0 = 0; g0 < G; g0 += 32) {
     __syncthreads();
@@ -809,7 +812,8 @@ extern "C" int tpg_alt_freq_dip_pseudo(tpg_ctx* ctx, const tpg_view* v, const do
   GroupedCounts gc;
   TPG_TRY(tpg_grouped_counts(ctx, v, cp.cls.data(), cp.nclass, &gc));
   // reuse the grouped finalize (mode 0 with G = 1 has the m x 2 layout wanted), then NA guard on the host side
-  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3((unsigned)ceil_div(v->m, 64)), dim3(256), 0,
+  (void)hipFuncSetAttribute((const void*)tpg_grouped_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 65 * 8);
+  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3((unsigned)ceil_div(v->m, 64)), dim3(256), 2 * 32 * 65 * 8,
              gc.cnt, gc.Mpad, gc.Cpad, v->m, 1, cp.has_hap, 0, as_counts, (const int32_t*)nullptr, o.dev<double>(),
              (double*)nullptr, (double*)nullptr, (double*)nullptr);
   TPG_CHECK_LAUNCH();
@@ -833,7 +837,9 @@ static int grouped_common(tpg_ctx* ctx, const tpg_view* v, const int32_t* groupI
   if (o3) TPG_TRY(b3.init(o3, sizeof(double) * mg));
   InBuf gs;
   TPG_TRY(gs.init(ctx, cp.group_size.data(), sizeof(int32_t) * (size_t)ngroups));
-  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3((unsigned)ceil_div(v->m, 64)), dim3(256), 0,
+  (void)hipFuncSetAttribute((const void*)tpg_grouped_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 65 * 8);
+  TPG_LAUNCH(ctx, "grouped_finalize", tpg_grouped_finalize_kernel, dim3((unsigned)ceil_div(v->m, 64)), dim3(256),
+             (size_t)(mode == 0 ? 2 : mode == 1 ? 1 : 4) * 32 * 65 * 8,
              gc.cnt, gc.Mpad, gc.Cpad, v->m, ngroups, cp.has_hap, mode, as_counts, gs.dev<int32_t>(), b0.dev<double>(),
              b1.dev<double>(), b2.dev<double>(), b3.dev<double>());
   TPG_CHECK_LAUNCH();  // outputs in device memory are ready in stream order; host outputs are waited for in commit()
