@@ -1125,6 +1125,49 @@ __global__ __launch_bounds__(256) void tpg_right_mult_kernel(const double* __res
   }
 }
 
+// Rayleigh-Ritz rotation and residuals in one pass over the block: Y0 = A X (Ritz vectors), Y1 = Yk X (K times them,
+// Yk = K A) and, per workgroup of 32 rows, the column sums of (Y1 - Y0 diag(theta))^2 -- only the residual NORMS are
+// wanted, not the Gram matrix of the residuals; tpg_gram_reduce_kernel adds the partial sums in block order.
+__global__ __launch_bounds__(256) void tpg_ritz_kernel(const double* __restrict__ A, const double* __restrict__ Yk, int n,
+                                                       int p, const double* __restrict__ X,
+                                                       const double* __restrict__ theta, double* __restrict__ Y0,
+                                                       double* __restrict__ Y1, double* __restrict__ rpart) {
+  __shared__ double xs[64 * 64];
+  for (int idx = threadIdx.x; idx < p * p; idx += 256) xs[idx] = X[idx];
+  __syncthreads();
+  const int row = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int cg = threadIdx.x >> 5;  // 8 groups of 8 columns
+  const bool live = row < n;
+  double a0[8], a1[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) a0[c] = 0, a1[c] = 0;
+  if (live)
+    for (int i = 0; i < p; i++) {
+      const double a = A[row + (int64_t)i * n], y = Yk[row + (int64_t)i * n];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int j = cg * 8 + c;
+        const double x = j < p ? xs[i + j * p] : 0.0;
+        a0[c] += a * x;
+        a1[c] += y * x;
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const int j = cg * 8 + c;
+    double r = 0;
+    if (live && j < p) {
+      Y0[row + (int64_t)j * n] = a0[c];
+      Y1[row + (int64_t)j * n] = a1[c];
+      r = a1[c] - theta[j] * a0[c];
+      r *= r;
+    }
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) r += __shfl_xor(r, off, 32);
+    if ((threadIdx.x & 31) == 0 && j < p) rpart[(int64_t)blockIdx.x * p + j] = r;
+  }
+}
+
 __global__ void tpg_fill_random_kernel(double* __restrict__ Q, int64_t total, uint64_t seed) {
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     uint64_t x = (uint64_t)idx * 0x9E3779B97F4A7C15ull + seed;
@@ -1165,17 +1208,20 @@ static void host_upper_inverse(const std::vector<double>& R, int b, std::vector<
   }
 }
 
-// cyclic Jacobi for a symmetric b x b matrix: eigenvalues (descending) and eigenvectors (columns of X)
 // Symmetric eigen-decomposition of a small dense matrix: Householder reduction to tridiagonal form with the
 // transformations accumulated, then implicit-shift QL (the classic tred2 / tql2 pair).  ~4/3 n^3 + ~3 n^3 flops
 // instead of the ~16 n^3 of eight cyclic Jacobi sweeps: the Rayleigh-Ritz matrices here are up to 64 x 64 and
 // sit on the critical path between two launches.  H is column-major symmetric; eigenvalues come back in
 // descending order with the eigenvectors as the columns of X (column-major).
-static void host_sym_eig(const std::vector<double>& H, int n, std::vector<double>& theta, std::vector<double>& X) {
-  std::vector<double> Vv((size_t)n * n), d((size_t)n), e((size_t)n);
-  auto V = [&](int i, int j) -> double& { return Vv[(size_t)i * n + j]; };
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < n; j++) V(i, j) = 0.5 * (H[i + (size_t)j * n] + H[j + (size_t)i * n]);
+//
+// The working matrix is column-major and every inner loop runs down a column, so the host compiler vectorises them (an
+// AVX2 clone is picked at load time where the CPU has it); the 2 x 2 rotations use sqrt(p^2 + e^2), the caller having
+// scaled the matrix to entries of at most 1 (hypot() alone was 40 % of the time).
+#define V(i, j) Vp[(size_t)(j) * n + (i)]
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("arch=x86-64-v3", "default")))
+#endif
+static void sym_eig_core(double* __restrict Vp, double* __restrict d, double* __restrict e, int n) {
   // --- Householder tridiagonalisation, last row first
   for (int j = 0; j < n; j++) d[j] = V(n - 1, j);
   for (int i = n - 1; i > 0; i--) {
@@ -1235,7 +1281,7 @@ static void host_sym_eig(const std::vector<double>& H, int n, std::vector<double
   double f = 0, tst1 = 0;
   const double eps = 2.220446049250313e-16;
   for (int l = 0; l < n; l++) {
-    tst1 = std::max(tst1, fabs(d[l]) + fabs(e[l]));
+    tst1 = fmax(tst1, fabs(d[l]) + fabs(e[l]));
     int m = l;
     while (m < n - 1 && fabs(e[m]) > eps * tst1) m++;
     if (m > l) {
@@ -1243,7 +1289,7 @@ static void host_sym_eig(const std::vector<double>& H, int n, std::vector<double
       do {
         double g = d[l];
         double p = (d[l + 1] - g) / (2 * e[l]);
-        double r = hypot(p, 1.0);
+        double r = sqrt(p * p + 1.0);
         if (p < 0) r = -r;
         d[l] = e[l] / (p + r);
         d[l + 1] = e[l] * (p + r);
@@ -1258,7 +1304,7 @@ static void host_sym_eig(const std::vector<double>& H, int n, std::vector<double
           c3 = c2; c2 = c; s2 = s;
           g = c * e[i];
           h = c * p;
-          r = hypot(p, e[i]);
+          r = sqrt(p * p + e[i] * e[i]);
           e[i + 1] = s * r;
           s = e[i] / r;
           c = p / r;
@@ -1278,14 +1324,25 @@ static void host_sym_eig(const std::vector<double>& H, int n, std::vector<double
     d[l] += f;
     e[l] = 0;
   }
+}
+#undef V
+
+static void host_sym_eig(const std::vector<double>& H, int n, std::vector<double>& theta, std::vector<double>& X) {
+  std::vector<double> Vv((size_t)n * n), d((size_t)n), e((size_t)n);
+  double big = 0;
+  for (size_t t = 0; t < (size_t)n * n; t++) big = std::max(big, fabs(H[t]));
+  const double inv = big > 0 ? 1.0 / big : 1.0;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) Vv[(size_t)j * n + i] = 0.5 * (H[i + (size_t)j * n] + H[j + (size_t)i * n]) * inv;
+  sym_eig_core(Vv.data(), d.data(), e.data(), n);
   std::vector<int> ord((size_t)n);
   for (int i = 0; i < n; i++) ord[(size_t)i] = i;
   std::sort(ord.begin(), ord.end(), [&](int x, int y) { return d[x] > d[y]; });
   theta.resize((size_t)n);
   X.assign((size_t)n * n, 0.0);
   for (int j = 0; j < n; j++) {
-    theta[(size_t)j] = d[ord[(size_t)j]];
-    for (int i = 0; i < n; i++) X[i + (size_t)j * n] = V(i, ord[(size_t)j]);
+    theta[(size_t)j] = d[(size_t)ord[(size_t)j]] * (big > 0 ? big : 1.0);
+    for (int i = 0; i < n; i++) X[i + (size_t)j * n] = Vv[(size_t)ord[(size_t)j] * n + i];
   }
 }
 
@@ -1308,8 +1365,10 @@ struct EigWork {
   int init() {
     S = 1;
     const int row_blocks = (n + 63) / 64;
-    while (row_blocks * S < 4 * ctx->num_cu && S < 32 && n / (S * 2) >= 128) S *= 2;
-    rows_per_chunk = 128;
+    while (row_blocks * S < 4 * ctx->num_cu && S < 32 && n / (S * 2) >= 64) S *= 2;
+    // A'B over chunks of rows: a workgroup per 32 (64) rows, so that a product on a few thousand rows is one short round
+    // of many workgroups instead of a long loop in a few
+    rows_per_chunk = n <= 4096 ? 32 : 64;
     nchunks = (n + rows_per_chunk - 1) / rows_per_chunk;
     TPG_HIP(tpg_pmalloc((void**)&part, sizeof(double) * (size_t)S * (size_t)b * (size_t)n));
     TPG_HIP(tpg_pmalloc((void**)&gpart, sizeof(double) * (size_t)nchunks * 64 * 64));  // nchunks = n/32
@@ -1365,6 +1424,26 @@ struct EigWork {
                (const double*)gpart, nchunks, p, bb, (const double*)nullptr, cdev);
     C.assign((size_t)p * bb, 0.0);
     TPG_HIP(hipMemcpyAsync(C.data(), cdev, sizeof(double) * (size_t)p * bb, hipMemcpyDeviceToHost, ctx->stream));
+    TPG_HIP(hipStreamSynchronize(ctx->stream));
+    return TPG_OK;
+  }
+  // Ritz step: Y0 = A X, Y1 = Yk X, res2[j] = |Y1_j - theta_j Y0_j|^2 (host, after a synchronisation)
+  int ritz(const double* A, const double* Yk, int p, const std::vector<double>& X, const std::vector<double>& theta,
+           double* Y0, double* Y1, std::vector<double>& res2) {
+    if (xslot + 2 > XSLOTS) { TPG_HIP(hipStreamSynchronize(ctx->stream)); xslot = 0; }
+    double* hx = xpin + (size_t)xslot * 64 * 64;
+    double* dx = xdev + (size_t)xslot * 64 * 64;
+    memcpy(hx, X.data(), sizeof(double) * (size_t)p * p);
+    memcpy(hx + 64 * 64, theta.data(), sizeof(double) * (size_t)p);
+    xslot += 2;
+    TPG_HIP(hipMemcpyAsync(dx, hx, sizeof(double) * (64 * 64 + (size_t)p), hipMemcpyHostToDevice, ctx->stream));
+    const int nblk = (n + 31) / 32;
+    TPG_LAUNCH(ctx, "eig_ritz", tpg_ritz_kernel, dim3((unsigned)nblk), dim3(256), 0, A, Yk, n, p, (const double*)dx,
+               (const double*)(dx + 64 * 64), Y0, Y1, gpart);
+    TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((p + 255) / 256)), dim3(256), 0,
+               (const double*)gpart, nblk, p, 1, (const double*)nullptr, cdev);
+    res2.assign((size_t)p, 0.0);
+    TPG_HIP(hipMemcpyAsync(res2.data(), cdev, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, ctx->stream));
     TPG_HIP(hipStreamSynchronize(ctx->stream));
     return TPG_OK;
   }
@@ -1432,9 +1511,9 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
   };
 
   // CholQR (twice) of the `act` columns at A, after projecting out the `nl` locked columns at L
-  auto orthonormalize = [&](double* A, int act, const double* L, int nl, double* tmp) -> int {
+  auto orthonormalize = [&](double* A, int act, const double* L, int nl, double* tmp, int passes = 2) -> int {
     int extra_passes = 0;
-    for (int pass = 0; pass < 2; pass++) {
+    for (int pass = 0; pass < passes; pass++) {
       if (nl > 0) {
         std::vector<double> Cm;
         TPG_TRY(w.gram(L, nl, A, act, Cm));      // nl x act
@@ -1463,7 +1542,7 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
           const double sc = 1.0 / sqrt(std::max(lamg[(size_t)j], floor_));
           for (int i = 0; i < act; i++) Ri[i + (size_t)j * act] = Vg[i + (size_t)j * act] * sc;
         }
-        if (pass == 1) pass = 0, extra_passes++;  // one more clean-up pass
+        if (pass == passes - 1) pass = passes - 2, extra_passes++;  // one more clean-up pass
         if (extra_passes > 3) { tpg_set_error("eigen solver: block lost rank"); return TPG_ENUMERIC; }
       }
       for (int j = 0; j < act; j++)
@@ -1476,7 +1555,9 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
 
   StageTimer st(ctx, "eig");
   TPG_LAUNCH(ctx, "eig_random", tpg_fill_random_kernel, dim3(512), dim3(256), 0, Q, (int64_t)n * b, (uint64_t)0x5EED);
-  TPG_TRY(orthonormalize(Q, b, nullptr, 0, Y));
+  // uniform random columns are well conditioned: one CholQR pass leaves them orthonormal to ~1e-13, which is all the
+  // first Rayleigh-Ritz step (spectral bounds for the filter) asks for
+  TPG_TRY(orthonormalize(Q, b, nullptr, 0, Y, 1));
   st.mark("init + orthonormalize");
   std::vector<double> lam((size_t)b, 0.0), theta, X, H;
   int nl = 0;
@@ -1500,27 +1581,28 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
       }
     host_sym_eig(H, act, theta, X);
     st.mark("host_sym_eig");
-    TPG_TRY(w.rmult(A, act, X, act, Y0));  // Ritz vectors
-    TPG_TRY(w.rmult(Y, act, X, act, Y1));  // K * Ritz vectors
-    TPG_HIP(hipMemcpyAsync(A, Y0, colbytes(act), hipMemcpyDeviceToDevice, ctx->stream));
-    if (nl == 0) lam1 = fabs(theta[0]) > 0 ? fabs(theta[0]) : 1.0;
-    // residuals R = K a - theta a
-    std::vector<double> negtheta((size_t)act * act, 0.0);
-    for (int j = 0; j < act; j++) negtheta[j + (size_t)j * act] = -theta[(size_t)j];
-    TPG_TRY(w.rmult(A, act, negtheta, act, Y));
-    TPG_TRY(axpby(Y, 1.0, Y1, 1.0, Y, act));
+    // The random start block has no converged pair and the filter works on any basis of the subspace: its first
+    // Rayleigh-Ritz step only supplies the Ritz VALUES (the filter's interval), so the rotation to Ritz vectors and the
+    // residuals (three products, a Gram matrix and a host round trip) are left out
+    const bool first = it == 0 && b < n;  // (a block that spans the whole space is exact at once)
     std::vector<double> RR;
-    TPG_TRY(w.gram(Y, act, Y, act, RR));
-    st.mark("ritz vectors + residuals");
+    if (first) {
+      lam1 = fabs(theta[0]) > 0 ? fabs(theta[0]) : 1.0;
+    } else {
+      TPG_TRY(w.ritz(A, Y, act, X, theta, Y0, Y1, RR));  // Ritz vectors, K * Ritz vectors, |K a - theta a|^2
+      TPG_HIP(hipMemcpyAsync(A, Y0, colbytes(act), hipMemcpyDeviceToDevice, ctx->stream));
+      if (nl == 0) lam1 = fabs(theta[0]) > 0 ? fabs(theta[0]) : 1.0;
+      st.mark("ritz vectors + residuals");
+    }
     int newly = 0;
-    while (newly < act && nl + newly < k && sqrt(std::max(0.0, RR[newly + (size_t)newly * act])) < TOL * lam1) newly++;
+    while (!first && newly < act && nl + newly < k && sqrt(std::max(0.0, RR[(size_t)newly])) < TOL * lam1) newly++;
     for (int j = 0; j < newly; j++) lam[(size_t)(nl + j)] = theta[(size_t)j];
     nl += newly;
     if (nl >= k) break;
     const int act2 = b - nl;
     TPG_REQUIRE(act2 >= 2, TPG_ENUMERIC, "eigen solver ran out of active vectors");
     double* A2 = Q + (size_t)n * nl;
-    const double* KA2 = Y1 + (size_t)n * newly;  // K * (active Ritz vectors), still valid
+    const double* KA2 = first ? Y : Y1 + (size_t)n * newly;  // K * (active Ritz vectors), still valid
     // Chebyshev filter damping [0, smallest active Ritz value], scaled at the largest active one
     const double up = std::max(theta[(size_t)act - 1], 1e-300 * lam1), lo = 0.0;
     const double a0 = std::max(theta[(size_t)newly], up * (1 + 1e-8));
@@ -1534,7 +1616,7 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
     if (getenv("TPG_DEBUG"))
       fprintf(stderr, "[eig] it %d act %d locked %d (+%d) deg %d theta_first %.4g theta_last %.4g lam1 %.4g res0 %.3g\n", it,
               act, nl, newly, deg, theta[(size_t)newly], theta[(size_t)act - 1], lam1,
-              sqrt(std::max(0.0, RR[newly + (size_t)newly * act])) / lam1);
+              first ? -1.0 : sqrt(std::max(0.0, RR[(size_t)newly])) / lam1);
     w.b = act2;
     TPG_TRY(w.set_locked(Q, nl, lam.data()));
     // KA2 was formed with the previous deflation; the newly locked directions are (numerically)
@@ -1543,8 +1625,8 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
     const double sigma1 = sigma;
     // first step: cur = (sigma1/e)(K A2 - c A2), prev = A2
     double* prev = Y0;
-    double* cur = Y;
-    double* nxt = Y1;
+    double* cur = first ? Y1 : Y;  // never the buffer KA2 lives in
+    double* nxt = first ? Y : Y1;
     TPG_HIP(hipMemcpyAsync(prev, A2, colbytes(act2), hipMemcpyDeviceToDevice, ctx->stream));
     TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, KA2, 1, (int64_t)n * act2,
                sigma1 / ec, (const double*)prev, -cc * sigma1 / ec, (const double*)nullptr, 0.0, cur,
