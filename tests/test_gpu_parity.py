@@ -905,16 +905,19 @@ def test_pca_gram_weight_classes_equal_digits_and_numpy(tpg, n, m):
     v = tpg.View(X)
     center, scale = tpg.pca_center_scale(v)
     ref = _np_gram(g, center, scale)
-    with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None):
-        Kc = tpg.pca_gram(v, center, scale)
+    sc = np.abs(ref).max()
+    # exact class Gram matrices and double weights; the default fold takes neighbouring classes in groups and adds their
+    # small weight differences in FP32 (TPG_GRAM_FOLD64=0; 1e-9 is a few times what it shows), =1 folds every class in FP64;
+    # left alone the library picks by the number of classes per block
+    for fold64, tol in (("0", 1e-9), ("1", 1e-11)):
+        with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None, TPG_GRAM_FOLD64=fold64):
+            Kc = tpg.pca_gram(v, center, scale)
+            assert np.array_equal(Kc, Kc.T)
+            assert np.abs(Kc - ref).max() <= tol * sc
+            assert np.array_equal(tpg.pca_gram(v, center, scale), Kc)  # run-to-run identical (ordered slab sums)
     with _env(TPG_GRAM_DIGITS="1", TPG_GRAM_CLASSES=None):
         Kd = tpg.pca_gram(v, center, scale)
-    sc = np.abs(ref).max()
-    assert np.array_equal(Kc, Kc.T)
-    assert np.abs(Kc - ref).max() <= 1e-11 * sc   # exact class Gram matrices, double weights, FP64 sums
     assert np.abs(Kd - ref).max() <= 1e-6 * sc    # 2^-24 weight rounding
-    with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None):
-        assert np.array_equal(tpg.pca_gram(v, center, scale), Kc)  # run-to-run identical (ordered slab sums)
 
 
 def test_pca_gram_weight_classes_general_center_and_scale(tpg):
@@ -928,16 +931,17 @@ def test_pca_gram_weight_classes_general_center_and_scale(tpg):
     center = rng.uniform(0.1, 1.9, m)
     for scale in (rng.choice([0.5, 0.75, 1.0, 1.25, 3.0], m), rng.uniform(0.3, 2.0, m)):
         ref = _np_gram(g, center, scale)
-        with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None):
-            Kc = tpg.pca_gram(v, center, scale)
-        assert np.abs(Kc - ref).max() <= 1e-11 * np.abs(ref).max()
+        for fold64, tol in (("0", 1e-9), ("1", 1e-11)):
+            with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None, TPG_GRAM_FOLD64=fold64):
+                Kc = tpg.pca_gram(v, center, scale)
+            assert np.abs(Kc - ref).max() <= tol * np.abs(ref).max()
         Ka = tpg.pca_gram(v, center, scale)  # whatever the cost model picks
         assert np.abs(Ka - ref).max() <= 1e-6 * np.abs(ref).max()
 
 
 def test_pca_gram_one_class_longer_than_an_exact_fp32_sum(tpg):
     """Every locus the same genotype column: ONE weight class of 4.2 million loci, i.e. more 64-locus blocks than FP32
-    accumulators can take (4 x 2^22 = 2^24): the class is folded every 2^16 blocks."""
+    accumulators can take (4 x 2^22 = 2^24): the class is folded every 2^14 blocks (every 2^16 by the FP64-fold kernel)."""
     n, m = 40, 64 * 65536 + 64 * 100 + 3
     col = np.array([2, 2, 0, 1, 2, 0, 1, 2, 2, 1] * 4, dtype=np.uint8)[:n]
     Xb = np.empty((n, m), dtype=np.uint8, order="F")
@@ -946,11 +950,12 @@ def test_pca_gram_one_class_longer_than_an_exact_fp32_sum(tpg):
     del Xb
     v = tpg.View(X)
     center, scale = tpg.pca_center_scale(v)
-    with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None):
-        K = tpg.pca_gram(v, center, scale)
     z = (col.astype(np.float64) - center[0]) / scale[0]
     ref = m * np.outer(z, z)
-    assert np.abs(K - ref).max() <= 1e-12 * np.abs(ref).max()
+    for fold64 in ("0", "1"):
+        with _env(TPG_GRAM_CLASSES="1", TPG_GRAM_DIGITS=None, TPG_GRAM_FOLD64=fold64):
+            K = tpg.pca_gram(v, center, scale)
+        assert np.abs(K - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("n,m,subset", [(300, 1000, False), (1000, 2500, False), (256, 1024, True)])

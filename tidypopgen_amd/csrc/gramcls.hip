@@ -112,6 +112,40 @@ __global__ void tpg_gcls_block_table_kernel(const unsigned long long* __restrict
   }
 }
 
+// Block table of the mixed-precision fold (tpg_gcls_gram2_kernel).  Classes are taken in GROUPS of neighbouring weights
+// (same exponent and leading GCLS_GQ mantissa bits: a relative span below 2^-GCLS_GQ; at most GCLS_GMAX classes; fewer than
+// 2^15 blocks, so that the running integer sums of a group stay below 2^23).  Inside a group the pair counts are never
+// reset: with P_c the running sums at the end of class c,
+//   sum_c w_c G_c = w_last P_last + sum_{c < last} (w_c - w_{c+1}) P_c        (summation by parts, exact),
+// and the second term is small (|w_c - w_{c+1}| <= 2^-GCLS_GQ w), so it is accumulated in FP32 by one packed FMA per two
+// elements and class (v_pk_fma_f32); only the group end pays the FP64 fold (cvt + fma for P_last, cvt + add for the FP32
+// sum).  Entry of block b: x = weight of its class (the keys end in five zero bits) | flags, y = bits of
+// (float)(w_c - w_{c+1}); flag 1 = last block of a class inside a group, flag 2 = full fold after this block (group end,
+// or 2^14 blocks of one class).
+#define GCLS_GQ 6
+#define GCLS_GMAX 64
+#define GCLS_GRUN 16384
+__global__ void tpg_gcls_block_table2_kernel(const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ blk_start,
+                                             const uint32_t* __restrict__ nblk, int nr, int64_t nblocks, int gmax, int gq,
+                                             ulonglong2* __restrict__ wblk) {
+  for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < nblocks; b += (int64_t)gridDim.x * blockDim.x) {
+    const int r = tpg_gcls_find_run(blk_start, nr, (uint32_t)b);
+    const uint32_t o = (uint32_t)b - blk_start[r];
+    const bool class_end = o + 1 == nblk[r];
+    bool full = (o % GCLS_GRUN) == GCLS_GRUN - 1;
+    if (class_end)
+      full = full || r == nr - 1 || (ukeys[r] >> (52 - gq)) != (ukeys[r + 1] >> (52 - gq)) ||
+             (r % gmax) == gmax - 1 || blk_start[r] / GCLS_GRUN != (blk_start[r] + nblk[r]) / GCLS_GRUN;
+    ulonglong2 e;
+    e.x = ukeys[r] | (full ? 2ull : class_end ? 1ull : 0ull);
+    e.y = 0;
+    if (class_end && !full)
+      e.y = (unsigned long long)__float_as_uint(
+          (float)(__longlong_as_double((long long)ukeys[r]) - __longlong_as_double((long long)ukeys[r + 1])));
+    wblk[b] = e;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // 2. gather into the class-sorted 2-BIT operand layout T2g of the Gram kernel.  One wave = a PAIR of sorted blocks
 // (2 bp, 2 bp + 1) x the four row tiles 4q .. 4q+3 (one 16-byte column of an L block per locus and lane half): lane l
@@ -342,6 +376,160 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram_kernel(const uint4* __re
   }
 }
 
+// 3b. the same contraction with the mixed-precision fold (table: tpg_gcls_block_table2_kernel), still two waves per SIMD:
+// a wave keeps the FP4 sums (64 registers), the FP32 sum of the small terms (64) and HALF of its FP64 result (tiles 0, 1:
+// 64 registers); the other half (tiles 2, 3: 16 KiB per wave) lives in LDS, where the group ends -- once per ~20 classes
+// -- read, update and write it.  A class end costs 32 v_pk_fma_f32 instead of 64 v_cvt_f64_f32 + 64 v_fma_f64.
+// (One wave per SIMD with everything in registers and AGPRs, which has room for all of it: 24 ms against 12 -- nothing
+// hides the scalar bookkeeping and the load latency of a single wave.)
+typedef float v2f __attribute__((ext_vector_type(2)));
+// cost model of this kernel (microseconds per wave and 32 x 32 tile): per class, per block
+#define GCLS2_T_CLASS 0.05
+#define GCLS2_T_BLOCK 0.079
+#define GCLS2_LDS_BYTES (4 * 2 * 16 * 64 * 8)
+#ifndef GCLS2_D
+#define GCLS2_D 2
+#endif
+__global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __restrict__ T2g, int64_t nblocks, int64_t rs2, int nrtv,
+                                                                const ulonglong2* __restrict__ wblk,
+                                                                const int2* __restrict__ order, int64_t nun, int S,
+                                                                double* __restrict__ slabs) {
+  extern __shared__ double olds_raw[];  // [wave][tile 2, 3][register][lane]
+  constexpr int WPE = 2;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* olds = olds_raw + (size_t)wv * (2 * 16 * 64) + lane;
+  const int hgrid = gridDim.x / WPE, half = (int)blockIdx.x / hgrid, bx = (int)blockIdx.x % hgrid;
+  const int xcd = bx & 7, cidx = bx >> 3, cpx = hgrid >> 3;
+  const int SH = S / WPE;  // splits per half (the host makes S even)
+  const int64_t npairs = (nblocks + 1) >> 1;
+  for (int64_t round = 0;; round++) {
+    const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
+    if (un >= nun * SH) break;
+    const int ks = half * SH + (int)(un / nun);
+    const int64_t u = un % nun;
+    const int2 ijv = order[u];
+    const int2 ij = make_int2(__builtin_amdgcn_readfirstlane(ijv.x), __builtin_amdgcn_readfirstlane(ijv.y));
+    const int64_t p0 = tpg_uniform64((npairs * ks) / S), p1 = tpg_uniform64((npairs * (ks + 1)) / S);  // block pairs
+    const int64_t bend = 2 * p1 < nblocks ? 2 * p1 : nblocks;                                          // blocks [2 p0, bend)
+    const uint4* pt[GA + GB];
+#pragma unroll
+    for (int t = 0; t < GA; t++) pt[t] = T2g + ((int64_t)min(GA * ij.x + t, nrtv - 1) * rs2) * 64;
+#pragma unroll
+    for (int t = 0; t < GB; t++) pt[GA + t] = T2g + ((int64_t)min(GB * ij.y + t, nrtv - 1) * rs2) * 64;
+
+    double o[2][16];
+    v2f dev[GP][8];
+    v16f acc[GP];
+#pragma unroll
+    for (int p = 0; p < GP; p++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; i++) dev[p][i] = v2f{0.f, 0.f};
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) { o[p][i] = 0.0; olds[(p * 16 + i) * 64] = 0.0; }
+
+    if (p0 < p1) {
+      const int64_t pl = p1 - 1, bl = bend - 1;
+      v4u R[GCLS2_D][GA + GB];
+      auto LD = [&](const uint4* p) {
+        uint32_t off = (uint32_t)lane * 16u;
+        asm("" : "+v"(off));
+        return *(const v4u*)((const char*)p + off);
+      };
+      tpg_static_for<GCLS2_D - 1>([&](auto dd) {
+        constexpr int d = decltype(dd)::value;
+        const int64_t pc = p0 + d < p1 ? p0 + d : pl;
+#pragma unroll
+        for (int t = 0; t < GA + GB; t++) R[d][t] = LD(pt[t] + pc * 64);
+      });
+      int st = 0;  // 2: the class end before this block is still to be folded
+      float pdelta = 0.f;
+      ulonglong2 wf_next = wblk[2 * p0];
+      for (int64_t pp = p0; pp < p1; pp += GCLS2_D) {
+        tpg_static_for<GCLS2_D>([&](auto cc) {
+          constexpr int C = decltype(cc)::value, M = (C + GCLS2_D - 1) % GCLS2_D;
+          const int64_t pr = pp + C;
+          const int64_t pn = pr + GCLS2_D - 1;
+          const int64_t pc = pn < p1 ? pn : pl;
+#pragma unroll
+          for (int t = 0; t < GA + GB; t++) R[M][t] = LD(pt[t] + pc * 64);
+          if (pr < p1) {
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+              const int64_t b = 2 * pr + hb;
+              if (b < bend) {
+                const ulonglong2 wf = wf_next;
+                wf_next = wblk[b < bl ? b + 1 : bl];
+                v4u X[GA + GB];
+#pragma unroll
+                for (int t = 0; t < GA + GB; t++) {
+                  const uint32_t w0 = R[C][t][2 * hb], w1 = R[C][t][2 * hb + 1];
+                  X[t] = v4u{w0 & 0x33333333u, (w0 >> 2) & 0x33333333u, w1 & 0x33333333u, (w1 >> 2) & 0x33333333u};
+                }
+                if (st & 2) {  // the class that ended with the previous block: dev += (w_c - w_{c+1}) * P_c
+                  const v2f dl = v2f{pdelta, pdelta};
+#pragma unroll
+                  for (int p = 0; p < GP; p++) {
+                    // (register pairs of the accumulator tuple as they are: a shuffle, not v2f{acc[2 i], acc[2 i + 1]}, which
+                    // hipcc builds with two v_mov_b32 per pair)
+                    tpg_static_for<8>([&](auto ii) {
+                      constexpr int i = decltype(ii)::value;
+                      dev[p][i] = __builtin_elementwise_fma(dl, __builtin_shufflevector(acc[p], acc[p], 2 * i, 2 * i + 1), dev[p][i]);
+                    });
+                  }
+                }
+#pragma unroll
+                for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2(X[p / GB], X[GA + p % GB], acc[p]);
+                st = 0;
+                const uint32_t fl = (uint32_t)wf.x & 3u;
+                if ((fl & 2u) || b == bl) {  // group end: the FP64 fold, then everything starts from zero
+                  const double w = __longlong_as_double((long long)(wf.x & ~3ull));
+                  // four rounds of 8 elements of a register tile and 8 of an LDS tile: the LDS reads of a round are in
+                  // flight while its register elements are folded, and a round needs 16 temporaries, not more
+                  tpg_static_for<4>([&](auto hh) {
+                    constexpr int h = decltype(hh)::value, pr_ = h >> 1, pl_ = 2 + (h >> 1), e0 = (h & 1) * 8;
+                    double t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) t[e] = olds[((pl_ - 2) * 16 + e0 + e) * 64];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                      const int i = e0 + e;
+                      o[pr_][i] = __builtin_fma((double)acc[pr_][i], w, o[pr_][i]) + (double)dev[pr_][i >> 1][i & 1];
+                      acc[pr_][i] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                      const int i = e0 + e;
+                      olds[((pl_ - 2) * 16 + i) * 64] = __builtin_fma((double)acc[pl_][i], w, t[e]) + (double)dev[pl_][i >> 1][i & 1];
+                      acc[pl_][i] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) dev[pr_][(e0 >> 1) + e] = dev[pl_][(e0 >> 1) + e] = v2f{0.f, 0.f};
+                    __builtin_amdgcn_sched_barrier(0);
+                  });
+                } else if (fl & 1u) {
+                  pdelta = __uint_as_float((uint32_t)wf.y);
+                  st = 2;
+                }
+              }
+            }
+          }
+        });
+      }
+    }
+    double* slab = slabs + ((int64_t)ks * nun + u) * GCLS_SLAB + lane;
+#pragma unroll
+    for (int p = 0; p < GP; p++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) slab[(p * 16 + i) * 64] = p < 2 ? o[p][i] : olds[((p - 2) * 16 + i) * 64];
+  }
+}
+
 // 4. the S slabs of every unit, added in split order, into both triangles of K (n x n, column-major)
 __global__ __launch_bounds__(256) void tpg_gcls_assemble_kernel(const double* __restrict__ slabs, const int2* __restrict__ order,
                                                                 int64_t nun, int S, int n, double* __restrict__ K) {
@@ -378,12 +566,24 @@ struct GclsBufs {
 // cost models (microseconds per wave), fitted on the two kernels at n = 5 000 (12.2 ms at 1 000 000 loci, 6.0 ms on a
 // shard of 125 000 loci that holds as many classes): per tile 0.136 us per class (fold) + 0.079 us per block (expansion,
 // MFMA, operand streaming); digit kernel 1.0 us per 128 loci.  S is even: the two halves of the grid take S / 2 splits each.
+// Which fold: the FP64 fold of every class (tpg_gcls_gram_kernel) when the classes are long -- below 0.15 classes per block
+// the group ends of the mixed-precision kernel (three times a plain fold each) cost more than its cheap class ends save:
+// 0.28 against 0.35 ms at 1 000 x 650 000 (949 classes, 10 634 blocks), 12.1 against 11.3 ms at 5 000 x 1 000 000 (4 728
+// classes, 17 888 blocks) -- or when TPG_GRAM_FOLD64 asks for it (TPG_GRAM_FOLD64=0: never).
+static bool gcls_fold64(int64_t nruns, int64_t nblocks) {
+  const char* e = getenv("TPG_GRAM_FOLD64");
+  if (e) return atoi(e) != 0;
+  return (double)nruns < 0.15 * (double)nblocks;
+}
+
 static double gcls_cost_classes(int64_t nunits, int64_t nruns, int64_t nblocks, int nwaves, int* bestS) {
   double best = -1;
+  const bool f64 = gcls_fold64(nruns, nblocks);
+  const double t_class = f64 ? 0.136 : GCLS2_T_CLASS, t_block = f64 ? 0.079 : GCLS2_T_BLOCK;
   for (int S = 2; S <= 32; S += 2) {
     if (nblocks / S < 4 && S > 2) break;
     const int64_t rounds = ceil_div(nunits * S, (int64_t)nwaves);
-    const double per = ((double)nruns / S + 1.0) * GP * 0.136 + (double)ceil_div(nblocks, (int64_t)S) * GP * 0.079 + 6.0;
+    const double per = ((double)nruns / S + 1.0) * GP * t_class + (double)ceil_div(nblocks, (int64_t)S) * GP * t_block + 6.0;
     // + the assemble pass over the S slabs of every unit (0.48 ms at S = 18 and 3 160 units)
     const double cost = (double)rounds * per + (double)S * (double)nunits * 8.5e-3;
     if (best < 0 || cost < best * 0.995) { best = cost; *bestS = S; }
@@ -449,6 +649,7 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   const int64_t nun = (int64_t)order.size();
   int ncu8 = ctx->num_cu / 8 * 8;
   if (ncu8 < 8) ncu8 = 8;
+  const bool f64 = gcls_fold64(nruns, nblocks);
   const int nblk_grid = 2 * ncu8;  // two workgroups per CU = two waves per SIMD
   const int nwaves = 4 * nblk_grid;
   int S = 2;
@@ -457,6 +658,7 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   // the digit kernel: 32 x 128 wave tiles, 64 int8 MFMAs (~1.0 us) per 128 loci, 4 row tiles x super-tiles of 4
   const int64_t nun_dig = (int64_t)nrtv * ceil_div((int64_t)nrtv, 4) / 2 + nrtv;
   const double cost_dig = (double)ceil_div(nun_dig, (int64_t)(4 * ncu8)) * ((double)ceil_div(m, 128) * 1.0) + 65.0;
+  if (getenv("TPG_GRAM_S")) S = std::max(2, atoi(getenv("TPG_GRAM_S")) & ~1);  // (experiments)
   if (getenv("TPG_DEBUG"))
     fprintf(stderr, "[tpg] gram classes: %lld classes, %lld blocks for %lld loci, S = %d, model %.0f us (digits %.0f us)\n",
             (long long)nruns, (long long)nblocks, (long long)m, S, cost_cls, cost_dig);
@@ -465,10 +667,12 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   int32_t* d_src = nullptr;
   double* d_slabs = nullptr;
   unsigned long long* d_wblk = nullptr;
+  ulonglong2* d_wblk2 = nullptr;
   uint4* d_T2g = nullptr;
   int2* d_order = nullptr;
   TPG_HIP(B.get(&d_src, (size_t)nblocks * 64));
-  TPG_HIP(B.get(&d_wblk, (size_t)nblocks));
+  if (f64) TPG_HIP(B.get(&d_wblk, (size_t)nblocks));
+  else TPG_HIP(B.get(&d_wblk2, (size_t)nblocks));
   const int64_t rs2 = (nblocks + 1) / 2;  // row-tile stride of T2g: a uint4 per lane and PAIR of blocks
   TPG_HIP(B.get(&d_T2g, (size_t)(4 * Q) * (size_t)rs2 * 64));
   TPG_HIP(B.get(&d_order, (size_t)nun));
@@ -480,8 +684,14 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
     hipLaunchKernelGGL(tpg_gcls_place_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)d_idx2,
                        (const unsigned long long*)d_ukeys, (const uint32_t*)d_estart, (const uint32_t*)d_bstart, (int)nruns, m,
                        d_src, d_what);
-    hipLaunchKernelGGL(tpg_gcls_block_table_kernel, dim3(256), dim3(256), 0, ctx->stream, (const unsigned long long*)d_ukeys,
-                       (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks, d_wblk);
+    if (f64)
+      hipLaunchKernelGGL(tpg_gcls_block_table_kernel, dim3(256), dim3(256), 0, ctx->stream, (const unsigned long long*)d_ukeys,
+                         (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks, d_wblk);
+    else
+      hipLaunchKernelGGL(tpg_gcls_block_table2_kernel, dim3(256), dim3(256), 0, ctx->stream, (const unsigned long long*)d_ukeys,
+                         (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks,
+                         getenv("TPG_GRAM_GMAX") ? std::max(1, atoi(getenv("TPG_GRAM_GMAX"))) : GCLS_GMAX,
+                         getenv("TPG_GRAM_GQ") ? std::min(40, std::max(1, atoi(getenv("TPG_GRAM_GQ")))) : GCLS_GQ, d_wblk2);
   }
   {
     const int64_t tasks = Q * rs2;
@@ -489,8 +699,15 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
     TPG_LAUNCH(ctx, "gcls_gather", tpg_gcls_gather_kernel, dim3(grid), dim3(256), 0, src, Q, (const int32_t*)d_src, nblocks, rs2,
                d_T2g);
   }
-  TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T2g, nblocks,
-             rs2, nrtv, (const unsigned long long*)d_wblk, (const int2*)d_order, nun, S, d_slabs);
+  if (f64)
+    TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T2g, nblocks,
+               rs2, nrtv, (const unsigned long long*)d_wblk, (const int2*)d_order, nun, S, d_slabs);
+  else
+  {
+    (void)hipFuncSetAttribute((const void*)tpg_gcls_gram2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
+    TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram2_kernel, dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
+               (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
+  }
   TPG_LAUNCH(ctx, "gcls_assemble", tpg_gcls_assemble_kernel, dim3((unsigned)std::min<int64_t>(nun, 4096)), dim3(256), 0,
              (const double*)d_slabs, (const int2*)d_order, nun, S, (int)n, d_K);
   TPG_CHECK_LAUNCH();
