@@ -142,25 +142,30 @@ extern "C" int tpg_gt_pi_diploid(tpg_ctx* ctx, const tpg_view* v, double* pi) {
 }
 
 // ---------------------------------------------------------------------------
-// one-hot B fragments: OH[q][s][gt][lane = (c,h)][16 B], element e <-> individual
-// 128 q + 32 s + 16 h + e, byte = (cls[individual] == 32 gt + c)
+// one-hot B fragments of the grouped counts, as FP4 operands (nibble 0x2 = 1.0): OH[q][S][gt][lane = (c, h)][16 B] for the
+// two 64-individual steps S of a 128-individual group q.  The A side of that kernel takes the dwords s = 2 S, 2 S + 1 of an
+// L block apart into their even and odd 2-bit slots (P & 0x33333333, (P >> 2) & 0x33333333), so operand dword d = 2 s' + odd
+// holds, at nibble j, element e = (j >> 1) + 8 (j & 1) + 4 odd of source dword s = 2 S + s' (tpg_elem_shift), i.e.
+// individual 128 q + 32 s + 16 h + e.
 __global__ void tpg_onehot_kernel(const int32_t* __restrict__ cls, int64_t n, int64_t Q, int GT,
                                   uint4* __restrict__ OH) {
-  const int64_t total = Q * 4 * GT * 64;
+  const int64_t total = Q * 2 * GT * 64;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
     const int64_t t = idx >> 6;
     const int gt = (int)(t % GT);
-    const int64_t qs = t / GT;
-    const int s = (int)(qs & 3);
-    const int64_t q = qs >> 2;
+    const int64_t qS = t / GT;
+    const int S = (int)(qS & 1);
+    const int64_t q = qS >> 1;
     const int c = 32 * gt + (lane & 31), h = lane >> 5;
     uint32_t w[4] = {0, 0, 0, 0};
-    for (int e = 0; e < 16; e++) {
-      const int64_t i = 128 * q + 32 * s + 16 * h + e;
-      if (i < n && cls[i] == c) w[e >> 2] |= 1u << (8 * (e & 3));
-    }
+    for (int d = 0; d < 4; d++)
+      for (int j = 0; j < 8; j++) {
+        const int e = (j >> 1) + 8 * (j & 1) + 4 * (d & 1);
+        const int64_t i = 128 * q + 32 * (2 * S + (d >> 1)) + 16 * h + e;
+        if (i < n && cls[i] == c) w[d] |= 2u << (4 * j);
+      }
     OH[idx] = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
@@ -169,21 +174,41 @@ __global__ void tpg_onehot_kernel(const int32_t* __restrict__ cls, int64_t n, in
 // One wave owns GC_NLT consecutive 32-locus tiles and GT class tiles (3 planes x GT x GC_NLT accumulator tiles); the
 // four waves of a workgroup share the one-hot fragments of a 128-individual group through double-buffered LDS (each
 // wave fetches a quarter, one barrier per group), so a 1-KiB fragment fetched from L2 feeds 4 x 3 x GC_NLT MFMAs.
-// (With one locus tile per wave and a fragment per MFMA straight from global memory, every wave re-read the whole
-// one-hot array: 10 GB through the L1s per launch at 5 000 x 1 000 000 x 51 groups, 1.07 ms for 1.25 GB of genotypes.)
-// Per 32 loci x 128 individuals the MFMA pipe does 4 x 3 x GT instructions: at GT = 2 the kernel is bound by the
-// int8 MFMA rate (3 * 2 * N * 64 ops per locus), not by the N / 4 bytes per locus it streams.
-#define GC_NLT 2
+// (With a fragment per MFMA straight from global memory, every wave re-read the whole one-hot array: 10 GB through the
+// L1s per launch at 5 000 x 1 000 000 x 51 groups, 1.07 ms for 1.25 GB of genotypes.)  One locus tile per wave and three
+// workgroups per CU: a workgroup lives for 40 groups, and with one resident workgroup per CU (two tiles per wave, 432
+// registers) its prologue, its barriers and its flush were all exposed -- 0.84 ms against 0.59.
+//
+// The products are 0 / 1, so they run on the FP4 matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4: 64 individuals per
+// instruction where the int8 form takes 32; sums of at most n ones, exact in FP32 below 2^24).  The 2-bit code IS the
+// operand: with X a dword of eight codes in nibbles, Y = X & 0x11111111 (bit 0: heterozygous or missing, FP4 0.5, block
+// scale 2), Z = X & 0x22222222 (bit 1: homozygous alt or missing, FP4 1.0) and W = Y & (Z >> 1) (missing) are three
+// operand dwords for four instructions; het = sum Y - sum W, hom-alt = sum Z - sum W, valid = class size - sum W.
+#define GC_NLT 1
+#define GC_D 4
+template <int C, class F>
+__device__ __forceinline__ void gc_static_for(F&& f) {
+  if constexpr (C > 0) {
+    gc_static_for<C - 1>(f);
+    f(std::integral_constant<int, C - 1>{});
+  }
+}
+typedef int gc_v8i __attribute__((ext_vector_type(8)));
+typedef float gc_v16f __attribute__((ext_vector_type(16)));
+#define GC_MFMA(a, b, c, sa) \
+  __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((gc_v8i){(int)(a)[0], (int)(a)[1], (int)(a)[2], (int)(a)[3], 0, 0, 0, 0}, \
+                                                  (gc_v8i){(int)(b).x, (int)(b).y, (int)(b).z, (int)(b).w, 0, 0, 0, 0}, (c), 4, 4, 0, (sa), 0, 0x7F7F7F7F)
 template <int GT>
-__global__ __launch_bounds__(256, 1) void tpg_grouped_counts_kernel(const uint4* __restrict__ L,
+__global__ __launch_bounds__(256, 3) void tpg_grouped_counts_kernel(const uint4* __restrict__ L,
                                                                     const uint4* __restrict__ OH, int64_t n_lt,
                                                                     int64_t Q, int gt0, int GT_total,
+                                                                    const int32_t* __restrict__ csize,
                                                                     int32_t* __restrict__ cnt, int64_t Mpad,
                                                                     int Cpad) {
-  __shared__ __attribute__((aligned(16))) uint4 ohb[2][4 * GT][64];  // [buffer][K step * GT + class tile][lane]
+  __shared__ __attribute__((aligned(16))) uint4 ohb[2][2 * GT][64];  // [buffer][step * GT + class tile][lane]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t lt0 = ((int64_t)blockIdx.x * 4 + wv) * GC_NLT;  // may lie past n_lt: the wave still serves the LDS
-  v16i acc[3][GC_NLT][GT];
+  gc_v16f acc[3][GC_NLT][GT];
 #pragma unroll
   for (int p = 0; p < 3; p++)
 #pragma unroll
@@ -191,60 +216,61 @@ __global__ __launch_bounds__(256, 1) void tpg_grouped_counts_kernel(const uint4*
 #pragma unroll
       for (int g = 0; g < GT; g++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[p][t][g][r] = 0;
+        for (int r = 0; r < 16; r++) acc[p][t][g][r] = 0.f;
   const uint4* pa[GC_NLT];
 #pragma unroll
   for (int t = 0; t < GC_NLT; t++) pa[t] = L + ((lt0 + t < n_lt ? lt0 + t : 0) * Q) * 64 + lane;  // past the end: a copy
-  // this wave's share of a group's 4 * GT one-hot fragments: items wv, wv + 4, ... (fragment (s, g) of group q sits at
-  // OH[((q * 4 + s) * GT_total + gt0 + g) * 64 + lane])
-  constexpr int NIT = (4 * GT + 3) / 4;
+  // this wave's share of a group's 2 * GT one-hot fragments: items wv, wv + 4, ... (fragment (S, g) of group q sits at
+  // OH[((q * 2 + S) * GT_total + gt0 + g) * 64 + lane])
+  constexpr int NIT = (2 * GT + 3) / 4;
   const uint4* po = OH + (int64_t)gt0 * 64 + lane;
-  auto frag = [&](int64_t q, int it) { return po[((q * 4 + it / GT) * GT_total + it % GT) * 64]; };
-  // genotype blocks of groups q, q + 1, q + 2 in three rotating register slots (the HBM stream is fetched two groups
-  // ahead; the loop is unrolled by three so that no slot is copied -- a copy would wait for the load just issued)
-  uint4 R[3][GC_NLT], on[NIT];
+  auto frag = [&](int64_t q, int it) { return po[((q * 2 + it / GT) * GT_total + it % GT) * 64]; };
+  // genotype blocks of groups q .. q + GC_D - 1 in GC_D rotating register slots (the HBM stream is fetched GC_D - 1 groups
+  // ahead; the loop is unrolled by GC_D so that no slot is copied -- a copy would wait for the load just issued)
+  uint4 R[GC_D][GC_NLT], on[NIT];
 #pragma unroll
-  for (int t = 0; t < GC_NLT; t++) { R[0][t] = pa[t][0]; R[1][t] = pa[t][(Q > 1 ? 1 : 0) * 64]; }
+  for (int d = 0; d < GC_D - 1; d++)
+#pragma unroll
+    for (int t = 0; t < GC_NLT; t++) R[d][t] = pa[t][(d < Q ? d : Q - 1) * 64];
 #pragma unroll
   for (int j = 0; j < NIT; j++) {
     const int it = wv + 4 * j;
-    if (it < 4 * GT) ohb[0][it][lane] = frag(0, it);
+    if (it < 2 * GT) ohb[0][it][lane] = frag(0, it);
   }
   tpg_lds_barrier();
   auto group = [&](auto Cc, auto Mm, int64_t q) {
     constexpr int C = decltype(Cc)::value, M = decltype(Mm)::value;
-    const int64_t qn = q + 1 < Q ? q + 1 : q, qn2 = q + 2 < Q ? q + 2 : Q - 1;
+    const int64_t qn = q + 1 < Q ? q + 1 : q, qn2 = q + GC_D - 1 < Q ? q + GC_D - 1 : Q - 1;
     const int cur = (int)(q & 1);
 #pragma unroll
     for (int t = 0; t < GC_NLT; t++) R[M][t] = pa[t][qn2 * 64];
 #pragma unroll
     for (int j = 0; j < NIT; j++) {
       const int it = wv + 4 * j;
-      if (it < 4 * GT) on[j] = frag(qn, it);
+      if (it < 2 * GT) on[j] = frag(qn, it);
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      v4i fh[GC_NLT], f2[GC_NLT], fv[GC_NLT];
+    for (int S = 0; S < 2; S++) {
+      uint32_t fy[GC_NLT][4], fz[GC_NLT][4], fw[GC_NLT][4];
 #pragma unroll
       for (int t = 0; t < GC_NLT; t++) {
-        const uint32_t w = s == 0 ? R[C][t].x : s == 1 ? R[C][t].y : s == 2 ? R[C][t].z : R[C][t].w;
+        const uint32_t P[2] = {S == 0 ? R[C][t].x : R[C][t].z, S == 0 ? R[C][t].y : R[C][t].w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t c = tpg_codes(w, k);
-          fh[t][k] = tpg_lut(TPG_LUT_H, c);
-          f2[t][k] = tpg_lut(TPG_LUT_E2, c);
-          fv[t][k] = tpg_lut(TPG_LUT_V, c);
+        for (int d = 0; d < 4; d++) {
+          const uint32_t X = (d & 1) ? (P[d >> 1] >> 2) & 0x33333333u : P[d >> 1] & 0x33333333u;
+          fy[t][d] = X & 0x11111111u;
+          fz[t][d] = X & 0x22222222u;
+          fw[t][d] = fy[t][d] & (fz[t][d] >> 1);
         }
       }
 #pragma unroll
       for (int g = 0; g < GT; g++) {
-        const uint4 b = ohb[cur][s * GT + g][lane];
-        v4i fb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+        const uint4 b = ohb[cur][S * GT + g][lane];
 #pragma unroll
         for (int t = 0; t < GC_NLT; t++) {
-          acc[0][t][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fh[t], fb, acc[0][t][g], 0, 0, 0);
-          acc[1][t][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f2[t], fb, acc[1][t][g], 0, 0, 0);
-          acc[2][t][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fv[t], fb, acc[2][t][g], 0, 0, 0);
+          acc[0][t][g] = GC_MFMA(fy[t], b, acc[0][t][g], (int)0x80808080);
+          acc[1][t][g] = GC_MFMA(fz[t], b, acc[1][t][g], 0x7F7F7F7F);
+          acc[2][t][g] = GC_MFMA(fw[t], b, acc[2][t][g], (int)0x80808080);
         }
       }
     }
@@ -252,30 +278,31 @@ __global__ __launch_bounds__(256, 1) void tpg_grouped_counts_kernel(const uint4*
 #pragma unroll
     for (int j = 0; j < NIT; j++) {
       const int it = wv + 4 * j;
-      if (it < 4 * GT) ohb[cur ^ 1][it][lane] = on[j];
+      if (it < 2 * GT) ohb[cur ^ 1][it][lane] = on[j];
     }
     tpg_lds_barrier();
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  for (int64_t q = 0; q < Q; q += 3) {  // Q is the same for every wave: all of them meet every barrier
-    group(I0{}, I2{}, q);
-    if (q + 1 < Q) group(I1{}, I0{}, q + 1);
-    if (q + 2 < Q) group(I2{}, I1{}, q + 2);
-  }
+  for (int64_t q = 0; q < Q; q += GC_D)  // Q is the same for every wave: all of them meet every barrier
+    gc_static_for<GC_D>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      if (q + k < Q) group(std::integral_constant<int, k>{}, std::integral_constant<int, (k + GC_D - 1) % GC_D>{}, q + k);
+    });
 #pragma unroll
   for (int t = 0; t < GC_NLT; t++) {
     if (lt0 + t >= n_lt) break;
 #pragma unroll
-    for (int p = 0; p < 3; p++)
+    for (int g = 0; g < GT; g++) {
+      const int cs = csize[32 * (gt0 + g) + (lane & 31)];
 #pragma unroll
-      for (int g = 0; g < GT; g++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int64_t row = (lt0 + t) * 32 + tpg_cd_row(r, lane);
-          cnt[((int64_t)p * Mpad + row) * Cpad + 32 * (gt0 + g) + (lane & 31)] = acc[p][t][g][r];
-        }
+      for (int r = 0; r < 16; r++) {
+        const int64_t row = (lt0 + t) * 32 + tpg_cd_row(r, lane);
+        const int64_t o = row * Cpad + 32 * (gt0 + g) + (lane & 31);
+        const int nmiss = (int)acc[2][t][g][r];
+        cnt[o] = (int)acc[0][t][g][r] - nmiss;
+        cnt[Mpad * Cpad + o] = (int)acc[1][t][g][r] - nmiss;
+        cnt[2 * Mpad * Cpad + o] = cs - nmiss;
+      }
+    }
   }
 }
 
@@ -301,13 +328,18 @@ int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, in
   out->Cpad = GT * 32;
   out->nclass = nclass;
   TPG_HIP(tpg_pmalloc((void**)&out->cnt, sizeof(int32_t) * 3 * (size_t)out->Mpad * (size_t)out->Cpad));
+  TPG_REQUIRE(v->n < (1 << 24), TPG_EUNSUPPORTED, "grouped counts of more than 2^24 individuals");  // FP32 sums of ones
+  // class sizes (the valid count of a class is its size minus its missing genotypes), behind the class ids
+  std::vector<int32_t> h_up((size_t)v->n + (size_t)GT * 32, 0);
+  memcpy(h_up.data(), h_cls, sizeof(int32_t) * (size_t)v->n);
+  for (int64_t i = 0; i < v->n; i++) h_up[(size_t)v->n + (size_t)h_cls[i]]++;
   int32_t* d_cls = nullptr;
   uint4* d_oh = nullptr;
-  TPG_HIP(tpg_pmalloc((void**)&d_cls, sizeof(int32_t) * (size_t)v->n));
-  hipError_t e = tpg_pmalloc((void**)&d_oh, (size_t)v->Q * 4 * GT * 1024);
+  TPG_HIP(tpg_pmalloc((void**)&d_cls, sizeof(int32_t) * h_up.size()));
+  hipError_t e = tpg_pmalloc((void**)&d_oh, (size_t)v->Q * 2 * GT * 1024);
   if (e != hipSuccess) { tpg_pfree(d_cls); tpg_set_error("hipMalloc one-hot: %s", hipGetErrorString(e)); return TPG_EHIP; }
   int rc = TPG_OK;
-  e = tpg_h2d_async(ctx, d_cls, h_cls, sizeof(int32_t) * (size_t)v->n);
+  e = tpg_h2d_async(ctx, d_cls, h_up.data(), sizeof(int32_t) * h_up.size());
   if (e != hipSuccess) { tpg_set_error("class upload: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   if (rc == TPG_OK) {
     TPG_LAUNCH(ctx, "onehot", tpg_onehot_kernel, dim3(1024), dim3(256), 0, d_cls, v->n, v->Q, GT, d_oh);
@@ -316,11 +348,11 @@ int tpg_grouped_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t* h_cls, in
     while (g0 < GT) {
       if (GT - g0 >= 2) {
         TPG_LAUNCH(ctx, "grouped_counts", tpg_grouped_counts_kernel<2>, dim3(grid), dim3(256), 0, (const uint4*)v->L,
-                   (const uint4*)d_oh, n_lt, v->Q, g0, GT, out->cnt, out->Mpad, out->Cpad);
+                   (const uint4*)d_oh, n_lt, v->Q, g0, GT, (const int32_t*)(d_cls + v->n), out->cnt, out->Mpad, out->Cpad);
         g0 += 2;
       } else {
         TPG_LAUNCH(ctx, "grouped_counts", tpg_grouped_counts_kernel<1>, dim3(grid), dim3(256), 0, (const uint4*)v->L,
-                   (const uint4*)d_oh, n_lt, v->Q, g0, GT, out->cnt, out->Mpad, out->Cpad);
+                   (const uint4*)d_oh, n_lt, v->Q, g0, GT, (const int32_t*)(d_cls + v->n), out->cnt, out->Mpad, out->Cpad);
         g0 += 1;
       }
     }
