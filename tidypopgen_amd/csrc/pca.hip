@@ -1883,15 +1883,16 @@ __global__ __launch_bounds__(256) void tpg_uq_colsum_kernel(const double* __rest
 }
 
 // out[locus][column] = sum_i g_i,locus * UD[i][column].  One wave owns LD_NLT consecutive 32-locus tiles and CTP
-// column tiles (LD_NLT * CTP accumulator tiles, up to 256 AGPRs, one wave per SIMD), and the four waves of a
+// column tiles (LD_NLT * CTP accumulator tiles, up to 128 AGPRs, two workgroups per CU: with four locus tiles per wave
+// and one resident workgroup its prologue, barriers and flush were exposed, 0.70 against 0.59 ms), and the four waves of a
 // workgroup share the digit fragments of a 128-individual group through double-buffered LDS (each wave fetches a
 // quarter, one barrier per group): a 1-KiB fragment of UD fetched from L2 feeds 4 * LD_NLT MFMAs.  With one locus
 // tile per wave and a fragment per MFMA straight from L2 the kernel moved 20 GB per launch at C5 through the L1s
 // and was bound by that (1.6 ms).  The A side is the code bytes themselves (no missing values here, see the Gram
 // kernel).
-#define LD_NLT 4
+#define LD_NLT 2
 template <int CTP>
-__global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
+__global__ __launch_bounds__(256, 2) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
                                                                    const uint4* __restrict__ UD, int64_t n_lt,
                                                                    int64_t Q, int ct0, int CT,
                                                                    int32_t* __restrict__ out, int Cpad) {
@@ -1908,9 +1909,9 @@ __global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* 
   const uint4* pa[LD_NLT];
 #pragma unroll
   for (int t = 0; t < LD_NLT; t++) pa[t] = L + ((lt0 + t < n_lt ? lt0 + t : 0) * Q) * 64 + lane;  // past the end: a copy
-  uint4 a[LD_NLT], an[LD_NLT];
+  uint4 a[LD_NLT], a1[LD_NLT], a2[LD_NLT];  // the genotype stream is fetched two groups ahead
 #pragma unroll
-  for (int t = 0; t < LD_NLT; t++) a[t] = pa[t][0];
+  for (int t = 0; t < LD_NLT; t++) { a[t] = pa[t][0]; a1[t] = pa[t][(Q > 1 ? 1 : 0) * 64]; }
   // this wave's share of a group's fragments: items wv, wv + 4, ... of the 4 * CTP (K step, column tile) pairs
   const uint4* pu = UD + ct0 * 64 + lane;  // fragment (ks, c) = pu[(ks * CT + c) * 64]
   uint4 un[CTP];
@@ -1921,10 +1922,10 @@ __global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* 
   }
   tpg_lds_barrier();
   for (int64_t q = 0; q < Q; q++) {
-    const int64_t qn = q + 1 < Q ? q + 1 : q;
+    const int64_t qn = q + 1 < Q ? q + 1 : q, qn2 = q + 2 < Q ? q + 2 : Q - 1;
     const int cur = (int)(q & 1);
 #pragma unroll
-    for (int t = 0; t < LD_NLT; t++) an[t] = pa[t][qn * 64];
+    for (int t = 0; t < LD_NLT; t++) a2[t] = pa[t][qn2 * 64];
 #pragma unroll
     for (int j = 0; j < CTP; j++) {
       const int it = wv + 4 * j;
@@ -1948,7 +1949,7 @@ __global__ __launch_bounds__(256, 1) void tpg_loadings_mfma_kernel(const uint4* 
       }
     }
 #pragma unroll
-    for (int t = 0; t < LD_NLT; t++) a[t] = an[t];
+    for (int t = 0; t < LD_NLT; t++) { a[t] = a1[t]; a1[t] = a2[t]; }
     // the other buffer was last read in group q - 1, which every wave left through the barrier below
 #pragma unroll
     for (int j = 0; j < CTP; j++) ubuf[cur ^ 1][wv + 4 * j][lane] = un[j];
