@@ -1985,15 +1985,43 @@ __global__ void tpg_loadings_finalize_kernel(const int32_t* __restrict__ acc, in
   }
 }
 
+// out[0] = max |x| (NaN if any element is NaN); one workgroup
+__global__ __launch_bounds__(1024) void tpg_absmax_kernel(const double* __restrict__ x, int64_t total, double* __restrict__ out) {
+  __shared__ double sh[1024];
+  double mx = 0;
+  bool bad = false;
+  for (int64_t i = threadIdx.x; i < total; i += 1024) {
+    const double a = fabs(x[i]);
+    if (a != a) bad = true;
+    mx = a > mx ? a : mx;
+  }
+  sh[threadIdx.x] = bad ? __longlong_as_double(0x7FF8000000000000ll) : mx;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      const double a = sh[threadIdx.x], b = sh[threadIdx.x + w];
+      sh[threadIdx.x] = (a != a || b != b) ? __longlong_as_double(0x7FF8000000000000ll) : (a > b ? a : b);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
 // device pointers throughout; requires a view without missing values (checked by the callers' counts)
 static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_center, const double* d_scale,
                                const double* d_U, const double* d_dk, int k, double* d_V) {
   const int64_t n = v->n, m = v->m;
-  std::vector<double> hu((size_t)n * (size_t)k);
-  TPG_HIP(hipMemcpyAsync(hu.data(), d_U, sizeof(double) * hu.size(), hipMemcpyDeviceToHost, ctx->stream));
-  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  // the scale of the digits: max |u|, found on the device (8 bytes come back, not the n x k matrix)
   double amax = 0;
-  for (double x : hu) amax = std::max(amax, fabs(x));
+  {
+    double* d_amax = nullptr;
+    TPG_HIP(tpg_pmalloc((void**)&d_amax, sizeof(double)));
+    TPG_LAUNCH(ctx, "loadings_u_digits", tpg_absmax_kernel, dim3(1), dim3(1024), 0, d_U, n * (int64_t)k, d_amax);
+    hipError_t ea = hipMemcpyAsync(&amax, d_amax, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (ea == hipSuccess) ea = hipStreamSynchronize(ctx->stream);
+    tpg_pfree(d_amax);
+    TPG_HIP(ea);
+  }
   TPG_REQUIRE(amax > 0 && amax == amax && amax < 1e300, TPG_ENUMERIC, "degenerate eigenvectors");
   int ex = 0;
   frexp(amax, &ex);                      // amax < 2^ex
