@@ -675,12 +675,13 @@ def main():
                       peak=10000.0),
             mfma_roof("pca_gram_mfma", "tpg_pca_gram_kernel (v_mfma_i32_32x32x32_i8)", 4.0 * n * n * m_pca,
                       "PCA Gram: 4 weight digits x symmetric int8 product = 4 * N^2 M / 2 MACs"),
-            mfma_roof("pca_gram_classes", "tpg_gcls_gram_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 dosages from 2-bit codes)",
-                      1.0 * n * n * m_pca,
+            mfma_roof("pca_gram_classes", "tpg_gcls_gram2_kernel / tpg_gcls_gram_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 "
+                      "dosages from 2-bit codes)", 1.0 * n * n * m_pca,
                       "PCA Gram by weight classes: ONE unweighted symmetric product = N^2 M / 2 MACs on exact FP4 dosages "
-                      "(2-bit codes over the L2 -> CU path, expanded to FP4 nibbles in registers: 6 VALU per MFMA), then "
-                      "16 cvt + 16 FP64 fma per 32 x 32 tile and class (8.5 VALU per MFMA); 64 x 64 wave tiles, two waves per "
-                      "SIMD; bound by VALU issue (16 per MFMA) with the MFMA pipe 27 % busy",
+                      "(2-bit codes over the L2 -> CU path, expanded to FP4 nibbles in registers: 6 VALU per MFMA); a class "
+                      "end is 8 v_pk_fma_f32 per 32 x 32 tile (small weight differences of a group of neighbouring classes, "
+                      "summation by parts), a group end the FP64 fold; 64 x 64 wave tiles, two waves per SIMD; bound by operand "
+                      "latency on the L2 -> CU path (MFMA pipe 28 % busy, s_waitcnt 28 %), not by issue any more",
                       peak=10000.0),
         ]
         roofs = [r for r in roofs if r]
@@ -718,10 +719,11 @@ def main():
                      "quarter of every 64-byte sector fetched) + N M / 4 written"),
             hbm_roof("loci_counts", "tpg_loci_counts_kernel", 0.25 * n * m + 16.0 * m,
                      "per-locus genotype counts: N M / 4 read + 16 B per locus written"),
-            hbm_roof("grouped_counts", "tpg_grouped_counts_kernel (int8 MFMA one-hot contraction)",
+            hbm_roof("grouped_counts", "tpg_grouped_counts_kernel (FP4 MFMA one-hot contraction)",
                      0.25 * n * m + 12.0 * Cpad * m,
                      "grouped counts: N M / 4 read once + 3 int32 count planes of Cpad classes per locus written "
-                     "(also 3*2*N*Cpad int8 ops per locus on the MFMA pipe: bound by neither)"),
+                     "(the 3*2*N*Cpad ops per locus run on the FP4 matrix cores with the 2-bit code as the operand: 0.2 ms of "
+                     "MFMA time at C4)"),
             hbm_roof("grouped_finalize", "tpg_grouped_finalize_kernel", (12.0 * Cpad + 16.0 * G) * m,
                      "counts -> the m x 2G doubles grouped_alt_freq returns: 12 Cpad B read + 16 G B written per locus"),
             valu_roof("fst_hudson", "tpg_fst_hudson_gemm_kernel (totals as three masked G x M x G products)", 12.0 * P * m,
@@ -748,7 +750,7 @@ def main():
             "unit": "SNP-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "fp4-e2m1 operands (exact integers, f32 accumulate) for the cross-products and the PCA Gram, int8 (int32 accumulate) for counts, f64 for statistics",
+            "dtype": "fp4-e2m1 operands (exact integers, f32 accumulate) for the cross-products, the PCA Gram and the grouped counts, int8 (int32 accumulate) for the loadings, f64 for statistics",
             "data": "synthetic",
             "config": {"workload": wl, "analyses": analyses, "pca_included": bool(st.has_pca),
                        "pca_gram_path": ("whole weight classes per rank (packed columns by one all-to-all)" if "gclx_alltoall" in prof

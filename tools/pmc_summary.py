@@ -33,7 +33,7 @@ avg_ns = {}
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         avg_ns[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
-WIDE = ("tpg_pairwise_kernel", "tpg_pca_gram_kernel", "tpg_gcls_gram_kernel")
+WIDE = ("tpg_pairwise_kernel", "tpg_pca_gram_kernel", "tpg_gcls_gram_kernel", "tpg_gcls_gram2_kernel")
 out, traffic = {}, {}
 for k, c in sorted(acc.items()):
     d = disp[k]
@@ -66,11 +66,11 @@ for k, c in sorted(acc.items()):
             traffic["pairwise_mfma"] = der["hbm_read_bytes_per_launch"] + der["hbm_write_bytes_per_launch"]
         if k.startswith("tpg_pca_gram_kernel"):
             traffic["pca_gram_mfma"] = der["hbm_read_bytes_per_launch"] + der["hbm_write_bytes_per_launch"]
-        if k.startswith("tpg_gcls_gram_kernel"):
+        if k.startswith("tpg_gcls_gram_kernel") or k.startswith("tpg_gcls_gram2_kernel"):
             traffic["pca_gram_classes"] = der["hbm_read_bytes_per_launch"] + der["hbm_write_bytes_per_launch"]
 json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc_one_step.json"), "w"), indent=1)
 json.dump({"workload": "5000 x 1000000 per GPU, 51 populations, k = 20", "source": f"profiles/{tag}_pmc_one_step.json",
            "hbm_bytes_per_launch": traffic}, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 for k, o in out.items():
-    if any(s in k for s in ("pairwise_kernel", "gram_kernel", "gcls", "t4_expand", "pack_fast", "fst_kernel")):
+    if any(s in k for s in ("pairwise_kernel", "gram_kernel", "gram2_kernel", "gcls", "t4_expand", "pack_fast", "fst_kernel", "grouped_counts")):
         print(k, json.dumps({a: (round(b, 4) if isinstance(b, float) else b) for a, b in o["derived"].items()}))
