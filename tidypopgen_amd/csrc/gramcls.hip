@@ -14,7 +14,10 @@
 // per 32 x 32 tile and class (tools/ubench_fold.hip: ~130 ns against ~17 ns per MFMA), which pays as long as classes
 // are not much shorter than a few dozen loci; tpg_gram_classes says "not done" otherwise and the caller runs the
 // digit kernel.  The result is MORE accurate than the digit kernel's: class Gram matrices are exact, the weights are
-// doubles (identified up to 2^-47 relative, so that c and 2N - c share a class) and the sums are FP64.
+// doubles (identified up to 2^-47 relative, so that c and 2N - c share a class) and the sums are FP64.  Where classes are
+// short the fold is taken apart (tpg_gcls_gram2_kernel): neighbouring classes form groups, the small weight differences
+// inside a group are added in packed FP32 (a quarter of the instructions), FP64 comes in at the group ends: 3e-10 of the
+// all-FP64 result.
 //
 // Steps, all on the device:
 //   1. key_j = bit pattern of w_j with the last five mantissa bits rounded away; radix sort of (key, locus);
@@ -23,8 +26,8 @@
 //      2^16 blocks = 2^22 loci since the last fold: 4 x 2^22 is the largest FP32 sum that is still exact).
 //   2. tpg_gcls_gather_kernel: the class-sorted operand layout T2g -- block (rt, b) = 32 individuals x the 64 loci
 //      of sorted block b, the 2-bit dosage codes (missing -> 0) -- gathered from the view's L layout.
-//   3. tpg_gcls_gram_kernel: one wave = a 64 x 64 tile of pairs (2 x 2 accumulator tiles) over a range of blocks, two
-//      waves per SIMD.  A 16-byte load per lane carries the operand of two blocks; one v_and_b32 (+ one shift) per
+//   3. tpg_gcls_gram_kernel / tpg_gcls_gram2_kernel: one wave = a 64 x 64 tile of pairs (2 x 2 accumulator tiles) over a
+//      range of blocks, two waves per SIMD.  A 16-byte load per lane carries the operand of two blocks; one v_and_b32 (+ one shift) per
 //      operand word makes the FP4 nibbles in registers.  K split S: each (unit, split) writes its own FP64 slab.
 //   4. tpg_gcls_assemble_kernel: the S slabs of a unit are added in a fixed order (run-to-run identical results)
 //      and written to both triangles of the n x n matrix.
