@@ -781,13 +781,14 @@ __global__ __launch_bounds__(256) void tpg_offdiag_sum_band_kernel(const double*
                                                                    double* __restrict__ part_cnt) {
   __shared__ double ssum[256], scnt[256];
   double s = 0, c = 0;
-  const int64_t rows = r1 - r0, total = rows * (int64_t)n;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int i = r0 + (int)(idx % rows), j = (int)(idx / rows);
-    if (j <= i) continue;
-    const double x = M[i + (int64_t)j * n];
-    if (x == x) { s += x; c += 1; }
+  // a workgroup takes whole columns j (the stored elements above the diagonal are the rows i < j of column j: contiguous)
+  for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    const int i1 = r1 < j ? r1 : j;
+    const double* col = M + (int64_t)j * n;
+    for (int i = r0 + (int)threadIdx.x; i < i1; i += 256) {
+      const double x = col[i];
+      if (x == x) { s += x; c += 1; }
+    }
   }
   ssum[threadIdx.x] = s;
   scnt[threadIdx.x] = c;
@@ -799,12 +800,23 @@ __global__ __launch_bounds__(256) void tpg_offdiag_sum_band_kernel(const double*
   if (threadIdx.x == 0) { part_sum[blockIdx.x] = ssum[0]; part_cnt[blockIdx.x] = scnt[0]; }
 }
 
-__global__ void tpg_sum2_kernel(const double* __restrict__ a, const double* __restrict__ b, int nb, double* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0, c = 0;
-    for (int k = 0; k < nb; k++) { s += a[k]; c += b[k]; }
-    out[0] = 2 * s;  // both triangles
-    out[1] = 2 * c;
+// out = 2 * (sum a, sum b): 256 threads, every thread a strided share in index order, then a fixed tree (the same sums on
+// every run)
+__global__ __launch_bounds__(256) void tpg_sum2_kernel(const double* __restrict__ a, const double* __restrict__ b, int nb,
+                                                       double* __restrict__ out) {
+  __shared__ double ss[256], sc[256];
+  double s = 0, c = 0;
+  for (int k = threadIdx.x; k < nb; k += 256) { s += a[k]; c += b[k]; }
+  ss[threadIdx.x] = s;
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { ss[threadIdx.x] += ss[threadIdx.x + w]; sc[threadIdx.x] += sc[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = 2 * ss[0];  // both triangles
+    out[1] = 2 * sc[0];
   }
 }
 
@@ -820,7 +832,7 @@ __global__ void tpg_grm_rect_kernel(double* __restrict__ M, int n, int ra, int r
 }
 
 static int grm_from_as_band(tpg_ctx* ctx, tpg_comm* comm, int n, const PwBand& band, double* d_M) {
-  const int NB = 256;
+  const int NB = 2048;
   double* d_part = nullptr;
   TPG_HIP(tpg_pmalloc((void**)&d_part, sizeof(double) * (2 * NB + 2)));
   double* d_sc = d_part + 2 * NB;
@@ -830,7 +842,7 @@ static int grm_from_as_band(tpg_ctx* ctx, tpg_comm* comm, int n, const PwBand& b
     if (band.r1 > band.r0)
       TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_offdiag_sum_band_kernel, dim3(NB), dim3(256), 0, (const double*)d_M, n,
                  (int)band.r0, (int)band.r1, d_part, d_part + NB);
-    TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_sum2_kernel, dim3(1), dim3(64), 0, (const double*)d_part,
+    TPG_LAUNCH(ctx, "grm_offdiag_sum", tpg_sum2_kernel, dim3(1), dim3(256), 0, (const double*)d_part,
                (const double*)(d_part + NB), NB, d_sc);
     if (comm) rc = tpg_comm_allreduce(comm, d_sc, 2, 1);  // sum and count over all ranks
     if (rc == TPG_OK && band.r1 > band.r0) {
