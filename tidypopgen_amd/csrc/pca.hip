@@ -1085,15 +1085,24 @@ __global__ __launch_bounds__(256) void tpg_gram_small_kernel(const double* __res
     }
 }
 
-// C[i + j p] = rowscale[i] * sum_chunks part[chunk][i + j p]   (device-side finish of gram_small)
-__global__ void tpg_gram_reduce_kernel(const double* __restrict__ part, int nchunks, int p, int b,
-                                       const double* __restrict__ rowscale, double* __restrict__ Cm) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p * b) return;
+// C[i + j p] = rowscale[i] * sum_chunks part[chunk][i + j p]   (device-side finish of gram_small).  64 outputs per
+// workgroup, its four waves take every fourth chunk each (a single thread per output walked all ~80 - 160 chunks with
+// dependent adds: 26 us per call); the four partial sums are added in wave order, so every run gives the same sums.
+__global__ __launch_bounds__(256) void tpg_gram_reduce_kernel(const double* __restrict__ part, int nchunks, int p, int b,
+                                                              const double* __restrict__ rowscale, double* __restrict__ Cm) {
+  __shared__ double sh[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
   double s = 0;
-  for (int c = 0; c < nchunks; c++) s += part[(int64_t)c * p * b + idx];
-  if (rowscale) s *= rowscale[idx % p];
-  Cm[idx] = s;
+  if (idx < p * b)
+    for (int c = sl; c < nchunks; c += 4) s += part[(int64_t)c * p * b + idx];
+  sh[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && idx < p * b) {
+    s = ((sh[0][o] + sh[1][o]) + sh[2][o]) + sh[3][o];
+    if (rowscale) s *= rowscale[idx % p];
+    Cm[idx] = s;
+  }
 }
 
 // Y[row + j n] = sum_i A[row + i n] * X[i + j p]   (X small, p <= 64, b2 <= 64); optional residual
@@ -1405,7 +1414,7 @@ struct EigWork {
     if (nl > 0) {
       TPG_LAUNCH(ctx, "eig_gram_small", tpg_gram_small_kernel, dim3((unsigned)nchunks), dim3(256), 0, L, nl, Q, b, n,
                  rows_per_chunk, gpart);
-      TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((nl * b + 255) / 256)), dim3(256), 0,
+      TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((nl * b + 63) / 64)), dim3(256), 0,
                  (const double*)gpart, nchunks, nl, b, (const double*)lam_dev, cdev);
       TPG_LAUNCH(ctx, "eig_right_mult", tpg_right_mult_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, L, n, nl,
                  (const double*)cdev, b, dtmp);
@@ -1420,7 +1429,7 @@ struct EigWork {
   int gram(const double* A, int p, const double* B, int bb, std::vector<double>& C) {
     TPG_LAUNCH(ctx, "eig_gram_small", tpg_gram_small_kernel, dim3((unsigned)nchunks), dim3(256), 0, A, p, B, bb, n,
                rows_per_chunk, gpart);
-    TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((p * bb + 255) / 256)), dim3(256), 0,
+    TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((p * bb + 63) / 64)), dim3(256), 0,
                (const double*)gpart, nchunks, p, bb, (const double*)nullptr, cdev);
     C.assign((size_t)p * bb, 0.0);
     TPG_HIP(hipMemcpyAsync(C.data(), cdev, sizeof(double) * (size_t)p * bb, hipMemcpyDeviceToHost, ctx->stream));
@@ -1440,7 +1449,7 @@ struct EigWork {
     const int nblk = (n + 31) / 32;
     TPG_LAUNCH(ctx, "eig_ritz", tpg_ritz_kernel, dim3((unsigned)nblk), dim3(256), 0, A, Yk, n, p, (const double*)dx,
                (const double*)(dx + 64 * 64), Y0, Y1, gpart);
-    TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((p + 255) / 256)), dim3(256), 0,
+    TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((p + 63) / 64)), dim3(256), 0,
                (const double*)gpart, nblk, p, 1, (const double*)nullptr, cdev);
     res2.assign((size_t)p, 0.0);
     TPG_HIP(hipMemcpyAsync(res2.data(), cdev, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, ctx->stream));
