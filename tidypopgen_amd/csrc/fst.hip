@@ -493,6 +493,7 @@ __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64
       double sn = sum_num[k], sd = sum_den[k];
 #pragma unroll 4
       for (int l = 0; l < lmax; l++) {
+#pragma clang fp contract(fast)  // totals only (1e-11 of the exact sum is the contract here, not the reference's rounding)
         const uint32_t lo = (uint32_t)l * (uint32_t)gs;
         const v4d s1 = *(const v4d*)(shb + a1 + lo * 32u), s2 = *(const v4d*)(shb + a2 + lo * 32u);  // {n, p, H, e}
         // valid alleles of the pair = 2 (n1 + n2): an exact small integer in FP64 (an empty population has n = 0)
