@@ -208,9 +208,27 @@ size_t tpg_pairwise_buffer_bytes(int64_t n);
 int tpg_pairwise_create(tpg_ctx* ctx, int64_t n, void* ext_buffer, tpg_pairwise** out);
 void tpg_pairwise_free(tpg_pairwise* pw);
 int tpg_pairwise_zero(tpg_ctx* ctx, tpg_pairwise* pw);
-/* add loci [col_begin, col_end) of the view (0-based, end exclusive; -1 = m) */
+/* add loci [col_begin, col_end) of the view (0-based, end exclusive; -1 = m): all five products */
 int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
                             int64_t col_end);
+/* The same for the products one analysis needs (the reference runs 2 / 6 / 4 dense products for allele sharing / IBS /
+ * KING: src/snp_as.cpp:64-65, src/snp_ibs.cpp:67-72, src/snp_king.cpp:70-72): `products` = OR of TPG_PW_V (typed x
+ * typed), TPG_PW_D (dosage-1 x dosage-1), TPG_PW_H (het x het), TPG_PW_A (het x typed, both orientations).  Each set
+ * has a kernel with a wave tile of its own (fewer sums per pair leave registers for more pairs per operand byte).
+ * Products that were left out stay unknown until the next tpg_pairwise_zero: the count / epilogue entry points
+ * refuse (TPG_EINVAL) an output that needs one of them. */
+#define TPG_PW_V 1
+#define TPG_PW_D 2
+#define TPG_PW_H 4
+#define TPG_PW_A 8
+#define TPG_PW_FOR_AS (TPG_PW_V | TPG_PW_D)               /* snp_allele_sharing, pairwise_grm */
+#define TPG_PW_FOR_IBS (TPG_PW_V | TPG_PW_D | TPG_PW_H)   /* snp_ibs */
+#define TPG_PW_FOR_KING (TPG_PW_V | TPG_PW_D | TPG_PW_A)  /* snp_king */
+#define TPG_PW_ALL (TPG_PW_V | TPG_PW_D | TPG_PW_H | TPG_PW_A)
+int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
+                                     int64_t col_end, int products);
+/* the products whose sums are complete since the last tpg_pairwise_zero (TPG_PW_ALL when nothing was left out) */
+int tpg_pairwise_products(const tpg_pairwise* pw);
 /* Reference quirk Q1, opt-in.  increment_as_counts adds +1 to EVERY element of the allele-sharing
  * numerator for every block of the R driver that is one column narrower than the widest (src/snp_as.cpp:57-63 with
  * the scratch matrices of R/snp_allele_sharing.R:55-56).  The default (0 blocks) is the mathematically intended

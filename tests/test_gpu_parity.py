@@ -267,6 +267,69 @@ def test_pairwise_counts_bit_exact_and_epilogues(tpg, n, m, miss):
     assert np.array_equal(pw.epilogues(which=("grm",))["grm"], ep["grm"], equal_nan=True)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("which", ["as", "ibs", "king"])
+@pytest.mark.parametrize("n,m,miss", [(1, 1, 0.0), (65, 129, 0.05), (130, 700, 0.3), (333, 5001, 0.1), (500, 8000, 0.02)])
+def test_pairwise_product_sets_bit_exact(tpg, monkeypatch, n, m, miss, which, variant):
+    """tpg_pairwise_accumulate_products: the kernels specialised for {V, D} / {V, D, H} / {V, D, A} (every wave-tile
+    variant: TPG_PW_VARIANT) fill the same accumulators as the five-product kernel -- counts bit-exact against the oracle
+    (src/snp_as.cpp:64-65, src/snp_ibs.cpp:67-72, src/snp_king.cpp:70-72), epilogues identical -- and the entry points
+    refuse outputs whose products were left out."""
+    monkeypatch.setenv("TPG_PW_VARIANT", str(variant))
+    fbm = orc.synth_fbm(37, n, m, npop=min(n, 7), miss=miss)
+    X = tpg.FBM.from_numpy(fbm)
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, n)
+    assert pw.products() == tpg.PW_ALL
+    sets = {"as": tpg.PW_FOR_AS, "ibs": tpg.PW_FOR_IBS, "king": tpg.PW_FOR_KING}
+    # in two aligned pieces when the panel is long enough: a second launch adds to the same slabs
+    cut = (m // 2) // 128 * 128
+    if cut:
+        pw.accumulate(v, 0, cut, products=sets[which])
+        pw.accumulate(v, cut, m, products=sets[which])
+    else:
+        pw.accumulate(v, products=sets[which])
+    assert pw.products() == sets[which]
+    K = np.zeros((n, n), order="F"); K2 = np.zeros((n, n), order="F")
+    if which == "as":
+        c = pw.counts(("as_num", "as_den"))
+        orc.increment_as_counts(K, K2, fbm, None, None)
+        assert np.array_equal(c["as_num"], K) and np.array_equal(c["as_den"], K2)
+        assert np.array_equal(pw.allele_sharing(), orc.snp_allele_sharing(fbm), equal_nan=True)
+        assert np.allclose(pw.grm(), orc.pairwise_grm(orc.snp_allele_sharing(fbm)), rtol=1e-12, atol=1e-13, equal_nan=True)
+        refused = (lambda: pw.ibs(), lambda: pw.king(), lambda: pw.counts(("ibs",)), lambda: pw.counts(("n_Aa_i",)),
+                   lambda: pw.epilogues(which=("king",)))
+    elif which == "ibs":
+        c = pw.counts(("ibs", "ibs_valid", "as_num", "as_den"))
+        orc.increment_ibs_counts(K, K2, fbm, None, None)
+        assert np.array_equal(c["ibs"], K) and np.array_equal(c["ibs_valid"], K2)
+        assert np.array_equal(pw.ibs("proportion"), orc.snp_ibs(fbm), equal_nan=True)
+        assert np.array_equal(pw.allele_sharing(), orc.snp_allele_sharing(fbm), equal_nan=True)  # V, D are in the set
+        refused = (lambda: pw.king(), lambda: pw.counts(("king_num",)), lambda: pw.epilogues(which=("ibs", "king")))
+    else:
+        c = pw.counts(("king_num", "n_Aa_i", "as_num", "as_den"))
+        orc.increment_king_numerator(K, K2, fbm, None, None)
+        assert np.array_equal(c["king_num"], K) and np.array_equal(c["n_Aa_i"], K2)
+        assert np.array_equal(pw.king(), orc.snp_king(fbm), equal_nan=True)
+        ep = pw.epilogues(which=("king", "grm"))  # BASELINE config 2's pair of analyses from one pass of four products
+        assert np.array_equal(ep["king"], orc.snp_king(fbm), equal_nan=True)
+        assert np.allclose(ep["grm"], orc.pairwise_grm(orc.snp_allele_sharing(fbm)), rtol=1e-12, atol=1e-13, equal_nan=True)
+        refused = (lambda: pw.ibs(), lambda: pw.counts(("ibs",)), lambda: pw.epilogues(which=("ibs",)))
+    for f in refused:
+        with pytest.raises(tpg._lib.TpgError):
+            f()
+    # a later pass with all five products does not make the earlier loci's missing products appear
+    pw.accumulate(v)
+    assert pw.products() == sets[which]
+    pw.zero()
+    assert pw.products() == tpg.PW_ALL
+    # the R-level entry points take the minimal set themselves
+    if variant == 0 and n > 1:
+        assert np.array_equal(tpg.snp_king(X), orc.snp_king(fbm), equal_nan=True)
+        assert np.array_equal(tpg.snp_ibs(X), orc.snp_ibs(fbm), equal_nan=True)
+        assert np.array_equal(tpg.snp_allele_sharing(X), orc.snp_allele_sharing(fbm), equal_nan=True)
+
+
 def test_pairwise_block_invariance_and_subsets(tpg):
     # block invariance (test_snp_ibs.R:35-36, test_snp_king.R:160-161): accumulate in aligned pieces
     n, m = 150, 1000

@@ -55,6 +55,7 @@ lib.tpg_view_m.argtypes = [vp]
 lib.tpg_as_pad_quirk_blocks.restype = C.c_int64
 lib.tpg_as_pad_quirk_blocks.argtypes = [C.c_int64, C.c_int64]
 lib.tpg_pairwise_set_as_pad_quirk.argtypes = [vp, C.c_int64]
+lib.tpg_pairwise_products.argtypes = [vp]
 lib.tpg_filter_high_relatedness.argtypes = [vp, vp, C.c_int64, C.c_double, vp, vp]
 lib.tpg_multi_ctx.restype = vp
 lib.tpg_multi_comm.restype = vp
@@ -92,6 +93,7 @@ SYMBOLS = [
     "tpg_pairwise_create_sharded", "tpg_pairwise_reduce", "tpg_pairwise_band", "tpg_pairwise_band_of", "tpg_pairwise_epilogues_sharded",
     "tpg_pca_partial_svd_sharded", "tpg_multi_create", "tpg_multi_destroy", "tpg_multi_ndev", "tpg_multi_ctx", "tpg_multi_comm", "tpg_multi_pairwise",
     "tpg_multi_grouped_alt_freq", "tpg_multi_pop_fst", "tpg_multi_pca_partial_svd",
+    "tpg_pairwise_accumulate_products", "tpg_pairwise_products",
 ]
 
 

@@ -34,6 +34,9 @@ CODE_IMPUTE_PRED[:3] = [0.0, 1.0, 2.0]
 CODE_IMPUTE_PRED[4:7] = [0.0, 1.0, 2.0]
 
 FST_METHODS = {"Hudson": 0, "Nei87": 1, "WC84": 2}
+# cross-products of the pairwise accumulators (include/tpg.h: TPG_PW_*)
+PW_V, PW_D, PW_H, PW_A = 1, 2, 4, 8
+PW_FOR_AS, PW_FOR_IBS, PW_FOR_KING, PW_ALL = PW_V | PW_D, PW_V | PW_D | PW_H, PW_V | PW_D | PW_A, 15
 
 
 def _ptr(x):
@@ -271,8 +274,18 @@ class Pairwise:
     def zero(self):
         check(lib.tpg_pairwise_zero(self.ctx.h, self.h))
 
-    def accumulate(self, view: View, col_begin: int = 0, col_end: int = -1):
-        check(lib.tpg_pairwise_accumulate(self.ctx.h, self.h, view.h, C.c_int64(col_begin), C.c_int64(col_end)))
+    def accumulate(self, view: View, col_begin: int = 0, col_end: int = -1, products=None):
+        """products: None = all five cross-products; else an OR of PW_V / PW_D / PW_H / PW_A or one of the sets
+        PW_FOR_AS / PW_FOR_IBS / PW_FOR_KING (the kernel specialised for that set runs: include/tpg.h)"""
+        if products is None:
+            check(lib.tpg_pairwise_accumulate(self.ctx.h, self.h, view.h, C.c_int64(col_begin), C.c_int64(col_end)))
+        else:
+            check(lib.tpg_pairwise_accumulate_products(self.ctx.h, self.h, view.h, C.c_int64(col_begin), C.c_int64(col_end),
+                                                       C.c_int(int(products))))
+
+    def products(self) -> int:
+        """the products whose sums are complete since the last zero()"""
+        return int(lib.tpg_pairwise_products(self.h))
 
     def set_as_pad_quirk(self, narrow_blocks: int):
         """opt-in emulation of reference quirk Q1 (include/tpg.h): +narrow_blocks on every allele-sharing numerator"""
@@ -537,10 +550,10 @@ def _raw_view(X: FBM, ind_row, ind_col) -> View:
     return View(X, ind_row, ind_col, code256=None)
 
 
-def _pairwise_pass(X: FBM, ind_row, ind_col):
+def _pairwise_pass(X: FBM, ind_row, ind_col, products=None):
     v = _raw_view(X, ind_row, ind_col)
     pw = Pairwise(X.ctx, v.n)
-    pw.accumulate(v)
+    pw.accumulate(v, products=products)
     return v, pw
 
 
@@ -549,7 +562,7 @@ def snp_ibs(X: FBM, ind_row=None, ind_col=None, type: str = "proportion", block_
     range is swept in one device pass (results do not depend on it)."""
     if type not in ("proportion", "adjusted_counts", "raw_counts"):
         raise ValueError("'arg' should be one of 'proportion', 'adjusted_counts', 'raw_counts'")
-    v, pw = _pairwise_pass(X, ind_row, ind_col)
+    v, pw = _pairwise_pass(X, ind_row, ind_col, PW_FOR_IBS)  # V, D, H: 3 of the 5 cross-products
     if type == "raw_counts":
         c = pw.counts(("ibs", "ibs_valid"))
         return dict(ibs=c["ibs"], valid_n=c["ibs_valid"])
@@ -558,7 +571,7 @@ def snp_ibs(X: FBM, ind_row=None, ind_col=None, type: str = "proportion", block_
 
 def snp_king(X: FBM, ind_row=None, ind_col=None, block_size=None):
     """R/snp_king.R:32-103"""
-    _, pw = _pairwise_pass(X, ind_row, ind_col)
+    _, pw = _pairwise_pass(X, ind_row, ind_col, PW_FOR_KING)  # V, D, A, A': 4 of 5
     return pw.king()
 
 
@@ -568,7 +581,7 @@ def as_pad_quirk_blocks(m: int, block_size: int) -> int:
 
 
 def _as_pass(X, ind_row, ind_col, block_size, emulate_as_pad_quirk):
-    v, pw = _pairwise_pass(X, ind_row, ind_col)
+    v, pw = _pairwise_pass(X, ind_row, ind_col, PW_FOR_AS)  # V, D: 2 of 5
     if emulate_as_pad_quirk:
         # what the reference BINARY returns: +1 on every numerator per narrower block (src/snp_as.cpp:57-63)
         pw.set_as_pad_quirk(as_pad_quirk_blocks(v.m, block_size or block_size_default(X.nrow)))

@@ -623,6 +623,9 @@ extern "C" int tpg_multi_pairwise(tpg_multi* mg, const uint8_t* fbm_bytes, int64
   TPG_TRY(multi_check_args(mg, fbm_bytes, nrow, ncol, rowInd1, &n, colInd1, &m));
   std::vector<MultiShard> st((size_t)mg->ndev);
   std::vector<tpg_pairwise*> pw((size_t)mg->ndev, nullptr);
+  // only the cross-products the requested matrices are made of (2 of 5 for allele sharing / GRM alone, 3 for IBS, 4 for KING)
+  const int products = (ibs ? TPG_PW_FOR_IBS : 0) | (king ? TPG_PW_FOR_KING : 0) | (allele_sharing || grm ? TPG_PW_FOR_AS : 0);
+  TPG_REQUIRE(products, TPG_EINVAL, "no output requested");
   // phase 1, no exchange: upload, pack and accumulate this device's loci.  The phases are separate thread teams so
   // that a failure on one device (out of memory, a bad index) is known to all before anyone enters a collective --
   // a rank that skipped the reduce-scatter would leave the others waiting in it for ever.
@@ -632,7 +635,7 @@ extern "C" int tpg_multi_pairwise(tpg_multi* mg, const uint8_t* fbm_bytes, int64
     TPG_TRY(tpg_pairwise_create_sharded(ctx, mg->comm[(size_t)r], n, &pw[(size_t)r]));
     TPG_TRY(multi_shard_view(mg, r, fbm_bytes, nrow, rowInd1, n, colInd1, m, nullptr /* raw bytes */, &st[(size_t)r]));
     if (!st[(size_t)r].v) return TPG_OK;  // nothing of its own, still takes part below
-    return tpg_pairwise_accumulate(ctx, pw[(size_t)r], st[(size_t)r].v, 0, -1);
+    return tpg_pairwise_accumulate_products(ctx, pw[(size_t)r], st[(size_t)r].v, 0, -1, products);
   });
   // phase 2: one reduce-scatter, then every device finishes its band and writes it into the caller's matrices
   if (rc == TPG_OK)

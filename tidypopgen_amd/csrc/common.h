@@ -168,6 +168,10 @@ struct tpg_pairwise {
   std::vector<int32_t> band;   // nranks + 1 super-tile boundaries: band r = rows [band[r], band[r + 1])
   int64_t* rowpad = nullptr;   // device int64[nst]
   bool reduced = false;        // after tpg_pairwise_reduce: only this rank's band holds (complete) sums
+  // products (TPG_PW_V | D | H | A) every accumulate since the last zero has added: what the epilogues may read
+  int have = 15;
+  // unit tables of the product-subset kernels (pairwise.hip), one per wave-tile shape: key 16 RA + RB -> (device int2[], count)
+  std::map<int, std::pair<void*, int64_t>> orders;
 };
 #define TPG_PW_MAX_LOCI 2147483647ll
 

@@ -256,6 +256,170 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
 }
 
 // ---------------------------------------------------------------------------
+// Product subsets.  A stand-alone snp_allele_sharing / pairwise_grm needs V and D only, snp_ibs V, D, H, snp_king V, D,
+// A, A' (the reference runs 2 / 6 / 4 dense products for them: src/snp_as.cpp:64-65, src/snp_ibs.cpp:67-72,
+// src/snp_king.cpp:70-72).  Fewer sums per pair leave accumulator registers for MORE PAIRS per wave, i.e. more MFMAs per
+// operand byte crossing the L2 -> CU path, which is what the five-product 96 x 32 tile is short of when products are
+// dropped from it (6 MFMAs per 4 fragments for {V, D}).  One kernel template, instantiated per product set with a wave
+// tile of (32 RA) x (32 RB) pairs:
+//   {V, D}        128 x 64   16 accumulator tiles, 16 MFMAs per 6 fragments and 64 loci
+//   {V, D, H}      64 x 64   12 accumulator tiles, 12 MFMAs per 4 fragments
+//   {V, D, A, A'}  64 x 64   16 accumulator tiles, 16 MFMAs per 4 fragments
+// Same T4 operands, same slab layout as the five-product kernel (a tile (rt, ct) of the wave is sub-tile rt % 3 of slab
+// (rt / 3, ct)), so accumulators, reduce-scatter and epilogues do not care which kernel filled them; planes of products
+// that were not asked for stay zero and tpg_pairwise.have says which sums are complete.  Only tiles on or above the
+// diagonal (ct >= rt) with data are written.  Operand blocks (64 loci) go through NS rotating register slots: while the
+// MFMAs of block b issue, the planes of block b + 1 are masked out of slot (b + 1) % NS and block b + NS - 1 is fetched
+// into the slot block b - 1 left (prefetch distance NS - 1 steps).
+template <int MASK>
+struct PwSet {
+  static constexpr bool pV = (MASK & TPG_PW_V) != 0, pD = (MASK & TPG_PW_D) != 0, pH = (MASK & TPG_PW_H) != 0,
+                        pA = (MASK & TPG_PW_A) != 0;
+  static constexpr int NP = (pV ? 1 : 0) + (pD ? 1 : 0) + (pH ? 1 : 0) + (pA ? 2 : 0);
+  static constexpr bool wv = pV || pA, wd = pD, wh = pH || pA;  // operand planes wanted
+  static constexpr int NPL = (wv ? 1 : 0) + (wd ? 1 : 0) + (wh ? 1 : 0);
+};
+
+template <int MASK>
+__device__ __forceinline__ Frag3 tpg_planes_of(v4u w, uint32_t mv, uint32_t md, uint32_t mh) {
+  Frag3 f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if constexpr (PwSet<MASK>::wv) f.v[k] = (int)(w[k] & mv);
+    if constexpr (PwSet<MASK>::wd) f.d[k] = (int)(w[k] & md);
+    if constexpr (PwSet<MASK>::wh) f.h[k] = (int)(w[k] & mh);
+  }
+  return f;
+}
+
+template <int RA, int RB, int MASK, int NS>
+__global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* __restrict__ T4, int64_t KG,
+                                                                     int64_t kb_begin, int64_t kb_end, int nst, int nct,
+                                                                     const int2* __restrict__ order, int64_t nun, int S,
+                                                                     const int64_t* __restrict__ rowpad,
+                                                                     int32_t* __restrict__ acc_out) {
+  using PS = PwSet<MASK>;
+  constexpr int NT = RA + RB;                    // operand fragments per 64 loci
+  constexpr int NM = RA * RB * PS::NP;           // MFMAs per 64 loci
+  constexpr int NV = NT * 4 * PS::NPL;           // plane masks (v_and_b32) per 64 loci
+  constexpr int U = (NS % 2 == 0) ? NS : 2 * NS; // steps per unrolled loop body: slots and plane sets both come round
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t kbs = kb_end - kb_begin;
+  const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+  const int sc1 = TPG_SC_ONE, sc2 = TPG_SC_TWO, sch = TPG_SC_HALF;
+  for (int64_t round = 0;; round++) {
+    const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
+    if (un >= nun * S) break;
+    const int ks = (int)(un / nun);
+    const int2 ij = order[un % nun];
+    const int I = __builtin_amdgcn_readfirstlane(ij.x), J = __builtin_amdgcn_readfirstlane(ij.y);
+    const int64_t kb0 = kb_begin + (kbs * ks) / S, kb1 = kb_begin + (kbs * (ks + 1)) / S;
+    // row tiles of the wave: RA A tiles (rows of the output), RB B tiles (columns).  A tile past the last one with data
+    // reads tile 0 instead; what it yields is never stored
+    const uint4* pt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int tile = t < RA ? RA * I + t : RB * J + (t - RA);
+      pt[t] = T4 + ((int64_t)(tile < nct ? tile : 0) * KG * 2) * 64;
+    }
+    v16f cV[RA][RB], cD[RA][RB], cH[RA][RB], cHV[RA][RB], cVH[RA][RB];
+#pragma unroll
+    for (int a = 0; a < RA; a++)
+#pragma unroll
+      for (int b = 0; b < RB; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { cV[a][b][r] = 0.f; cD[a][b][r] = 0.f; cH[a][b][r] = 0.f; cHV[a][b][r] = 0.f; cVH[a][b][r] = 0.f; }
+
+    if (kb0 < kb1) {
+      const int64_t kl = kb1 - 1;
+      v4u R[NS][NT];
+      auto LD = [&](const uint4* p) {
+        uint32_t off = (uint32_t)lane * 16u;
+        asm("" : "+v"(off));
+        return *(const v4u*)((const char*)p + off);
+      };
+#pragma unroll
+      for (int s = 0; s < NS - 1; s++) {
+        const int64_t b = kb0 + s < kb1 ? kb0 + s : kl;
+#pragma unroll
+        for (int t = 0; t < NT; t++) R[s][t] = LD(pt[t] + b * 64);
+        // in THIS order: hipcc's wait-count pass merges the loop's entry state with its back edge, so a prologue that
+        // loads the slot the first step needs last costs a vmcnt(0) at the top of every loop body
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      Frag3 P[2][NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) P[0][t] = tpg_planes_of<MASK>(R[0][t], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
+      auto step = [&](auto Sc, int64_t kb) {
+        constexpr int s = decltype(Sc)::value, cur = s & 1, nx = cur ^ 1, sl = (s + 1) % NS, ld = (s + NS - 1) % NS;
+        // the slot whose planes were taken in the previous step is free: block kb + NS - 1
+        const int64_t bl = kb + NS - 1 < kb1 ? kb + NS - 1 : kl;
+#pragma unroll
+        for (int t = 0; t < NT; t++) R[ld][t] = LD(pt[t] + bl * 64);
+        // planes of the next block (zero A planes past the K range: the tail of the last unrolled body adds nothing)
+        const bool live1 = kb + 1 < kb1;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const bool keep = t >= RA || live1;
+          P[nx][t] = tpg_planes_of<MASK>(R[sl][t], keep ? TPG_NIB_V : 0u, keep ? TPG_NIB_D : 0u, keep ? TPG_NIB_H : 0u);
+        }
+#pragma unroll
+        for (int a = 0; a < RA; a++)
+#pragma unroll
+          for (int b = 0; b < RB; b++) {
+            if constexpr (PS::pV) cV[a][b] = MFMA_F4(P[cur][a].v, P[cur][RA + b].v, cV[a][b], sc1, sc1);
+            if constexpr (PS::pD) cD[a][b] = MFMA_F4(P[cur][a].d, P[cur][RA + b].d, cD[a][b], sch, sch);
+            if constexpr (PS::pH) cH[a][b] = MFMA_F4(P[cur][a].h, P[cur][RA + b].h, cH[a][b], sc2, sc2);
+            if constexpr (PS::pA) cHV[a][b] = MFMA_F4(P[cur][a].h, P[cur][RA + b].v, cHV[a][b], sc2, sc1);
+            if constexpr (PS::pA) cVH[a][b] = MFMA_F4(P[cur][a].v, P[cur][RA + b].h, cVH[a][b], sc1, sc2);
+          }
+        // NV plane masks (+ address arithmetic) and NT loads spread over the NM MFMAs of the step
+#pragma unroll
+        for (int q = 0; q < NM; q++) {
+          __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(SGB_VALU, (NV + NM - 1) / NM + 1, 0);
+          if ((NT * (q + 1)) / NM != (NT * q) / NM) __builtin_amdgcn_sched_group_barrier(SGB_VMEM_READ, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int64_t kb = kb0; kb < kb1; kb += U) {
+        step(std::integral_constant<int, 0>{}, kb);
+        if constexpr (U > 1) step(std::integral_constant<int, 1>{}, kb + 1);
+        if constexpr (U > 2) step(std::integral_constant<int, 2>{}, kb + 2);
+        if constexpr (U > 3) step(std::integral_constant<int, 3>{}, kb + 3);
+        if constexpr (U > 4) step(std::integral_constant<int, 4>{}, kb + 4);
+        if constexpr (U > 5) step(std::integral_constant<int, 5>{}, kb + 5);
+        if constexpr (U > 6) step(std::integral_constant<int, 6>{}, kb + 6);
+        if constexpr (U > 7) step(std::integral_constant<int, 7>{}, kb + 7);
+        if constexpr (U > 8) step(std::integral_constant<int, 8>{}, kb + 8);
+        if constexpr (U > 9) step(std::integral_constant<int, 9>{}, kb + 9);
+        static_assert(U <= 10, "more steps per loop body than written out");
+      }
+    }
+    // integer sums (<= 2^24 loci per wave-unit): exact in int32.  Tiles on or above the diagonal only.
+#pragma unroll
+    for (int a = 0; a < RA; a++)
+#pragma unroll
+      for (int b = 0; b < RB; b++) {
+        const int rt = RA * I + a, ct = RB * J + b;
+        if (rt < nct && ct < nct && ct >= rt) {
+          const int I3 = rt / TA, a3 = rt - TA * I3;
+          int32_t* slab = acc_out + (tpg_pw_unit_index(nst, I3, ct) + rowpad[I3]) * TPG_PW_TILE_INTS + a3 * 16 * 64 + lane;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            if constexpr (PS::pV) atomicAdd(slab + 0 * TPG_PW_PLANE_INTS + r * 64, (int)cV[a][b][r]);
+            if constexpr (PS::pD) atomicAdd(slab + 1 * TPG_PW_PLANE_INTS + r * 64, (int)cD[a][b][r]);
+            if constexpr (PS::pH) atomicAdd(slab + 2 * TPG_PW_PLANE_INTS + r * 64, (int)cH[a][b][r]);
+            if constexpr (PS::pA) atomicAdd(slab + 3 * TPG_PW_PLANE_INTS + r * 64, (int)cHV[a][b][r]);
+            if constexpr (PS::pA) atomicAdd(slab + 4 * TPG_PW_PLANE_INTS + r * 64, (int)cVH[a][b][r]);
+          }
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
 // Bands: super-tile rows dealt to `nranks` ranks in contiguous runs of (nearly) equal unit counts (row I holds
 // TA (nst - I) units).  -> band boundaries and the padded chunk size (units) every band gets in the buffer.
@@ -406,6 +570,7 @@ extern "C" void tpg_pairwise_free(tpg_pairwise* pw) {
   if (pw->owns && pw->acc) tpg_pfree(pw->acc);
   tpg_pfree(pw->order);
   tpg_pfree(pw->rowpad);
+  for (auto& o : pw->orders) tpg_pfree(o.second.first);
   delete pw;
 }
 
@@ -416,6 +581,7 @@ extern "C" int tpg_pairwise_zero(tpg_ctx* ctx, tpg_pairwise* pw) {
   TPG_HIP(hipMemsetAsync(pw->acc, 0, pw_buffer_bytes(pw->n, pw->nranks), ctx->stream));
   pw->loci = 0;
   pw->reduced = false;
+  pw->have = TPG_PW_ALL;
   return TPG_OK;
 }
 
@@ -450,36 +616,77 @@ extern "C" int64_t tpg_as_pad_quirk_blocks(int64_t m, int64_t block_size) {
   return narrow;
 }
 
-extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
-                                       int64_t col_end) {
-  TpgEnter _enter(ctx);
-  TPG_REQUIRE(ctx && pw && v, TPG_EINVAL, "null argument");
-  TPG_REQUIRE(pw->n == v->n, TPG_EINVAL, "pairwise n = %lld but view n = %lld", (long long)pw->n, (long long)v->n);
-  TPG_REQUIRE(!pw->reduced, TPG_EINVAL, "the accumulators were reduced over the ranks: zero them before accumulating again");
-  if (col_end < 0) col_end = v->m;
-  TPG_REQUIRE(col_begin >= 0 && col_begin <= col_end && col_end <= v->m, TPG_EINVAL, "bad locus range [%lld,%lld)",
-              (long long)col_begin, (long long)col_end);
-  // the kernel works on whole 128-locus groups; a range that is not aligned would need masking
-  TPG_REQUIRE(col_begin % 128 == 0 && (col_end % 128 == 0 || col_end == v->m), TPG_EINVAL,
-              "locus range must start on a multiple of 128 and end on one (or at m)");
-  if (col_begin == col_end) return TPG_OK;
-  // int32 accumulators: every product is bounded by the number of loci accumulated (the epilogues form their sums
-  // in 64 bits), so the total must stay below 2^31
-  TPG_REQUIRE(pw->loci + (col_end - col_begin) <= TPG_PW_MAX_LOCI, TPG_EUNSUPPORTED,
-              "%lld loci accumulated + %lld more would overflow the int32 pair counts (limit %lld)", (long long)pw->loci,
-              (long long)(col_end - col_begin), (long long)TPG_PW_MAX_LOCI);
-  pw->loci += col_end - col_begin;
-  // the FP4 operand form of the view: written by the pack kernel (tpg_view_create_pair) or made here on first use
-  if (!v->T4) {
-    TPG_TRY(tpg_view_need_T(ctx, v));
-    uint4* t4 = nullptr;
-    TPG_HIP(tpg_pmalloc((void**)&t4, 2 * v->bytes_each));
-    const int64_t nblocks = 4 * v->Q * v->KG;
-    int grid = (int)std::min<int64_t>(ceil_div(nblocks * 64, 256), (int64_t)ctx->num_cu * 32);
-    TPG_LAUNCH(ctx, "t4_expand", tpg_t4_expand_kernel, dim3((unsigned)grid), dim3(256), 0, (const uint4*)v->T, t4, nblocks);
-    v->T4 = t4;
+// ---- the product-subset kernels: unit tables and launch ----
+// units (I, J) of a (32 RA) x (32 RB) wave tile: row group I (row tiles RA I ...), column group J (row tiles RB J ...),
+// kept when they hold a tile on or above the diagonal; patch order as for the five-product kernel (blocks of ~16 column
+// tiles, inside a block row after row: consecutive units share their A tiles, a run of 128 units is what one XCD's
+// waves take in a round)
+static int pw_order_for(tpg_ctx* ctx, tpg_pairwise* pw, int RA, int RB, const int2** d_order, int64_t* nun) {
+  const int key = 16 * RA + RB;
+  auto it = pw->orders.find(key);
+  if (it == pw->orders.end()) {
+    const int nct = (int)ceil_div(pw->n, 32);
+    const int nrg = (int)ceil_div(nct, RA), ncg = (int)ceil_div(nct, RB);
+    const int PG = std::max(1, 16 / RB);
+    std::vector<int2> order;
+    for (int pc = 0; pc * PG < ncg; pc++) {
+      const int j1 = std::min(ncg, pc * PG + PG);
+      for (int I = 0; I < nrg; I++)
+        for (int J = pc * PG; J < j1; J++)
+          if (RB * J + RB - 1 >= RA * I) order.push_back(make_int2(I, J));
+    }
+    void* d = nullptr;
+    TPG_HIP(tpg_pmalloc(&d, sizeof(int2) * order.size()));
+    hipError_t e = hipMemcpyAsync(d, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host vector goes out of scope
+    if (e != hipSuccess) { tpg_pfree(d); tpg_set_error("pairwise unit table: %s", hipGetErrorString(e)); return TPG_EHIP; }
+    it = pw->orders.emplace(key, std::make_pair(d, (int64_t)order.size())).first;
   }
-  const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
+  *d_order = (const int2*)it->second.first;
+  *nun = it->second.second;
+  return TPG_OK;
+}
+
+// K split of units x S wave-units over the resident waves: a round costs its K range plus the flush of the
+// accumulators; t_step in us per K step, t_flush in us
+static int pw_ksplit(int64_t nun, int64_t steps, int64_t min_steps_per_unit, int64_t minS, int64_t nwaves, double t_step,
+                     double t_flush) {
+  int bestS = (int)minS;
+  double best = -1;
+  const int64_t cap = steps / min_steps_per_unit;
+  const int64_t maxS = std::max<int64_t>(minS, cap > 0 ? std::min<int64_t>(cap, 96) : 1);
+  for (int64_t S = minS; S <= maxS; S++) {
+    const int64_t rounds = ceil_div(nun * S, nwaves);
+    const double cost = (double)rounds * ((double)ceil_div(steps, S) * t_step + t_flush);
+    if (best < 0 || cost < best * 0.995) { best = cost; bestS = (int)S; }
+  }
+  return bestS;
+}
+
+template <int RA, int RB, int MASK, int NS>
+static int pw_launch_set(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t kg0, int64_t kg1, const char* name) {
+  const int2* d_order = nullptr;
+  int64_t nun = 0;
+  TPG_TRY(pw_order_for(ctx, pw, RA, RB, &d_order, &nun));
+  constexpr int NM = RA * RB * PwSet<MASK>::NP;
+  const int64_t max_groups = 131072;  // 2^24 loci per wave-unit: FP32 sums of integers stay exact
+  int nblk = ctx->num_cu / 8 * 8;
+  if (nblk < 8) nblk = 8;
+  const int64_t nwaves = 4 * (int64_t)nblk;
+  for (int64_t c0 = kg0; c0 < kg1; c0 += 8 * max_groups) {
+    const int64_t c1 = std::min(kg1, c0 + 8 * max_groups);
+    const int64_t kgs = c1 - c0;
+    // per 64-locus block: NM MFMAs at ~18 ns; flush: 16 atomic wave-instructions per accumulator tile (12 us for 15)
+    const int S = pw_ksplit(nun, 2 * kgs, 16, ceil_div(kgs, max_groups), nwaves, 0.0183 * NM, 0.8 * NM);
+    if (getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] %s: %d x %d tiles, %lld units, S = %d\n", name, RA, RB, (long long)nun, S);
+    TPG_LAUNCH(ctx, name, (tpg_pairwise_set_kernel<RA, RB, MASK, NS>), dim3((unsigned)nblk), dim3(256), 0,
+               (const uint4*)v->T4, v->KG, 2 * c0, 2 * c1, (int)pw->nst, (int)ceil_div(pw->n, 32), d_order, nun, S,
+               (const int64_t*)pw->rowpad, pw->acc);
+  }
+  return TPG_OK;
+}
+
+static int pw_launch_all(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t kg0, int64_t kg1) {
   // K split S: units x S wave-units over the resident waves (one workgroup per CU, one wave per SIMD; a multiple of
   // the 8 XCDs), at least 8 K groups (1024 loci) per unit.  Cost model: rounds(S) = ceil(units S / waves) rounds, a
   // round costs its K range (about 0.55 us per 128-locus group: 30 MFMAs at ~34 cycles) plus the flush of the
@@ -494,23 +701,85 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
   for (int64_t c0 = kg0; c0 < kg1; c0 += 8 * max_groups) {
     const int64_t c1 = std::min(kg1, c0 + 8 * max_groups);
     const int64_t kgs = c1 - c0;
-    const int64_t minS = ceil_div(kgs, max_groups);
-    int bestS = (int)minS;
-    double best = -1;
-    const int64_t maxS = std::max<int64_t>(minS, kgs / 8 > 0 ? (kgs / 8 < 96 ? kgs / 8 : 96) : 1);
-    for (int64_t S = minS; S <= maxS; S++) {
-      const int64_t rounds = ceil_div(pw->nun * S, nwaves);
-      const double cost = (double)rounds * ((double)ceil_div(kgs, S) * 0.55 + 12.0);
-      if (best < 0 || cost < best * 0.995) { best = cost; bestS = (int)S; }
-    }
+    const int bestS = pw_ksplit(pw->nun, kgs, 8, ceil_div(kgs, max_groups), nwaves, 0.55, 12.0);
     if (getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] pairwise: %lld units, S = %d\n", (long long)pw->nun, bestS);
     TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T4, v->KG,
                c0, c1, (int)pw->nst, (int)ceil_div(pw->n, 32), (const int2*)pw->order, pw->nun, bestS,
                (const int64_t*)pw->rowpad, pw->acc);
   }
+  return TPG_OK;
+}
+
+// wave tile and slot count per product set; TPG_PW_VARIANT=<k> picks another instantiation (A/B runs, tools/pw_only.py)
+static int pw_variant() {
+  const char* e = getenv("TPG_PW_VARIANT");
+  return e ? atoi(e) : 0;
+}
+
+extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
+                                                int64_t col_end, int products) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && pw && v, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(pw->n == v->n, TPG_EINVAL, "pairwise n = %lld but view n = %lld", (long long)pw->n, (long long)v->n);
+  TPG_REQUIRE(!pw->reduced, TPG_EINVAL, "the accumulators were reduced over the ranks: zero them before accumulating again");
+  TPG_REQUIRE(products > 0 && (products & ~TPG_PW_ALL) == 0, TPG_EINVAL, "bad product set 0x%x", products);
+  if (col_end < 0) col_end = v->m;
+  TPG_REQUIRE(col_begin >= 0 && col_begin <= col_end && col_end <= v->m, TPG_EINVAL, "bad locus range [%lld,%lld)",
+              (long long)col_begin, (long long)col_end);
+  // the kernel works on whole 128-locus groups; a range that is not aligned would need masking
+  TPG_REQUIRE(col_begin % 128 == 0 && (col_end % 128 == 0 || col_end == v->m), TPG_EINVAL,
+              "locus range must start on a multiple of 128 and end on one (or at m)");
+  if (col_begin == col_end) return TPG_OK;
+  // int32 accumulators: every product is bounded by the number of loci accumulated (the epilogues form their sums
+  // in 64 bits), so the total must stay below 2^31
+  TPG_REQUIRE(pw->loci + (col_end - col_begin) <= TPG_PW_MAX_LOCI, TPG_EUNSUPPORTED,
+              "%lld loci accumulated + %lld more would overflow the int32 pair counts (limit %lld)", (long long)pw->loci,
+              (long long)(col_end - col_begin), (long long)TPG_PW_MAX_LOCI);
+  // the kernels that exist: {V, D}, {V, D, H}, {V, D, A}, all five; anything else takes the smallest one that covers it
+  int set = products | TPG_PW_V | TPG_PW_D;
+  if ((set & TPG_PW_H) && (set & TPG_PW_A)) set = TPG_PW_ALL;
+  pw->loci += col_end - col_begin;
+  pw->have &= set;
+  // the FP4 operand form of the view: written by the pack kernel (tpg_view_create_pair) or made here on first use
+  if (!v->T4) {
+    TPG_TRY(tpg_view_need_T(ctx, v));
+    uint4* t4 = nullptr;
+    TPG_HIP(tpg_pmalloc((void**)&t4, 2 * v->bytes_each));
+    const int64_t nblocks = 4 * v->Q * v->KG;
+    int grid = (int)std::min<int64_t>(ceil_div(nblocks * 64, 256), (int64_t)ctx->num_cu * 32);
+    TPG_LAUNCH(ctx, "t4_expand", tpg_t4_expand_kernel, dim3((unsigned)grid), dim3(256), 0, (const uint4*)v->T, t4, nblocks);
+    v->T4 = t4;
+  }
+  const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
+  const int var = pw_variant();
+  if (set == TPG_PW_FOR_AS) {
+    if (var == 1) TPG_TRY((pw_launch_set<3, 2, TPG_PW_FOR_AS, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+    else if (var == 2) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 3>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+    else if (var == 3) TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_AS, 6>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+    else TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+  } else if (set == TPG_PW_FOR_IBS) {
+    if (var == 1) TPG_TRY((pw_launch_set<3, 1, TPG_PW_FOR_IBS, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_ibs")));
+    else if (var == 2) TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_IBS, 3>(ctx, pw, v, kg0, kg1, "pairwise_mfma_ibs")));
+    else if (var == 3) TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_IBS, 5>(ctx, pw, v, kg0, kg1, "pairwise_mfma_ibs")));
+    else TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_IBS, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_ibs")));
+  } else if (set == TPG_PW_FOR_KING) {
+    if (var == 1) TPG_TRY((pw_launch_set<3, 1, TPG_PW_FOR_KING, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_king")));
+    else if (var == 2) TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_KING, 3>(ctx, pw, v, kg0, kg1, "pairwise_mfma_king")));
+    else if (var == 3) TPG_TRY((pw_launch_set<4, 1, TPG_PW_FOR_KING, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_king")));
+    else TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_KING, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_king")));
+  } else {
+    TPG_TRY(pw_launch_all(ctx, pw, v, kg0, kg1));
+  }
   TPG_CHECK_LAUNCH();
   return TPG_OK;
 }
+
+extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
+                                       int64_t col_end) {
+  return tpg_pairwise_accumulate_products(ctx, pw, v, col_begin, col_end, TPG_PW_ALL);
+}
+
+extern "C" int tpg_pairwise_products(const tpg_pairwise* pw) { return pw ? pw->have : 0; }
 
 // ---------------------------------------------------------------------------
 // epilogues.  FP64 arithmetic follows the R drivers' operation order (file compiled with
@@ -644,6 +913,14 @@ static int pw_commit(tpg_ctx* ctx, OutBuf& o, int64_t n, const PwBand& b) {
   return TPG_OK;
 }
 
+// an output may only be formed from products every accumulate since the last zero has added (tpg_pairwise_accumulate_products)
+static int pw_need(const tpg_pairwise* pw, int products, const char* what) {
+  TPG_REQUIRE((pw->have & products) == products, TPG_EINVAL,
+              "%s needs the products 0x%x but only 0x%x were accumulated (TPG_PW_V = 1, D = 2, H = 4, A = 8): pass them to "
+              "tpg_pairwise_accumulate_products", what, products, pw->have);
+  return TPG_OK;
+}
+
 static int run_epilogue(tpg_ctx* ctx, const tpg_pairwise* pw, int mode, double scale, double* outs[6]) {
   const size_t bytes = sizeof(double) * (size_t)pw->n * (size_t)pw->n;
   const PwBand band = pw_band(pw);
@@ -667,6 +944,12 @@ extern "C" int tpg_pairwise_counts(tpg_ctx* ctx, const tpg_pairwise* pw, double*
                                    double* king_num, double* n_Aa_i, double* as_num, double* as_den) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
+  if (ibs) TPG_TRY(pw_need(pw, TPG_PW_FOR_IBS, "ibs"));
+  if (ibs_valid) TPG_TRY(pw_need(pw, TPG_PW_V, "ibs_valid"));
+  if (king_num) TPG_TRY(pw_need(pw, TPG_PW_FOR_KING, "king_num"));
+  if (n_Aa_i) TPG_TRY(pw_need(pw, TPG_PW_A, "n_Aa_i"));
+  if (as_num) TPG_TRY(pw_need(pw, TPG_PW_D, "as_num"));
+  if (as_den) TPG_TRY(pw_need(pw, TPG_PW_V, "as_den"));
   double* outs[6] = {ibs, ibs_valid, king_num, n_Aa_i, as_num, as_den};
   return run_epilogue(ctx, pw, 0, 1.0, outs);
 }
@@ -675,6 +958,7 @@ extern "C" int tpg_pairwise_ibs(tpg_ctx* ctx, const tpg_pairwise* pw, int type, 
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(type == TPG_IBS_PROPORTION || type == TPG_IBS_ADJUSTED_COUNTS, TPG_EINVAL, "bad IBS type %d", type);
+  TPG_TRY(pw_need(pw, TPG_PW_FOR_IBS, "IBS"));
   double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
   return run_epilogue(ctx, pw, 1, type == TPG_IBS_PROPORTION ? 1.0 : (double)m, outs);
 }
@@ -682,6 +966,7 @@ extern "C" int tpg_pairwise_ibs(tpg_ctx* ctx, const tpg_pairwise* pw, int type, 
 extern "C" int tpg_pairwise_king(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
+  TPG_TRY(pw_need(pw, TPG_PW_FOR_KING, "KING"));
   double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
   return run_epilogue(ctx, pw, 2, 1.0, outs);
 }
@@ -689,6 +974,7 @@ extern "C" int tpg_pairwise_king(tpg_ctx* ctx, const tpg_pairwise* pw, double* o
 extern "C" int tpg_pairwise_allele_sharing(tpg_ctx* ctx, const tpg_pairwise* pw, double* out) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
+  TPG_TRY(pw_need(pw, TPG_PW_FOR_AS, "allele sharing"));
   double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
   return run_epilogue(ctx, pw, 3, 1.0, outs);
 }
@@ -700,6 +986,10 @@ static int epilogues_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_pairwise* pw, 
                           double* king, double* allele_sharing, double* grm) {
   TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
   TPG_REQUIRE(ibs_type == TPG_IBS_PROPORTION || ibs_type == TPG_IBS_ADJUSTED_COUNTS, TPG_EINVAL, "bad IBS type");
+  // every rank has accumulated the same product set (the sharded entry points pass the same mask everywhere)
+  if (ibs) TPG_TRY(pw_need(pw, TPG_PW_FOR_IBS, "IBS"));
+  if (king) TPG_TRY(pw_need(pw, TPG_PW_FOR_KING, "KING"));
+  if (allele_sharing || grm) TPG_TRY(pw_need(pw, TPG_PW_FOR_AS, "allele sharing / GRM"));
   const int n = (int)pw->n;
   const PwBand band = pw_band(pw);
   TPG_REQUIRE(band.whole || !grm || comm, TPG_EINVAL,
@@ -1191,7 +1481,9 @@ static int increment_common(tpg_ctx* ctx, int which, double* A, double* B, const
   std::vector<int32_t> cols;
   int rc = upload_block_columns(ctx, fbm_bytes, nrow, ncol, colInd1, m, &f, cols);
   if (rc == TPG_OK) rc = tpg_view_create(ctx, f, rowInd1, n, cols.data(), m, nullptr /* raw bytes, src/snp_ibs.cpp:47-54 */, &v);
-  if (rc == TPG_OK) rc = tpg_pairwise_accumulate(ctx, pw, v, 0, -1);
+  // the products this entry point's two matrices are made of (src/snp_ibs.cpp:67-72, src/snp_king.cpp:70-72, src/snp_as.cpp:64-65)
+  const int products = which == 0 ? TPG_PW_FOR_IBS : which == 1 ? TPG_PW_FOR_KING : TPG_PW_FOR_AS;
+  if (rc == TPG_OK) rc = tpg_pairwise_accumulate_products(ctx, pw, v, 0, -1, products);
   if (rc == TPG_OK && pw == r->spare) rc = add_counts_to_caller(ctx, which, pw, A, B);  // immediate: as the reference
   tpg_view_free(v);  // stream-ordered: the blocks return to this context's pool
   tpg_fbm_free(f);
