@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-loci", type=int, default=0, help="loci of the CPU baseline sample (default M / 20)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host file -> HBM -> host results measurement")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the R-shim block-loop measurement (part of end_to_end)")
+    ap.add_argument("--no-standalone", action="store_true", help="skip the stand-alone pairwise_grm / snp_king / snp_ibs timings")
     ap.add_argument("--digest", default=None, help="rank 0 writes a small JSON digest of the results (tests)")
     return ap.parse_args()
 
@@ -490,6 +492,11 @@ def end_to_end(st):
                "route": "bigstatsr .bk (1 byte per genotype, warm page cache) -> HBM in 8 locus blocks uploaded by a second "
                         "thread / stream beside pack + accumulate -> all results in host memory",
                "overlapped": ovl, "serial": ser}
+        if not st.args.no_dropin:
+            try:
+                out["dropin"] = dropin(st, path)
+            except Exception as e:  # noqa: BLE001 -- the leg must not take the bench line down with it
+                out["dropin"] = {"failed": f"{type(e).__name__}: {e}"}
         os.remove(path)  # room for the .bed
         try:
             bed_path = _e2e_bed_file(st, os.path.dirname(path))
@@ -510,6 +517,145 @@ def end_to_end(st):
                     os.remove(p_)
             except OSError:
                 pass
+
+
+def standalone(st):
+    """The three pairwise analyses called ON THEIR OWN on the resident panel -- what `pairwise_grm()`, `snp_king()`,
+    `snp_ibs()` cost when a session asks for one of them -- and BASELINE config 2's literal workload (KING + GRM at
+    1 000 x 650 000).  Each accumulates only the cross-products it needs (tpg_pairwise_accumulate_products: 2 / 4 / 3 of
+    the 5) and `frac` prices the kernel on exactly those (2 / 5 / 6 N^2 M ops for AS / KING / IBS in the
+    reference's own algebra; here the kernels' real 2 / 4 / 3 N^2 M, the smaller figures).  `ms` = view pack + kernel +
+    epilogue, outputs left in HBM."""
+    tpg, api, lib, ctx, a = st.tpg, st.api, st.lib, st.ctx, st.args
+    chk = tpg._lib.check
+    out = {}
+
+    def one(name, X, n, m, products, ops_per, key, epilogue, note):
+        pw = api.Pairwise(ctx, n)
+        d = [ctx.dev_alloc(8 * n * n) for _ in range(2)]
+        best = None
+        for _ in range(3):
+            ctx.prof_reset()
+            ctx.sync()
+            t0 = time.perf_counter()
+            v = api.View(X, None, None, code256=None)
+            pw.zero()
+            pw.accumulate(v, products=products)
+            epilogue(pw, d, m)
+            v.free()
+            ctx.sync()
+            ms = (time.perf_counter() - t0) * 1e3
+            prof = ctx.prof_dump()
+            k_ms = prof.get(key, (0, 0.0))[1]
+            if best is None or ms < best[0]:
+                best = (ms, k_ms, {k_: round(v_[1], 4) for k_, v_ in sorted(prof.items())})
+        for p_ in d:
+            ctx.dev_free(p_)
+        pw.free()
+        ops = ops_per * n * n * m
+        out[name] = {"workload": f"{n} x {m}", "ms": best[0], "kernel_ms": best[1], "kernel": key,
+                     "products": note, "algorithmic_ops": ops, "achieved_TOPs": ops / (best[1] * 1e-3) / 1e12 if best[1] else None,
+                     "peak_TOPs": 10000.0, "frac": ops / (best[1] * 1e-3) / 1e12 / 10000.0 if best[1] else None,
+                     "kernel_ms_all": best[2]}
+
+    n, m = a.n, st.m
+    ctx.prof_enable(True)
+    one("pairwise_grm", st.X, n, m, api.PW_FOR_AS, 2.0, "pairwise_mfma_as",
+        lambda pw, d, m_: chk(lib.tpg_pairwise_grm(ctx.h, pw.h, d[0])), "V, D (2 of 5): src/snp_as.cpp:64-65")
+    one("snp_king", st.X, n, m, api.PW_FOR_KING, 4.0, "pairwise_mfma_king",
+        lambda pw, d, m_: chk(lib.tpg_pairwise_king(ctx.h, pw.h, d[0])), "V, D, A, A' (4 of 5): src/snp_king.cpp:70-72")
+    one("snp_ibs", st.X, n, m, api.PW_FOR_IBS, 3.0, "pairwise_mfma_ibs",
+        lambda pw, d, m_: chk(lib.tpg_pairwise_ibs(ctx.h, pw.h, C.c_int(0), C.c_int64(m_), d[0])),
+        "V, D, H (3 of 5): src/snp_ibs.cpp:67-72")
+    # BASELINE config 2, literally: pairwise_king + pairwise_grm of an HGDP-like 1 000 x 650 000 panel on one MI355X
+    n2, m2 = 1000, 650000
+    X2 = tpg.FBM.synth(2, n2, m2, npop=a.pops, miss=0.02, imputed_bytes=True, ctx=ctx, code256=tpg.CODE_012)
+    one("config2_king_plus_grm", X2, n2, m2, api.PW_FOR_KING, 4.0, "pairwise_mfma_king",
+        lambda pw, d, m_: chk(lib.tpg_pairwise_epilogues(ctx.h, pw.h, C.c_int(0), C.c_int64(m_), C.c_void_p(None), d[0],
+                                                         C.c_void_p(None), d[1])),
+        "V, D, A, A' (4 of 5) serve both KING and GRM")
+    X2.free()
+    ctx.prof_enable(False)
+    return out
+
+
+def dropin(st, path):
+    """What an UNMODIFIED tidypopgen session pays for `snp_ibs()` (R/snp_ibs.R:59-95) when its native symbols are this
+    library's: the compiled shim (shim/tpg_rshim.c) driven through tests/rmock (a stand-in for R's C API: R is not in the
+    image) exactly as the R driver drives it -- blocks of bigstatsr::block_size(n) loci, `_tidypopgen_increment_ibs_counts`
+    per block on the genotype .bk and two file-backed N x N double FBMs, default (non-deferred) mode: per block an upload of
+    its columns, pack, the {V, D, H} kernel, and K / K2 incremented in the caller's mapping before the call returns.  Beside
+    it the opt-in deferred mode (one download at tpg_flush) and the whole-analysis entry point the shim adds
+    (`_tidypopgen_tpg_snp_pairwise`: tpg_multi_pairwise on the host mapping, which = ibs)."""
+    import shutil
+    import tempfile
+
+    from tests import rmock
+
+    api, a = st.api, st.args
+    n, m = a.n, st.m
+    tmp = tempfile.mkdtemp(prefix="tpg_dropin_", dir=os.path.dirname(path))
+    out = {"route": "rmock -> shim/tpg_rshim.c -> libtpg_hip.so; genotype .bk warm in the page cache; R absent from the image"}
+    saved = {k_: os.environ.get(k_) for k_ in ("TPG_RSHIM_DEFERRED", "TPG_DEVICES", "TPG_RSHIM_CACHE")}
+    try:
+        rows = np.arange(1, n + 1, dtype=np.int32)
+        cols = np.arange(1, m + 1, dtype=np.int32)
+        block = api.block_size(n)
+        lo, up = api.cut_by_size(m, block)
+
+        def session(deferred):
+            os.environ.pop("TPG_RSHIM_CACHE", None)
+            os.environ["TPG_DEVICES"] = "1"
+            if deferred:
+                os.environ["TPG_RSHIM_DEFERRED"] = "1"
+            else:
+                os.environ.pop("TPG_RSHIM_DEFERRED", None)
+            lib = rmock.build(tmp)
+            return lib, rmock.Session(lib)
+
+        def accumulators(r, tag):
+            files = []
+            for nm in ("k", "k2"):
+                f = os.path.join(tmp, f"{tag}_{nm}.bk")
+                np.zeros(n * n).tofile(f)  # bigstatsr::FBM(n, n, init = 0)
+                files.append(f)
+            return files, [r.fbm(f, n, n) for f in files]
+
+        for mode, deferred in (("block_loop_default", False), ("block_loop_deferred", True)):
+            lib, r = session(deferred)
+            BM = r.fbm(path, n, m, st.code_012)
+            files, (K, K2) = accumulators(r, mode)
+            t0 = time.perf_counter()
+            rmock.driver_loop(r, "ibs", BM, K, K2, rows, cols, lo, up, scratch_width=1)
+            if deferred:
+                r.call("tpg_flush")
+            dt = time.perf_counter() - t0
+            k = np.fromfile(files[0], dtype=np.float64, count=2 * n).reshape(2, n)  # first two columns of K
+            out[mode] = {"seconds": dt, "blocks": int(len(lo)), "block_loci": int(block), "value": n * m / dt,
+                         "K_first_entries": k[0, :3].tolist()}
+            lib.R_unload_tpgshim(None)
+            lib.rmock_reset()
+            for f in files:
+                os.remove(f)
+        lib, r = session(False)
+        BM = r.fbm(path, n, m, st.code_012)
+        t0 = time.perf_counter()
+        res = r.call("tpg_snp_pairwise", BM, r.int(rows), r.int(cols), r.lib.rmock_lgl(0), r.int([1]))
+        dt = time.perf_counter() - t0
+        ibs = r.list_elt(res, 0, (n, n))
+        out["tpg_snp_pairwise_ibs"] = {"seconds": dt, "value": n * m / dt, "ibs_first_entries": ibs[0, :3].tolist()}
+        # the three routes computed the same matrix: proportion = K / K2 (R/snp_ibs.R:88-95) for the first entries
+        lib.R_unload_tpgshim(None)
+        lib.rmock_reset()
+        out["unit"] = "seconds per snp_ibs() of the whole panel; value = SNP-genotypes/s"
+    finally:
+        for k_, v_ in saved.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def cpu_baseline(args):
@@ -765,8 +911,12 @@ def main():
             "kernel_ms_per_step": {k_: round(v_[1] / args.steps, 4) for k_, v_ in sorted(prof.items())},
             "kernel_launches_per_step": {k_: v_[0] / args.steps for k_, v_ in sorted(prof.items())},
         }
+        if world == 1 and not args.no_standalone:
+            out["standalone"] = standalone(st)
         if world == 1 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end(st)
+            if "dropin" in out["end_to_end"]:
+                out["dropin"] = out["end_to_end"].pop("dropin")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

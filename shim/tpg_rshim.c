@@ -78,24 +78,37 @@ static const char* field_path(SEXP env, const char* name) {
   return R_ExpandFileName(CHAR(STRING_ELT(v, 0)));
 }
 
-/* A backing file mapped into this process, and (for genotype FBMs) its copy in HBM.  The 5 GB upload happens once per
- * data set, not once per call -- but bigsnpr::snp_fastImputeSimple (R/gt_impute_simple.R:86) and gt_set_imputed-style
- * writes change the backing file IN PLACE, so the HBM copy is only trusted while the file's size, modification time
- * and a fingerprint of 512 pages spread over it are what they were at upload; anything else re-uploads.
- * TPG_RSHIM_NO_CACHE=1 uploads at every call. */
+/* A backing file mapped into this process, and (opt-in, for genotype FBMs) its copy in HBM.
+ * DEFAULT: no HBM copy outlives a call.  Every per-locus entry point uploads the columns its colInd covers (the R drivers
+ * call block by block, so a driver loop moves the file once), exactly as the increment_* mirrors do: an FBM that is
+ * rewritten in place between two calls -- bigsnpr::snp_fastImputeSimple (R/gt_impute_simple.R:86), gt_set_imputed-style
+ * writes, any store through bigstatsr's own mapping -- can never be served stale.
+ * TPG_RSHIM_CACHE=1 (opt-in): the whole genotype FBM is uploaded once and kept in HBM while the file's size, modification
+ * time and a fingerprint of 512 pages spread over it are what they were at upload.  That is a HEURISTIC: stores through a
+ * mapping do not reliably move the modification time before msync / munmap on tmpfs or NFS, and a sparse edit can miss
+ * the sampled pages (0.04 % of a 5 GB file) -- enable it only for read-only data sets, or call tpg_invalidate(BM) /
+ * tpg_release() after anything that writes to the FBM. */
 typedef struct {
   char* path;
   void* map;
   size_t bytes;
   int writable;
   int64_t nrow, ncol;
-  tpg_fbm* dev; /* NULL for the double N x N accumulators */
+  tpg_fbm* dev; /* NULL for the double N x N accumulators, and always unless TPG_RSHIM_CACHE=1 */
   int64_t mtime_ns;
   uint64_t fingerprint;
+  uint64_t stamp; /* g_call of the last increment_* call that used this (writable) mapping */
 } mapped_file;
 
-static mapped_file* g_files = NULL;
+/* an array of POINTERS: a mapped_file* handed out stays valid when the table grows or an entry is forgotten */
+static mapped_file** g_files = NULL;
 static int g_nfiles = 0;
+static uint64_t g_call = 0; /* counts increment_* calls */
+
+static int cache_on(void) {
+  const char* e = getenv("TPG_RSHIM_CACHE");
+  return e && e[0] == '1';
+}
 
 static uint64_t fingerprint_of(const uint8_t* p, size_t bytes) { /* FNV-1a over up to 512 whole 4-KiB pages (2 MB read) */
   const size_t page = 4096, npages = (bytes + page - 1) / page, want = npages < 512 ? npages : 512;
@@ -120,17 +133,19 @@ static int64_t mtime_of(const char* path, size_t* size) {
 }
 
 static void forget_file(int k) { /* unmap, free the HBM copy, close the gap in g_files */
-  if (g_files[k].dev) tpg_fbm_free(g_files[k].dev);
-  munmap(g_files[k].map, g_files[k].bytes);
-  free(g_files[k].path);
+  mapped_file* f = g_files[k];
+  if (f->dev) tpg_fbm_free(f->dev);
+  munmap(f->map, f->bytes);
+  free(f->path);
+  free(f);
   g_files[k] = g_files[g_nfiles - 1];
   g_nfiles--;
 }
 
 static mapped_file* map_file(const char* path, size_t bytes, int writable, int64_t nrow, int64_t ncol) {
   for (int k = 0; k < g_nfiles; k++)
-    if (strcmp(g_files[k].path, path) == 0 && g_files[k].bytes == bytes && g_files[k].writable == writable)
-      return &g_files[k];
+    if (strcmp(g_files[k]->path, path) == 0 && g_files[k]->bytes == bytes && g_files[k]->writable == writable)
+      return g_files[k];
   int fd = open(path, writable ? O_RDWR : O_RDONLY);
   if (fd < 0) Rf_error("cannot open backing file '%s'", path);
   struct stat st;
@@ -142,39 +157,39 @@ static mapped_file* map_file(const char* path, size_t bytes, int writable, int64
   void* p = mmap(NULL, bytes, writable ? (PROT_READ | PROT_WRITE) : PROT_READ, MAP_SHARED, fd, 0);
   close(fd);
   if (p == MAP_FAILED) Rf_error("mmap of '%s' failed", path);
-  mapped_file* nf = (mapped_file*)realloc(g_files, sizeof(mapped_file) * (size_t)(g_nfiles + 1));
-  if (!nf) {
+  mapped_file** nf = (mapped_file**)realloc(g_files, sizeof(mapped_file*) * (size_t)(g_nfiles + 1));
+  mapped_file* f = nf ? (mapped_file*)calloc(1, sizeof(mapped_file)) : NULL;
+  char* pc = f ? strdup(path) : NULL;
+  if (nf) g_files = nf;
+  if (!pc) {
+    free(f);
     munmap(p, bytes);
     Rf_error("out of memory");
   }
-  g_files = nf;
-  mapped_file* f = &g_files[g_nfiles++];
-  f->path = strdup(path);
+  g_files[g_nfiles++] = f;
+  f->path = pc;
   f->map = p;
   f->bytes = bytes;
   f->writable = writable;
   f->nrow = nrow;
   f->ncol = ncol;
-  f->dev = NULL;
-  f->mtime_ns = 0;
-  f->fingerprint = 0;
   return f;
 }
 
-/* the genotype FBM.code256 behind `BM`: host mapping (for the increment_* mirrors) and HBM copy (everything else) */
+/* the genotype FBM.code256 behind `BM`: its host mapping */
 static mapped_file* genotype_fbm(SEXP BM) {
   const int64_t nrow = field_i64(BM, "nrow"), ncol = field_i64(BM, "ncol");
   return map_file(field_path(BM, "backingfile"), (size_t)nrow * (size_t)ncol, 0, nrow, ncol);
 }
 
+/* TPG_RSHIM_CACHE=1 only: the HBM copy of the whole FBM, re-uploaded when the heuristic above says the bytes changed */
 static tpg_fbm* genotype_fbm_dev(SEXP BM) {
   mapped_file* f = genotype_fbm(BM);
   size_t size = 0;
   const int64_t mt = mtime_of(f->path, &size);
   if (size < f->bytes) Rf_error("backing file '%s' shrank below the FBM it should hold", f->path);
   const uint64_t fp = fingerprint_of((const uint8_t*)f->map, f->bytes);
-  const char* nc = getenv("TPG_RSHIM_NO_CACHE");
-  if (f->dev && ((nc && nc[0] == '1') || mt != f->mtime_ns || fp != f->fingerprint)) { /* the bytes changed under us */
+  if (f->dev && (mt != f->mtime_ns || fp != f->fingerprint)) { /* the bytes changed under us */
     tpg_fbm_free(f->dev);
     f->dev = NULL;
   }
@@ -193,31 +208,73 @@ static const double* code256_of(SEXP BM) {
   return REAL(c);
 }
 
-/* a double FBM (the N x N accumulators the R drivers allocate with bigstatsr::FBM(n, n, init = 0)): mapped for the
- * time the library may write to it -- this call by default, until the flush under TPG_RSHIM_DEFERRED=1 -- and unmapped
- * then (release_accumulators), so that a session does not pile up mappings of R's deleted temp files */
+/* a double FBM (the N x N accumulators the R drivers allocate with bigstatsr::FBM(n, n, init = 0)).  Its mapping is kept
+ * while the block loop that uses it runs -- mapping a 200 MB file afresh for every block costs its 49 000 page faults
+ * every time: 65 ms per call against 14 with the mapping kept (two matrices of 5 000 x 5 000, 8 threads adding) -- and is
+ * dropped by the first increment_* call that does NOT use it (the next analysis), by tpg_flush / tpg_release and at unload,
+ * so that a session holds at most one analysis' pair of R temp files mapped. */
 static double* double_fbm(SEXP K, int64_t n) {
   const int64_t nrow = field_i64(K, "nrow"), ncol = field_i64(K, "ncol");
   if (nrow != n || ncol != n) Rf_error("accumulator FBM is %lld x %lld, expected %lld x %lld", (long long)nrow,
                                        (long long)ncol, (long long)n, (long long)n);
-  return (double*)map_file(field_path(K, "backingfile"), sizeof(double) * (size_t)n * (size_t)n, 1, n, n)->map;
+  mapped_file* f = map_file(field_path(K, "backingfile"), sizeof(double) * (size_t)n * (size_t)n, 1, n, n);
+  f->stamp = g_call;
+  return (double*)f->map;
 }
 
-static void release_accumulators(void) {
+static void release_accumulators(int all) {
   for (int k = g_nfiles - 1; k >= 0; k--)
-    if (g_files[k].writable) forget_file(k);
+    if (g_files[k]->writable && (all || g_files[k]->stamp != g_call)) forget_file(k);
 }
 
-/* after an increment_* call: by default its sums are already in k / k2 and their mappings can go */
+/* after an increment_* call: by default its sums are already in k / k2; the accumulators of EARLIER analyses can go */
 static void after_increment(void) {
-  if (!deferred()) release_accumulators();
+  if (!deferred()) release_accumulators(0);
 }
 
+/* the packed (rowInd, colInd, code256) view a per-locus entry point works on.  Default: the columns colInd covers are
+ * uploaded for this call alone (the contiguous blocks of the R drivers: their covering range; a scattered colInd: gathered
+ * on the host first) and released with it; TPG_RSHIM_CACHE=1: packed from the cached HBM copy of the whole FBM. */
 static tpg_view* view_of(SEXP BM, SEXP rowInd, SEXP colInd, int raw_bytes) {
   if (TYPEOF(rowInd) != INTSXP || TYPEOF(colInd) != INTSXP) Rf_error("rowInd / colInd must be integer vectors");
+  const int64_t n = (int64_t)XLENGTH(rowInd), m = (int64_t)XLENGTH(colInd);
+  const double* code = raw_bytes ? NULL : code256_of(BM);
   tpg_view* v = NULL;
-  TPG_R(tpg_view_create(ctx(), genotype_fbm_dev(BM), INTEGER(rowInd), (int64_t)XLENGTH(rowInd), INTEGER(colInd),
-                        (int64_t)XLENGTH(colInd), raw_bytes ? NULL : code256_of(BM), &v));
+  if (cache_on()) {
+    TPG_R(tpg_view_create(ctx(), genotype_fbm_dev(BM), INTEGER(rowInd), n, INTEGER(colInd), m, code, &v));
+    return v;
+  }
+  mapped_file* f = genotype_fbm(BM);
+  const uint8_t* bytes = (const uint8_t*)f->map;
+  const int64_t nrow = f->nrow, ncol = f->ncol;
+  if (m < 1) Rf_error("tidypopgen (GPU): empty colInd");
+  const int* ci = INTEGER(colInd);
+  int lo = ci[0], hi = ci[0];
+  for (int64_t j = 0; j < m; j++) {
+    if (ci[j] < 1 || ci[j] > ncol) Rf_error("tidypopgen (GPU): colInd[%lld] = %d out of [1,%lld]", (long long)j, ci[j], (long long)ncol);
+    if (ci[j] < lo) lo = ci[j];
+    if (ci[j] > hi) hi = ci[j];
+  }
+  const int64_t span = (int64_t)hi - lo + 1;
+  int* cols = (int*)R_alloc((size_t)m, sizeof(int)); /* R's transient storage: freed when .Call returns or errors */
+  tpg_fbm* dev = NULL;
+  if (span <= 2 * m + 64) {
+    for (int64_t j = 0; j < m; j++) cols[j] = ci[j] - (lo - 1);
+    TPG_R(tpg_fbm_from_host(ctx(), bytes + (size_t)(lo - 1) * (size_t)nrow, nrow, span, &dev));
+  } else {
+    uint8_t* stage = (uint8_t*)malloc((size_t)nrow * (size_t)m);
+    if (!stage) Rf_error("tidypopgen (GPU): out of memory gathering %lld columns", (long long)m);
+    for (int64_t j = 0; j < m; j++) {
+      memcpy(stage + (size_t)j * (size_t)nrow, bytes + (size_t)(ci[j] - 1) * (size_t)nrow, (size_t)nrow);
+      cols[j] = (int)(j + 1);
+    }
+    const int rc = tpg_fbm_from_host(ctx(), stage, nrow, m, &dev); /* waited for: the staging buffer may go */
+    free(stage);
+    TPG_R(rc);
+  }
+  const int rc = tpg_view_create(ctx(), dev, INTEGER(rowInd), n, cols, m, code, &v);
+  tpg_fbm_free(dev); /* stream-ordered: the pack kernel has been enqueued, the block returns to the pool behind it */
+  TPG_R(rc);
   return v;
 }
 
@@ -406,7 +463,7 @@ SEXP _tidypopgen_pairwise_fst_nei87_loop(SEXP pairwise_combn, SEXP n, SEXP het_o
 
 /* ---- pairwise individual matrices: the per-block increment functions ----------------------------------------------
  * The R drivers (R/snp_ibs.R:59-82, R/snp_king.R:51-77, R/snp_allele_sharing.R:49-70) call these once per locus block
- * with the same FBM and the same two N x N double FBMs.  The library keeps the genotype FBM and the accumulators in
+ * with the same FBM and the same two N x N double FBMs.
  * Default: every call uploads the columns of its block, accumulates, and adds the sums to k / k2 before it returns.
  * TPG_RSHIM_DEFERRED=1: the accumulators stay in HBM across the calls and the sums reach k / k2 when
  * _tidypopgen_tpg_flush is called.  The scratch matrices the reference fills are not touched. */
@@ -414,6 +471,7 @@ SEXP _tidypopgen_pairwise_fst_nei87_loop(SEXP pairwise_combn, SEXP n, SEXP het_o
 /* increment_ibs_counts(k, k2, genotype0, genotype1, genotype2, BM, rowInd, colInd)   src/snp_ibs.cpp:22-74 */
 SEXP _tidypopgen_increment_ibs_counts(SEXP k, SEXP k2, SEXP g0, SEXP g1, SEXP g2, SEXP BM, SEXP rowInd, SEXP colInd) {
   (void)g0; (void)g1; (void)g2;
+  g_call++;
   mapped_file* f = genotype_fbm(BM);
   const int64_t n = (int64_t)XLENGTH(rowInd);
   TPG_R(tpg_increment_ibs_counts(ctx(), double_fbm(k, n), double_fbm(k2, n), (const uint8_t*)f->map, f->nrow, f->ncol,
@@ -427,6 +485,7 @@ SEXP _tidypopgen_increment_ibs_counts(SEXP k, SEXP k2, SEXP g0, SEXP g1, SEXP g2
 SEXP _tidypopgen_increment_king_numerator(SEXP k, SEXP n_Aa_i, SEXP g0, SEXP g1, SEXP g2, SEXP gv, SEXP BM, SEXP rowInd,
                                           SEXP colInd) {
   (void)g0; (void)g1; (void)g2; (void)gv;
+  g_call++;
   mapped_file* f = genotype_fbm(BM);
   const int64_t n = (int64_t)XLENGTH(rowInd);
   TPG_R(tpg_increment_king_numerator(ctx(), double_fbm(k, n), double_fbm(n_Aa_i, n), (const uint8_t*)f->map, f->nrow,
@@ -441,6 +500,7 @@ SEXP _tidypopgen_increment_king_numerator(SEXP k, SEXP n_Aa_i, SEXP g0, SEXP g1,
  * reproduces the reference binary bit for bit. */
 SEXP _tidypopgen_increment_as_counts(SEXP k, SEXP k2, SEXP na_mat, SEXP dos_mat, SEXP BM, SEXP rowInd, SEXP colInd) {
   (void)na_mat;
+  g_call++;
   mapped_file* f = genotype_fbm(BM);
   const int64_t n = (int64_t)XLENGTH(rowInd), m = (int64_t)XLENGTH(colInd);
   double* K = double_fbm(k, n);
@@ -460,7 +520,7 @@ SEXP _tidypopgen_increment_as_counts(SEXP k, SEXP k2, SEXP na_mat, SEXP dos_mat,
  * reference symbol. */
 SEXP _tidypopgen_tpg_flush(void) {
   if (g_ctx) TPG_R(tpg_increment_flush(g_ctx));
-  release_accumulators();
+  release_accumulators(1);
   return R_NilValue;
 }
 
@@ -474,6 +534,17 @@ SEXP _tidypopgen_tpg_release(void) {
   free(g_files);
   g_files = NULL;
   g_nfiles = 0;
+  return R_NilValue;
+}
+
+/* tpg_invalidate(BM): forget the HBM copy of this FBM (only TPG_RSHIM_CACHE=1 keeps one): call it after anything that
+ * writes to the FBM -- tpgshim's wrappers of the mutating functions do */
+SEXP _tidypopgen_tpg_invalidate(SEXP BM) {
+  mapped_file* f = genotype_fbm(BM);
+  if (f->dev) {
+    tpg_fbm_free(f->dev);
+    f->dev = NULL;
+  }
   return R_NilValue;
 }
 
@@ -525,16 +596,23 @@ static void check_ind(SEXP rowInd, SEXP colInd) {
   if (TYPEOF(rowInd) != INTSXP || TYPEOF(colInd) != INTSXP) Rf_error("rowInd / colInd must be integer vectors");
 }
 
-/* tpg_snp_pairwise(BM, rowInd, colInd, adjusted_counts) -> list(ibs, king, allele_sharing, grm), each n x n */
-SEXP _tidypopgen_tpg_snp_pairwise(SEXP BM, SEXP rowInd, SEXP colInd, SEXP adjusted_counts) {
+/* tpg_snp_pairwise(BM, rowInd, colInd, adjusted_counts, which) -> list(ibs, king, allele_sharing, grm), each n x n or NULL.
+ * which: integer mask of the matrices wanted (1 ibs, 2 king, 4 allele_sharing, 8 grm; NULL = all four).  Only the
+ * cross-products those need are accumulated (tpg_multi_pairwise): 2 of 5 for the GRM alone, 4 for KING + GRM. */
+SEXP _tidypopgen_tpg_snp_pairwise(SEXP BM, SEXP rowInd, SEXP colInd, SEXP adjusted_counts, SEXP which) {
   check_ind(rowInd, colInd);
   mapped_file* f = genotype_fbm(BM);
+  const uint8_t* bytes = (const uint8_t*)f->map;
+  const int64_t nrow = f->nrow, ncol = f->ncol;
   const int n = (int)XLENGTH(rowInd);
+  const int want = which == R_NilValue ? 15 : Rf_asInteger(which);
+  if (want < 1 || want > 15) Rf_error("tidypopgen (HIP): which must be a mask of 1 (ibs), 2 (king), 4 (allele_sharing), 8 (grm)");
   SEXP mats[4];
-  for (int k = 0; k < 4; k++) mats[k] = PROTECT(Rf_allocMatrix(REALSXP, n, n));
-  TPG_R(tpg_multi_pairwise(multi(), (const uint8_t*)f->map, f->nrow, f->ncol, INTEGER(rowInd), n, INTEGER(colInd),
-                           (int64_t)XLENGTH(colInd), Rf_asLogical(adjusted_counts) ? TPG_IBS_ADJUSTED_COUNTS : TPG_IBS_PROPORTION,
-                           REAL(mats[0]), REAL(mats[1]), REAL(mats[2]), REAL(mats[3])));
+  for (int k = 0; k < 4; k++) mats[k] = PROTECT((want >> k) & 1 ? Rf_allocMatrix(REALSXP, n, n) : R_NilValue);
+  TPG_R(tpg_multi_pairwise(multi(), bytes, nrow, ncol, INTEGER(rowInd), n, INTEGER(colInd), (int64_t)XLENGTH(colInd),
+                           Rf_asLogical(adjusted_counts) ? TPG_IBS_ADJUSTED_COUNTS : TPG_IBS_PROPORTION,
+                           mats[0] != R_NilValue ? REAL(mats[0]) : NULL, mats[1] != R_NilValue ? REAL(mats[1]) : NULL,
+                           mats[2] != R_NilValue ? REAL(mats[2]) : NULL, mats[3] != R_NilValue ? REAL(mats[3]) : NULL));
   static const char* names[4] = {"ibs", "king", "allele_sharing", "grm"};
   SEXP out = named_list(4, names, mats);
   UNPROTECT(4);
@@ -633,7 +711,8 @@ const R_CallMethodDef tpg_rshim_entries[] = {
     /* additions (not in the reference): */
     {"_tidypopgen_tpg_flush", (DL_FUNC)&_tidypopgen_tpg_flush, 0},
     {"_tidypopgen_tpg_release", (DL_FUNC)&_tidypopgen_tpg_release, 0},
-    {"_tidypopgen_tpg_snp_pairwise", (DL_FUNC)&_tidypopgen_tpg_snp_pairwise, 4},
+    {"_tidypopgen_tpg_invalidate", (DL_FUNC)&_tidypopgen_tpg_invalidate, 1},
+    {"_tidypopgen_tpg_snp_pairwise", (DL_FUNC)&_tidypopgen_tpg_snp_pairwise, 5},
     {"_tidypopgen_tpg_grouped_alt_freq", (DL_FUNC)&_tidypopgen_tpg_grouped_alt_freq, 7},
     {"_tidypopgen_tpg_pairwise_pop_fst", (DL_FUNC)&_tidypopgen_tpg_pairwise_pop_fst, 10},
     {"_tidypopgen_tpg_pca_partial_svd", (DL_FUNC)&_tidypopgen_tpg_pca_partial_svd, 4},

@@ -41,11 +41,16 @@ tpg_disable <- function() {
 # only needed under TPG_RSHIM_DEFERRED=1 (then: after the block loop of snp_ibs / snp_king / snp_allele_sharing)
 tpg_flush <- function() invisible(.Call(`_tidypopgen_tpg_flush`))
 tpg_release <- function() invisible(.Call(`_tidypopgen_tpg_release`))
+# only needed under TPG_RSHIM_CACHE=1 (an HBM copy of the whole FBM kept between calls): after anything that writes to X
+tpg_invalidate <- function(X) invisible(.Call(`_tidypopgen_tpg_invalidate`, X))
 
 # whole analyses on every GPU of the node (TPG_DEVICES); X is the FBM.code256 of a gen_tibble (attr(x$genotypes, "fbm"))
+# which: the matrices wanted; only the cross-products they need are computed (GRM alone: 2 of 5, KING + GRM: 4 of 5)
 tpg_snp_pairwise <- function(X, ind.row = bigstatsr::rows_along(X), ind.col = bigstatsr::cols_along(X),
-                             adjusted_counts = FALSE) {
-  .Call(`_tidypopgen_tpg_snp_pairwise`, X, as.integer(ind.row), as.integer(ind.col), adjusted_counts)
+                             adjusted_counts = FALSE, which = c("ibs", "king", "allele_sharing", "grm")) {
+  which <- match.arg(which, several.ok = TRUE)
+  mask <- sum(c(ibs = 1L, king = 2L, allele_sharing = 4L, grm = 8L)[unique(which)])
+  .Call(`_tidypopgen_tpg_snp_pairwise`, X, as.integer(ind.row), as.integer(ind.col), adjusted_counts, as.integer(mask))
 }
 tpg_grouped_alt_freq <- function(X, ind.row, ind.col, group_ids0 = NULL, n_groups = 0L, ploidy, as_counts = FALSE) {
   .Call(`_tidypopgen_tpg_grouped_alt_freq`, X, as.integer(ind.row), as.integer(ind.col), group_ids0, as.integer(n_groups),

@@ -43,6 +43,7 @@ void SET_STRING_ELT(SEXP x, R_xlen_t i, SEXP v);
 SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v);
 const char* CHAR(SEXP x);
 const char* R_ExpandFileName(const char* s);
+char* R_alloc(size_t n, int size); /* R_ext/Memory.h */
 
 SEXP Rf_allocVector(SEXPTYPE type, R_xlen_t n);
 SEXP Rf_allocMatrix(SEXPTYPE type, int nrow, int ncol);

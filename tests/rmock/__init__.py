@@ -55,3 +55,74 @@ def entries(lib):
             break
         out[e.name.decode()] = (e.fun, e.numArgs)
     return out
+
+
+import numpy as np  # noqa: E402
+
+
+class Session:
+    """the few R objects the drivers handle, built in the mock runtime (tests/test_gpu_rshim.py; bench.py's drop-in leg)"""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.ent = entries(lib)
+
+    def fbm(self, path, nrow, ncol, code256=None):
+        env = self.lib.rmock_new_env()
+        self.lib.rmock_env_set(env, b"backingfile", self.lib.rmock_str(str(path).encode()))
+        self.lib.rmock_env_set(env, b"nrow", self.real([float(nrow)]))
+        self.lib.rmock_env_set(env, b"ncol", self.real([float(ncol)]))
+        if code256 is not None:
+            self.lib.rmock_env_set(env, b"code256", self.real(code256))
+        return env
+
+    def real(self, v):
+        a = np.ascontiguousarray(v, dtype=np.float64)
+        return self.lib.rmock_real(a.ctypes.data, a.size)
+
+    def int(self, v):
+        a = np.ascontiguousarray(v, dtype=np.int32)
+        return self.lib.rmock_int(a.ctypes.data, a.size)
+
+    def matrix(self, a):
+        a = np.asfortranarray(a, dtype=np.float64)
+        return self.lib.rmock_real_matrix(a.ctypes.data, a.shape[0], a.shape[1])
+
+    def call(self, name, *args):
+        fn, arity = self.ent["_tidypopgen_" + name]
+        assert arity == len(args), (name, arity, len(args))
+        arr = (C.c_void_p * max(1, len(args)))(*args)
+        out = self.lib.rmock_call(fn, len(args), arr)
+        if out is None:
+            raise RuntimeError(self.lib.rmock_last_error().decode())
+        return out
+
+    def as_numpy(self, sexp, shape=None):
+        n = self.lib.XLENGTH(sexp)
+        t = self.lib.TYPEOF(sexp)
+        ct = C.c_double if t == 14 else C.c_int
+        a = np.ctypeslib.as_array(C.cast(self.lib.rmock_data(sexp), C.POINTER(ct)), shape=(n,)).copy()
+        return a.reshape(shape, order="F") if shape else a
+
+    def list_elt(self, sexp, k, shape=None):
+        return self.as_numpy(self.lib.VECTOR_ELT(sexp, k), shape)
+
+
+def driver_loop(r, which, BM, K, K2, rows, cols, lo, up, scratch_width=None):
+    """the block loop of snp_ibs / snp_king / snp_allele_sharing (R/snp_ibs.R:59-82, R/snp_king.R:51-77,
+    R/snp_allele_sharing.R:49-70), scratch matrices included (the shim ignores them): blocks cols[lo[b]-1 : up[b]] (1-based,
+    inclusive bounds, as CutBySize returns them)"""
+    n = len(rows)
+    # the R drivers allocate n x (widest block) scratch matrices (1 GiB each at 5 000 x 26 843); a timing harness may pass
+    # narrower ones -- the shim reads only ncol(dos_mat), and only under TPG_EMULATE_AS_PAD_QUIRK=1
+    width = int((np.asarray(up) - np.asarray(lo) + 1).max()) if scratch_width is None else scratch_width
+    scratch = [r.matrix(np.zeros((n, width))) for _ in range(4)]
+    ri = r.int(rows)
+    for a, b in zip(lo, up):
+        cb = r.int(cols[a - 1:b])
+        if which == "ibs":
+            r.call("increment_ibs_counts", K, K2, scratch[0], scratch[1], scratch[2], BM, ri, cb)
+        elif which == "king":
+            r.call("increment_king_numerator", K, K2, scratch[0], scratch[1], scratch[2], scratch[3], BM, ri, cb)
+        else:
+            r.call("increment_as_counts", K, K2, scratch[0], scratch[1], BM, ri, cb)

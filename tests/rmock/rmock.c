@@ -66,6 +66,9 @@ void Rf_error(const char* fmt, ...) {
   abort();
 }
 
+/* R_alloc: transient storage R reclaims when .Call returns; here it lives until rmock_reset like every object */
+char* R_alloc(size_t n, int size) { return (char*)new_rec(CHARSXP, (R_xlen_t)(n ? n : 1), (size_t)size)->data; }
+
 int TYPEOF(SEXP x) { return (int)x->type; }
 R_xlen_t XLENGTH(SEXP x) { return x->len; }
 R_len_t Rf_length(SEXP x) { return (R_len_t)x->len; }
@@ -184,7 +187,9 @@ const char* rmock_last_error(void) { return g_err; }
 /* call a .Call entry point with up to 10 arguments; NULL (and rmock_last_error) when it raised an R error */
 SEXP rmock_call(DL_FUNC fn, int nargs, SEXP* a) {
   typedef SEXP (*F0)(void);
+  typedef SEXP (*F1)(SEXP);
   typedef SEXP (*F4)(SEXP, SEXP, SEXP, SEXP);
+  typedef SEXP (*F5)(SEXP, SEXP, SEXP, SEXP, SEXP);
   typedef SEXP (*F6)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
   typedef SEXP (*F7)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
   typedef SEXP (*F8)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
@@ -196,7 +201,9 @@ SEXP rmock_call(DL_FUNC fn, int nargs, SEXP* a) {
   SEXP out = NULL;
   switch (nargs) {
     case 0: out = ((F0)fn)(); break;
+    case 1: out = ((F1)fn)(a[0]); break;
     case 4: out = ((F4)fn)(a[0], a[1], a[2], a[3]); break;
+    case 5: out = ((F5)fn)(a[0], a[1], a[2], a[3], a[4]); break;
     case 6: out = ((F6)fn)(a[0], a[1], a[2], a[3], a[4], a[5]); break;
     case 7: out = ((F7)fn)(a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
     case 8: out = ((F8)fn)(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]); break;

@@ -15,52 +15,7 @@ from tests import rmock
 pytestmark = pytest.mark.gpu
 
 
-class R:
-    """the few R objects the drivers handle, built in the mock runtime"""
-
-    def __init__(self, lib):
-        self.lib = lib
-        self.ent = rmock.entries(lib)
-
-    def fbm(self, path, nrow, ncol, code256=None):
-        env = self.lib.rmock_new_env()
-        self.lib.rmock_env_set(env, b"backingfile", self.lib.rmock_str(str(path).encode()))
-        self.lib.rmock_env_set(env, b"nrow", self.real([float(nrow)]))
-        self.lib.rmock_env_set(env, b"ncol", self.real([float(ncol)]))
-        if code256 is not None:
-            self.lib.rmock_env_set(env, b"code256", self.real(code256))
-        return env
-
-    def real(self, v):
-        a = np.ascontiguousarray(v, dtype=np.float64)
-        return self.lib.rmock_real(a.ctypes.data, a.size)
-
-    def int(self, v):
-        a = np.ascontiguousarray(v, dtype=np.int32)
-        return self.lib.rmock_int(a.ctypes.data, a.size)
-
-    def matrix(self, a):
-        a = np.asfortranarray(a, dtype=np.float64)
-        return self.lib.rmock_real_matrix(a.ctypes.data, a.shape[0], a.shape[1])
-
-    def call(self, name, *args):
-        fn, arity = self.ent["_tidypopgen_" + name]
-        assert arity == len(args), (name, arity, len(args))
-        arr = (C.c_void_p * max(1, len(args)))(*args)
-        out = self.lib.rmock_call(fn, len(args), arr)
-        if out is None:
-            raise RuntimeError(self.lib.rmock_last_error().decode())
-        return out
-
-    def as_numpy(self, sexp, shape=None):
-        n = self.lib.XLENGTH(sexp)
-        t = self.lib.TYPEOF(sexp)
-        ct = C.c_double if t == 14 else C.c_int
-        a = np.ctypeslib.as_array(C.cast(self.lib.rmock_data(sexp), C.POINTER(ct)), shape=(n,)).copy()
-        return a.reshape(shape, order="F") if shape else a
-
-    def list_elt(self, sexp, k, shape=None):
-        return self.as_numpy(self.lib.VECTOR_ELT(sexp, k), shape)
+R = rmock.Session
 
 
 def _double_fbm(tmp_path, name, n, fill=0.0):
@@ -84,19 +39,8 @@ def shim(tmp_path, monkeypatch):
 
 
 def _driver_loop(r, which, BM, K, K2, rows, cols, block):
-    """the block loop of snp_ibs / snp_king / snp_allele_sharing, scratch matrices included (the shim ignores them)"""
-    n = len(rows)
     lo, up = orc.cut_by_size(len(cols), block)
-    width = int((up - lo + 1).max())
-    scratch = [r.matrix(np.zeros((n, width))) for _ in range(4)]
-    for a, b in zip(lo, up):
-        cb = r.int(cols[a - 1:b])
-        if which == "ibs":
-            r.call("increment_ibs_counts", K, K2, scratch[0], scratch[1], scratch[2], BM, r.int(rows), cb)
-        elif which == "king":
-            r.call("increment_king_numerator", K, K2, scratch[0], scratch[1], scratch[2], scratch[3], BM, r.int(rows), cb)
-        else:
-            r.call("increment_as_counts", K, K2, scratch[0], scratch[1], BM, r.int(rows), cb)
+    rmock.driver_loop(r, which, BM, K, K2, rows, cols, lo, up)
 
 
 def _oracle_counts(which, fbm, rows, cols):
@@ -129,9 +73,12 @@ def test_unmodified_drivers_are_correct_by_default(shim, tmp_path):
     _driver_loop(shim, "ibs", BM, shim.fbm(kp, n, n), shim.fbm(k2p, n, n), rows, sub, 100)
     A, B = _oracle_counts("ibs", fbm, rows, sub)
     assert np.array_equal(_read_double_fbm(kp, n), A) and np.array_equal(_read_double_fbm(k2p, n), B)
-    # no writable mapping is left behind: the accumulator files are not mapped by this process any more
+    # the accumulators of an analysis stay mapped while its block loop runs and go when the next analysis starts (or at
+    # tpg_release / unload): a session never holds more than one analysis' pair of temp files
     maps = open("/proc/self/maps").read()
-    assert "ibs_k.bk" not in maps and "s_k2.bk" not in maps
+    assert "ibs_k.bk" not in maps and "king_k2.bk" not in maps and "as_k.bk" not in maps
+    shim.call("tpg_release")
+    assert "s_k2.bk" not in open("/proc/self/maps").read()
 
 
 def test_deferred_mode_is_opt_in(shim, tmp_path, monkeypatch):
@@ -152,8 +99,15 @@ def test_deferred_mode_is_opt_in(shim, tmp_path, monkeypatch):
     assert "k2.bk" not in open("/proc/self/maps").read()  # unmapped at the flush
 
 
-def test_backing_file_rewritten_in_place_is_reuploaded(shim, tmp_path):
-    """gt_impute_simple rewrites the .bk in place (R/gt_impute_simple.R:86); the next call must see the new bytes"""
+@pytest.mark.parametrize("cache", [False, True])
+def test_backing_file_rewritten_in_place_is_reuploaded(shim, tmp_path, monkeypatch, cache):
+    """gt_impute_simple rewrites the .bk in place (R/gt_impute_simple.R:86); the next call must see the new bytes.  Default:
+    nothing of the FBM outlives a call.  TPG_RSHIM_CACHE=1 (opt-in): an HBM copy guarded by size + mtime + page fingerprint,
+    and tpg_invalidate(BM) for edits the heuristic could miss."""
+    if cache:
+        monkeypatch.setenv("TPG_RSHIM_CACHE", "1")
+    else:
+        monkeypatch.delenv("TPG_RSHIM_CACHE", raising=False)
     n, m = 120, 4000
     fbm = orc.synth_fbm(47, n, m, npop=4, miss=0.06)
     bk = tmp_path / "geno.bk"
@@ -169,7 +123,7 @@ def test_backing_file_rewritten_in_place_is_reuploaded(shim, tmp_path):
 
     before = alt_freq()
     assert np.array_equal(before, orc.alt_freq_dip_pseudo_cpp(fbm, rows, cols, ploidy, True, orc.CODE_IMPUTE_PRED))
-    assert np.array_equal(alt_freq(), before)  # second call: served from the HBM copy
+    assert np.array_equal(alt_freq(), before)  # second call (cache: served from the HBM copy)
     imputed = np.where(fbm == 3, np.uint8(4 + 1), fbm)  # every missing genotype imputed as heterozygous (bytes 5)
     mm = np.memmap(bk, dtype=np.uint8, mode="r+")
     st0 = os.stat(bk)
@@ -180,6 +134,26 @@ def test_backing_file_rewritten_in_place_is_reuploaded(shim, tmp_path):
     after = alt_freq()
     want = orc.alt_freq_dip_pseudo_cpp(imputed, rows, cols, ploidy, True, orc.CODE_IMPUTE_PRED)
     assert np.array_equal(after, want) and not np.array_equal(after, before)
+    # a sparse edit (one genotype in a page the fingerprint may not sample) with the modification time put back: always seen
+    # by default; under the cache only tpg_invalidate(BM) guarantees it
+    mm = np.memmap(bk, dtype=np.uint8, mode="r+")
+    j_edit = m // 2 + 7
+    old_byte = int(mm[j_edit * n + 3])
+    mm[j_edit * n + 3] = (old_byte + 1) % 3
+    mm.flush()
+    del mm
+    os.utime(bk, ns=(st0.st_atime_ns, st0.st_mtime_ns))
+    imputed2 = imputed.copy()
+    imputed2[3, j_edit] = (old_byte + 1) % 3
+    if cache:
+        shim.call("tpg_invalidate", BM)
+    assert np.array_equal(alt_freq(), orc.alt_freq_dip_pseudo_cpp(imputed2, rows, cols, ploidy, True, orc.CODE_IMPUTE_PRED))
+    # a scattered colInd goes through the gathered upload (default) / the cached copy
+    sub = cols[::9].copy()
+    out = shim.call("alt_freq_dip_pseudo_cpp", BM, shim.int(rows), shim.int(sub), shim.real(ploidy), shim.int([1]),
+                    shim.lib.rmock_lgl(1))
+    assert np.array_equal(shim.as_numpy(out, (len(sub), 2)),
+                          orc.alt_freq_dip_pseudo_cpp(imputed2, rows, sub, ploidy, True, orc.CODE_IMPUTE_PRED))
 
 
 def test_whole_analysis_entry_points(shim, tmp_path, monkeypatch):
@@ -196,9 +170,15 @@ def test_whole_analysis_entry_points(shim, tmp_path, monkeypatch):
     rows = np.arange(1, n + 1, dtype=np.int32)
     gid = (np.arange(n) % G).astype(np.int32)
     mc = len(cols)
-    out = shim.call("tpg_snp_pairwise", BM, shim.int(rows), shim.int(cols), shim.lib.rmock_lgl(0))
+    out = shim.call("tpg_snp_pairwise", BM, shim.int(rows), shim.int(cols), shim.lib.rmock_lgl(0), shim.lib.rmock_nil())
     assert np.array_equal(shim.list_elt(out, 0, (n, n)), orc.snp_ibs(fbm, rows, cols), equal_nan=True)
     assert np.array_equal(shim.list_elt(out, 1, (n, n)), orc.snp_king(fbm, rows, cols), equal_nan=True)
+    # which = king + grm (BASELINE config 2): four of the five cross-products; the others come back NULL
+    out = shim.call("tpg_snp_pairwise", BM, shim.int(rows), shim.int(cols), shim.lib.rmock_lgl(0), shim.int([2 | 8]))
+    assert shim.lib.TYPEOF(shim.lib.VECTOR_ELT(out, 0)) == 0 and shim.lib.TYPEOF(shim.lib.VECTOR_ELT(out, 2)) == 0  # NILSXP
+    assert np.array_equal(shim.list_elt(out, 1, (n, n)), orc.snp_king(fbm, rows, cols), equal_nan=True)
+    assert np.allclose(shim.list_elt(out, 3, (n, n)), orc.pairwise_grm(orc.snp_allele_sharing(fbm, rows, cols)), rtol=1e-12,
+                       atol=1e-13, equal_nan=True)
     gf = shim.call("tpg_grouped_alt_freq", BM, shim.int(rows), shim.int(cols), shim.int(gid), shim.int([G]),
                    shim.real(np.full(n, 2.0)), shim.lib.rmock_lgl(0))
     assert np.array_equal(shim.as_numpy(gf, (mc, 2 * G)),

@@ -1293,3 +1293,13 @@ def block_size(n: int, ncores: int = 1) -> int:
 
 
 block_size_default = block_size
+
+
+def cut_by_size(m: int, block_size: int):
+    """CutBySize (R/local_reimplementations.R:13-15) = bigparallelr::split_len(m, nb = ceiling(m / block.size)) (third
+    party, recalled: upper_b = round(b m / nb) with R's round-half-even): (lower, upper), 1-based inclusive -- the blocks the
+    R drivers loop over (R/snp_ibs.R:59-82)"""
+    nb = int(math.ceil(m / block_size))
+    up = np.rint(np.arange(1, nb + 1, dtype=np.float64) * (m / nb)).astype(np.int64)
+    lo = np.concatenate([[1], up[:-1] + 1])
+    return lo.astype(np.int32), up.astype(np.int32)

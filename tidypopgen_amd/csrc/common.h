@@ -113,6 +113,7 @@ struct tpg_fbm {
   uint8_t* d_bytes;
   int64_t nrow, ncol;
   int64_t bed_bpl = 0;  // > 0: d_bytes is a PLINK .bed payload with this many bytes per SNP (4 genotypes per byte)
+  bool pooled = false;  // d_bytes came from the context's pool (the per-block uploads of the increment_* mirrors)
 };
 
 // class-wise counts via MFMA: cls[n] in [0, nclass); cnt[3][Mpad][Cpad] (het, hom-alt, valid)

@@ -262,9 +262,10 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
 // operand byte crossing the L2 -> CU path, which is what the five-product 96 x 32 tile is short of when products are
 // dropped from it (6 MFMAs per 4 fragments for {V, D}).  One kernel template, instantiated per product set with a wave
 // tile of (32 RA) x (32 RB) pairs:
-//   {V, D}        128 x 64   16 accumulator tiles, 16 MFMAs per 6 fragments and 64 loci
-//   {V, D, H}      64 x 64   12 accumulator tiles, 12 MFMAs per 4 fragments
-//   {V, D, A, A'}  64 x 64   16 accumulator tiles, 16 MFMAs per 4 fragments
+//   {V, D}        128 x 64   16 accumulator tiles, 16 MFMAs per 6 fragments and 64 loci    8.7 - 8.9 ms at 5 000 x 1 000 000
+//   {V, D, H}      64 x 64   12 accumulator tiles, 12 MFMAs per 4 fragments               13.6 ms
+//   {V, D, A, A'}  64 x 64   16 accumulator tiles, 16 MFMAs per 4 fragments               16.1 - 16.2 ms
+// (all five, the kernel above: 96 x 32, 15 tiles, 15 MFMAs per 4 fragments: 19.3 - 19.5 ms)
 // Same T4 operands, same slab layout as the five-product kernel (a tile (rt, ct) of the wave is sub-tile rt % 3 of slab
 // (rt / 3, ct)), so accumulators, reduce-scatter and epilogues do not care which kernel filled them; planes of products
 // that were not asked for stay zero and tpg_pairwise.have says which sums are complete.  Only tiles on or above the
@@ -290,6 +291,11 @@ __device__ __forceinline__ Frag3 tpg_planes_of(v4u w, uint32_t mv, uint32_t md, 
     if constexpr (PwSet<MASK>::wh) f.h[k] = (int)(w[k] & mh);
   }
   return f;
+}
+
+template <typename F, int... Ss>
+__device__ __forceinline__ void tpg_unrolled_steps(F& step, int64_t kb, std::integer_sequence<int, Ss...>) {
+  (step(std::integral_constant<int, Ss>{}, kb + Ss), ...);
 }
 
 template <int RA, int RB, int MASK, int NS>
@@ -383,19 +389,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      for (int64_t kb = kb0; kb < kb1; kb += U) {
-        step(std::integral_constant<int, 0>{}, kb);
-        if constexpr (U > 1) step(std::integral_constant<int, 1>{}, kb + 1);
-        if constexpr (U > 2) step(std::integral_constant<int, 2>{}, kb + 2);
-        if constexpr (U > 3) step(std::integral_constant<int, 3>{}, kb + 3);
-        if constexpr (U > 4) step(std::integral_constant<int, 4>{}, kb + 4);
-        if constexpr (U > 5) step(std::integral_constant<int, 5>{}, kb + 5);
-        if constexpr (U > 6) step(std::integral_constant<int, 6>{}, kb + 6);
-        if constexpr (U > 7) step(std::integral_constant<int, 7>{}, kb + 7);
-        if constexpr (U > 8) step(std::integral_constant<int, 8>{}, kb + 8);
-        if constexpr (U > 9) step(std::integral_constant<int, 9>{}, kb + 9);
-        static_assert(U <= 10, "more steps per loop body than written out");
-      }
+      for (int64_t kb = kb0; kb < kb1; kb += U) tpg_unrolled_steps(step, kb, std::make_integer_sequence<int, U>{});
     }
     // integer sums (<= 2^24 loci per wave-unit): exact in int32.  Tiles on or above the diagonal only.
 #pragma unroll
@@ -752,24 +746,28 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
   }
   const int64_t kg0 = col_begin / 128, kg1 = ceil_div(col_end, 128);
   const int var = pw_variant();
+#define PW_SET(RA, RB, MASK, NS, name) TPG_TRY((pw_launch_set<RA, RB, MASK, NS>(ctx, pw, v, kg0, kg1, name)))
+  // measured at 5 000 x 1 000 000 (tools/pw_only.py; ms, the same GPU): {V, D} 128 x 64 with 5 / 4 / 3 slots 8.9 / 9.1 / 12.4,
+  // 96 x 64 9.8, 64 x 64 11.8; {V, D, H} 64 x 64 with 5 / 4 / 3 / 6 / 7 slots 13.6 / 14.3 / 22.6 / 13.9 / 14.0, 96 x 32 15.7;
+  // {V, D, A} 64 x 64 with 5 / 4 / 3 / 6 slots 16.2 / 16.5 / 23.5 / 16.4, 128 x 32 17.9, 96 x 32 17.8; all five through
+  // this template (96 x 32, 4 ... 7 slots) 20.2 - 21.8 against 19.5 for the kernel above with its two-block groups
   if (set == TPG_PW_FOR_AS) {
-    if (var == 1) TPG_TRY((pw_launch_set<3, 2, TPG_PW_FOR_AS, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
-    else if (var == 2) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 3>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
-    else if (var == 3) TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_AS, 6>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
-    else TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+    if (var == 1) PW_SET(4, 2, TPG_PW_FOR_AS, 4, "pairwise_mfma_as");
+    else if (var == 2) PW_SET(3, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
+    else PW_SET(4, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
   } else if (set == TPG_PW_FOR_IBS) {
-    if (var == 1) TPG_TRY((pw_launch_set<3, 1, TPG_PW_FOR_IBS, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_ibs")));
-    else if (var == 2) TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_IBS, 3>(ctx, pw, v, kg0, kg1, "pairwise_mfma_ibs")));
-    else if (var == 3) TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_IBS, 5>(ctx, pw, v, kg0, kg1, "pairwise_mfma_ibs")));
-    else TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_IBS, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_ibs")));
+    if (var == 1) PW_SET(2, 2, TPG_PW_FOR_IBS, 4, "pairwise_mfma_ibs");
+    else if (var == 2) PW_SET(3, 1, TPG_PW_FOR_IBS, 6, "pairwise_mfma_ibs");
+    else PW_SET(2, 2, TPG_PW_FOR_IBS, 5, "pairwise_mfma_ibs");
   } else if (set == TPG_PW_FOR_KING) {
-    if (var == 1) TPG_TRY((pw_launch_set<3, 1, TPG_PW_FOR_KING, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_king")));
-    else if (var == 2) TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_KING, 3>(ctx, pw, v, kg0, kg1, "pairwise_mfma_king")));
-    else if (var == 3) TPG_TRY((pw_launch_set<4, 1, TPG_PW_FOR_KING, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_king")));
-    else TPG_TRY((pw_launch_set<2, 2, TPG_PW_FOR_KING, 4>(ctx, pw, v, kg0, kg1, "pairwise_mfma_king")));
+    if (var == 1) PW_SET(2, 2, TPG_PW_FOR_KING, 4, "pairwise_mfma_king");
+    else if (var == 2) PW_SET(3, 1, TPG_PW_FOR_KING, 6, "pairwise_mfma_king");
+    else PW_SET(2, 2, TPG_PW_FOR_KING, 5, "pairwise_mfma_king");
   } else {
-    TPG_TRY(pw_launch_all(ctx, pw, v, kg0, kg1));
+    if (var == 1) PW_SET(3, 1, TPG_PW_ALL, 4, "pairwise_mfma");
+    else TPG_TRY(pw_launch_all(ctx, pw, v, kg0, kg1));
   }
+#undef PW_SET
   TPG_CHECK_LAUNCH();
   return TPG_OK;
 }
@@ -1394,6 +1392,8 @@ struct Resident {
   bool defer = false;
   std::vector<ResidentAcc> accs;
   tpg_pairwise* spare = nullptr;  // the accumulators of the last immediate call, reused while n stays the same
+  int32_t* stage = nullptr;       // pinned host staging of the two int32 count matrices (add_counts_to_caller)
+  size_t stage_ints = 0;
 };
 
 static Resident* resident_of(tpg_ctx* ctx) {
@@ -1406,25 +1406,115 @@ void tpg_resident_release(tpg_ctx* ctx) {  // called by tpg_ctx_destroy and tpg_
   if (!r) return;
   for (auto& a : r->accs) tpg_pairwise_free(a.pw);
   tpg_pairwise_free(r->spare);
+  if (r->stage) (void)hipHostFree(r->stage);
   delete r;
   ctx->resident = nullptr;
 }
 
-// K += sums, K2 += sums: exact (integer-valued doubles), so the order of the blocks does not matter
+// The two count matrices of one increment_* entry point as int32, both triangles, column-major: half the bytes of the
+// double outputs of tpg_pairwise_counts on their way to the host.  which 0: IBS = V + D + H, 2 V; 1: KING numerator
+// D - V + A + A', A; 2: D (+ quirk), V.  Same tile walk as tpg_pairwise_epilogue_kernel.
+__global__ __launch_bounds__(256) void tpg_pairwise_counts2_i32_kernel(const int32_t* __restrict__ acc,
+                                                                       const int64_t* __restrict__ rowpad, int nst, int n,
+                                                                       int which, int quirk, int32_t* __restrict__ oA,
+                                                                       int32_t* __restrict__ oB) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (ti > tj) return;
+  __shared__ int sp[5][32][33];
+  const int32_t* p = acc + (tpg_pw_unit_index(nst, ti / TA, tj) + rowpad[ti / TA]) * TPG_PW_TILE_INTS + ((ti % TA) * 16) * 64;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int idx = threadIdx.x + 256 * e, reg = idx >> 6, lane = idx & 63;
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 5; q++) sp[q][row][col] = p[q * TPG_PW_PLANE_INTS + reg * 64 + lane];
+  }
+  __syncthreads();
+  auto emit = [&](int row, int col, int64_t idx, bool mirrored) {
+    const int V = sp[0][row][col], D = sp[1][row][col], H = sp[2][row][col];
+    const int Aij = mirrored ? sp[4][row][col] : sp[3][row][col], Aji = mirrored ? sp[3][row][col] : sp[4][row][col];
+    if (which == 0) { oA[idx] = V + D + H; oB[idx] = 2 * V; }
+    else if (which == 1) { oA[idx] = D - V + Aij + Aji; oB[idx] = Aij; }
+    else { oA[idx] = D + quirk; oB[idx] = V; }
+  };
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int idx = threadIdx.x + 256 * e;
+    {
+      const int row = idx & 31, col = idx >> 5;
+      const int gi = 32 * ti + row, gj = 32 * tj + col;
+      if (gi < n && gj < n) emit(row, col, gi + (int64_t)gj * n, false);
+    }
+    if (ti != tj) {
+      const int col = idx & 31, row = idx >> 5;
+      const int gi = 32 * ti + row, gj = 32 * tj + col;
+      if (gi < n && gj < n) emit(row, col, gj + (int64_t)gi * n, true);
+    }
+  }
+}
+
+// K += sums, K2 += sums: exact (integer-valued doubles), so the order of the blocks does not matter.  This is what an
+// unmodified R driver pays PER BLOCK (38 times at 5 000 x 1 000 000), so it is built for that: the two matrices leave the
+// device as int32 (2 x 100 MB instead of 2 x 200 MB) into pinned staging buffers the context keeps between calls (no
+// 400 MB of fresh pages per block), and a team of threads adds the first to K while the second is still on its way.
 static int add_counts_to_caller(tpg_ctx* ctx, int which, const tpg_pairwise* pw, double* A, double* B) {
   const size_t nn = (size_t)pw->n * (size_t)pw->n;
-  std::vector<double> ta(nn), tb(nn);
-  if (which == 0) TPG_TRY(tpg_pairwise_counts(ctx, pw, ta.data(), tb.data(), nullptr, nullptr, nullptr, nullptr));
-  else if (which == 1) TPG_TRY(tpg_pairwise_counts(ctx, pw, nullptr, nullptr, ta.data(), tb.data(), nullptr, nullptr));
-  else TPG_TRY(tpg_pairwise_counts(ctx, pw, nullptr, nullptr, nullptr, nullptr, ta.data(), tb.data()));
-  const int NT = nn >= (1u << 20) ? 8 : 1;
-  std::vector<std::thread> th;
-  auto body = [&](int t) {
-    for (size_t k = nn * (size_t)t / (size_t)NT; k < nn * (size_t)(t + 1) / (size_t)NT; k++) { A[k] += ta[k]; B[k] += tb[k]; }
+  Resident* r = resident_of(ctx);
+  // every int32 entry is bounded by 2 x loci + quirk
+  const bool fits = 2 * pw->loci + pw->as_pad_quirk < (1ll << 31) && pw->nranks == 1;
+  const int NT = nn >= (1u << 20) ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+  auto team = [&](auto body) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < NT; t++) th.emplace_back(body, t);
+    body(0);
+    for (auto& t : th) t.join();
   };
-  for (int t = 1; t < NT; t++) th.emplace_back(body, t);
-  body(0);
-  for (auto& t : th) t.join();
+  if (!fits) {  // very long panels (or sharded accumulators): the double outputs of tpg_pairwise_counts
+    std::vector<double> ta(nn), tb(nn);
+    if (which == 0) TPG_TRY(tpg_pairwise_counts(ctx, pw, ta.data(), tb.data(), nullptr, nullptr, nullptr, nullptr));
+    else if (which == 1) TPG_TRY(tpg_pairwise_counts(ctx, pw, nullptr, nullptr, ta.data(), tb.data(), nullptr, nullptr));
+    else TPG_TRY(tpg_pairwise_counts(ctx, pw, nullptr, nullptr, nullptr, nullptr, ta.data(), tb.data()));
+    team([&](int t) {
+      for (size_t k = nn * (size_t)t / (size_t)NT; k < nn * (size_t)(t + 1) / (size_t)NT; k++) { A[k] += ta[k]; B[k] += tb[k]; }
+    });
+    return TPG_OK;
+  }
+  TPG_TRY(pw_need(pw, which == 0 ? TPG_PW_FOR_IBS : which == 1 ? TPG_PW_FOR_KING : TPG_PW_FOR_AS, "increment"));
+  if (r->stage_ints < 2 * nn) {
+    if (r->stage) (void)hipHostFree(r->stage);
+    r->stage = nullptr;
+    r->stage_ints = 0;
+    TPG_HIP(hipHostMalloc((void**)&r->stage, sizeof(int32_t) * 2 * nn, hipHostMallocDefault));
+    r->stage_ints = 2 * nn;
+  }
+  int32_t* d_out = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_out, sizeof(int32_t) * 2 * nn));
+  const unsigned nt = (unsigned)ceil_div(pw->n, 32);
+  hipEvent_t evA = nullptr;
+  hipError_t e = hipEventCreateWithFlags(&evA, hipEventDisableTiming);
+  if (e == hipSuccess) {
+    TPG_LAUNCH(ctx, "pairwise_counts_i32", tpg_pairwise_counts2_i32_kernel, dim3(nt, nt), dim3(256), 0, (const int32_t*)pw->acc,
+               (const int64_t*)pw->rowpad, (int)pw->nst, (int)pw->n, which, (int)pw->as_pad_quirk, d_out, d_out + nn);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(r->stage, d_out, sizeof(int32_t) * nn, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipEventRecord(evA, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(r->stage + nn, d_out + nn, sizeof(int32_t) * nn, hipMemcpyDeviceToHost, ctx->stream);
+  tpg_pfree(d_out);  // stream-ordered
+  if (e == hipSuccess) e = hipEventSynchronize(evA);
+  if (e == hipSuccess) {
+    const int32_t* sa = r->stage;
+    team([&](int t) {
+      for (size_t k = nn * (size_t)t / (size_t)NT; k < nn * (size_t)(t + 1) / (size_t)NT; k++) A[k] += (double)sa[k];
+    });
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  if (evA) (void)hipEventDestroy(evA);
+  if (e != hipSuccess) { tpg_set_error("increment: counts to the caller: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  const int32_t* sb = r->stage + nn;
+  team([&](int t) {
+    for (size_t k = nn * (size_t)t / (size_t)NT; k < nn * (size_t)(t + 1) / (size_t)NT; k++) B[k] += (double)sb[k];
+  });
   return TPG_OK;
 }
 

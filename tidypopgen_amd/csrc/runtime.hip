@@ -460,10 +460,13 @@ extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nro
   TPG_HIP(hipSetDevice(ctx->device));
   tpg_fbm* f = new tpg_fbm{ctx, nullptr, nrow, ncol};
   size_t sz = (size_t)nrow * (size_t)ncol;
-  hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
-  if (e != hipSuccess) { delete f; tpg_set_error("tpg_pmalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
+  // the blocks of a driver loop (131 MB at 5 000 x 26 843) come from the context's pool: hipMalloc / hipFree cost
+  // milliseconds each and synchronise the device; whole panels keep their own allocation
+  f->pooled = sz <= ((size_t)1 << 30);
+  hipError_t e = f->pooled ? tpg_pmalloc((void**)&f->d_bytes, sz) : hipMalloc((void**)&f->d_bytes, sz);
+  if (e != hipSuccess) { delete f; tpg_set_error("device allocation of %zu bytes failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
   e = tpg_upload(ctx, f->d_bytes, bytes, sz);
-  if (e != hipSuccess) { (void)hipFree(f->d_bytes); delete f; tpg_set_error("FBM upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  if (e != hipSuccess) { tpg_fbm_free(f); tpg_set_error("FBM upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
   *out = f;
   return TPG_OK;
 }
@@ -586,7 +589,10 @@ extern "C" int tpg_fbm_to_host(tpg_ctx* ctx, const tpg_fbm* fbm, uint8_t* bytes)
 
 extern "C" void tpg_fbm_free(tpg_fbm* fbm) {
   if (!fbm) return;
-  if (fbm->d_bytes) (void)hipFree(fbm->d_bytes);
+  if (fbm->d_bytes) {
+    if (fbm->pooled) tpg_pfree(fbm->d_bytes);  // stream-ordered: behind the kernels that read it on its context's stream
+    else (void)hipFree(fbm->d_bytes);
+  }
   delete fbm;
 }
 
