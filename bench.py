@@ -658,10 +658,12 @@ def dropin(st, path):
     return out
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, st=None):
     """The oracle's "as the reference does it" path (oracle/oracle.py: dense FP64 one-hot blocks + BLAS
     products for IBS/KING/AS, C loops for the per-locus statistics and Fst, numpy Gram for PCA), timed on
-    this host's cores over a bounded sample of the same workload."""
+    this host's cores over a bounded sample of the same workload.  With `st` (the resident step's context) the GPU then
+    computes the same analyses on the same sample and `parity` reports max |delta| against the oracle's results: the second
+    half of BASELINE.json's metric, in the one leg of bench.py that may call the oracle (as the checker, after the timing)."""
     from oracle import oracle as orc
 
     n, G = args.n, args.pops
@@ -679,13 +681,13 @@ def cpu_baseline(args):
         orc.blas_increment_king(K[2], K[3], fbm, r, c)
         orc.blas_increment_as(K[4], K[5], fbm, r, c)
     c = np.arange(1, B + 1, dtype=np.int32)
-    orc.king_epilogue(K[2], K[3])
-    orc.pairwise_grm(orc.as_epilogue(K[4], K[5]))
-    orc.alt_freq_dip_pseudo_cpp(fbm, r, c, ploidy)
-    orc.grouped_alt_freq_dip_pseudo_cpp(fbm, r, c, gid, G, ploidy)
+    ref = {"king": orc.king_epilogue(K[2], K[3])}
+    ref["grm"] = orc.pairwise_grm(orc.as_epilogue(K[4], K[5]))
+    ref["freq"] = orc.alt_freq_dip_pseudo_cpp(fbm, r, c, ploidy)
+    ref["gfreq"] = orc.grouped_alt_freq_dip_pseudo_cpp(fbm, r, c, gid, G, ploidy)
     with np.errstate(invalid="ignore", divide="ignore"):
-        orc.pairwise_pop_fst(fbm, r, c, gid, G, method="Hudson")
-        orc.pairwise_pop_fst(fbm, r, c, gid, G, method="WC84")
+        ref["Hudson"] = orc.pairwise_pop_fst(fbm, r, c, gid, G, method="Hudson")["fst_tot"]
+        ref["WC84"] = orc.pairwise_pop_fst(fbm, r, c, gid, G, method="WC84")["fst_tot"]
     # PCA Gram of the sample (K = Z Z' through BLAS), as bigstatsr::big_SVD accumulates it per block
     Kp = np.zeros((n, n))
     for a in range(0, B, blk):
@@ -706,11 +708,74 @@ def cpu_baseline(args):
             cores = min(cores, max(blas))
     except ImportError:
         pass
-    return {"value": n * B / dt, "unit": "SNP-genotypes/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x {B} loci (M / {args.m // B if B else 0}) of the same synthetic panel, extrapolated linearly in M: "
-                      f"IBS+KING+AS via numpy/BLAS FP64 one-hot products "
-                      f"(reference's 6/4/2 products per block of {blk} loci, multi-threaded), per-locus + Fst (Hudson, WC84) C loops "
-                      f"(OpenMP), PCA Gram via BLAS; {dt:.1f} s; eigen step excluded"}
+    out = {"value": n * B / dt, "unit": "SNP-genotypes/s", "cores": cores, "kind": "port",
+           "sample": f"{n} x {B} loci (M / {args.m // B if B else 0}) of the same synthetic panel, extrapolated linearly in M: "
+                     f"IBS+KING+AS via numpy/BLAS FP64 one-hot products "
+                     f"(reference's 6/4/2 products per block of {blk} loci, multi-threaded), per-locus + Fst (Hudson, WC84) C loops "
+                     f"(OpenMP), PCA Gram via BLAS; {dt:.1f} s; eigen step excluded"}
+    if st is not None:
+        try:
+            out["parity"] = _parity_vs_oracle(st, fbm, K, ref, Kp, B)
+        except Exception as e:  # noqa: BLE001 -- the check must not take the bench line down with it
+            out["parity"] = {"failed": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def _parity_vs_oracle(st, fbm, K, ref, Kp, B):
+    """max |delta| of the HIP path against the oracle's results on the cpu_baseline sample (the first B loci of the bench panel:
+    the device generator and the oracle's are the same pure function of (seed, individual, locus), checked first)"""
+    tpg, api, a = st.tpg, st.api, st.args
+    n, G, k = a.n, a.pops, a.k
+    ctx = st.ctx
+    X = tpg.FBM.synth(3, n, B, npop=G, miss=0.02, imputed_bytes=True, ctx=ctx, code256=tpg.CODE_012)
+    out = {"sample": f"{n} x {B}", "same_input_bytes": bool(np.array_equal(X.to_numpy(), fbm))}
+    v = api.View(X, None, None, code256=None)
+    pw = api.Pairwise(ctx, n)
+    pw.accumulate(v)
+    cnt = pw.counts()
+    out["counts_max_abs"] = float(max(np.abs(cnt[name] - K[i]).max() for i, name in
+                                      enumerate(("ibs", "ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den"))))
+    ep = pw.epilogues(which=("ibs", "king", "grm"))
+
+    def max_rel(x, y):
+        both = np.isfinite(x) & np.isfinite(y)
+        if not np.array_equal(np.isfinite(x), np.isfinite(y)):
+            return float("inf")
+        den = np.maximum(np.abs(y[both]), 1e-300)
+        return float((np.abs(x[both] - y[both]) / den).max()) if both.any() else 0.0
+
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out["ibs_max_rel"] = max_rel(ep["ibs"], K[0] / K[1])  # R/snp_ibs.R:88-95
+    out["king_max_rel"] = max_rel(ep["king"], ref["king"])
+    # GRM = 2 (M - mb) / (1 - mb) passes through zero: relative to the largest entry
+    out["grm_max_rel_of_max"] = float(np.nanmax(np.abs(ep["grm"] - ref["grm"])) / np.nanmax(np.abs(ref["grm"])))
+    pw.free()
+    v.free()
+    f = tpg.loci_alt_freq(X)
+    out["alt_freq_max_abs"] = float(np.abs(f - ref["freq"][:, 0]).max()) if f.ndim == 1 else float(np.abs(f - ref["freq"]).max())
+    gid = (np.arange(n) % G).astype(np.int32)
+    vv = api.View(X, None, None, code256=tpg.CODE_012)
+    gf = np.zeros((B, 2 * G), order="F")
+    tpg._lib.check(st.lib.tpg_grouped_alt_freq_dip_pseudo(ctx.h, vv.h, api._ptr(gid), C.c_int(G), api._ptr(np.full(n, 2.0)),
+                                                          C.c_int(0), api._ptr(gf)))
+    vv.free()
+    out["grouped_alt_freq_max_abs"] = float(np.nanmax(np.abs(gf - ref["gfreq"])))
+    fst_rel = 0.0
+    for method in ("Hudson", "WC84"):
+        t = tpg.pairwise_pop_fst(X, None, None, gid, G, method=method)["fst_tot"]
+        fst_rel = max(fst_rel, max_rel(np.asarray(t), np.asarray(ref[method])))
+    out["fst_max_rel"] = fst_rel
+    # PCA: d of the polymorphic loci of the sample against sqrt of the top eigenvalues of the oracle's BLAS Gram (LAPACK)
+    dec = np.where(fbm > 3, fbm - 4, fbm).astype(np.int64)
+    alt = dec.sum(axis=0)
+    pc = (np.where((alt > 0) & (alt < 2 * n))[0] + 1).astype(np.int32)
+    t = tpg.gt_pca_partialSVD(X, None, pc, k=k)
+    from scipy.linalg import eigh
+
+    lam = eigh(Kp, eigvals_only=True, subset_by_index=[n - k, n - 1])[::-1]
+    out["pca_d_max_rel"] = float(np.max(np.abs(t["d"] / np.sqrt(lam) - 1)))
+    X.free()
+    return out
 
 
 def launch_ranks(args):
@@ -891,7 +956,7 @@ def main():
             wl = (f"{n} individuals x {args.m} SNPs per GPU ({world} GPU, panel of {st.m_total}), 51 populations, 2% missing "
                   f"(imputed bytes), seed 3 [BASELINE configs 2-4]")
         out = {
-            "metric": "SNP-genotypes/s (N x M) for IBS+KING+GRM+Fst+PCA",
+            "metric": "SNP-genotypes/s (N x M) for IBS+KING+GRM+Fst+PCA; max |delta| vs CPU ref (cpu_baseline.parity)",
             "value": total_genotypes / (dt / args.steps),
             "unit": "SNP-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -918,7 +983,7 @@ def main():
             if "dropin" in out["end_to_end"]:
                 out["dropin"] = out["end_to_end"].pop("dropin")
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, st)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         import torch.distributed as dist

@@ -33,7 +33,7 @@ def test_two_shards_equal_one(tmp_path, scaling, exchange):
     gramcls.hip) instead of every rank's own loci -- forced here, the cost model keeps it for long panels"""
     d1, d2 = str(tmp_path / "one.json"), str(tmp_path / "two.json")
     common = ["--steps", "1", "--warmup", "0", "--indiv", "700", "--pops", "9", "--k", "8", "--no-cpu-baseline",
-              "--no-end-to-end", "--scaling", scaling]
+              "--no-end-to-end", "--no-standalone", "--scaling", scaling]
     _run([sys.executable, "bench.py", "--gpus", "1", "--snps", "60000", "--digest", d1] + common, {})
     _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
           "127.0.0.1", "--master-port", "29537" if exchange else ("29533" if scaling == "strong" else "29535"), "bench.py", "--gpus", "2", "--snps",
@@ -292,4 +292,99 @@ def test_pca_with_whole_classes_per_rank(ndev, monkeypatch):
     t2 = mg.gt_pca_partialSVD(fbm, None, few, k=k)
     o2 = orc.gt_pca_partialSVD(fbm, None, few, k=k)
     assert np.allclose(t2["d"], o2["d"], rtol=1e-6, atol=0)
+    mg.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Real multi-GPU hardware.  Everything above rehearses the sharded paths on ONE GPU (gloo / in-process transports).  The
+# tests below run the same comparisons over RCCL on DISTINCT devices -- the first real ncclReduceScatter with N > 1, the
+# first real ncclAllToAllv, ncclCommInitAll on several devices -- and are skipped on a box with fewer GPUs than they need,
+# so they cost nothing today and verify the transport the first time 2 or 8 GPUs are there (axis being sharded:
+# R/snp_ibs.R:59-82).
+def _ngpu():
+    import torch  # counting devices does not initialise HIP
+
+    return torch.cuda.device_count()
+
+
+def _need_gpus(k):
+    return pytest.mark.skipif(_ngpu() < k, reason=f"needs {k} GPUs, this box has {_ngpu()}")
+
+
+def _digests_match(a, b, exchange):
+    for name in ("ibs", "king", "grm"):
+        assert a[name + "_nan"] == b[name + "_nan"]
+        tol = 1e-12 if name == "grm" else 0
+        assert np.allclose(a[name + "_corner"], b[name + "_corner"], rtol=tol, atol=tol, equal_nan=True), name
+        assert np.allclose(a[name + "_last"], b[name + "_last"], rtol=tol, atol=tol, equal_nan=True), name
+        assert a[name + "_sum"] == pytest.approx(b[name + "_sum"], rel=1e-12)
+    for name in ("fst_hudson", "fst_wc84"):
+        assert np.allclose(a[name], b[name], rtol=1e-12, atol=0)
+    assert np.allclose(a["pca_d"], b["pca_d"], rtol=1e-9 if exchange else 1e-7)
+    assert a["pca_fro"] == pytest.approx(b["pca_fro"], rel=1e-12)
+    assert np.allclose(a["pca_u_abs_colsum"], b["pca_u_abs_colsum"], rtol=1e-5)
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("ngpu,exchange", [pytest.param(2, False, marks=_need_gpus(2)), pytest.param(2, True, marks=_need_gpus(2)),
+                                           pytest.param(8, False, marks=_need_gpus(8)), pytest.param(8, True, marks=_need_gpus(8))])
+def test_rccl_ranks_on_distinct_gpus_equal_one_gpu(tmp_path, ngpu, exchange):
+    """`bench.py --gpus N --digest` over RCCL (no TPG_BENCH_SHARE_GPU: one process per GPU, ncclCommInitRank, the real
+    reduce-scatter / all-reduces; exchange: the first real ncclAllToAllv) must reproduce the 1-GPU digest with the
+    tolerances of test_two_shards_equal_one, and the line must say the collectives ran over rccl."""
+    d1, dn = str(tmp_path / "one.json"), str(tmp_path / "n.json")
+    common = ["--steps", "1", "--warmup", "0", "--indiv", "700", "--pops", "9", "--k", "8", "--no-cpu-baseline",
+              "--no-end-to-end", "--no-standalone", "--snps", "120000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TPG_BENCH_SHARE_GPU")}
+    _run([sys.executable, "bench.py", "--gpus", "1", "--digest", d1] + common, {})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(ngpu), "--digest", dn] + common, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900, env=dict(env, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                                                        **({"TPG_GRAM_EXCHANGE": "1"} if exchange else {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == ngpu
+    assert "transport rccl" in line["config"]["collectives"], line["config"]["collectives"]
+    if exchange:
+        assert "all-to-all" in line["config"]["pca_gram_path"], line["config"]["pca_gram_path"]
+    _digests_match(json.load(open(d1)), json.load(open(dn)), exchange)
+
+
+@pytest.mark.parametrize("ndev", [pytest.param(2, marks=_need_gpus(2)), pytest.param(8, marks=_need_gpus(8))])
+def test_multi_on_distinct_gpus_against_oracle(ndev, monkeypatch):
+    """tpg.Multi(ndev) on devices 0 .. ndev-1 (ncclCommInitAll, one host thread per device, RCCL between them) against the
+    oracle, as test_multi_fst_freq_pca_against_oracle does with one device listed several times; once more with the class
+    exchange forced (ncclAllToAllv inside tpg_multi_pca_partial_svd)."""
+    import tidypopgen_amd as tpg
+    from oracle import oracle as orc
+
+    n, m, G, k = 260, 12000, 5, 6
+    fbm = orc.synth_fbm(37, n, m, npop=G, miss=0.04, imputed_bytes=True)
+    gid = (np.arange(n) % G).astype(np.int32)
+    mg = tpg.Multi(ndev)
+    out = mg.pairwise(fbm)
+    assert np.array_equal(out["ibs"], orc.snp_ibs(fbm), equal_nan=True)
+    assert np.array_equal(out["king"], orc.snp_king(fbm), equal_nan=True)
+    as_ = orc.snp_allele_sharing(fbm)
+    assert np.array_equal(out["allele_sharing"], as_, equal_nan=True)
+    assert np.allclose(out["grm"], orc.pairwise_grm(as_), rtol=1e-12, atol=1e-14)
+    only = mg.pairwise(fbm, which=("king", "grm"))  # the {V, D, A} kernel on every device, one reduce-scatter
+    assert np.array_equal(only["king"], out["king"], equal_nan=True) and np.array_equal(only["grm"], out["grm"], equal_nan=True)
+    assert np.array_equal(mg.loci_alt_freq(fbm, None, None, gid, G),
+                          orc.grouped_alt_freq_dip_pseudo_cpp(fbm, None, None, gid, G, np.full(n, 2.0)))
+    for method in ("Hudson", "WC84"):
+        o = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method, by_locus=True)
+        t = mg.pairwise_pop_fst(fbm, None, None, gid, G, method=method, by_locus=True)
+        assert np.array_equal(t["fst_locus"], o["fst_locus"], equal_nan=True), method
+        assert np.allclose(t["fst_tot"], o["fst_tot"], rtol=1e-12, atol=0), method
+    dec = np.where(fbm > 3, fbm - 4, fbm)
+    pc = (np.where((dec.sum(axis=0) > 0) & (dec.sum(axis=0) < 2 * n))[0] + 1).astype(np.int32)
+    o = orc.gt_pca_partialSVD(fbm, None, pc, k=k)
+    for exchange in (False, True):
+        if exchange:
+            monkeypatch.setenv("TPG_GRAM_EXCHANGE", "1")
+        t = mg.gt_pca_partialSVD(fbm, None, pc, k=k)
+        assert np.array_equal(t["center"], o["center"]) and np.array_equal(t["scale"], o["scale"])
+        assert np.allclose(t["d"], o["d"], rtol=1e-6, atol=0)
+        so = o["u"] * o["d"]
+        assert np.max(np.abs(_align_sign(t["u"] * t["d"], so) - so)) <= 1e-6 * np.max(np.abs(so))
     mg.close()

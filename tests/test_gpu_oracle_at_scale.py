@@ -102,11 +102,15 @@ def _check_fst_sample(tpg, orc, X, seed, n, m):
     pf = orc.grouped_summaries_dip_pseudo_cpp(sub, None, None, gid_sub, len(pops), np.full(len(rows), 2.0))
     del sub
     with np.errstate(invalid="ignore", divide="ignore"):
-        for method in ("Hudson", "WC84"):
+        for method in ("Hudson", "WC84", "Nei87"):
             if method == "Hudson":  # src/pairwise_fst_hudson_loop.cpp:23-62
                 o = orc.pairwise_fst_hudson_loop(pairs_sub, pf["n"], pf["freq_alt"], pf["freq_ref"], by_locus=True)
                 ond = orc.pairwise_fst_hudson_loop(pairs_sub, pf["n"], pf["freq_alt"], pf["freq_ref"], by_locus=True,
                                                    return_num_dem=True)
+            elif method == "Nei87":  # src/pairwise_fst_nei87_loop.cpp:23-114 (not in BASELINE's list: run beside the two that are)
+                o = orc.pairwise_fst_nei87_loop(pairs_sub, pf["n"], pf["het_obs"], pf["freq_alt"], pf["freq_ref"], by_locus=True)
+                ond = orc.pairwise_fst_nei87_loop(pairs_sub, pf["n"], pf["het_obs"], pf["freq_alt"], pf["freq_ref"],
+                                                  by_locus=True, return_num_dem=True)
             else:                   # src/pairwise_fst_wc84_loop.cpp:22-120
                 o = orc.pairwise_fst_wc84_loop(pairs_sub, pf["n"], pf["freq_alt"], pf["het_obs"], by_locus=True)
                 ond = orc.pairwise_fst_wc84_loop(pairs_sub, pf["n"], pf["freq_alt"], pf["het_obs"], by_locus=True,
@@ -182,8 +186,12 @@ def _check_pca_sample(tpg, orc, X, seed, n, m, k):
         if sub0 is None:
             sub0 = sub
         Kd = K[np.ix_(rs, rs)]
-        assert np.abs(Kd - Ks).max() <= 1e-6 * np.abs(Ks).max()
-        assert np.allclose(np.diag(Kd), np.diag(Ks), rtol=1e-6)
+        # every entry relative to the scale of ITS pair, sqrt(K_ii K_jj) (the diagonal is ~10^6, an off-diagonal entry 10^3 -
+        # 10^4: a bound relative to max |K| would let one be wrong by 1 in 10^3).  1e-9 of that scale is 3e-7 .. 1e-5 relative
+        # for an off-diagonal entry: the class path's weights are within 2^-47 and its fold within 3e-10 of max |K|
+        dg = np.sqrt(np.abs(np.diag(Ks)))
+        assert np.all(np.abs(Kd - Ks) <= 1e-9 * np.outer(dg, dg)), float((np.abs(Kd - Ks) / np.outer(dg, dg)).max())
+        assert np.allclose(np.diag(Kd), np.diag(Ks), rtol=1e-9)
     # u spans eigenvectors of K
     assert np.abs(K @ r["u"] - r["u"] * r["d"] ** 2).max() <= 1e-9 * r["d"][0] ** 2
     del K, U_all

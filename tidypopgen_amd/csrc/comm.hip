@@ -41,7 +41,6 @@ struct RcclApi {
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllToAllv)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, ncclDataType_t, ncclComm_t,
                             hipStream_t) = nullptr;
-  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -75,10 +74,11 @@ static void rccl_load() {
   RSYM(CommDestroy, "ncclCommDestroy");
   RSYM(AllReduce, "ncclAllReduce");
   RSYM(ReduceScatter, "ncclReduceScatter");
-  RSYM(AllToAllv, "ncclAllToAllv");
-  RSYM(AllGather, "ncclAllGather");
   RSYM(GetErrorString, "ncclGetErrorString");
 #undef RSYM
+  // ncclAllToAllv is an RCCL extension only the optional class exchange of the PCA Gram uses: a library without it
+  // keeps every other multi-GPU path (tpg_comm_alltoall_usable then says no, on every rank alike -- same library)
+  *(void**)(&api.AllToAllv) = dlsym(api.handle, "ncclAllToAllv");
 }
 
 // several host threads (one context each) may ask at once: the loader runs once, the others wait for it
@@ -273,10 +273,14 @@ int tpg_comm_alltoallv64(tpg_comm* comm, const void* d_send, const size_t* scnt,
   }
   if (comm->host_fn) {
     std::vector<int32_t> cm((size_t)R * R, 0);
-    for (int d = 0; d < R; d++) {
-      TPG_REQUIRE(scnt[d] < (1ull << 30), TPG_EUNSUPPORTED, "rehearsal all-to-all too large");
-      cm[(size_t)me * R + d] = (int32_t)scnt[d];
-    }
+    auto sizes = [&]() -> int {
+      for (int d = 0; d < R; d++) {
+        TPG_REQUIRE(scnt[d] < (1ull << 30), TPG_EUNSUPPORTED, "rehearsal all-to-all too large");
+        cm[(size_t)me * R + d] = (int32_t)scnt[d];
+      }
+      return TPG_OK;
+    };
+    TPG_TRY(tpg_comm_agree(comm, sizes()));
     TPG_REQUIRE(comm->host_fn(comm->host_user, cm.data(), (int64_t)R * R, 0) == 0, TPG_EHIP, "the host all-reduce callback failed");
     std::vector<size_t> base((size_t)R + 1, 0);
     for (int d = 0; d < R; d++) {
@@ -284,16 +288,23 @@ int tpg_comm_alltoallv64(tpg_comm* comm, const void* d_send, const size_t* scnt,
       for (int r = 0; r < R; r++) in += (size_t)cm[(size_t)r * R + d];
       base[(size_t)d + 1] = base[(size_t)d] + in;
     }
-    for (int r = 0; r < R; r++) TPG_REQUIRE((size_t)cm[(size_t)r * R + me] == rcnt[r], TPG_EINVAL, "all-to-all counts do not match");
+    // everything that can fail on this rank alone between the two host all-reduces is checked first and AGREED on: a rank
+    // that bailed out here would leave the others blocked in the payload all-reduce (a condition variable, no timeout)
     const size_t total = base[(size_t)R];
-    TPG_REQUIRE(total < (1ull << 28), TPG_EUNSUPPORTED, "rehearsal all-to-all too large");
-    std::vector<uint64_t> H(total ? total : 1, 0);
-    for (int d = 0; d < R; d++) {
-      size_t o = base[(size_t)d];
-      for (int r = 0; r < me; r++) o += (size_t)cm[(size_t)r * R + d];
-      if (scnt[d]) TPG_HIP(hipMemcpyAsync(H.data() + o, (const uint64_t*)d_send + soff[d], 8 * scnt[d], hipMemcpyDeviceToHost, s));
-    }
-    TPG_HIP(hipStreamSynchronize(s));
+    std::vector<uint64_t> H;
+    auto local = [&]() -> int {
+      for (int r = 0; r < R; r++) TPG_REQUIRE((size_t)cm[(size_t)r * R + me] == rcnt[r], TPG_EINVAL, "all-to-all counts do not match");
+      TPG_REQUIRE(total < (1ull << 28), TPG_EUNSUPPORTED, "rehearsal all-to-all too large");
+      H.assign(total ? total : 1, 0);
+      for (int d = 0; d < R; d++) {
+        size_t o = base[(size_t)d];
+        for (int r = 0; r < me; r++) o += (size_t)cm[(size_t)r * R + d];
+        if (scnt[d]) TPG_HIP(hipMemcpyAsync(H.data() + o, (const uint64_t*)d_send + soff[d], 8 * scnt[d], hipMemcpyDeviceToHost, s));
+      }
+      TPG_HIP(hipStreamSynchronize(s));
+      return TPG_OK;
+    };
+    TPG_TRY(tpg_comm_agree(comm, local()));
     TPG_REQUIRE(comm->host_fn(comm->host_user, H.data(), (int64_t)(2 * total), 0) == 0, TPG_EHIP, "the host all-reduce callback failed");
     size_t o = base[(size_t)me];
     for (int r = 0; r < R; r++) {
@@ -305,6 +316,7 @@ int tpg_comm_alltoallv64(tpg_comm* comm, const void* d_send, const size_t* scnt,
   }
   RcclApi* api = rccl();
   TPG_REQUIRE(api && comm->nccl, TPG_EHIP, "communicator has no transport");
+  TPG_REQUIRE(api->AllToAllv, TPG_EUNSUPPORTED, "this librccl.so has no ncclAllToAllv");
   TPG_RCCL(api, api->AllToAllv(d_send, scnt, soff, d_recv, rcnt, roff, ncclUint64, (ncclComm_t)comm->nccl, s));
   return TPG_OK;
 }
@@ -316,6 +328,10 @@ int tpg_comm_alltoallv64(tpg_comm* comm, const void* d_send, const size_t* scnt,
 bool tpg_comm_alltoall_usable(tpg_comm* comm) {
   if (!comm) return false;
   if (comm->a2a_state != 0) return comm->a2a_state > 0;
+  if (comm->nccl && !comm->host_fn) {
+    RcclApi* api = rccl();
+    if (!api || !api->AllToAllv) { comm->a2a_state = -1; return false; }  // every rank loads the same library: alike everywhere
+  }
   const int R = comm->nranks, me = comm->rank, W = 4;
   std::vector<uint64_t> hs((size_t)R * W), hr((size_t)R * W, 0);
   std::vector<size_t> cnt((size_t)R, (size_t)W), off((size_t)R);
@@ -416,6 +432,9 @@ struct InprocGroup {
   int n = 0, arrived = 0, left = 0;
   uint64_t gen = 0;
   std::vector<void*> slot;
+  std::vector<int64_t> slot_count;
+  std::vector<int> slot_dtype;
+  bool bad = false;  // the ranks of the last exchange disagreed on count / type
   std::vector<uint8_t> acc;
 };
 struct InprocRank { InprocGroup* g; int rank; };
@@ -427,12 +446,21 @@ static int inproc_allreduce(void* user, void* buf, int64_t count, int dtype) {
   g->cv.wait(lk, [&] { return g->left == 0; });  // the previous exchange has been read by everybody
   const uint64_t my_gen = g->gen;
   g->slot[(size_t)me->rank] = buf;
+  g->slot_count[(size_t)me->rank] = count;
+  g->slot_dtype[(size_t)me->rank] = dtype;
   if (++g->arrived == g->n) {
-    const size_t es = dtype == 0 ? sizeof(int32_t) : sizeof(double);
-    g->acc.assign((size_t)count * es, 0);
-    for (int r = 0; r < g->n; r++) {
-      if (dtype == 0) { int32_t* a = (int32_t*)g->acc.data(); const int32_t* b = (const int32_t*)g->slot[(size_t)r]; for (int64_t i = 0; i < count; i++) a[i] += b[i]; }
-      else { double* a = (double*)g->acc.data(); const double* b = (const double*)g->slot[(size_t)r]; for (int64_t i = 0; i < count; i++) a[i] += b[i]; }
+    // the ranks must have passed the same count and type: anything else is reported to ALL of them (nothing is summed or
+    // copied past the end of a shorter buffer)
+    g->bad = false;
+    for (int r = 0; r < g->n; r++)
+      if (g->slot_count[(size_t)r] != count || g->slot_dtype[(size_t)r] != dtype) g->bad = true;
+    if (!g->bad) {
+      const size_t es = dtype == 0 ? sizeof(int32_t) : sizeof(double);
+      g->acc.assign((size_t)count * es, 0);
+      for (int r = 0; r < g->n; r++) {
+        if (dtype == 0) { int32_t* a = (int32_t*)g->acc.data(); const int32_t* b = (const int32_t*)g->slot[(size_t)r]; for (int64_t i = 0; i < count; i++) a[i] += b[i]; }
+        else { double* a = (double*)g->acc.data(); const double* b = (const double*)g->slot[(size_t)r]; for (int64_t i = 0; i < count; i++) a[i] += b[i]; }
+      }
     }
     g->arrived = 0;
     g->left = g->n;
@@ -441,9 +469,10 @@ static int inproc_allreduce(void* user, void* buf, int64_t count, int dtype) {
   } else {
     g->cv.wait(lk, [&] { return g->gen != my_gen; });
   }
-  memcpy(buf, g->acc.data(), g->acc.size());
+  const bool bad = g->bad;
+  if (!bad) memcpy(buf, g->acc.data(), g->acc.size());
   if (--g->left == 0) g->cv.notify_all();
-  return 0;
+  return bad ? 1 : 0;
 }
 
 struct tpg_multi {
@@ -482,6 +511,8 @@ extern "C" int tpg_multi_create(int ndev, const int* devices, tpg_multi** out) {
   if (ndev > 1 && host_transport) {
     mg->inproc.n = ndev;
     mg->inproc.slot.assign((size_t)ndev, nullptr);
+    mg->inproc.slot_count.assign((size_t)ndev, 0);
+    mg->inproc.slot_dtype.assign((size_t)ndev, 0);
     mg->inproc_rank.resize((size_t)ndev);
   } else if (ndev > 1) {
     RcclApi* api = rccl();

@@ -916,9 +916,13 @@ int tpg_gram_classes_exchanged(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, 
   // who sends how many loci to whom: row `me` of an R x R table, summed over the ranks
   {
     int32_t* d_cm = nullptr;
-    TPG_HIP(B.get(&d_cm, (size_t)R * R));
-    for (int d = 0; d < R; d++) cm[(size_t)me * R + d] = per_dest[(size_t)d];
-    TPG_HIP(tpg_h2d_async(ctx, d_cm, cm.data(), sizeof(int32_t) * (size_t)R * R));
+    auto cm_up = [&]() -> int {  // rank-local (an allocation, a copy): agreed on before the all-reduce like the steps above
+      TPG_HIP(B.get(&d_cm, (size_t)R * R));
+      for (int d = 0; d < R; d++) cm[(size_t)me * R + d] = per_dest[(size_t)d];
+      TPG_HIP(tpg_h2d_async(ctx, d_cm, cm.data(), sizeof(int32_t) * (size_t)R * R));
+      return TPG_OK;
+    };
+    TPG_TRY(tpg_comm_agree(comm, cm_up()));
     TPG_TRY(tpg_comm_allreduce(comm, d_cm, (int64_t)R * R, 0));
     TPG_HIP(hipMemcpyAsync(cm.data(), d_cm, sizeof(int32_t) * (size_t)R * R, hipMemcpyDeviceToHost, ctx->stream));
     TPG_HIP(hipStreamSynchronize(ctx->stream));

@@ -1802,11 +1802,19 @@ static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, 
   st.mark("frobenius + alloc K");
   // Several ranks: every rank takes whole weight classes (the packed columns are exchanged once, gramcls.hip) when that
   // pays -- decided alike on every rank --, otherwise the Gram matrix of its own loci.
-  bool exchanged = false;
-  if (exchange) TPG_TRY(tpg_gram_classes_exchanged(ctx, comm, v, d_counts, os.dev<double>(), d_K, &exchanged));
-  if (exchanged) TPG_TRY(pca_double_center_inplace(ctx, d_K, n));
-  // a failure of the Gram kernels themselves (launch error) is not rank-local in practice: same code, same shapes
-  else TPG_TRY(pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true));
+  // The Gram branch CAN fail on one rank alone (after the exchange a rank holds the loci of its classes, a different
+  // number on every rank: its allocations, the 2^31 limit of the class path, the pool) and what follows is an all-reduce
+  // RCCL never times out of: one status for the whole branch, agreed on before the triangle travels.  (Inside
+  // tpg_gram_classes_exchanged the ranks agree before each of ITS collectives; a failure there comes back alike everywhere.)
+  auto gram_branch = [&]() -> int {
+    bool exchanged = false;
+    if (exchange) TPG_TRY(tpg_gram_classes_exchanged(ctx, comm, v, d_counts, os.dev<double>(), d_K, &exchanged));
+    if (exchanged) return pca_double_center_inplace(ctx, d_K, n);
+    return pca_gram_device(ctx, v, oc.dev<double>(), os.dev<double>(), d_K, true);
+  };
+  int grc = gram_branch();
+  if (exchange) grc = tpg_comm_agree(comm, grc);
+  TPG_TRY(grc);
   st.mark("gram");
   if (exchange) {  // K = sum over the ranks' loci of z_j z_j'
     // only the upper triangle travels: n (n + 1) / 2 doubles instead of n^2 (K is symmetric bit for bit on every rank)
