@@ -756,7 +756,8 @@ def _parity_vs_oracle(st, fbm, K, ref, Kp, B):
     gid = (np.arange(n) % G).astype(np.int32)
     vv = api.View(X, None, None, code256=tpg.CODE_012)
     gf = np.zeros((B, 2 * G), order="F")
-    tpg._lib.check(st.lib.tpg_grouped_alt_freq_dip_pseudo(ctx.h, vv.h, api._ptr(gid), C.c_int(G), api._ptr(np.full(n, 2.0)),
+    pl = np.full(n, 2.0)  # kept alive across the call (a temporary's buffer may be gone by the time the library reads it)
+    tpg._lib.check(st.lib.tpg_grouped_alt_freq_dip_pseudo(ctx.h, vv.h, api._ptr(gid), C.c_int(G), api._ptr(pl),
                                                           C.c_int(0), api._ptr(gf)))
     vv.free()
     out["grouped_alt_freq_max_abs"] = float(np.nanmax(np.abs(gf - ref["gfreq"])))

@@ -57,7 +57,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        # TPG_ORACLE_SO: another build of the same source (tests/test_host_sanitizers.py: -fsanitize=address,undefined)
+        _lib = C.CDLL(os.environ.get("TPG_ORACLE_SO") or build())
         _lib.orc_square_frobenius.restype = C.c_double
         _lib.orc_pca_center_scale_gram.restype = C.c_int
     return _lib

@@ -1,0 +1,276 @@
+// tests/host/host_pieces.cpp -- self-checking driver for the host-only pieces of libtpg_hip.so (tidypopgen_amd/csrc/host/*.h),
+// built WITHOUT HIP by tests/test_host_sanitizers.py with -fsanitize=address,undefined and (the transport) -fsanitize=thread:
+// the CPU-side equivalent of the reference's valgrind job (.github/workflows/R-CMD-check-valgrind.yaml:50-51).
+//   host_pieces eig | bands | relfilter | inproc [threads] | inproc_mismatch
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#define TPG_HOST_NO_CLONES 1  // one plain build of the QL (function multiversioning and sanitizers do not mix everywhere)
+#include "host/host_bands.h"
+#include "host/host_eig.h"
+#include "host/host_inproc.h"
+#include "host/host_relfilter.h"
+
+static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
+static double urand() {  // splitmix64 -> [0, 1)
+  uint64_t x = (g_rng += 0x9E3779B97F4A7C15ull);
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+#define CHECK(cond, ...)                                    \
+  do {                                                      \
+    if (!(cond)) {                                          \
+      fprintf(stderr, "FAILED %s:%d: ", __FILE__, __LINE__); \
+      fprintf(stderr, __VA_ARGS__);                         \
+      fprintf(stderr, "\n");                                \
+      return 1;                                             \
+    }                                                       \
+  } while (0)
+
+// symmetric eigen-decomposition, Cholesky and triangular inverse at the sizes the eigen solver uses (b = 2 k + 12 <= 64)
+static int test_eig() {
+  for (int n : {1, 2, 3, 7, 32, 52, 64}) {
+    for (int kind = 0; kind < 3; kind++) {
+      std::vector<double> H((size_t)n * n);
+      for (int j = 0; j < n; j++)
+        for (int i = 0; i <= j; i++) {
+          double v = kind == 0 ? urand() - 0.5 : kind == 1 ? (i == j ? (double)(n - i) * 1e3 : 1e-3 * (urand() - 0.5)) : (i == j ? 1.0 : 0.0);
+          H[i + (size_t)j * n] = H[j + (size_t)i * n] = v;
+        }
+      std::vector<double> th, X;
+      host_sym_eig(H, n, th, X);
+      CHECK((int)th.size() == n && (int)X.size() == n * n, "sizes");
+      double hmax = 0;
+      for (double v : H) hmax = std::max(hmax, fabs(v));
+      for (int j = 0; j < n; j++) {
+        if (j) CHECK(th[j - 1] >= th[j], "eigenvalues not descending at %d (n = %d)", j, n);
+        double res = 0;
+        for (int i = 0; i < n; i++) {
+          double s = 0;
+          for (int k = 0; k < n; k++) s += H[i + (size_t)k * n] * X[k + (size_t)j * n];
+          res = std::max(res, fabs(s - th[j] * X[i + (size_t)j * n]));
+        }
+        CHECK(res <= 1e-12 * hmax * n, "residual %g (n = %d, kind %d, pair %d)", res, n, kind, j);
+        for (int l = 0; l <= j; l++) {
+          double dot = 0;
+          for (int k = 0; k < n; k++) dot += X[k + (size_t)j * n] * X[k + (size_t)l * n];
+          CHECK(fabs(dot - (l == j ? 1.0 : 0.0)) <= 1e-12 * n, "orthonormality %g (n = %d)", dot, n);
+        }
+      }
+    }
+    // G = B'B + I is positive definite: R'R = G, R Ri = I
+    std::vector<double> B((size_t)n * n), G((size_t)n * n, 0.0);
+    for (double& v : B) v = urand() - 0.5;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) {
+        double s = i == j ? 1.0 : 0.0;
+        for (int k = 0; k < n; k++) s += B[k + (size_t)i * n] * B[k + (size_t)j * n];
+        G[i + (size_t)j * n] = s;
+      }
+    std::vector<double> R = G, Ri;
+    CHECK(host_cholesky_upper(R, n), "cholesky refused a positive definite matrix (n = %d)", n);
+    host_upper_inverse(R, n, Ri);
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) {
+        double rr = 0, ri = 0;
+        for (int k = 0; k < n; k++) { rr += R[k + (size_t)i * n] * R[k + (size_t)j * n]; ri += R[i + (size_t)k * n] * Ri[k + (size_t)j * n]; }
+        CHECK(fabs(rr - G[i + (size_t)j * n]) <= 1e-12 * n, "R'R != G (n = %d)", n);
+        CHECK(fabs(ri - (i == j ? 1.0 : 0.0)) <= 1e-10 * n, "R Ri != I (n = %d): %g", n, ri);
+      }
+    std::vector<double> bad((size_t)n * n, 0.0);  // not positive definite: refused, no out-of-bounds access on the way
+    bad[0] = -1.0;
+    CHECK(!host_cholesky_upper(bad, n), "cholesky accepted an indefinite matrix");
+  }
+  return 0;
+}
+
+// bands: contiguous, cover every super-tile row once, every band fits the padded chunk
+static int test_bands() {
+  for (int64_t nst = 1; nst <= 70; nst++)
+    for (int nranks : {1, 2, 3, 4, 7, 8, 16, 64}) {
+      std::vector<int32_t> band;
+      int64_t chunk = -1;
+      pw_bands(nst, nranks, band, chunk);
+      CHECK((int)band.size() == nranks + 1 && band[0] == 0 && band[(size_t)nranks] == nst, "band ends (nst %lld, %d ranks)", (long long)nst, nranks);
+      auto off = [&](int64_t I) { return TPG_PW_TA * (I * nst - (I * (I - 1)) / 2); };
+      for (int r = 0; r < nranks; r++) {
+        CHECK(band[(size_t)r] <= band[(size_t)r + 1], "band %d runs backwards", r);
+        CHECK(off(band[(size_t)r + 1]) - off(band[(size_t)r]) <= chunk, "band %d does not fit its chunk", r);
+      }
+      CHECK(chunk >= 1 && chunk * nranks >= off(nst), "chunks do not hold all units");
+    }
+  return 0;
+}
+
+// the literal loop of R/filter_high_relatedness.R:55-137 (both means recomputed from scratch for every comparison, in
+// long double like R's mean()), against the incremental implementation
+static int literal_filter(const std::vector<double>& Ain, size_t N, double thr, std::vector<uint8_t>& keep) {
+  std::vector<double> A(Ain);
+  for (double& x : A) x = fabs(x);
+  std::vector<double> cm(N), col;
+  for (size_t j = 0; j < N; j++) {
+    col.clear();
+    for (size_t i = 0; i < N; i++)
+      if (i != j && A[i + j * N] == A[i + j * N]) col.push_back(A[i + j * N]);
+    cm[j] = r_mean_ld(col);
+  }
+  std::vector<int32_t> ord(N);
+  for (size_t j = 0; j < N; j++) ord[j] = (int32_t)j;
+  std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+    const double x = cm[(size_t)a], y = cm[(size_t)b];
+    const bool xn = x != x, yn = y != y;
+    if (xn || yn) return !xn && yn;
+    return x > y;
+  });
+  std::vector<double> M(N * N), M2;
+  for (size_t b = 0; b < N; b++)
+    for (size_t a = 0; a < N; a++) M[a + b * N] = A[(size_t)ord[a] + (size_t)ord[b] * N];
+  M2 = M;
+  for (size_t k = 0; k < N; k++) M2[k + k * N] = NAN;
+  std::vector<uint8_t> del(N, 0);
+  std::vector<double> tmp;
+  for (size_t i = 0; i + 1 < N; i++) {
+    bool any = false;
+    for (double x : M2) any |= (x == x && x > thr);
+    if (!any) break;
+    if (del[i]) continue;
+    for (size_t j = i + 1; j < N; j++) {
+      if (del[i] || del[j]) continue;
+      if (!(M[i + j * N] > thr)) continue;
+      tmp.clear();
+      for (size_t l = 0; l < N; l++) if (M2[i + l * N] == M2[i + l * N]) tmp.push_back(M2[i + l * N]);
+      const double mn1 = r_mean_ld(tmp);
+      tmp.clear();
+      for (size_t l = 0; l < N; l++)
+        for (size_t k = 0; k < N; k++) if (k != j && M2[k + l * N] == M2[k + l * N]) tmp.push_back(M2[k + l * N]);
+      const double mn2 = r_mean_ld(tmp);
+      const size_t d = mn1 > mn2 ? i : j;
+      del[d] = 1;
+      for (size_t k = 0; k < N; k++) { M2[d + k * N] = NAN; M2[k + d * N] = NAN; }
+    }
+  }
+  keep.assign(N, 0);
+  for (size_t k = 0; k < N; k++) keep[(size_t)ord[k]] = !del[k];
+  return 0;
+}
+
+static int test_relfilter() {
+  for (int rep = 0; rep < 40; rep++) {
+    const size_t N = 1 + (size_t)(urand() * 45);
+    std::vector<double> A(N * N);
+    for (size_t j = 0; j < N; j++)
+      for (size_t i = 0; i <= j; i++) {
+        double v = i == j ? 0.5 : (urand() < 0.15 ? 0.1 + 0.4 * urand() : 0.05 * (urand() - 0.5));
+        if (rep % 5 == 4 && i != j && urand() < 0.02) v = 0.25;  // ties
+        A[i + j * N] = A[j + i * N] = v;
+      }
+    const double thr = rep % 3 == 0 ? 0.2 : 0.0884;
+    std::vector<uint8_t> want, got(N, 7);
+    std::vector<int32_t> order(N, -1);
+    literal_filter(A, N, thr, want);
+    std::vector<double> Ac(A);
+    std::string err;
+    CHECK(tpg_host_filter_high_relatedness(Ac, (int64_t)N, thr, got.data(), order.data(), err) == 0, "filter failed: %s", err.c_str());
+    for (size_t k = 0; k < N; k++) CHECK(got[k] == want[k], "decision for individual %zu differs (rep %d, N = %zu)", k, rep, N);
+    std::vector<int> seen(N, 0);
+    for (size_t k = 0; k < N; k++) { CHECK(order[k] >= 0 && (size_t)order[k] < N, "order out of range"); seen[(size_t)order[k]]++; }
+    for (size_t k = 0; k < N; k++) CHECK(seen[k] == 1, "order is not a permutation");
+  }
+  {  // an NA among the compared relatednesses is R's error, not a crash
+    const size_t N = 5;
+    std::vector<double> A(N * N, 0.3);
+    A[1 + 0 * N] = A[0 + 1 * N] = NAN;
+    std::vector<uint8_t> keep(N);
+    std::string err;
+    const int rc = tpg_host_filter_high_relatedness(A, (int64_t)N, 0.2, keep.data(), nullptr, err);
+    CHECK(rc != 0 && err.find("missing value") != std::string::npos, "NA not reported: rc %d '%s'", rc, err.c_str());
+  }
+  return 0;
+}
+
+// R threads, many rounds of all-reduces of both types and changing sizes; every rank must see the exact sums every round
+static int test_inproc(int R) {
+  InprocGroup g;
+  g.n = R;
+  g.slot.assign((size_t)R, nullptr);
+  g.slot_count.assign((size_t)R, 0);
+  g.slot_dtype.assign((size_t)R, 0);
+  std::vector<InprocRank> ranks((size_t)R);
+  std::vector<int> fails((size_t)R, 0);
+  auto body = [&](int r) {
+    for (int round = 0; round < 300; round++) {
+      const int64_t count = 1 + (round * 37) % 513;
+      if (round & 1) {
+        std::vector<int32_t> b((size_t)count);
+        for (int64_t i = 0; i < count; i++) b[(size_t)i] = (int32_t)(r * 1000 + i + round);
+        if (inproc_allreduce(&ranks[(size_t)r], b.data(), count, 0) != 0) fails[(size_t)r]++;
+        for (int64_t i = 0; i < count; i++)
+          if (b[(size_t)i] != (int32_t)(1000 * (R * (R - 1) / 2) + R * (i + round))) fails[(size_t)r]++;
+      } else {
+        std::vector<double> b((size_t)count);
+        for (int64_t i = 0; i < count; i++) b[(size_t)i] = 0.5 * r + (double)i;
+        if (inproc_allreduce(&ranks[(size_t)r], b.data(), count, 1) != 0) fails[(size_t)r]++;
+        for (int64_t i = 0; i < count; i++)
+          if (b[(size_t)i] != 0.5 * (R * (R - 1) / 2) + (double)R * (double)i) fails[(size_t)r]++;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int r = 0; r < R; r++) { ranks[(size_t)r] = InprocRank{&g, r}; }
+  for (int r = 0; r < R; r++) th.emplace_back(body, r);
+  for (auto& t : th) t.join();
+  for (int r = 0; r < R; r++) CHECK(fails[(size_t)r] == 0, "rank %d saw %d wrong sums", r, fails[(size_t)r]);
+  return 0;
+}
+
+// ranks that disagree on the count: every one of them gets an error back, nobody reads past a shorter buffer, and the
+// group is usable afterwards
+static int test_inproc_mismatch() {
+  const int R = 3;
+  InprocGroup g;
+  g.n = R;
+  g.slot.assign((size_t)R, nullptr);
+  g.slot_count.assign((size_t)R, 0);
+  g.slot_dtype.assign((size_t)R, 0);
+  std::vector<InprocRank> ranks((size_t)R);
+  for (int r = 0; r < R; r++) ranks[(size_t)r] = InprocRank{&g, r};
+  std::vector<int> rc1((size_t)R, -1), rc2((size_t)R, -1);
+  std::vector<double> sums((size_t)R, 0);
+  auto body = [&](int r) {
+    std::vector<int32_t> a((size_t)(r == 1 ? 4 : 64), 1);
+    rc1[(size_t)r] = inproc_allreduce(&ranks[(size_t)r], a.data(), (int64_t)a.size(), 0);
+    std::vector<double> b(8, 1.0 + r);
+    rc2[(size_t)r] = inproc_allreduce(&ranks[(size_t)r], b.data(), 8, 1);
+    sums[(size_t)r] = b[7];
+  };
+  std::vector<std::thread> th;
+  for (int r = 0; r < R; r++) th.emplace_back(body, r);
+  for (auto& t : th) t.join();
+  for (int r = 0; r < R; r++) {
+    CHECK(rc1[(size_t)r] != 0, "rank %d did not see the mismatch", r);
+    CHECK(rc2[(size_t)r] == 0 && sums[(size_t)r] == 6.0, "group unusable after a mismatch (rank %d: rc %d, sum %g)", r, rc2[(size_t)r], sums[(size_t)r]);
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const std::string what = argc > 1 ? argv[1] : "";
+  int rc = 2;
+  if (what == "eig") rc = test_eig();
+  else if (what == "bands") rc = test_bands();
+  else if (what == "relfilter") rc = test_relfilter();
+  else if (what == "inproc") rc = test_inproc(argc > 2 ? atoi(argv[2]) : 4);
+  else if (what == "inproc_mismatch") rc = test_inproc_mismatch();
+  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | inproc [threads] | inproc_mismatch\n");
+  if (rc == 0) printf("ok %s\n", what.c_str());
+  return rc;
+}

@@ -27,7 +27,11 @@ def build(out_dir):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr)
-    lib = C.CDLL(out)
+    return bind(C.CDLL(out))
+
+
+def bind(lib):
+    """ctypes signatures of the mock runtime's helpers and of the few R API functions the tests call themselves"""
     vp = C.c_void_p
     for name, res, args in (("rmock_new_env", vp, []), ("rmock_env_set", None, [vp, C.c_char_p, vp]),
                             ("rmock_real", vp, [vp, C.c_ssize_t]), ("rmock_int", vp, [vp, C.c_ssize_t]),

@@ -415,29 +415,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
 
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
-// Bands: super-tile rows dealt to `nranks` ranks in contiguous runs of (nearly) equal unit counts (row I holds
-// TA (nst - I) units).  -> band boundaries and the padded chunk size (units) every band gets in the buffer.
-static void pw_bands(int64_t nst, int nranks, std::vector<int32_t>& band, int64_t& chunk) {
-  const int64_t total = TA * nst * (nst + 1) / 2;
-  band.assign((size_t)nranks + 1, (int32_t)nst);
-  band[0] = 0;
-  // boundary r = the row boundary whose cumulative unit count is nearest to r / nranks of the total
-  int64_t cum = 0;
-  int r = 1;
-  for (int64_t I = 0; I < nst && r < nranks; I++) {
-    const int64_t before = cum;
-    cum += TA * (nst - I);
-    while (r < nranks && cum * nranks >= total * r) {
-      const bool cut_before = (total * r - before * nranks) < (cum * nranks - total * r) && (int32_t)I > band[(size_t)r - 1];
-      band[(size_t)r] = (int32_t)(cut_before ? I : I + 1);
-      r++;
-    }
-  }
-  chunk = 0;
-  auto off = [&](int64_t I) { return TA * (I * nst - (I * (I - 1)) / 2); };
-  for (int q = 0; q < nranks; q++) chunk = std::max(chunk, off(band[(size_t)q + 1]) - off(band[(size_t)q]));
-  if (chunk < 1) chunk = 1;
-}
+#include "host/host_bands.h"  // pw_bands
 
 static size_t pw_buffer_bytes(int64_t n, int nranks) {
   const int64_t nst = ceil_div(n, 32 * TA);
@@ -1250,17 +1228,7 @@ extern "C" int tpg_block_means(tpg_ctx* ctx, const double* A, int64_t n, const i
 // grand total are kept up to date in long double, and a comparison whose two means are closer than 1e-12 relative is
 // recomputed literally -- R's two-pass long-double mean() over the same entries in the same order -- so the decisions
 // are R's.
-static double r_mean_ld(const std::vector<double>& x) {  // R's mean() of the non-NA values (summary.c, recalled)
-  const size_t n = x.size();
-  if (n == 0) return NAN;
-  long double s = 0;
-  for (double v : x) s += v;
-  s /= (long double)n;
-  long double t = 0;
-  for (double v : x) t += (long double)v - s;
-  s += t / (long double)n;
-  return (double)s;
-}
+#include "host/host_relfilter.h"  // r_mean_ld, tpg_host_filter_high_relatedness
 
 extern "C" int tpg_filter_high_relatedness(tpg_ctx* ctx, const double* matrix, int64_t n, double kings_threshold,
                                            uint8_t* keep, int32_t* new_order0) {
@@ -1276,97 +1244,9 @@ extern "C" int tpg_filter_high_relatedness(tpg_ctx* ctx, const double* matrix, i
   } else {
     memcpy(A.data(), matrix, sizeof(double) * N * N);
   }
-  if (n == 1) {  // :46-52
-    keep[0] = 1;
-    if (new_order0) new_order0[0] = 0;
-    return TPG_OK;
-  }
-  for (double& x : A) x = fabs(x);  // :55 (NaN stays NaN)
-  // :69-73 column means without the diagonal, R's mean(); order(decreasing = TRUE) is stable and puts NA last
-  std::vector<double> cm(N);
-  {
-    std::vector<double> col;
-    col.reserve(N);
-    for (size_t j = 0; j < N; j++) {
-      col.clear();
-      for (size_t i = 0; i < N; i++)
-        if (i != j && A[i + j * N] == A[i + j * N]) col.push_back(A[i + j * N]);
-      cm[j] = r_mean_ld(col);
-    }
-  }
-  std::vector<int32_t> ord(N);
-  for (size_t j = 0; j < N; j++) ord[j] = (int32_t)j;
-  std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
-    const double x = cm[(size_t)a], y = cm[(size_t)b];
-    const bool xn = x != x, yn = y != y;
-    if (xn || yn) return !xn && yn;  // NA last
-    return x > y;
-  });
-  std::vector<double> M(N * N);  // :76 matrix[order, order]
-  for (size_t b = 0; b < N; b++)
-    for (size_t a = 0; a < N; a++) M[a + b * N] = A[(size_t)ord[a] + (size_t)ord[b] * N];
-  std::vector<double>().swap(A);
-  // matrix2 = M with the diagonal (and the rows / columns of deleted individuals) set to NA, kept implicitly
-  std::vector<uint8_t> alive(N, 1);
-  std::vector<long double> rs(N, 0);
-  std::vector<int64_t> rc(N, 0);
-  long double S = 0;
-  int64_t C = 0, above = 0;
-  for (size_t l = 0; l < N; l++)
-    for (size_t k = 0; k < N; k++) {
-      const double x = M[k + l * N];
-      if (k == l || x != x) continue;
-      rs[k] += x;
-      rc[k]++;
-      if (x > kings_threshold) above++;
-    }
-  for (size_t k = 0; k < N; k++) { S += rs[k]; C += rc[k]; }
-  auto in_m2 = [&](size_t k, size_t l) { return k != l && alive[k] && alive[l] && M[k + l * N] == M[k + l * N]; };
-  std::vector<double> tmp;
-  for (size_t i = 0; i + 1 < N; i++) {  // :90
-    if (above == 0) break;              // :91-96 !any(matrix2 > threshold)
-    if (!alive[i]) continue;            // :97
-    for (size_t j = i + 1; j < N; j++) {
-      if (!alive[i] || !alive[j]) continue;  // :101
-      const double x = M[i + j * N];
-      TPG_REQUIRE(x == x, TPG_EINVAL, "missing value where TRUE/FALSE needed (relatedness of individuals %d and %d is NA)",
-                  ord[i] + 1, ord[j] + 1);
-      if (!(x > kings_threshold)) continue;  // :102
-      TPG_REQUIRE(rc[i] > 0 && C - rc[j] > 0, TPG_EINVAL, "missing value where TRUE/FALSE needed (empty mean)");
-      double mn1 = (double)(rs[i] / (long double)rc[i]);
-      double mn2 = (double)((S - rs[j]) / (long double)(C - rc[j]));
-      const double scale = std::max(fabs(mn1), fabs(mn2));
-      if (fabs(mn1 - mn2) <= 1e-12 * scale) {  // too close to call from running sums: R's own arithmetic, literally
-        tmp.clear();
-        for (size_t l = 0; l < N; l++)
-          if (in_m2(i, l)) tmp.push_back(M[i + l * N]);  // mean(matrix2[i, ], na.rm = TRUE), :103
-        mn1 = r_mean_ld(tmp);
-        tmp.clear();
-        for (size_t l = 0; l < N; l++)  // mean(matrix2[-j, ], na.rm = TRUE), :104: column-major walk without row j
-          for (size_t k = 0; k < N; k++)
-            if (k != j && in_m2(k, l)) tmp.push_back(M[k + l * N]);
-        mn2 = r_mean_ld(tmp);
-      }
-      const size_t d = mn1 > mn2 ? i : j;  // :119-131
-      // matrix2[d, ] <- NA; matrix2[, d] <- NA
-      for (size_t k = 0; k < N; k++) {
-        if (!in_m2(k, d)) continue;
-        const double c1 = M[k + d * N];  // column d, row k
-        rs[k] -= c1; rc[k]--;
-        S -= c1; C--;
-        if (c1 > kings_threshold) above--;
-      }
-      for (size_t l = 0; l < N; l++)
-        if (in_m2(d, l) && M[d + l * N] > kings_threshold) above--;  // row d
-      S -= rs[d]; C -= rc[d];
-      rs[d] = 0; rc[d] = 0;
-      alive[d] = 0;
-    }
-  }
-  for (size_t k = 0; k < N; k++) {
-    keep[(size_t)ord[k]] = alive[k];
-    if (new_order0) new_order0[k] = ord[k];
-  }
+  std::string err;
+  const int rc = tpg_host_filter_high_relatedness(A, n, kings_threshold, keep, new_order0, err);
+  TPG_REQUIRE(rc == 0, TPG_EINVAL, "%s", err.c_str());
   return TPG_OK;
 }
 
