@@ -75,13 +75,6 @@ __global__ void tpg_gcls_run_blocks_kernel(const uint32_t* __restrict__ counts, 
   }
 }
 
-__global__ void tpg_gcls_totals_kernel(const int* __restrict__ nruns, const uint32_t* __restrict__ blk_start,
-                                       const uint32_t* __restrict__ nblk, long long* __restrict__ totals) {
-  const int nr = nruns[0];
-  totals[0] = nr;
-  totals[1] = nr > 0 ? (long long)blk_start[nr - 1] + nblk[nr - 1] : 0;
-}
-
 __device__ __forceinline__ int tpg_gcls_find_run(const uint32_t* __restrict__ start, int nr, uint32_t x) {
   int lo = 0, hi = nr - 1;  // last r with start[r] <= x
   while (lo < hi) {
@@ -89,6 +82,62 @@ __device__ __forceinline__ int tpg_gcls_find_run(const uint32_t* __restrict__ st
     if (start[mid] <= x) lo = mid; else hi = mid - 1;
   }
   return lo;
+}
+
+// Groups of neighbouring classes (the mixed-precision fold, see tpg_gcls_block_table2_kernel) for the one-wave-per-SIMD
+// kernel: a group must END on a multiple of `body` blocks, so that its FP64 fold only ever falls between two bodies of the
+// kernel's unrolled loop.  Group ends are a property of the classes alone (key prefix, position in the run of classes), so
+// every group starts on a multiple of `body` if all before it do, and the padding of a group is its own size rounded up:
+// the last class of every group gets the extra (empty) blocks.  sblk[r] = blocks reserved for class r, ge[r] = last of its group.
+__global__ void tpg_gcls_group_pad_kernel(const unsigned long long* __restrict__ ukeys, const int* __restrict__ nruns, int64_t m,
+                                          const uint32_t* __restrict__ nblk, int gmax, int gq, int body,
+                                          uint32_t* __restrict__ sblk, uint8_t* __restrict__ ge) {
+  const int nr = nruns[0];
+  auto group_end = [&](int r) {
+    return r == nr - 1 || (ukeys[r] >> (52 - gq)) != (ukeys[r + 1] >> (52 - gq)) || (r % gmax) == gmax - 1;
+  };
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x) {
+    if (r >= nr) { sblk[r] = 0; ge[r] = 0; continue; }
+    const bool e = group_end((int)r);
+    uint32_t tot = nblk[r];
+    if (e && body > 1) {
+      for (int q = (int)r - 1; q >= 0 && !group_end(q); q--) tot += nblk[q];  // at most gmax classes
+      sblk[r] = nblk[r] + (uint32_t)((body - (int)(tot % (uint32_t)body)) % body);
+    } else {
+      sblk[r] = nblk[r];
+    }
+    ge[r] = e ? 1 : 0;
+  }
+}
+
+// Block table of tpg_gcls_gram3_kernel over the padded layout: entry as in tpg_gcls_block_table2_kernel (x = weight | flags,
+// y = bits of (float)(w_c - w_{c+1})); flag 1 = last block of a class that is not the last of its group; flag 2 = FP64 fold
+// after this block -- the last (possibly empty) block of a group, or a block whose index is GCLS3_GRUN - 1 modulo GCLS3_GRUN
+// (integer sums stay exact: 4 * 64 * 16 320 < 2^23): always the last block of a body, GCLS3_GRUN being a multiple of 8, 10, 12.
+#define GCLS3_GRUN 16320
+__global__ void tpg_gcls_block_table3_kernel(const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ blk_start,
+                                             const uint32_t* __restrict__ nblk, const uint32_t* __restrict__ sblk,
+                                             const uint8_t* __restrict__ ge, int nr, int64_t nblocks, ulonglong2* __restrict__ wblk) {
+  for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < nblocks; b += (int64_t)gridDim.x * blockDim.x) {
+    const int r = tpg_gcls_find_run(blk_start, nr, (uint32_t)b);
+    const uint32_t o = (uint32_t)b - blk_start[r];
+    const bool full = (ge[r] && o + 1 == sblk[r]) || (b % GCLS3_GRUN) == GCLS3_GRUN - 1;
+    const bool class_end = !ge[r] && o + 1 == nblk[r];
+    ulonglong2 e;
+    e.x = ukeys[r] | (full ? 2ull : class_end ? 1ull : 0ull);
+    e.y = 0;
+    if (class_end && !full)
+      e.y = (unsigned long long)__float_as_uint(
+          (float)(__longlong_as_double((long long)ukeys[r]) - __longlong_as_double((long long)ukeys[r + 1])));
+    wblk[b] = e;
+  }
+}
+
+__global__ void tpg_gcls_totals_kernel(const int* __restrict__ nruns, const uint32_t* __restrict__ blk_start,
+                                       const uint32_t* __restrict__ nblk, long long* __restrict__ totals) {
+  const int nr = nruns[0];
+  totals[0] = nr;
+  totals[1] = nr > 0 ? (long long)blk_start[nr - 1] + nblk[nr - 1] : 0;
 }
 
 // sorted element i -> its slot in the padded layout; the class weight goes back to the locus (what)
@@ -393,6 +442,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef GCLS2_D
 #define GCLS2_D 2
 #endif
+// VT: the block table through one vector load per loop body + v_readlane_b32 instead of one scalar load per block (see 3c)
+template <bool VT>
 __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __restrict__ T2g, int64_t nblocks, int64_t rs2, int nrtv,
                                                                 const ulonglong2* __restrict__ wblk,
                                                                 const int2* __restrict__ order, int64_t nun, int S,
@@ -453,7 +504,26 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
       int st = 0;  // 2: the class end before this block is still to be folded
       float pdelta = 0.f;
       ulonglong2 wf_next = wblk[2 * p0];
+      typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+      auto LDT = [&](int64_t first_block) {  // lane l: the table entry of block first_block + l (three dwords: x, low half of y)
+        const int64_t bb = first_block + lane;
+        return *(const v3u*)(wblk + (bb < bl ? bb : bl));
+      };
+      v3u TB = {0, 0, 0};
+      if constexpr (VT) TB = LDT(2 * p0);
+      uint32_t tx0[2 * GCLS2_D], tx1[2 * GCLS2_D], ty0[2 * GCLS2_D];
       for (int64_t pp = p0; pp < p1; pp += GCLS2_D) {
+        if constexpr (VT) {
+#pragma unroll
+          for (int k = 0; k < 2 * GCLS2_D; k++) {
+            tx0[k] = (uint32_t)__builtin_amdgcn_readlane((int)TB[0], k);
+            tx1[k] = (uint32_t)__builtin_amdgcn_readlane((int)TB[1], k);
+            ty0[k] = (uint32_t)__builtin_amdgcn_readlane((int)TB[2], k);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          TB = LDT(2 * (pp + GCLS2_D));
+          __builtin_amdgcn_sched_barrier(0);
+        }
         tpg_static_for<GCLS2_D>([&](auto cc) {
           constexpr int C = decltype(cc)::value, M = (C + GCLS2_D - 1) % GCLS2_D;
           const int64_t pr = pp + C;
@@ -466,8 +536,14 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
             for (int hb = 0; hb < 2; hb++) {
               const int64_t b = 2 * pr + hb;
               if (b < bend) {
-                const ulonglong2 wf = wf_next;
-                wf_next = wblk[b < bl ? b + 1 : bl];
+                ulonglong2 wf;
+                if constexpr (VT) {
+                  wf.x = ((unsigned long long)tx1[2 * C + hb] << 32) | tx0[2 * C + hb];
+                  wf.y = ty0[2 * C + hb];
+                } else {
+                  wf = wf_next;
+                  wf_next = wblk[b < bl ? b + 1 : bl];
+                }
                 v4u X[GA + GB];
 #pragma unroll
                 for (int t = 0; t < GA + GB; t++) {
@@ -530,6 +606,195 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
     for (int p = 0; p < GP; p++)
 #pragma unroll
       for (int i = 0; i < 16; i++) slab[(p * 16 + i) * 64] = p < 2 ? o[p][i] : olds[((p - 2) * 16 + i) * 64];
+  }
+}
+
+// 3c. the mixed-precision fold at ONE wave per SIMD, built like the pairwise kernel (pairwise.hip): what two waves per SIMD
+// buy the kernel above is that one wave's loads and folds hide behind the other's MFMAs -- with ONE block pair of prefetch
+// each (a third operand slot does not fit 256 registers beside three sets of sums), which leaves the MFMA pipe 28 % busy
+// and the waves waiting for operands 29 % of the time.  Here a wave has the whole register file of its SIMD and nobody to
+// hide behind, so everything is explicit:
+//   * operands go through NS rotating register slots (one 16-byte load per lane = a PAIR of blocks), fetched NS - 1 pairs
+//     ahead of their use; the prologue issues them slot by slot (sched_barrier) so that hipcc's wait-count pass, which merges
+//     the loop entry with the back edge, does not put a vmcnt(0) at the top of every loop body (pairwise.hip);
+//   * the 2-bit -> FP4 expansion of block b + 1 is done while the MFMAs of block b issue (an MFMA whose operands were
+//     written by the VALU just before it waits for them: tools/ubench_mfma_dep.hip);
+//   * a class end is not folded when its last block has been issued -- that would wait for its MFMAs to drain -- but as
+//     the first thing of the NEXT block;
+//   * group ends fall between two bodies of the unrolled loop by construction (tpg_gcls_group_pad_kernel pads every group to
+//     a multiple of 2 NS blocks), so the FP64 fold exists once, not in every step, and the steps have two variants only;
+//   * the FP64 result lives in LDS (32 KiB per wave, 128 KiB per workgroup, one workgroup per CU): touched at group
+//     ends only, and an LDS read-modify-write is cheaper than moving 128 registers through AGPRs;
+//   * the block table comes through ONE vector load per body, issued a body ahead and taken apart into SGPRs
+//     (v_readlane_b32) at the top of the body.  (Scalar loads return out of order, so each use is an s_waitcnt lgkmcnt(0):
+//     with one wave per SIMD a full scalar-load latency per block -- 1 750 cycles per block, 44 ms, measured; a load under a
+//     condition, or a loaded register copied into another, makes hipcc drain every load in flight.)
+// Slabs and the assemble pass are those of the kernel above; K ranges start on multiples of NS pairs.
+#define GCLS3_LDS_BYTES (4 * GP * 16 * 64 * 8)
+template <int NS>
+__global__ __launch_bounds__(256, 1) void tpg_gcls_gram3_kernel(const uint4* __restrict__ T2g, int64_t nblocks, int64_t rs2, int nrtv,
+                                                                   const ulonglong2* __restrict__ wblk,
+                                                                   const int2* __restrict__ order, int64_t nun, int S,
+                                                                   double* __restrict__ slabs) {
+  extern __shared__ double olds_raw[];  // [wave][tile][register][lane]
+  constexpr int NT = GA + GB, BODY = 2 * NS;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* olds = olds_raw + (size_t)wv * (GP * 16 * 64) + lane;
+  const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+  const int64_t nbodies = (nblocks + BODY - 1) / BODY;
+  for (int64_t round = 0;; round++) {
+    const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
+    if (un >= nun * S) break;
+    const int ks = (int)(un / nun);
+    const int64_t u = un % nun;
+    const int2 ijv = order[u];
+    const int2 ij = make_int2(__builtin_amdgcn_readfirstlane(ijv.x), __builtin_amdgcn_readfirstlane(ijv.y));
+    // whole bodies (NS block pairs) per split
+    const int64_t p0 = tpg_uniform64(NS * ((nbodies * ks) / S)), p1 = tpg_uniform64(NS * ((nbodies * (ks + 1)) / S));
+    const int64_t bend = 2 * p1 < nblocks ? 2 * p1 : nblocks;  // blocks [2 p0, bend)
+    const uint4* pt[NT];
+#pragma unroll
+    for (int t = 0; t < GA; t++) pt[t] = T2g + ((int64_t)min(GA * ij.x + t, nrtv - 1) * rs2) * 64;
+#pragma unroll
+    for (int t = 0; t < GB; t++) pt[GA + t] = T2g + ((int64_t)min(GB * ij.y + t, nrtv - 1) * rs2) * 64;
+
+    v2f dev[GP][8];
+    v16f acc[GP];
+#pragma unroll
+    for (int p = 0; p < GP; p++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) { acc[p][i] = 0.f; olds[(p * 16 + i) * 64] = 0.0; }
+#pragma unroll
+      for (int i = 0; i < 8; i++) dev[p][i] = v2f{0.f, 0.f};
+    }
+    // out += w * sums + dev; sums and dev start again from zero.  Four elements at a time: the fold is rare, what matters is
+    // that it needs few registers (every temporary it holds is a register the steps lose to spills)
+    auto fold = [&](double w) {
+#pragma unroll
+      for (int p = 0; p < GP; p++)
+        tpg_static_for<4>([&](auto qq) {
+          constexpr int q = decltype(qq)::value;
+          double t[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) t[e] = olds[(p * 16 + 4 * q + e) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int i = 4 * q + e;
+            olds[(p * 16 + i) * 64] = __builtin_fma((double)acc[p][i], w, t[e]) + (double)dev[p][i >> 1][i & 1];
+            acc[p][i] = 0.f;
+          }
+          dev[p][2 * q] = v2f{0.f, 0.f};
+          dev[p][2 * q + 1] = v2f{0.f, 0.f};
+          __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    if (p0 < p1) {
+      const int64_t pl = (bend + 1) / 2 - 1, bl = bend - 1;  // last pair that holds a block, last block
+      v4u R[NS][NT];
+      auto LD = [&](const uint4* p) {
+        uint32_t off = (uint32_t)lane * 16u;
+        asm("" : "+v"(off));
+        return *(const v4u*)((const char*)p + off);
+      };
+      // lane l: the table entry of block first_block + l (past the range: the last block's)
+      // (three dwords: with a fourth, dead, register in the tuple hipcc parks the loads' lane offset in it and waits for
+      // the table load -- for every load in flight -- right after issuing it)
+      typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+      auto LDT = [&](int64_t first_block) {
+        const int64_t bb = first_block + lane;
+        return *(const v3u*)(wblk + (bb < bl ? bb : bl));
+      };
+      v3u TB = LDT(2 * p0);
+      __builtin_amdgcn_sched_barrier(0);
+      tpg_static_for<NS - 1>([&](auto dd) {
+        constexpr int d = decltype(dd)::value;
+        const int64_t pc = p0 + d < pl ? p0 + d : pl;
+#pragma unroll
+        for (int t = 0; t < NT; t++) R[d][t] = LD(pt[t] + pc * 64);
+        __builtin_amdgcn_sched_barrier(0);  // in this order (see above)
+      });
+      // FP4 operand words of one block: half hb of a slot; a block past the range gives zeros
+      auto expand = [&](const v4u& r, int hb, uint32_t m) {
+        const uint32_t w0 = r[2 * hb], w1 = r[2 * hb + 1];
+        return v4u{w0 & m, (w0 >> 2) & m, w1 & m, (w1 >> 2) & m};
+      };
+      v4u X[2][NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) X[0][t] = expand(R[0][t], 0, 0x33333333u);
+      bool pend = false;   // the block before ended a class inside its group: dev += pdelta * sums before this block's MFMAs
+      float pdelta = 0.f;  // w_c - w_{c+1}
+      uint32_t fl[BODY], dl[BODY], wlo = 0, whi = 0;  // this body's table entries, in SGPRs
+
+      auto step = [&](auto Cc, auto Hh, int64_t pr) {
+        constexpr int C = decltype(Cc)::value, hb = decltype(Hh)::value, cur = hb, nx = hb ^ 1;
+        constexpr int M = (C + NS - 1) % NS;                        // the slot the pair before this one left
+        constexpr int SN = hb == 0 ? C : (C + 1) % NS, HN = hb ^ 1;  // slot and half of the NEXT block
+        const int64_t b = 2 * pr + hb;
+        if constexpr (hb == 0) {
+          const int64_t pn = pr + NS - 1, pc = pn < pl ? pn : pl;
+#pragma unroll
+          for (int t = 0; t < NT; t++) R[M][t] = LD(pt[t] + pc * 64);
+        }
+        if (pend) {
+          const v2f dlt = v2f{pdelta, pdelta};
+#pragma unroll
+          for (int p = 0; p < GP; p++)
+            tpg_static_for<8>([&](auto ii) {
+              constexpr int i = decltype(ii)::value;
+              dev[p][i] = __builtin_elementwise_fma(dlt, __builtin_shufflevector(acc[p], acc[p], 2 * i, 2 * i + 1), dev[p][i]);
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t mn = b + 1 < bend ? 0x33333333u : 0u;
+#pragma unroll
+        for (int t = 0; t < NT; t++) X[nx][t] = expand(R[SN][t], HN, mn);
+#pragma unroll
+        for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2(X[cur][p / GB], X[cur][GA + p % GB], acc[p]);
+#pragma unroll
+        for (int q = 0; q < GP; q++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+          if (hb == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pend = (fl[2 * C + hb] & 1u) != 0 && b < bl;  // (the last block of the range is folded in FP64 below)
+        pdelta = __uint_as_float(dl[2 * C + hb]);
+      };
+      for (int64_t pp = p0; pp < p1; pp += NS) {
+        // this body's table entries -> SGPRs, then the load of the next body's into the same register
+#pragma unroll
+        for (int k = 0; k < BODY; k++) {
+          fl[k] = (uint32_t)__builtin_amdgcn_readlane((int)TB[0], k);
+          dl[k] = (uint32_t)__builtin_amdgcn_readlane((int)TB[2], k);
+        }
+        wlo = (uint32_t)__builtin_amdgcn_readlane((int)TB[0], BODY - 1);
+        whi = (uint32_t)__builtin_amdgcn_readlane((int)TB[1], BODY - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        TB = LDT(2 * (pp + NS));
+        __builtin_amdgcn_sched_barrier(0);
+        tpg_static_for<NS>([&](auto cc) {
+          step(cc, std::integral_constant<int, 0>{}, pp + decltype(cc)::value);
+          step(cc, std::integral_constant<int, 1>{}, pp + decltype(cc)::value);
+        });
+        // a group (or 16 320 blocks) ends with this body's last block: the FP64 fold, here and nowhere else
+        if ((wlo & 2u) && 2 * (pp + NS) - 1 < bl) {
+          fold(__longlong_as_double((long long)(((uint64_t)whi << 32) | (wlo & ~3u))));
+          pend = false;
+        }
+      }
+      // the end of the range: whatever the sums hold belongs to the class of the last block
+      {
+        const ulonglong2 e = wblk[bl];
+        fold(__longlong_as_double((long long)(e.x & ~3ull)));
+      }
+    }
+    double* slab = slabs + ((int64_t)ks * nun + u) * GCLS_SLAB + lane;
+#pragma unroll
+    for (int p = 0; p < GP; p++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) slab[(p * 16 + i) * 64] = olds[(p * 16 + i) * 64];
   }
 }
 
@@ -616,6 +881,16 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   const size_t t_bytes = std::max(t_sort, std::max(t_rle, t_scan));
   TPG_HIP(B.get((uint8_t**)&d_tmp, t_bytes));
   long long totals[2] = {0, 0};
+  // TPG_GRAM_KERNEL=3 / 4: the one-wave-per-SIMD form of the mixed fold with that many operand slots (tpg_gcls_gram3_kernel,
+  // a measured negative result kept for the A/B: 12.8 - 13.4 ms against 10.6 - 10.8): every group of classes is padded to
+  // whole bodies of its unrolled loop.  TPG_GRAM_KERNEL=1: the two-waves kernel with its block table by scalar loads.
+  const int kern3 = getenv("TPG_GRAM_KERNEL") ? atoi(getenv("TPG_GRAM_KERNEL")) : 0;
+  const int body = kern3 == 3 || kern3 == 4 ? 2 * kern3 : 0;
+  const int gmax = getenv("TPG_GRAM_GMAX") ? std::max(1, atoi(getenv("TPG_GRAM_GMAX"))) : GCLS_GMAX;
+  const int gq = getenv("TPG_GRAM_GQ") ? std::min(40, std::max(1, atoi(getenv("TPG_GRAM_GQ")))) : GCLS_GQ;
+  uint32_t* d_sblk = nullptr;
+  uint8_t* d_ge = nullptr;
+  TPG_HIP(B.get(&d_sblk, (size_t)m)); TPG_HIP(B.get(&d_ge, (size_t)m));
   {
     ProfScope ps(ctx, "gcls_classes");
     hipLaunchKernelGGL(tpg_gcls_keys_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_w, m, d_key, d_idx);
@@ -627,10 +902,13 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
                        (const int*)d_nruns, m, d_cnt, d_nblk);
     t = t_bytes;
     TPG_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, t, d_cnt, d_estart, (int)m, ctx->stream));
+    // blocks reserved per class: its own, plus (one-wave kernel) the padding that ends its group on a whole body
+    hipLaunchKernelGGL(tpg_gcls_group_pad_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const unsigned long long*)d_ukeys,
+                       (const int*)d_nruns, m, (const uint32_t*)d_nblk, gmax, gq, body, d_sblk, d_ge);
     t = t_bytes;
-    TPG_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, t, d_nblk, d_bstart, (int)m, ctx->stream));
+    TPG_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, t, d_sblk, d_bstart, (int)m, ctx->stream));
     hipLaunchKernelGGL(tpg_gcls_totals_kernel, dim3(1), dim3(1), 0, ctx->stream, (const int*)d_nruns,
-                       (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, d_totals);
+                       (const uint32_t*)d_bstart, (const uint32_t*)d_sblk, d_totals);
     TPG_HIP(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
   }
   TPG_HIP(hipStreamSynchronize(ctx->stream));
@@ -652,8 +930,8 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   const int64_t nun = (int64_t)order.size();
   int ncu8 = ctx->num_cu / 8 * 8;
   if (ncu8 < 8) ncu8 = 8;
-  const bool f64 = gcls_fold64(nruns, nblocks);
-  const int nblk_grid = 2 * ncu8;  // two workgroups per CU = two waves per SIMD
+  const bool f64 = body ? false : gcls_fold64(nruns, nblocks);
+  const int nblk_grid = body ? ncu8 : 2 * ncu8;  // two workgroups per CU = two waves per SIMD
   const int nwaves = 4 * nblk_grid;
   int S = 2;
   // + the sort, the gather (2.0 us per 1000 loci at n = 5 000: it scales with n m) and the assemble pass
@@ -690,11 +968,13 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
     if (f64)
       hipLaunchKernelGGL(tpg_gcls_block_table_kernel, dim3(256), dim3(256), 0, ctx->stream, (const unsigned long long*)d_ukeys,
                          (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks, d_wblk);
+    else if (body)
+      hipLaunchKernelGGL(tpg_gcls_block_table3_kernel, dim3(256), dim3(256), 0, ctx->stream, (const unsigned long long*)d_ukeys,
+                         (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (const uint32_t*)d_sblk, (const uint8_t*)d_ge,
+                         (int)nruns, nblocks, d_wblk2);
     else
       hipLaunchKernelGGL(tpg_gcls_block_table2_kernel, dim3(256), dim3(256), 0, ctx->stream, (const unsigned long long*)d_ukeys,
-                         (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks,
-                         getenv("TPG_GRAM_GMAX") ? std::max(1, atoi(getenv("TPG_GRAM_GMAX"))) : GCLS_GMAX,
-                         getenv("TPG_GRAM_GQ") ? std::min(40, std::max(1, atoi(getenv("TPG_GRAM_GQ")))) : GCLS_GQ, d_wblk2);
+                         (const uint32_t*)d_bstart, (const uint32_t*)d_nblk, (int)nruns, nblocks, gmax, gq, d_wblk2);
   }
   {
     const int64_t tasks = Q * rs2;
@@ -705,11 +985,26 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   if (f64)
     TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T2g, nblocks,
                rs2, nrtv, (const unsigned long long*)d_wblk, (const int2*)d_order, nun, S, d_slabs);
-  else
-  {
-    (void)hipFuncSetAttribute((const void*)tpg_gcls_gram2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
-    TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram2_kernel, dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
-               (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
+  else if (body) {
+    auto launch3 = [&](auto ns) {
+      constexpr int NS = decltype(ns)::value;
+      (void)hipFuncSetAttribute((const void*)tpg_gcls_gram3_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS3_LDS_BYTES);
+      TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram3_kernel<NS>, dim3((unsigned)nblk_grid), dim3(256), GCLS3_LDS_BYTES,
+                 (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
+    };
+    if (kern3 == 3) launch3(std::integral_constant<int, 3>{});
+    else launch3(std::integral_constant<int, 4>{});
+  } else {
+    // TPG_GRAM_KERNEL=1: the block table by scalar loads, one per block (rounds 2 and 3; A/B)
+    if (kern3 == 1) {
+      (void)hipFuncSetAttribute((const void*)tpg_gcls_gram2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
+      TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram2_kernel<false>, dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
+                 (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
+    } else {
+      (void)hipFuncSetAttribute((const void*)tpg_gcls_gram2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
+      TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram2_kernel<true>, dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
+                 (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
+    }
   }
   TPG_LAUNCH(ctx, "gcls_assemble", tpg_gcls_assemble_kernel, dim3((unsigned)std::min<int64_t>(nun, 4096)), dim3(256), 0,
              (const double*)d_slabs, (const int2*)d_order, nun, S, (int)n, d_K);
