@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "devfrag.h"
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define FST_NAN __longlong_as_double(0x7FF8000000000000ll)
 
@@ -425,17 +426,22 @@ __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64
                                                                double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int gs = GS ? GS : G;
-  // byte offsets inside the dynamic LDS block: staged {n, p, H, e} [l][g], then the table [A]
-  const uint32_t tab_b = (uint32_t)LB * gs * 32u;
+  // byte offsets inside the dynamic LDS block: staged {n, p} [l][g] and {H, e} [l][g] (16-byte entries: the pairs of a wave
+  // read consecutive populations, conflict-free at a 16-byte stride, two-way conflicts at 32), then the two tables [A]
+  const uint32_t sb_b = (uint32_t)LB * gs * 16u, tab_b = (uint32_t)LB * gs * 32u, tab2_b = tab_b + (uint32_t)(kmax + 1) * 16u;
   char* shb = (char*)sh;
   for (int A = threadIdx.x; A <= kmax; A += 256) {
     const double nt = 0.5 * (double)A, nb1 = 0.5 * nt - 1.0;
     const double r = 1.0 / nt, sv = 1.0 / nb1;  // nb1 = 0 (one individual per population): +inf, as the reference's 1 / 0
-    double* t = (double*)(shb + tab_b) + (size_t)A * FSTW_TAB;
+    // two tables of 16-byte entries, {t0, t1} and {t2, t3}: a 32-byte entry put the 30-odd entries a wave touches (the
+    // pairs' valid-allele counts differ by their missing genotypes) on FOUR bank positions, three conflict cycles per
+    // LDS instruction (rocprofv3 --pmc: SQ_LDS_BANK_CONFLICT 3.9e8 against SQ_ACTIVE_INST_LDS 1.3e8)
+    double* t = (double*)(shb + tab_b) + (size_t)A * 2;
     t[0] = r;
     t[1] = (0.5 * (nt - 1.0)) * r;
-    t[2] = (0.5 * nt) * sv;
-    t[3] = (0.25 * (nt * nt)) * sv;
+    double* t2 = (double*)(shb + tab2_b) + (size_t)A * 2;
+    t2[0] = (0.5 * nt) * sv;
+    t2[1] = (0.25 * (nt * nt)) * sv;
   }
   int pidx[PPT];
   uint32_t o1[PPT], o2[PPT];  // the pair's two populations
@@ -480,7 +486,8 @@ __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64
         const double vp = (double)(pn1[i] + 2 * pn2[i]) / vn, vh = (double)(2 * pn1[i]) / vn;  // 0 / 0 = NaN: no valid genotype
         const double ni = 0.5 * vn;
         const uint32_t q = (uint32_t)((idx / G) * gs + idx % G);
-        *(v4d*)(shb + q * 32u) = v4d{ni, vp, vh * ni, 1.0 / ni};
+        *(v2d*)(shb + q * 16u) = v2d{ni, vp};
+        *(v2d*)(shb + sb_b + q * 16u) = v2d{vh * ni, 1.0 / ni};
       }
     }
     __syncthreads();
@@ -489,16 +496,19 @@ __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
       if (pidx[k] >= P) continue;
-      const uint32_t a1 = o1[k] * 32u, a2 = o2[k] * 32u;
+      const uint32_t a1 = o1[k] * 16u, a2 = o2[k] * 16u;
       double sn = sum_num[k], sd = sum_den[k];
 #pragma unroll 4
       for (int l = 0; l < lmax; l++) {
 #pragma clang fp contract(fast)  // totals only (1e-11 of the exact sum is the contract here, not the reference's rounding)
         const uint32_t lo = (uint32_t)l * (uint32_t)gs;
-        const v4d s1 = *(const v4d*)(shb + a1 + lo * 32u), s2 = *(const v4d*)(shb + a2 + lo * 32u);  // {n, p, H, e}
+        const v2d s1a = *(const v2d*)(shb + a1 + lo * 16u), s2a = *(const v2d*)(shb + a2 + lo * 16u);                  // {n, p}
+        const v2d s1b = *(const v2d*)(shb + sb_b + a1 + lo * 16u), s2b = *(const v2d*)(shb + sb_b + a2 + lo * 16u);    // {H, e}
+        const v4d s1 = v4d{s1a[0], s1a[1], s1b[0], s1b[1]}, s2 = v4d{s2a[0], s2a[1], s2b[0], s2b[1]};
         // valid alleles of the pair = 2 (n1 + n2): an exact small integer in FP64 (an empty population has n = 0)
         const int A = min(__double2int_rz(2.0 * (s1[0] + s2[0])), kmax);
-        const v4d t = *(const v4d*)(shb + tab_b + (uint32_t)A * (FSTW_TAB * 8u));
+        const v2d ta = *(const v2d*)(shb + tab_b + (uint32_t)A * 16u), tb = *(const v2d*)(shb + tab2_b + (uint32_t)A * 16u);
+        const v4d t = v4d{ta[0], ta[1], tb[0], tb[1]};
         const double p_bar = fma(s2[1], s2[0], s1[1] * s1[0]) * t[0], h_bar = (s1[2] + s2[2]) * t[0];
         const double d = s1[1] - s2[1], d2 = d * d;
         const double half_s2 = (d2 * (s1[0] * s2[0])) * (t[0] * t[0]);
