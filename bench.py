@@ -484,13 +484,25 @@ def end_to_end(st):
     if path is None:
         return {"skipped": "no room for the backing file"}
     bed_path = None
+    def median_of(fn, *a, reps=3):
+        """the run with the median time of `reps` (transfers over PCIe from a shared host vary from run to run: on the
+        driver's box of round 3 the pipelined route took 0.336 s once where it takes 0.175 s)"""
+        runs = sorted((fn(*a) for _ in range(reps)), key=lambda r: r["seconds"])
+        mid = dict(runs[len(runs) // 2])
+        mid["seconds_all_runs"] = [r["seconds"] for r in runs]
+        return mid
+
     try:
-        ser = _e2e_serial(st, path)
+        ser = median_of(_e2e_serial, st, path)
         d_bk = st.pca_d.copy()
-        ovl = _e2e_overlapped(st, path)
-        out = {"value": ovl["value"], "unit": "SNP-genotypes/s", "seconds": ovl["seconds"],
-               "route": "bigstatsr .bk (1 byte per genotype, warm page cache) -> HBM in 8 locus blocks uploaded by a second "
-                        "thread / stream beside pack + accumulate -> all results in host memory",
+        ovl = median_of(_e2e_overlapped, st, path)
+        routes = {"serial": ("bigstatsr .bk (1 byte per genotype, warm page cache) -> HBM in one upload -> the step -> all "
+                             "results in host memory", ser),
+                  "overlapped": ("bigstatsr .bk (1 byte per genotype, warm page cache) -> HBM in 8 locus blocks uploaded by a "
+                                 "second thread / stream beside pack + accumulate -> all results in host memory", ovl)}
+        best = min(routes, key=lambda k_: routes[k_][1]["seconds"])
+        out = {"value": routes[best][1]["value"], "unit": "SNP-genotypes/s", "seconds": routes[best][1]["seconds"],
+               "route": routes[best][0], "best_bk_route": best, "statistic": "median of 3 runs per route; value = the faster .bk route",
                "overlapped": ovl, "serial": ser}
         if not st.args.no_dropin:
             try:
@@ -500,7 +512,7 @@ def end_to_end(st):
         os.remove(path)  # room for the .bed
         try:
             bed_path = _e2e_bed_file(st, os.path.dirname(path))
-            bed = _e2e_bed(st, bed_path)
+            bed = median_of(_e2e_bed, st, bed_path)
             # the .bed holds the imputed genotypes, so its PCA is the PCA of the .bk route (the pairwise statistics see
             # no missing genotype there, which is a different input: not compared)
             bed["pca_d_max_rel_diff_vs_bk_route"] = float(np.max(np.abs(st.pca_d / d_bk - 1))) if st.has_pca else None

@@ -658,7 +658,10 @@ static int view_create_impl(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* row
     // A pair is "the raw view of the pairwise statistics + the imputed view of the PCA": neither reads the 2-bit T
     // layout (the pairwise kernel reads T4, the class Gram its own sorted layout), so the pair is packed as L + T4 and
     // L; whoever does want T gets it from L (tpg_view_need_T).
-    if (!two) VHIP(tpg_pmalloc((void**)&v[k]->T, v[k]->bytes_each));
+    // A single RAW-byte view (code256 == NULL) is what the pairwise statistics alone ask for (increment_{ibs,king,as}_counts
+    // compare raw bytes, src/snp_ibs.cpp:47-54): it is packed as L + T4 too, which saves a stand-alone snp_ibs / snp_king /
+    // pairwise_grm call, and every block of an R driver loop, the T -> T4 pass (0.7 ms at 5 000 x 1 000 000).
+    if (!two && code256_a) VHIP(tpg_pmalloc((void**)&v[k]->T, v[k]->bytes_each));
     else if (k == 0) VHIP(tpg_pmalloc((void**)&v[k]->T4, 2 * v[k]->bytes_each));
     VHIP(tpg_pmalloc((void**)&v[k]->L, v[k]->bytes_each));
   }
