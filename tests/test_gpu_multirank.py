@@ -107,6 +107,11 @@ def test_multi_one_device_against_oracle():
     assert np.array_equal(sub["king"], orc.snp_king(fbm, rows, cols), equal_nan=True)
     with pytest.raises(tpg._lib.TpgError):
         mg.pairwise(fbm, None, np.array([m + 1], dtype=np.int32))
+    # only the cross-products the requested matrices need: {V, D} for the GRM alone, {V, D, A} for KING + GRM, {V, D, H} for IBS
+    assert np.array_equal(mg.pairwise(fbm, which=("grm",))["grm"], out["grm"], equal_nan=True)
+    kg = mg.pairwise(fbm, which=("king", "grm"))
+    assert np.array_equal(kg["king"], out["king"], equal_nan=True) and np.array_equal(kg["grm"], out["grm"], equal_nan=True)
+    assert np.array_equal(mg.pairwise(fbm, which=("ibs", "allele_sharing"))["ibs"], out["ibs"], equal_nan=True)
     mg.close()
 
 
@@ -127,16 +132,21 @@ def test_band_layout_of_many_ranks_on_one_gpu():
     cover = np.zeros((n, n), dtype=int)
     for r in range(W):
         comm = tpg.Comm.host(X.ctx, W, r, lambda a: a)  # identity "all-reduce": this rank's partials ARE the totals
-        sh = tpg.ShardedPairwise(comm, n)
-        sh.accumulate(v)
-        sh.reduce()
-        assert sh.band() == sharding.band_rows(n, W, r)
-        got = sh.epilogues(("ibs", "king", "allele_sharing"), m=m)
         mask = sharding.band_mask(n, W, r)
         cover += mask
-        for k in want:
-            assert np.array_equal(got[k][mask], want[k][mask], equal_nan=True), (r, k)
-            assert np.isnan(got[k][~mask]).all(), (r, k)  # nothing written outside the band
+        # the five-product kernel on odd ranks; on even ranks the product-set kernels, which fill the same band-padded slabs
+        runs = [(None, ("ibs", "king", "allele_sharing"))] if r % 2 else [(tpg.PW_FOR_KING, ("king", "allele_sharing")),
+                                                                         (tpg.PW_FOR_IBS, ("ibs",)), (tpg.PW_FOR_AS, ("allele_sharing",))]
+        for products, which in runs:
+            sh = tpg.ShardedPairwise(comm, n)
+            sh.accumulate(v, products=products)
+            sh.reduce()
+            assert sh.band() == sharding.band_rows(n, W, r)
+            got = sh.epilogues(which, m=m)
+            for k in which:
+                assert np.array_equal(got[k][mask], want[k][mask], equal_nan=True), (r, k)
+                assert np.isnan(got[k][~mask]).all(), (r, k)  # nothing written outside the band
+            sh.free()
         comm.close()
     assert cover.min() == 1 and cover.max() == 1
 
