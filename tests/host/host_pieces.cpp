@@ -1,7 +1,7 @@
 // tests/host/host_pieces.cpp -- self-checking driver for the host-only pieces of libtpg_hip.so (tidypopgen_amd/csrc/host/*.h),
 // built WITHOUT HIP by tests/test_host_sanitizers.py with -fsanitize=address,undefined and (the transport) -fsanitize=thread:
 // the CPU-side equivalent of the reference's valgrind job (.github/workflows/R-CMD-check-valgrind.yaml:50-51).
-//   host_pieces eig | bands | relfilter | inproc [threads] | inproc_mismatch
+//   host_pieces eig | bands | relfilter | nibpack | inproc [threads] | inproc_mismatch
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,6 +15,7 @@
 #include "host/host_bands.h"
 #include "host/host_eig.h"
 #include "host/host_inproc.h"
+#include "host/host_nibpack.h"
 #include "host/host_relfilter.h"
 
 static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
@@ -262,6 +263,29 @@ static int test_inproc_mismatch() {
   return 0;
 }
 
+// nibble pack (the packed FBM upload): every length and alignment around the 64-byte vector step, the OR of the input bytes
+static int test_nibpack() {
+  for (size_t n : {0, 2, 30, 62, 64, 66, 126, 128, 130, 4096, 4098, 100000}) {
+    for (int shift = 0; shift < 3; shift++) {
+      std::vector<uint8_t> in(n + 8), out(n / 2 + 8, 0xAA);
+      for (size_t i = 0; i < n; i++) in[shift + i] = (uint8_t)(urand() * 7);
+      const uint8_t seen = tpg_nibpack(in.data() + shift, out.data() + shift, n);
+      uint8_t want_seen = 0;
+      for (size_t i = 0; i < n; i++) want_seen |= in[shift + i];
+      CHECK(seen == want_seen && seen < 16, "OR of the input bytes: %u, want %u (n = %zu)", seen, want_seen, n);
+      for (size_t i = 0; i < n / 2; i++)
+        CHECK(out[shift + i] == (uint8_t)(in[shift + 2 * i] | (in[shift + 2 * i + 1] << 4)), "byte %zu of %zu", i, n / 2);
+      CHECK(out[shift + n / 2] == 0xAA, "wrote past the end (n = %zu)", n);
+      if (n >= 2) {  // one byte that does not fit a nibble, anywhere: reported
+        const size_t at = (size_t)(urand() * n);
+        in[shift + at] = (uint8_t)(16 + urand() * 200);
+        CHECK(tpg_nibpack(in.data() + shift, out.data() + shift, n) >= 16, "a byte >= 16 at %zu of %zu went unnoticed", at, n);
+      }
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "";
   int rc = 2;
@@ -270,7 +294,8 @@ int main(int argc, char** argv) {
   else if (what == "relfilter") rc = test_relfilter();
   else if (what == "inproc") rc = test_inproc(argc > 2 ? atoi(argv[2]) : 4);
   else if (what == "inproc_mismatch") rc = test_inproc_mismatch();
-  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | inproc [threads] | inproc_mismatch\n");
+  else if (what == "nibpack") rc = test_nibpack();
+  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | nibpack | inproc [threads] | inproc_mismatch\n");
   if (rc == 0) printf("ok %s\n", what.c_str());
   return rc;
 }

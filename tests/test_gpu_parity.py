@@ -98,6 +98,27 @@ def test_direct_bed_ingest(tpg):
     os.remove(tmp)
 
 
+def test_packed_upload_roundtrip(tpg, monkeypatch):
+    """Large FBMs cross PCIe as nibbles (host_nibpack.h + tpg_nib_expand_kernel) and arrive as the bytes they were: genotype
+    bytes 0 .. 6, odd sizes (an unpacked tail), and a chunk that holds a byte >= 16 (sent as it is)."""
+    rng = np.random.default_rng(5)
+    for nrow, ncol, spoil in ((8192, 9001, False), (5000, 14001, False), (8200, 9000, True)):
+        a = np.asfortranarray(rng.integers(0, 7, size=(nrow, ncol), dtype=np.uint8))
+        if spoil:
+            a[17, 3] = 200        # in the first chunk
+            a[nrow - 1, ncol - 1] = 16  # in the tail
+        X = tpg.FBM.from_numpy(a)
+        assert np.array_equal(X.to_numpy(), a)
+        X.free()
+    # the plain path gives the same device bytes
+    monkeypatch.setenv("TPG_UPLOAD_PACKED", "1")
+    a = np.asfortranarray(rng.integers(0, 4, size=(4096, 20000), dtype=np.uint8))
+    X = tpg.FBM.from_numpy(a)
+    f = tpg.loci_alt_freq(X, as_counts=True)
+    assert np.array_equal(f, orc.loci_alt_freq(a, as_counts=True))
+    X.free()
+
+
 def test_view_errors(tpg):
     X = tpg.FBM.from_numpy(orc.synth_fbm(1, 10, 20, npop=2))
     with pytest.raises(tpg._lib.TpgError):

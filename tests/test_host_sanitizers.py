@@ -4,7 +4,8 @@ AddressSanitizer is not available on the pool, and the host side is where thread
 a session table of mapped files and caches live:
 
   * tidypopgen_amd/csrc/host/*.h (the b x b eigen solver of the PCA, band arithmetic of the sharded pairwise slabs, the
-    greedy loop of filter_high_relatedness, the in-process all-reduce of tpg_multi_*) through tests/host/host_pieces.cpp,
+    greedy loop of filter_high_relatedness, the nibble pack of the FBM upload, the in-process all-reduce of tpg_multi_*)
+    through tests/host/host_pieces.cpp,
     with -fsanitize=address,undefined and, for the transport, -fsanitize=thread;
   * oracle/tpg_oracle.c with -fsanitize=address,undefined under its golden-vector tests;
   * shim/tpg_rshim.c + tests/rmock/rmock.c with -fsanitize=address,undefined against a host stand-in for the library
@@ -50,7 +51,7 @@ def pieces(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("what", ["eig", "bands", "relfilter", "inproc", "inproc_mismatch"])
+@pytest.mark.parametrize("what", ["eig", "bands", "relfilter", "nibpack", "inproc", "inproc_mismatch"])
 def test_host_pieces_under_address_and_undefined_sanitizers(pieces, what):
     r = _sh([pieces["asan"], what], env=ENV)
     assert r.stdout.strip() == f"ok {what}"

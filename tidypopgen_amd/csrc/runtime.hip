@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include "common.h"
+#include "host/host_nibpack.h"
 
 #include <mutex>
 #include <thread>
@@ -453,6 +454,115 @@ hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
   return hipSuccess;
 }
 
+// Nibbles -> bytes: dst[2 i] = src[i] & 15, dst[2 i + 1] = src[i] >> 4 (the other half of host_nibpack.h).  Sixteen packed
+// bytes in, thirty-two bytes out per thread and step, coalesced both ways.
+__global__ __launch_bounds__(256) void tpg_nib_expand_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 w = src[i];
+    const uint32_t in[4] = {w.x, w.y, w.z, w.w};
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t lo = in[k] & 0x0F0F0F0Fu, hi = (in[k] >> 4) & 0x0F0F0F0Fu;  // genotypes 0, 2, 4, 6 / 1, 3, 5, 7 of the dword
+      o[2 * k] = __builtin_amdgcn_perm(hi, lo, 0x05010400u);
+      o[2 * k + 1] = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+    }
+    dst[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+  }
+}
+
+// The same host -> device copy with the bytes PACKED to nibbles on the way (host_nibpack.h): the team of threads that
+// tpg_upload uses to fault the next chunk in packs it instead -- into one of two pinned buffers the context keeps -- while
+// the chunk before it is on its way and being expanded; half the bytes cross PCIe, out of pinned memory.  A chunk that
+// holds a byte >= 16 goes as it is.  TPG_UPLOAD_PACKED=0 switches it off.
+static constexpr size_t NIB_CHUNK = 256u << 20;  // input bytes per chunk: 128 MiB packed
+// Pinned staging (two halves of NIB_CHUNK / 2) belongs to the PROCESS, not to a context: pinning 256 MiB costs 35 - 40 ms,
+// which a context that lives for one call (the uploader thread of a pipeline, the device threads of tpg_multi_*) would pay
+// every time.  A buffer is taken for the length of one upload and handed back; concurrent uploads get one each.
+static std::mutex g_nib_mu;
+static std::vector<uint8_t*> g_nib_free;
+static uint8_t* nib_stage_acquire() {
+  {
+    std::lock_guard<std::mutex> lk(g_nib_mu);
+    if (!g_nib_free.empty()) { uint8_t* p = g_nib_free.back(); g_nib_free.pop_back(); return p; }
+  }
+  uint8_t* p = nullptr;
+  if (hipHostMalloc((void**)&p, NIB_CHUNK, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+static void nib_stage_release(uint8_t* p) {
+  std::lock_guard<std::mutex> lk(g_nib_mu);
+  g_nib_free.push_back(p);
+}
+
+static hipError_t tpg_upload_packed(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes) {
+  uint8_t* const pinned = nib_stage_acquire();
+  if (!pinned) return tpg_upload(ctx, dst, src, bytes);  // no pinned memory to be had: the plain copy
+  struct Back { uint8_t* p; ~Back() { nib_stage_release(p); } } back{pinned};
+  uint8_t* d_stage = nullptr;
+  hipError_t e = tpg_pmalloc((void**)&d_stage, NIB_CHUNK);  // two halves, like the pinned buffer
+  if (e != hipSuccess) return e;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+  bool used[2] = {false, false};
+  auto pack_chunk = [&](size_t a, size_t b, uint8_t* out) -> uint8_t {  // bytes [a, b) of src, b - a even
+    const size_t n = b - a, pages = (n + 4095) / 4096;
+    const int nth = (int)std::min<size_t>(XFER_THREADS, std::max<size_t>(1, pages / 256));
+    std::vector<uint8_t> seen((size_t)nth, 0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; t++) {
+      const size_t lo = std::min(n, pages * (size_t)t / (size_t)nth * 4096), hi = std::min(n, pages * ((size_t)t + 1) / (size_t)nth * 4096);
+      if (lo < hi) th.emplace_back([=, &seen]() { seen[(size_t)t] = tpg_nibpack(src + a + lo, out + lo / 2, hi - lo); });
+    }
+    for (auto& t : th) t.join();
+    uint8_t r = 0;
+    for (uint8_t x : seen) r |= x;
+    return r;
+  };
+  const size_t even = bytes & ~(size_t)31;  // whole 32-byte outputs of the expansion kernel; the tail goes as it is
+  int k = 0;
+  for (size_t a = 0; a < even && e == hipSuccess; a += NIB_CHUNK, k ^= 1) {
+    const size_t b = std::min(even, a + NIB_CHUNK);
+    uint8_t* pin = pinned + (size_t)k * (NIB_CHUNK / 2);
+    uint8_t* stg = d_stage + (size_t)k * (NIB_CHUNK / 2);
+    if (used[k]) e = hipEventSynchronize(ev[k]);  // the copy that last read this half of the pinned buffer is done
+    if (e != hipSuccess) break;
+    const uint8_t seen = pack_chunk(a, b, pin);   // ... while the other half is on its way
+    if (seen < 16) {
+      e = hipMemcpyAsync(stg, pin, (b - a) / 2, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipEventRecord(ev[k], ctx->stream);
+      used[k] = true;
+      if (e == hipSuccess) {
+        const int64_t n16 = (int64_t)((b - a) / 32);
+        const unsigned grid = (unsigned)std::min<int64_t>((n16 + 255) / 256, (int64_t)ctx->num_cu * 16);
+        hipLaunchKernelGGL(tpg_nib_expand_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)stg, (uint4*)(dst + a), n16);
+        e = hipGetLastError();
+      }
+    } else {  // bytes that do not fit a nibble: this chunk as it is
+      e = hipMemcpyAsync(dst + a, src + a, b - a, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+  }
+  if (e == hipSuccess && even < bytes) e = hipMemcpyAsync(dst + even, src + even, bytes - even, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  else (void)hipStreamSynchronize(ctx->stream);
+  for (int q = 0; q < 2; q++)
+    if (ev[q]) (void)hipEventDestroy(ev[q]);
+  tpg_pfree(d_stage);
+  return e;
+}
+
+// bulk FBM bytes: packed on the way when that can pay (large, 16-byte aligned destination) and is not switched off
+static hipError_t tpg_upload_fbm_bytes(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes) {
+  static const bool off = getenv("TPG_UPLOAD_PACKED") && atoi(getenv("TPG_UPLOAD_PACKED")) == 0;
+  if (!off && bytes >= XFER_BIG && (((uintptr_t)dst) & 15) == 0) {
+    ProfScope ps(ctx, "upload_packed");
+    return tpg_upload_packed(ctx, dst, src, bytes);
+  }
+  return tpg_upload(ctx, dst, src, bytes);
+}
+
 extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, tpg_fbm** out) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && bytes && out, TPG_EINVAL, "null argument");
@@ -465,7 +575,7 @@ extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nro
   f->pooled = sz <= ((size_t)1 << 30);
   hipError_t e = f->pooled ? tpg_pmalloc((void**)&f->d_bytes, sz) : hipMalloc((void**)&f->d_bytes, sz);
   if (e != hipSuccess) { delete f; tpg_set_error("device allocation of %zu bytes failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
-  e = tpg_upload(ctx, f->d_bytes, bytes, sz);
+  e = tpg_upload_fbm_bytes(ctx, f->d_bytes, bytes, sz);
   if (e != hipSuccess) { tpg_fbm_free(f); tpg_set_error("FBM upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
   *out = f;
   return TPG_OK;
@@ -492,7 +602,7 @@ extern "C" int tpg_fbm_upload_cols(tpg_ctx* ctx, tpg_fbm* fbm, const uint8_t* ho
   TPG_REQUIRE(fbm->bed_bpl == 0, TPG_EUNSUPPORTED, "a .bed store is uploaded as a whole");
   TPG_REQUIRE(col0 >= 0 && ncols >= 0 && col0 + ncols <= fbm->ncol, TPG_EINVAL, "columns [%lld, %lld) outside the FBM",
               (long long)col0, (long long)(col0 + ncols));
-  TPG_HIP(tpg_upload(ctx, fbm->d_bytes + (size_t)col0 * (size_t)fbm->nrow, host_cols, (size_t)ncols * (size_t)fbm->nrow));
+  TPG_HIP(tpg_upload_fbm_bytes(ctx, fbm->d_bytes + (size_t)col0 * (size_t)fbm->nrow, host_cols, (size_t)ncols * (size_t)fbm->nrow));
   return TPG_OK;
 }
 
