@@ -243,6 +243,7 @@ def _e2e_file(st):
             if s.f_bavail * s.f_frsize > need:
                 path = os.path.join(cand, f"tpg_bench_{os.getpid()}.bk")
                 st.X.to_numpy().T.tofile(path)  # column-major n x m bytes == row-major (m, n)
+                os.sync()  # the file is "in the page cache, clean": its write-back must not run beside the timed uploads
                 return path
         except (OSError, MemoryError):
             pass

@@ -120,6 +120,7 @@ __host__ __device__ __forceinline__ int64_t tpg_pw_unit_index(int nst, int I, in
 #define SGB_MFMA 0x008
 #define SGB_VALU 0x002
 #define SGB_VMEM_READ 0x020
+template <int NG>  // rotating load slots of one 128-locus group each: NG - 1 groups of prefetch (3 = rounds 2 and 3)
 __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __restrict__ T4, int64_t KG,
                                                                  int64_t kg_begin, int64_t kg_end, int nst, int nct,
                                                                  const int2* __restrict__ order, int64_t nun, int S,
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       // prefetch distance to one group.  Groups past k1 run with zero A planes.
       // native vectors, not HIP's uint4 struct: with the struct the register allocator splits the loaded tuple right
       // after the load (v_mov behind an s_waitcnt vmcnt: a full memory latency at the top of every group)
-      v4u RA[3][TA][2], RB[3][2];
+      v4u RA[NG][TA][2], RB[NG][2];
       // wave-uniform base (SGPRs) + one 32-bit lane offset: global_load_dwordx4 v, v_off, s[base]; the empty asm keeps
       // hipcc from folding the lane into loop-invariant 64-bit VGPR pointers (a v_lshl_add_u64 per load)
       auto LD = [&](const uint4* p) {
@@ -178,13 +179,16 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
         asm("" : "+v"(off));
         return *(const v4u*)((const char*)p + off);
       };
-      const int64_t i1 = k0 + 1 < k1 ? k0 + 1 : kl;
 #pragma unroll
-      for (int s = 0; s < 2; s++) {
+      for (int g = 0; g < NG - 1; g++) {
+        const int64_t ig = k0 + g < k1 ? k0 + g : kl;
 #pragma unroll
-        for (int t = 0; t < TA; t++) { RA[0][t][s] = LD(pa[t] + (k0 * 2 + s) * 64); RA[1][t][s] = LD(pa[t] + (i1 * 2 + s) * 64); }
-        RB[0][s] = LD(pb0 + (k0 * 2 + s) * 64);
-        RB[1][s] = LD(pb0 + (i1 * 2 + s) * 64);
+        for (int s = 0; s < 2; s++) {
+#pragma unroll
+          for (int t = 0; t < TA; t++) RA[g][t][s] = LD(pa[t] + (ig * 2 + s) * 64);
+          RB[g][s] = LD(pb0 + (ig * 2 + s) * 64);
+        }
+        if (NG > 3) __builtin_amdgcn_sched_barrier(0);  // slot by slot (see tpg_pairwise_set_kernel)
       }
       Frag3 P[2][TA + 1];
 #pragma unroll
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       P[0][TA] = tpg_planes(RB[0][0], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
       auto group = [&](auto Cc, auto Nn, auto Mm, int64_t kg) {
         constexpr int C = decltype(Cc)::value, N = decltype(Nn)::value, M = decltype(Mm)::value;
-        const int64_t i2 = kg + 2 < k1 ? kg + 2 : kl;
+        const int64_t i2 = kg + NG - 1 < k1 ? kg + NG - 1 : kl;
         const bool live = kg < k1, live1 = kg + 1 < k1;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
@@ -233,10 +237,20 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
-      for (int64_t kg = k0; kg < k1; kg += 3) {
-        group(I0{}, I1{}, I2{}, kg);
-        group(I1{}, I2{}, I0{}, kg + 1);
-        group(I2{}, I0{}, I1{}, kg + 2);
+      using I3 = std::integral_constant<int, 3>;
+      if constexpr (NG == 3) {
+        for (int64_t kg = k0; kg < k1; kg += 3) {
+          group(I0{}, I1{}, I2{}, kg);
+          group(I1{}, I2{}, I0{}, kg + 1);
+          group(I2{}, I0{}, I1{}, kg + 2);
+        }
+      } else {
+        for (int64_t kg = k0; kg < k1; kg += 4) {
+          group(I0{}, I1{}, I3{}, kg);
+          group(I1{}, I2{}, I0{}, kg + 1);
+          group(I2{}, I3{}, I1{}, kg + 2);
+          group(I3{}, I0{}, I2{}, kg + 3);
+        }
       }
     }
     // the accumulators hold integers (|sum| <= loci of the K range <= 2^24): exact in int32
@@ -658,6 +672,12 @@ static int pw_launch_set(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int6
   return TPG_OK;
 }
 
+// wave tile and slot count per product set; TPG_PW_VARIANT=<k> picks another instantiation (A/B runs, tools/pw_only.py)
+static int pw_variant() {
+  const char* e = getenv("TPG_PW_VARIANT");
+  return e ? atoi(e) : 0;
+}
+
 static int pw_launch_all(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t kg0, int64_t kg1) {
   // K split S: units x S wave-units over the resident waves (one workgroup per CU, one wave per SIMD; a multiple of
   // the 8 XCDs), at least 8 K groups (1024 loci) per unit.  Cost model: rounds(S) = ceil(units S / waves) rounds, a
@@ -675,17 +695,16 @@ static int pw_launch_all(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int6
     const int64_t kgs = c1 - c0;
     const int bestS = pw_ksplit(pw->nun, kgs, 8, ceil_div(kgs, max_groups), nwaves, 0.55, 12.0);
     if (getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] pairwise: %lld units, S = %d\n", (long long)pw->nun, bestS);
-    TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T4, v->KG,
-               c0, c1, (int)pw->nst, (int)ceil_div(pw->n, 32), (const int2*)pw->order, pw->nun, bestS,
-               (const int64_t*)pw->rowpad, pw->acc);
+    if (pw_variant() == 2)  // A/B: three groups of prefetch
+      TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T4, v->KG,
+                 c0, c1, (int)pw->nst, (int)ceil_div(pw->n, 32), (const int2*)pw->order, pw->nun, bestS,
+                 (const int64_t*)pw->rowpad, pw->acc);
+    else
+      TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T4, v->KG,
+                 c0, c1, (int)pw->nst, (int)ceil_div(pw->n, 32), (const int2*)pw->order, pw->nun, bestS,
+                 (const int64_t*)pw->rowpad, pw->acc);
   }
   return TPG_OK;
-}
-
-// wave tile and slot count per product set; TPG_PW_VARIANT=<k> picks another instantiation (A/B runs, tools/pw_only.py)
-static int pw_variant() {
-  const char* e = getenv("TPG_PW_VARIANT");
-  return e ? atoi(e) : 0;
 }
 
 extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,
