@@ -502,7 +502,7 @@ static hipError_t tpg_upload_packed(tpg_ctx* ctx, uint8_t* dst, const uint8_t* s
   struct Back { uint8_t* p; ~Back() { nib_stage_release(p); } } back{pinned};
   uint8_t* d_stage = nullptr;
   hipError_t e = tpg_pmalloc((void**)&d_stage, NIB_CHUNK);  // two halves, like the pinned buffer
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess) { (void)hipGetLastError(); return tpg_upload(ctx, dst, src, bytes); }  // HBM is that full: the plain copy
   hipEvent_t ev[2] = {nullptr, nullptr};
   for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
   bool used[2] = {false, false};
