@@ -63,6 +63,9 @@ int tpg_ctx_sync(tpg_ctx* ctx);
 /* per-kernel HIP-event timing (on the context's stream) */
 int tpg_prof_enable(tpg_ctx* ctx, int on);
 int tpg_prof_reset(tpg_ctx* ctx);
+/* time only the launches whose name is in the comma-separated list (NULL or "": all).  Two event records around a
+   launch cost ~5 us of idle GPU on the stream: a timed run brackets the few kernels it prices, not all of them */
+int tpg_prof_only(tpg_ctx* ctx, const char* names_csv);
 /* total milliseconds and launch count of kernels whose name starts with `prefix` */
 int tpg_prof_get(tpg_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches);
 /* writes "name\tlaunches\ttotal_ms\n" lines into buf (truncated to cap) */

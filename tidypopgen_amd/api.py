@@ -87,6 +87,10 @@ class Context:
     def prof_reset(self):
         check(lib.tpg_prof_reset(self.h))
 
+    def prof_only(self, names=None):
+        """time only these launches (None: all); see include/tpg.h"""
+        check(lib.tpg_prof_only(self.h, ",".join(names).encode() if names else None))
+
     def prof_get(self, prefix: str):
         ms = C.c_double()
         n = C.c_int64()

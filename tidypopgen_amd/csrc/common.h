@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -47,13 +48,13 @@ struct tpg_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool prof = false;
+  std::set<std::string> prof_only;  // empty: every launch is timed
   std::vector<ProfRec> prof_pending;
   std::map<std::string, std::pair<double, int64_t>> prof_acc;  // name -> (ms, launches)
   std::vector<hipEvent_t> event_pool;
   int num_cu = 256;
   int pool_id = 0;  // this context's device-memory pool (runtime.hip): blocks are reused in the order of ITS stream
   void* resident = nullptr;  // pairwise.hip: accumulators kept across increment_* calls
-  double* eig_pinned = nullptr;  // pca.hip: pinned staging slots of the eigen solver's small matrices
   // small host -> device copies without a stream synchronisation: a ring of pinned slots (runtime.hip: tpg_h2d_async)
   static constexpr int H2D_SLOTS = 8;
   static constexpr size_t H2D_SLOT_BYTES = 256u << 10;
@@ -61,6 +62,19 @@ struct tpg_ctx {
   hipEvent_t h2d_done[H2D_SLOTS] = {};
   bool h2d_used[H2D_SLOTS] = {};
   int h2d_next = 0;
+  // Small results and small inputs WITHOUT the runtime's copy engines or a stream synchronisation (runtime.hip:
+  // tpg_fetch_small / tpg_push_small): a one-workgroup kernel copies between device memory and a coherent pinned "mailbox"
+  // and raises a sequence number there; the host polls that word.  A hipMemcpyAsync + hipStreamSynchronize round trip
+  // costs ~90 us of idle GPU on these boxes (tools/gaps.py), the mailbox ~10.
+  static constexpr size_t MAIL_FETCH_BYTES = 64u << 10;   // one result at a time
+  static constexpr size_t MAIL_PUSH_BYTES = 512u << 10;   // ring of inputs in flight
+  static constexpr size_t MAIL_PUSH_MAX = 64u << 10;      // largest single input
+  uint8_t* mail_host = nullptr;  // [flags: 64 B][fetch area][push ring]
+  uint8_t* mail_dev = nullptr;   // the same memory as the device sees it
+  uint32_t mail_fetch_seq = 0;
+  uint32_t mail_push_seq = 0;    // sequence number of the last push
+  size_t mail_push_off = 0;      // next free byte of the ring
+  uint32_t mail_push_wrap_seq = 0;  // last push of the previous lap: must have been read before the ring is written again
 };
 
 struct ProfScope {
@@ -198,6 +212,14 @@ tpg_ctx* tpg_current_ctx();
 // host -> device on the context's stream.  Up to a slot's size the source is copied into pinned memory first, so the
 // caller's buffer is free at return and nothing waits for the stream; larger copies are waited for.
 hipError_t tpg_h2d_async(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);
+// device -> host for small results (a multiple of 4 bytes, at most MAIL_FETCH_BYTES; anything else takes the copy engine):
+// returns when the bytes are in host_dst, which is when everything enqueued before has run -- without draining the stream
+// through the runtime
+hipError_t tpg_fetch_small(tpg_ctx* ctx, void* host_dst, const void* d_src, size_t bytes);
+// the other direction (the caller's buffer is free at return, nothing is waited for)
+hipError_t tpg_push_small(tpg_ctx* ctx, void* d_dst, const void* host_src, size_t bytes);
+// device -> device on the stream by a kernel (a hipMemcpyAsync between two kernels costs 15 - 30 us of idle GPU)
+hipError_t tpg_copy_dev(tpg_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 // bulk transfers (waited for): large ones are chunked through pinned slots with a team of copying threads
 hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);
 hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);

@@ -630,23 +630,32 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
 //     with one wave per SIMD a full scalar-load latency per block -- 1 750 cycles per block, 44 ms, measured; a load under a
 //     condition, or a loaded register copied into another, makes hipcc drain every load in flight.)
 // Slabs and the assemble pass are those of the kernel above; K ranges start on multiples of NS pairs.
-#define GCLS3_LDS_BYTES (4 * GP * 16 * 64 * 8)
-template <int NS>
-__global__ __launch_bounds__(256, 1) void tpg_gcls_gram3_kernel(const uint4* __restrict__ T2g, int64_t nblocks, int64_t rs2, int nrtv,
-                                                                   const ulonglong2* __restrict__ wblk,
-                                                                   const int2* __restrict__ order, int64_t nun, int S,
-                                                                   double* __restrict__ slabs) {
+// WPE = 2: the same kernel at TWO waves per SIMD (grid = 2 x one workgroup per CU, 256 registers per wave, S even: the two
+// halves of the grid take different halves of the K range, as in tpg_gcls_gram2_kernel).  Its steps need 221 registers with
+// three operand slots -- where the two-waves kernel above keeps half of the FP64 result in registers and has room for two
+// slots and no pipelining -- because the FP64 result has left the register file altogether: tiles 0, 1 in LDS (16 KiB per
+// wave), tiles 2, 3 accumulated in the unit's own slab in HBM (a read-modify-write of 16 KiB per group end: 24 GB over the
+// kernel against 117 GB of operands, mostly L2 hits).
+#define GCLS3_LDS_TILES(WPE) ((WPE) == 1 ? GP : 2)
+#define GCLS3_LDS_BYTES_W(WPE) (4 * GCLS3_LDS_TILES(WPE) * 16 * 64 * 8)
+template <int NS, int WPE>
+__global__ __launch_bounds__(256, WPE) void tpg_gcls_gram3_kernel(const uint4* __restrict__ T2g, int64_t nblocks, int64_t rs2, int nrtv,
+                                                                     const ulonglong2* __restrict__ wblk,
+                                                                     const int2* __restrict__ order, int64_t nun, int S,
+                                                                     double* __restrict__ slabs) {
   extern __shared__ double olds_raw[];  // [wave][tile][register][lane]
-  constexpr int NT = GA + GB, BODY = 2 * NS;
+  constexpr int NT = GA + GB, BODY = 2 * NS, LT = GCLS3_LDS_TILES(WPE);  // LT result tiles in LDS, the others in the slab
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* olds = olds_raw + (size_t)wv * (GP * 16 * 64) + lane;
-  const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+  double* olds = olds_raw + (size_t)wv * (LT * 16 * 64) + lane;
+  const int hgrid = gridDim.x / WPE, half = (int)blockIdx.x / hgrid, bx = (int)blockIdx.x % hgrid;
+  const int xcd = bx & 7, cidx = bx >> 3, cpx = hgrid >> 3;
+  const int SH = S / WPE;  // splits per half of the grid
   const int64_t nbodies = (nblocks + BODY - 1) / BODY;
   for (int64_t round = 0;; round++) {
     const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
-    if (un >= nun * S) break;
-    const int ks = (int)(un / nun);
+    if (un >= nun * SH) break;
+    const int ks = half * SH + (int)(un / nun);
     const int64_t u = un % nun;
     const int2 ijv = order[u];
     const int2 ij = make_int2(__builtin_amdgcn_readfirstlane(ijv.x), __builtin_amdgcn_readfirstlane(ijv.y));
@@ -659,35 +668,55 @@ __global__ __launch_bounds__(256, 1) void tpg_gcls_gram3_kernel(const uint4* __r
 #pragma unroll
     for (int t = 0; t < GB; t++) pt[GA + t] = T2g + ((int64_t)min(GB * ij.y + t, nrtv - 1) * rs2) * 64;
 
+    // the unit's slab: a uniform base (SGPRs) + the lane's 32-bit offset, made opaque wherever it is used -- as 64-bit lane
+    // addresses hipcc hoists five of them out of the loops and, at two waves per SIMD, spills them
+    // (an address that went through an integer is FLAT to hipcc unless told otherwise -- and one flat access in the loop turns
+    // every vmcnt wait of the steps into vmcnt(0))
+    typedef __attribute__((address_space(1))) char gchar;
+    typedef __attribute__((address_space(1))) double gdouble;
+    gchar* const slab_u = (gchar*)tpg_uniform64((int64_t)(slabs + ((int64_t)ks * nun + u) * GCLS_SLAB));
+    auto slab_at = [&](int p, int i, uint32_t so) { return (gdouble*)(slab_u + (p * 16 + i) * 512 + so); };
     v2f dev[GP][8];
     v16f acc[GP];
 #pragma unroll
     for (int p = 0; p < GP; p++) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) { acc[p][i] = 0.f; olds[(p * 16 + i) * 64] = 0.0; }
+      for (int i = 0; i < 16; i++) {
+        acc[p][i] = 0.f;
+        if (p < LT) olds[(p * 16 + i) * 64] = 0.0;
+      }
 #pragma unroll
       for (int i = 0; i < 8; i++) dev[p][i] = v2f{0.f, 0.f};
     }
+    bool slab_fresh = true;  // nothing has been added to the slab's own tiles yet: the first fold writes instead of adding
     // out += w * sums + dev; sums and dev start again from zero.  Four elements at a time: the fold is rare, what matters is
     // that it needs few registers (every temporary it holds is a register the steps lose to spills)
     auto fold = [&](double w) {
+      uint32_t so = (uint32_t)lane * 8u;
+      asm volatile("" : "+v"(so));
 #pragma unroll
       for (int p = 0; p < GP; p++)
         tpg_static_for<4>([&](auto qq) {
           constexpr int q = decltype(qq)::value;
           double t[4];
 #pragma unroll
-          for (int e = 0; e < 4; e++) t[e] = olds[(p * 16 + 4 * q + e) * 64];
+          for (int e = 0; e < 4; e++) {
+            if (p < LT) t[e] = olds[(p * 16 + 4 * q + e) * 64];
+            else t[e] = slab_fresh ? 0.0 : *slab_at(p, 4 * q + e, so);
+          }
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const int i = 4 * q + e;
-            olds[(p * 16 + i) * 64] = __builtin_fma((double)acc[p][i], w, t[e]) + (double)dev[p][i >> 1][i & 1];
+            const double r = __builtin_fma((double)acc[p][i], w, t[e]) + (double)dev[p][i >> 1][i & 1];
+            if (p < LT) olds[(p * 16 + i) * 64] = r;
+            else *slab_at(p, i, so) = r;
             acc[p][i] = 0.f;
           }
           dev[p][2 * q] = v2f{0.f, 0.f};
           dev[p][2 * q + 1] = v2f{0.f, 0.f};
           __builtin_amdgcn_sched_barrier(0);
         });
+      slab_fresh = false;
     };
 
     if (p0 < p1) {
@@ -702,9 +731,12 @@ __global__ __launch_bounds__(256, 1) void tpg_gcls_gram3_kernel(const uint4* __r
       // (three dwords: with a fourth, dead, register in the tuple hipcc parks the loads' lane offset in it and waits for
       // the table load -- for every load in flight -- right after issuing it)
       typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+      // (32-bit lane arithmetic: the 64-bit lane index is one more pair of registers alive across the loop)
+      const uint32_t bl32 = (uint32_t)bl;
       auto LDT = [&](int64_t first_block) {
-        const int64_t bb = first_block + lane;
-        return *(const v3u*)(wblk + (bb < bl ? bb : bl));
+        uint32_t bb = (uint32_t)first_block + (uint32_t)lane;
+        bb = (bb < bl32 ? bb : bl32) * 16u;
+        return *(const v3u*)((const char*)wblk + bb);
       };
       v3u TB = LDT(2 * p0);
       __builtin_amdgcn_sched_barrier(0);
@@ -790,11 +822,15 @@ __global__ __launch_bounds__(256, 1) void tpg_gcls_gram3_kernel(const uint4* __r
         fold(__longlong_as_double((long long)(e.x & ~3ull)));
       }
     }
-    double* slab = slabs + ((int64_t)ks * nun + u) * GCLS_SLAB + lane;
+    uint32_t so = (uint32_t)lane * 8u;
+    asm volatile("" : "+v"(so));
 #pragma unroll
     for (int p = 0; p < GP; p++)
 #pragma unroll
-      for (int i = 0; i < 16; i++) slab[(p * 16 + i) * 64] = olds[(p * 16 + i) * 64];
+      for (int i = 0; i < 16; i++) {
+        if (p < LT) *slab_at(p, i, so) = olds[(p * 16 + i) * 64];
+        else if (slab_fresh) *slab_at(p, i, so) = 0.0;  // an empty K range: nothing was folded
+      }
   }
 }
 
@@ -885,7 +921,9 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   // a measured negative result kept for the A/B: 12.8 - 13.4 ms against 10.6 - 10.8): every group of classes is padded to
   // whole bodies of its unrolled loop.  TPG_GRAM_KERNEL=1: the two-waves kernel with its block table by scalar loads.
   const int kern3 = getenv("TPG_GRAM_KERNEL") ? atoi(getenv("TPG_GRAM_KERNEL")) : 0;
-  const int body = kern3 == 3 || kern3 == 4 ? 2 * kern3 : 0;
+  // 23 / 24: the same kernel at two waves per SIMD with 3 / 4 slots (its FP64 result in LDS + the slab)
+  const int body = kern3 == 3 || kern3 == 4 ? 2 * kern3 : kern3 >= 23 && kern3 <= 25 ? 2 * (kern3 - 20) : 0;
+  const bool one_wave = kern3 == 3 || kern3 == 4;
   const int gmax = getenv("TPG_GRAM_GMAX") ? std::max(1, atoi(getenv("TPG_GRAM_GMAX"))) : GCLS_GMAX;
   const int gq = getenv("TPG_GRAM_GQ") ? std::min(40, std::max(1, atoi(getenv("TPG_GRAM_GQ")))) : GCLS_GQ;
   uint32_t* d_sblk = nullptr;
@@ -909,9 +947,8 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
     TPG_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, t, d_sblk, d_bstart, (int)m, ctx->stream));
     hipLaunchKernelGGL(tpg_gcls_totals_kernel, dim3(1), dim3(1), 0, ctx->stream, (const int*)d_nruns,
                        (const uint32_t*)d_bstart, (const uint32_t*)d_sblk, d_totals);
-    TPG_HIP(hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
   }
-  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  TPG_HIP(tpg_fetch_small(ctx, totals, d_totals, sizeof(totals)));
   const int64_t nruns = totals[0], nblocks = totals[1];
   TPG_REQUIRE(nruns > 0 && nblocks > 0, TPG_EHIP, "class table is empty");
 
@@ -931,7 +968,7 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   int ncu8 = ctx->num_cu / 8 * 8;
   if (ncu8 < 8) ncu8 = 8;
   const bool f64 = body ? false : gcls_fold64(nruns, nblocks);
-  const int nblk_grid = body ? ncu8 : 2 * ncu8;  // two workgroups per CU = two waves per SIMD
+  const int nblk_grid = one_wave ? ncu8 : 2 * ncu8;  // two workgroups per CU = two waves per SIMD
   const int nwaves = 4 * nblk_grid;
   int S = 2;
   // + the sort, the gather (2.0 us per 1000 loci at n = 5 000: it scales with n m) and the assemble pass
@@ -986,14 +1023,21 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
     TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T2g, nblocks,
                rs2, nrtv, (const unsigned long long*)d_wblk, (const int2*)d_order, nun, S, d_slabs);
   else if (body) {
-    auto launch3 = [&](auto ns) {
-      constexpr int NS = decltype(ns)::value;
-      (void)hipFuncSetAttribute((const void*)tpg_gcls_gram3_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS3_LDS_BYTES);
-      TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram3_kernel<NS>, dim3((unsigned)nblk_grid), dim3(256), GCLS3_LDS_BYTES,
-                 (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
+    auto launch3 = [&](auto ns, auto wpe) {
+      constexpr int NS = decltype(ns)::value, WPE = decltype(wpe)::value;
+      (void)hipFuncSetAttribute((const void*)tpg_gcls_gram3_kernel<NS, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GCLS3_LDS_BYTES_W(WPE));
+      TPG_LAUNCH(ctx, "pca_gram_classes", (tpg_gcls_gram3_kernel<NS, WPE>), dim3((unsigned)nblk_grid), dim3(256),
+                 GCLS3_LDS_BYTES_W(WPE), (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2,
+                 (const int2*)d_order, nun, S, d_slabs);
     };
-    if (kern3 == 3) launch3(std::integral_constant<int, 3>{});
-    else launch3(std::integral_constant<int, 4>{});
+    using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>;
+    if (kern3 == 3) launch3(std::integral_constant<int, 3>{}, W1{});
+    else if (kern3 == 4) launch3(std::integral_constant<int, 4>{}, W1{});
+    else if (kern3 == 23) launch3(std::integral_constant<int, 3>{}, W2{});
+    else if (kern3 == 24) launch3(std::integral_constant<int, 4>{}, W2{});
+    else launch3(std::integral_constant<int, 5>{}, W2{});
   } else {
     // TPG_GRAM_KERNEL=1: the block table by scalar loads, one per block (rounds 2 and 3; A/B)
     if (kern3 == 1) {

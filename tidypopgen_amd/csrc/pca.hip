@@ -94,9 +94,8 @@ static int pca_counts_center_scale(tpg_ctx* ctx, const tpg_view* v, int32_t* d_c
   if (e == hipSuccess) {
     TPG_LAUNCH(ctx, "pca_center_scale", tpg_pca_center_scale_kernel, dim3(1024), dim3(256), 0, (const int4*)d_counts,
                v->m, v->n, d_center, d_scale, d_flags);
-    e = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream);
+    e = tpg_fetch_small(ctx, flags, d_flags, sizeof(flags));
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   tpg_pfree(d_flags);
   if (e != hipSuccess) { tpg_set_error("pca center/scale: %s", hipGetErrorString(e)); return TPG_EHIP; }
   // bigstatsr::big_SVD stops on missing values and on a zero scale
@@ -128,8 +127,7 @@ static int frobenius_from_counts(tpg_ctx* ctx, const tpg_view* v, const int32_t*
   TPG_LAUNCH(ctx, "pca_frobenius", tpg_pca_frobenius_kernel, dim3(NB), dim3(256), 0, (const int4*)d_counts, v->m, v->n,
              d_center, d_scale, d_part);
   std::vector<double> hp(NB);
-  hipError_t e = hipMemcpyAsync(hp.data(), d_part, sizeof(double) * NB, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = tpg_fetch_small(ctx, hp.data(), d_part, sizeof(double) * NB);
   tpg_pfree(d_part);
   if (e != hipSuccess) { tpg_set_error("frobenius: %s", hipGetErrorString(e)); return TPG_EHIP; }
   long double s = 0;
@@ -738,12 +736,11 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   TPG_HIP(tpg_pmalloc((void**)&d_rng, 2 * sizeof(unsigned long long)));
   const unsigned long long rng_init[2] = {0x7FF0000000000000ull, 0ull};  // +inf, no bad entry
   unsigned long long rng[2];
-  hipError_t er = hipMemcpyAsync(d_rng, rng_init, sizeof(rng_init), hipMemcpyHostToDevice, ctx->stream);
+  hipError_t er = tpg_push_small(ctx, d_rng, rng_init, sizeof(rng_init));
   if (er == hipSuccess) {
     hipLaunchKernelGGL(tpg_scale_range_kernel, dim3(512), dim3(256), 0, ctx->stream, d_scale, m, d_rng);
-    er = hipMemcpyAsync(rng, d_rng, sizeof(rng), hipMemcpyDeviceToHost, ctx->stream);
+    er = tpg_fetch_small(ctx, rng, d_rng, sizeof(rng));
   }
-  if (er == hipSuccess) er = hipStreamSynchronize(ctx->stream);
   tpg_pfree(d_rng);
   TPG_HIP(er);
   TPG_REQUIRE(rng[1] == 0, TPG_ENUMERIC, "zero or negative scale at locus %lld", (long long)(rng[1] - 1));
@@ -852,8 +849,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     TPG_LAUNCH(ctx, "pca_colmean", tpg_mean_kernel, dim3(1), dim3(256), 0, (const double*)d_r, (int)n, d_part);
     TPG_LAUNCH(ctx, "pca_double_center", tpg_double_center_kernel, dim3(2048), dim3(256), 0, d_K, (int)n,
                (const double*)d_r, (const double*)d_part);
-    GHIP(hipGetLastError());
-    GHIP(hipStreamSynchronize(ctx->stream));
+    GHIP(hipGetLastError());  // (no wait: the scratch blocks go back to the pool in stream order)
   }
   if (e == hipSuccess && !own_center) {
     // r_i = sum_j what_j c_j g_ij  (RAW sweep with a one-column table), C = sum_j what_j c_j^2
@@ -864,8 +860,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   if (e == hipSuccess && rc == TPG_OK && !own_center) {
     TPG_LAUNCH(ctx, "pca_dot", tpg_dot_kernel, dim3(512), dim3(256), 0, d_wc, d_center, m, d_part);
     std::vector<double> hp(512);
-    GHIP(hipMemcpyAsync(hp.data(), d_part, sizeof(double) * 512, hipMemcpyDeviceToHost, ctx->stream));
-    GHIP(hipStreamSynchronize(ctx->stream));
+    GHIP(tpg_fetch_small(ctx, hp.data(), d_part, sizeof(double) * 512));
     long double s = 0;
     for (int b = 0; b < 512; b++) s += hp[(size_t)b];
     Cc = (double)s;
@@ -875,12 +870,11 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
       TPG_LAUNCH(ctx, "pca_assemble", tpg_pca_assemble_kernel, dim3(2048), dim3(256), 0, d_slabs, (const int32_t*)d_lut, nsbf,
                  (int)n, F, (const double*)d_r, Cc, d_K);
     } else {  // K = S' - r 1' - 1 r' + C on the matrix the class path left in d_K
-      GHIP(tpg_h2d_async(ctx, d_part, &Cc, sizeof(double)));
+      GHIP(tpg_push_small(ctx, d_part, &Cc, sizeof(double)));
       TPG_LAUNCH(ctx, "pca_double_center", tpg_double_center_kernel, dim3(2048), dim3(256), 0, d_K, (int)n,
                  (const double*)d_r, (const double*)d_part);
     }
     GHIP(hipGetLastError());
-    GHIP(hipStreamSynchronize(ctx->stream));
   }
 #undef GHIP
   tpg_pfree(d_DG); tpg_pfree(d_what); tpg_pfree(d_wc); tpg_pfree(d_r); tpg_pfree(d_part);
@@ -929,8 +923,7 @@ extern "C" int tpg_pca_gram(tpg_ctx* ctx, const tpg_view* v, const double* cente
     e = hipMemsetAsync(d_flag, 0, 2 * sizeof(int), ctx->stream);
     TPG_LAUNCH(ctx, "pca_center_check", tpg_center_is_mean_kernel, dim3(1024), dim3(256), 0, (const int4*)d_counts,
                ic.dev<double>(), v->m, v->n, d_flag);
-    if (e == hipSuccess) e = hipMemcpyAsync(flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = tpg_fetch_small(ctx, flag, d_flag, 2 * sizeof(int));
     if (e != hipSuccess) { tpg_set_error("pca_gram: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   }
   tpg_pfree(d_counts);
@@ -1199,11 +1192,9 @@ struct EigWork {
   const double* L = nullptr;
   int nl = 0;
   double *lam_dev = nullptr, *cdev = nullptr, *dtmp = nullptr;
-  // small host matrices go to the device through a ring of pinned staging slots, so rmult() needs no host
-  // synchronisation (a slot is reused only after a stream synchronisation at wrap-around)
-  static constexpr int XSLOTS = 16;
-  double *xpin = nullptr, *xdev = nullptr;
-  int xslot = 0;
+  // small host matrices go to the device, and the small products come back, through the context's mailbox (runtime.hip:
+  // tpg_push_small / tpg_fetch_small): no copy engine and no stream synchronisation anywhere in the iteration
+  double* xdev = nullptr;
   int init() {
     S = 1;
     const int row_blocks = (n + 63) / 64;
@@ -1217,11 +1208,7 @@ struct EigWork {
     TPG_HIP(tpg_pmalloc((void**)&lam_dev, sizeof(double) * 64));
     TPG_HIP(tpg_pmalloc((void**)&cdev, sizeof(double) * 64 * 64));
     TPG_HIP(tpg_pmalloc((void**)&dtmp, sizeof(double) * (size_t)b * (size_t)n));
-    // 512 KB of pinned staging, allocated once per CONTEXT (pinning costs ~1 ms) and freed with it: several contexts
-    // may run the eigen step at the same time (the device threads of tpg_multi_*), each writes its own slots
-    if (!ctx->eig_pinned) TPG_HIP(hipHostMalloc((void**)&ctx->eig_pinned, sizeof(double) * 64 * 64 * XSLOTS, hipHostMallocDefault));
-    xpin = ctx->eig_pinned;
-    TPG_HIP(tpg_pmalloc((void**)&xdev, sizeof(double) * 64 * 64 * XSLOTS));
+    TPG_HIP(tpg_pmalloc((void**)&xdev, sizeof(double) * (64 * 64 + 64)));
     return TPG_OK;
   }
   ~EigWork() {
@@ -1231,12 +1218,11 @@ struct EigWork {
     if (cdev) tpg_pfree(cdev);
     if (dtmp) tpg_pfree(dtmp);
     if (xdev) tpg_pfree(xdev);
-    if (xpin) (void)hipStreamSynchronize(ctx->stream);  // pending copies out of the (process-wide) staging slots
   }
   int set_locked(const double* Lptr, int count, const double* lam_host) {
     L = Lptr;
     nl = count;
-    if (count > 0) TPG_HIP(tpg_h2d_async(ctx, lam_dev, lam_host, sizeof(double) * (size_t)count));  // pinned slot: no wait
+    if (count > 0) TPG_HIP(tpg_push_small(ctx, lam_dev, lam_host, sizeof(double) * (size_t)count));
     return TPG_OK;
   }
   // Y = alpha K' Q + beta Y1 + gamma Y0   with K' = K - L diag(lam) L'; no host synchronisation
@@ -1265,38 +1251,28 @@ struct EigWork {
     TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((p * bb + 63) / 64)), dim3(256), 0,
                (const double*)gpart, nchunks, p, bb, (const double*)nullptr, cdev);
     C.assign((size_t)p * bb, 0.0);
-    TPG_HIP(hipMemcpyAsync(C.data(), cdev, sizeof(double) * (size_t)p * bb, hipMemcpyDeviceToHost, ctx->stream));
-    TPG_HIP(hipStreamSynchronize(ctx->stream));
+    TPG_HIP(tpg_fetch_small(ctx, C.data(), cdev, sizeof(double) * (size_t)p * bb));
     return TPG_OK;
   }
   // Ritz step: Y0 = A X, Y1 = Yk X, res2[j] = |Y1_j - theta_j Y0_j|^2 (host, after a synchronisation)
   int ritz(const double* A, const double* Yk, int p, const std::vector<double>& X, const std::vector<double>& theta,
            double* Y0, double* Y1, std::vector<double>& res2) {
-    if (xslot + 2 > XSLOTS) { TPG_HIP(hipStreamSynchronize(ctx->stream)); xslot = 0; }
-    double* hx = xpin + (size_t)xslot * 64 * 64;
-    double* dx = xdev + (size_t)xslot * 64 * 64;
-    memcpy(hx, X.data(), sizeof(double) * (size_t)p * p);
-    memcpy(hx + 64 * 64, theta.data(), sizeof(double) * (size_t)p);
-    xslot += 2;
-    TPG_HIP(hipMemcpyAsync(dx, hx, sizeof(double) * (64 * 64 + (size_t)p), hipMemcpyHostToDevice, ctx->stream));
+    double* dx = xdev;
+    TPG_HIP(tpg_push_small(ctx, dx, X.data(), sizeof(double) * (size_t)p * p));
+    TPG_HIP(tpg_push_small(ctx, dx + 64 * 64, theta.data(), sizeof(double) * (size_t)p));
     const int nblk = (n + 31) / 32;
     TPG_LAUNCH(ctx, "eig_ritz", tpg_ritz_kernel, dim3((unsigned)nblk), dim3(256), 0, A, Yk, n, p, (const double*)dx,
                (const double*)(dx + 64 * 64), Y0, Y1, gpart);
     TPG_LAUNCH(ctx, "eig_gram_reduce", tpg_gram_reduce_kernel, dim3((unsigned)((p + 63) / 64)), dim3(256), 0,
                (const double*)gpart, nblk, p, 1, (const double*)nullptr, cdev);
     res2.assign((size_t)p, 0.0);
-    TPG_HIP(hipMemcpyAsync(res2.data(), cdev, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, ctx->stream));
-    TPG_HIP(hipStreamSynchronize(ctx->stream));
+    TPG_HIP(tpg_fetch_small(ctx, res2.data(), cdev, sizeof(double) * (size_t)p));
     return TPG_OK;
   }
   // Y = A X  (X host p x b2)
   int rmult(const double* A, int p, const std::vector<double>& X, int b2, double* Y) {
-    if (xslot == XSLOTS) { TPG_HIP(hipStreamSynchronize(ctx->stream)); xslot = 0; }
-    double* hx = xpin + (size_t)xslot * 64 * 64;
-    double* dx = xdev + (size_t)xslot * 64 * 64;
-    xslot++;
-    memcpy(hx, X.data(), sizeof(double) * (size_t)p * b2);
-    TPG_HIP(hipMemcpyAsync(dx, hx, sizeof(double) * (size_t)p * b2, hipMemcpyHostToDevice, ctx->stream));
+    double* dx = xdev;
+    TPG_HIP(tpg_push_small(ctx, dx, X.data(), sizeof(double) * (size_t)p * b2));
     TPG_LAUNCH(ctx, "eig_right_mult", tpg_right_mult_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, A, n, p,
                (const double*)dx, b2, Y);
     TPG_CHECK_LAUNCH();
@@ -1390,7 +1366,7 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
       for (int j = 0; j < act; j++)
         for (int i = 0; i < act; i++) Ri[i + (size_t)j * act] *= D[(size_t)i];
       TPG_TRY(w.rmult(A, act, Ri, act, tmp));
-      TPG_HIP(hipMemcpyAsync(A, tmp, colbytes(act), hipMemcpyDeviceToDevice, ctx->stream));
+      TPG_HIP(tpg_copy_dev(ctx, A, tmp, colbytes(act)));
     }
     return TPG_OK;
   };
@@ -1432,7 +1408,7 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
       lam1 = fabs(theta[0]) > 0 ? fabs(theta[0]) : 1.0;
     } else {
       TPG_TRY(w.ritz(A, Y, act, X, theta, Y0, Y1, RR));  // Ritz vectors, K * Ritz vectors, |K a - theta a|^2
-      TPG_HIP(hipMemcpyAsync(A, Y0, colbytes(act), hipMemcpyDeviceToDevice, ctx->stream));
+      TPG_HIP(tpg_copy_dev(ctx, A, Y0, colbytes(act)));
       if (nl == 0) lam1 = fabs(theta[0]) > 0 ? fabs(theta[0]) : 1.0;
       st.mark("ritz vectors + residuals");
     }
@@ -1469,7 +1445,7 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
     double* prev = Y0;
     double* cur = first ? Y1 : Y;  // never the buffer KA2 lives in
     double* nxt = first ? Y : Y1;
-    TPG_HIP(hipMemcpyAsync(prev, A2, colbytes(act2), hipMemcpyDeviceToDevice, ctx->stream));
+    TPG_HIP(tpg_copy_dev(ctx, prev, A2, colbytes(act2)));
     TPG_LAUNCH(ctx, "eig_combine", tpg_combine_kernel, dim3(1024), dim3(256), 0, KA2, 1, (int64_t)n * act2,
                sigma1 / ec, (const double*)prev, -cc * sigma1 / ec, (const double*)nullptr, 0.0, cur,
                (const double*)nullptr);
@@ -1479,15 +1455,14 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
       double* t = prev; prev = cur; cur = nxt; nxt = t;
       sigma = sigma2;
     }
-    TPG_HIP(hipMemcpyAsync(A2, cur, colbytes(act2), hipMemcpyDeviceToDevice, ctx->stream));
+    TPG_HIP(tpg_copy_dev(ctx, A2, cur, colbytes(act2)));
     st.mark("chebyshev filter");
     TPG_TRY(orthonormalize(A2, act2, Q, nl, prev));
     st.mark("orthonormalize");
   }
   TPG_REQUIRE(nl >= k, TPG_ENUMERIC, "eigen solver did not converge (%d of %d pairs)", nl, k);
   for (int j = 0; j < k; j++) lambda_host[j] = lam[(size_t)j];
-  TPG_HIP(hipMemcpyAsync(d_U, Q, colbytes(k), hipMemcpyDeviceToDevice, ctx->stream));
-  TPG_HIP(hipStreamSynchronize(ctx->stream));
+  TPG_HIP(tpg_copy_dev(ctx, d_U, Q, colbytes(k)));  // (stream order: the scratch blocks go back to the pool after it)
   return TPG_OK;
 }
 
@@ -1663,10 +1638,10 @@ static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, 
   st.mark("eig_topk");
   std::vector<double> dh((size_t)k);
   for (int j = 0; j < k; j++) dh[(size_t)j] = sqrt(lam[(size_t)j] > 0 ? lam[(size_t)j] : 0.0);
-  TPG_HIP(hipMemcpyAsync(d_dk, dh.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
+  TPG_HIP(tpg_push_small(ctx, d_dk, dh.data(), sizeof(double) * (size_t)k));
   // v = Z'u / d  (no missing values: checked by pca_counts_center_scale above)
   TPG_TRY(pca_loadings_device(ctx, v, oc.dev<double>(), os.dev<double>(), ou.dev<double>(), d_dk, k, ov.dev<double>()));
-  if (tpg_is_device_ptr(d)) TPG_HIP(hipMemcpyAsync(d, dh.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
+  if (tpg_is_device_ptr(d)) TPG_HIP(tpg_push_small(ctx, d, dh.data(), sizeof(double) * (size_t)k));
   else memcpy(d, dh.data(), sizeof(double) * (size_t)k);
   TPG_HIP(hipStreamSynchronize(ctx->stream));
   st.mark("loadings");

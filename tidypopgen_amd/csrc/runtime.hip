@@ -138,6 +138,7 @@ extern "C" const char* tpg_version(void) { return "tidypopgen_amd 0.1 (gfx950)";
 
 // ---------------------------------------------------------------------------
 ProfScope::ProfScope(tpg_ctx* c, const char* name) : ctx(c), on(c->prof) {
+  if (on && !c->prof_only.empty() && !c->prof_only.count(name)) on = false;
   if (!on) return;
   rec.name = name;
   auto get = [&]() {
@@ -177,6 +178,19 @@ extern "C" int tpg_prof_enable(tpg_ctx* ctx, int on) {
   TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
   TPG_TRY(tpg_prof_resolve(ctx));
   ctx->prof = on != 0;
+  return TPG_OK;
+}
+extern "C" int tpg_prof_only(tpg_ctx* ctx, const char* names_csv) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx, TPG_EINVAL, "null ctx");
+  TPG_TRY(tpg_prof_resolve(ctx));
+  ctx->prof_only.clear();
+  for (const char* p = names_csv; p && *p;) {
+    const char* q = strchr(p, ',');
+    const size_t len = q ? (size_t)(q - p) : strlen(p);
+    if (len) ctx->prof_only.insert(std::string(p, len));
+    p = q ? q + 1 : p + len;
+  }
   return TPG_OK;
 }
 extern "C" int tpg_prof_reset(tpg_ctx* ctx) {
@@ -260,7 +274,7 @@ extern "C" void tpg_ctx_destroy(tpg_ctx* ctx) {
       (void)hipHostFree(ctx->h2d_pinned);
     }
     tpg_resident_release(ctx);
-    if (ctx->eig_pinned) (void)hipHostFree(ctx->eig_pinned);
+    if (ctx->mail_host) (void)hipHostFree(ctx->mail_host);
     pool_close(ctx->pool_id);  // only this context's blocks
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }
@@ -349,7 +363,7 @@ OutBuf::~OutBuf() {
   if (owned && d) tpg_pfree(d);
 }
 
-hipError_t tpg_h2d_async(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+static hipError_t h2d_engine(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return hipSuccess;
   if (bytes > tpg_ctx::H2D_SLOT_BYTES) {
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
@@ -375,6 +389,116 @@ hipError_t tpg_h2d_async(tpg_ctx* ctx, void* dst, const void* src, size_t bytes)
   if (e == hipSuccess) e = hipEventRecord(ctx->h2d_done[k], ctx->stream);
   ctx->h2d_used[k] = true;
   return e;
+}
+
+// ---------------------------------------------------------------------------
+// The mailbox (common.h): small transfers by kernels through coherent pinned memory.
+__global__ __launch_bounds__(1024) void tpg_mail_fetch_kernel(const uint32_t* __restrict__ src, uint32_t* dst, size_t nwords,
+                                                               uint32_t* flag, uint32_t seq) {
+  for (size_t i = threadIdx.x; i < nwords; i += 1024) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(1024) void tpg_mail_push_kernel(const uint32_t* src, uint32_t* __restrict__ dst, size_t nwords,
+                                                              uint32_t* flag, uint32_t seq) {
+  for (size_t i = threadIdx.x; i < nwords; i += 1024) dst[i] = __builtin_nontemporal_load(src + i);
+  __syncthreads();  // every word has been READ: the host may write the ring slot again
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(256) void tpg_copy_dev_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
+                                                           const uint8_t* __restrict__ srcb, uint8_t* __restrict__ dstb, size_t tail) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x < tail) dstb[n16 * 16 + threadIdx.x] = srcb[n16 * 16 + threadIdx.x];
+}
+
+static hipError_t mail_init(tpg_ctx* ctx) {
+  if (ctx->mail_host) return hipSuccess;
+  const size_t total = 64 + tpg_ctx::MAIL_FETCH_BYTES + tpg_ctx::MAIL_PUSH_BYTES;
+  void* h = nullptr;
+  hipError_t e = hipHostMalloc(&h, total, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e != hipSuccess) return e;
+  void* d = nullptr;
+  e = hipHostGetDevicePointer(&d, h, 0);
+  if (e != hipSuccess) { (void)hipHostFree(h); return e; }
+  memset(h, 0, 64);
+  ctx->mail_host = (uint8_t*)h;
+  ctx->mail_dev = (uint8_t*)d;
+  return hipSuccess;
+}
+
+// wait until the 32-bit word at `flag` has reached `seq` (sequence numbers wrap: compare as a signed difference); the
+// stream is looked at now and then, so that a failed launch does not leave the host spinning for ever
+static hipError_t mail_wait(tpg_ctx* ctx, const volatile uint32_t* flag, uint32_t seq) {
+  int drained = 0;
+  for (uint64_t spins = 1;; spins++) {
+    if ((int32_t)(__atomic_load_n(flag, __ATOMIC_ACQUIRE) - seq) >= 0) return hipSuccess;
+    __builtin_ia32_pause();
+    if ((spins & 0x3FFF) == 0) {
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipErrorNotReady) continue;
+      if (q != hipSuccess) return q;
+      if (++drained > 2) return hipErrorUnknown;  // the stream is empty and the kernel never wrote: a lost launch
+    }
+  }
+}
+
+hipError_t tpg_fetch_small(tpg_ctx* ctx, void* host_dst, const void* d_src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  static const bool off = getenv("TPG_NO_MAILBOX") != nullptr;  // (A/B: the copy engine + a stream synchronisation)
+  if (off || bytes > tpg_ctx::MAIL_FETCH_BYTES || (bytes & 3) || ((uintptr_t)d_src & 3) || mail_init(ctx) != hipSuccess) {
+    hipError_t e = hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+  }
+  const uint32_t seq = ++ctx->mail_fetch_seq;
+  hipLaunchKernelGGL(tpg_mail_fetch_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)d_src,
+                     (uint32_t*)(ctx->mail_dev + 64), bytes / 4, (uint32_t*)ctx->mail_dev, seq);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = mail_wait(ctx, (const volatile uint32_t*)ctx->mail_host, seq);
+  if (e != hipSuccess) return e;
+  memcpy(host_dst, ctx->mail_host + 64, bytes);
+  return hipSuccess;
+}
+
+hipError_t tpg_push_small(tpg_ctx* ctx, void* d_dst, const void* host_src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  static const bool off = getenv("TPG_NO_MAILBOX") != nullptr;
+  if (off || bytes > tpg_ctx::MAIL_PUSH_MAX || (bytes & 3) || ((uintptr_t)d_dst & 3) || mail_init(ctx) != hipSuccess)
+    return h2d_engine(ctx, d_dst, host_src, bytes);
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  volatile uint32_t* done = (volatile uint32_t*)(ctx->mail_host + 4);  // sequence number of the last push that has been read
+  if (ctx->mail_push_off + need > tpg_ctx::MAIL_PUSH_BYTES) {
+    // a new lap of the ring: every push of the lap before must have been read (it has, long ago, unless the host has run
+    // MAIL_PUSH_BYTES ahead of the device)
+    ctx->mail_push_off = 0;
+    ctx->mail_push_wrap_seq = ctx->mail_push_seq;
+  }
+  if (ctx->mail_push_wrap_seq != 0) {
+    const hipError_t e = mail_wait(ctx, done, ctx->mail_push_wrap_seq);
+    if (e != hipSuccess) return e;
+  }
+  const size_t off_ring = 64 + tpg_ctx::MAIL_FETCH_BYTES + ctx->mail_push_off;
+  memcpy(ctx->mail_host + off_ring, host_src, bytes);
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  ctx->mail_push_off += need;
+  const uint32_t seq = ++ctx->mail_push_seq;
+  hipLaunchKernelGGL(tpg_mail_push_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)(ctx->mail_dev + off_ring),
+                     (uint32_t*)d_dst, bytes / 4, (uint32_t*)(ctx->mail_dev + 4), seq);
+  return hipGetLastError();
+}
+
+// (small inputs take the mailbox, the others the copy engine from a pinned slot)
+hipError_t tpg_h2d_async(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) { return tpg_push_small(ctx, dst, src, bytes); }
+
+hipError_t tpg_copy_dev(tpg_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+  if (bytes == 0 || d_dst == d_src) return hipSuccess;
+  if (((uintptr_t)d_dst | (uintptr_t)d_src) & 15) return hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+  const size_t n16 = bytes / 16;
+  const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>(1, (n16 + 1023) / 1024), (size_t)ctx->num_cu * 8);
+  hipLaunchKernelGGL(tpg_copy_dev_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)d_src, (uint4*)d_dst, n16,
+                     (const uint8_t*)d_src, (uint8_t*)d_dst, bytes & 15);
+  return hipGetLastError();
 }
 
 int InBuf::init(tpg_ctx* ctx, const void* user_ptr, size_t nbytes) {

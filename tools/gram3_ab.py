@@ -20,7 +20,7 @@ v = tpg.View(X, None, cols, code256=np.ascontiguousarray(tpg.CODE_IMPUTE_PRED))
 center, scale = tpg.pca_center_scale(v)
 os.environ["TPG_GRAM_FOLD64"] = "0"
 ref = None
-for kern in ("1", "2", "3", "4"):
+for kern in (os.environ.get("GRAM_AB_KERNELS") or "1,2,3,4,23,24").split(","):
     for S in Ss:
         if kern == "2":  # the default: two waves per SIMD, block table through vector loads
             os.environ.pop("TPG_GRAM_KERNEL", None)
