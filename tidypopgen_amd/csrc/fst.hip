@@ -687,9 +687,8 @@ extern "C" int tpg_pairwise_fst_loop(tpg_ctx* ctx, int method, const int32_t* pa
     if (e == hipSuccess) {
       hipLaunchKernelGGL(tpg_freq_ref_check_kernel, dim3(1024), dim3(256), 0, ctx->stream, bp.dev<double>(),
                          bq.dev<double>(), (int64_t)m * G, d_bad);
-      e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+      e = tpg_fetch_small(ctx, &bad, d_bad, sizeof(int));
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     tpg_pfree(d_bad);
     TPG_HIP(e);
     TPG_REQUIRE(!bad, TPG_EINVAL, "freq_ref is not 1 - freq_alt: the device path recomputes it and would not match the reference");

@@ -645,10 +645,11 @@ extern "C" int tpg_pop_global_stats(tpg_ctx* ctx, const tpg_view* v, const int32
                        gc.Cpad, m, ngroups, d_loc);
     if (overall) {
       hipLaunchKernelGGL(tpg_finite_colsum_kernel, dim3(NB, 10), dim3(256), 0, ctx->stream, (const double*)d_loc, m, 1, d_part);
-      e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, ctx->stream);
+      e = tpg_download(ctx, part.data(), d_part, sizeof(double) * part.size());  // (small: the mailbox) waits for the stream
+    } else {
+      e = hipStreamSynchronize(ctx->stream);
     }
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
   tpg_pfree(d_part);
   tpg_pfree(d_tmp);
@@ -780,10 +781,11 @@ extern "C" int tpg_pop_basic_stats(tpg_ctx* ctx, const tpg_view* v, const int32_
     if (colmeans) {
       hipLaunchKernelGGL(tpg_finite_colsum_kernel, dim3(NB, (unsigned)ngroups), dim3(256), 0, ctx->stream,
                          (const double*)d_loc, m, 0, d_part);
-      e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, ctx->stream);
+      e = tpg_download(ctx, part.data(), d_part, sizeof(double) * part.size());  // (small: the mailbox) waits for the stream
+    } else {
+      e = hipStreamSynchronize(ctx->stream);
     }
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
   tpg_pfree(d_part);
   tpg_pfree(d_tmp);

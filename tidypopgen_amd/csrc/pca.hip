@@ -1842,8 +1842,7 @@ static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_
     double* d_amax = nullptr;
     TPG_HIP(tpg_pmalloc((void**)&d_amax, sizeof(double)));
     TPG_LAUNCH(ctx, "loadings_u_digits", tpg_absmax_kernel, dim3(1), dim3(1024), 0, d_U, n * (int64_t)k, d_amax);
-    hipError_t ea = hipMemcpyAsync(&amax, d_amax, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (ea == hipSuccess) ea = hipStreamSynchronize(ctx->stream);
+    hipError_t ea = tpg_fetch_small(ctx, &amax, d_amax, sizeof(double));
     tpg_pfree(d_amax);
     TPG_HIP(ea);
   }
@@ -1925,8 +1924,7 @@ extern "C" int tpg_pca_loadings(tpg_ctx* ctx, const tpg_view* v, const double* c
     e = hipMemsetAsync(d_flag, 0, 2 * sizeof(int), ctx->stream);
     TPG_LAUNCH(ctx, "pca_center_check", tpg_center_is_mean_kernel, dim3(1024), dim3(256), 0, (const int4*)d_counts,
                ic.dev<double>(), m, n, d_flag);
-    if (e == hipSuccess) e = hipMemcpyAsync(flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = tpg_fetch_small(ctx, flag, d_flag, 2 * sizeof(int));
     if (e != hipSuccess) { tpg_set_error("pca_loadings: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   }
   tpg_pfree(d_counts);

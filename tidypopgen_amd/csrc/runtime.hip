@@ -541,6 +541,7 @@ static void xfer_parallel(size_t bytes, F f) {
 
 // device memory -> host memory the caller owns (pageable)
 hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes <= tpg_ctx::MAIL_FETCH_BYTES) return tpg_fetch_small(ctx, dst, src, bytes);  // (falls back to the copy engine by itself)
   if (bytes >= XFER_BIG) {  // make the pages present (the buffer is about to be overwritten anyway)
     volatile uint8_t* d = (volatile uint8_t*)dst;
     xfer_parallel(bytes, [=](int, size_t lo, size_t hi) { for (size_t o = lo; o < hi; o += 4096) d[o] = 0; });
@@ -913,8 +914,7 @@ static int view_create_impl(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* row
   if (rc != TPG_OK) return fail(rc);
   // the "a byte that occurs maps to no 2-bit code" flags: the one host round trip of a view creation
   uint8_t back[2 * (256 + 16)];
-  VHIP(hipMemcpyAsync(back, d_lut, (size_t)nv * (256 + 16), hipMemcpyDeviceToHost, ctx->stream));
-  VHIP(hipStreamSynchronize(ctx->stream));
+  VHIP(tpg_fetch_small(ctx, back, d_lut, (size_t)nv * (256 + 16)));
 #undef VHIP
   for (int k = 0; k < nv; k++) {
     int32_t bad;
