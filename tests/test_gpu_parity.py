@@ -119,6 +119,40 @@ def test_packed_upload_roundtrip(tpg, monkeypatch):
     X.free()
 
 
+def test_small_transfers_through_the_mailbox(tpg, monkeypatch):
+    """Small host <-> device transfers go through coherent pinned memory by one-workgroup kernels (runtime.hip:
+    tpg_push_small / tpg_fetch_small): every size class, unaligned sizes (which take the copy engine), and more pushes in
+    flight than the ring holds (a lap of the ring waits for the lap before)."""
+    import ctypes as C
+
+    lib, chk = tpg._lib.lib, tpg._lib.check
+    ctx = tpg.default_context()
+    rng = np.random.default_rng(11)
+    sizes = [4, 8, 60, 8000, 65532, 65536, 65540, 70001, 3, 131072]
+    d = ctx.dev_alloc(1 << 20)
+    for nb in sizes:
+        a = rng.integers(0, 256, size=nb, dtype=np.uint8)
+        b = np.zeros(nb, dtype=np.uint8)
+        chk(lib.tpg_dev_from_host(ctx.h, d, tpg.api._ptr(a), C.c_size_t(nb)))
+        chk(lib.tpg_dev_to_host(ctx.h, tpg.api._ptr(b), d, C.c_size_t(nb)))
+        assert np.array_equal(a, b), nb
+    # 60 pushes of 40 KiB (the ring holds 12) into distinct places, read back in two ways
+    piece = 40 << 10
+    big = ctx.dev_alloc(60 * piece)
+    src = rng.integers(0, 256, size=(60, piece), dtype=np.uint8)
+    for i in range(60):
+        chk(lib.tpg_dev_from_host(ctx.h, C.c_void_p(big.value + i * piece), tpg.api._ptr(src[i]), C.c_size_t(piece)))
+    back = np.zeros((60, piece), dtype=np.uint8)
+    chk(lib.tpg_dev_to_host(ctx.h, tpg.api._ptr(back), big, C.c_size_t(60 * piece)))  # one large copy
+    assert np.array_equal(src, back)
+    for i in (0, 13, 59):
+        one = np.zeros(piece, dtype=np.uint8)
+        chk(lib.tpg_dev_to_host(ctx.h, tpg.api._ptr(one), C.c_void_p(big.value + i * piece), C.c_size_t(piece)))
+        assert np.array_equal(one, src[i])
+    ctx.dev_free(d)
+    ctx.dev_free(big)
+
+
 def test_view_errors(tpg):
     X = tpg.FBM.from_numpy(orc.synth_fbm(1, 10, 20, npop=2))
     with pytest.raises(tpg._lib.TpgError):

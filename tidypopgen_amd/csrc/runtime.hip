@@ -326,6 +326,10 @@ extern "C" int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src
 extern "C" int tpg_dev_from_host(tpg_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && dev_dst && host_src, TPG_EINVAL, "null argument");
+  if (bytes <= tpg_ctx::MAIL_PUSH_MAX) {  // (the caller's buffer is free at return; the copy is in stream order)
+    TPG_HIP(tpg_push_small(ctx, dev_dst, host_src, bytes));
+    return TPG_OK;
+  }
   TPG_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   TPG_HIP(hipStreamSynchronize(ctx->stream));
   return TPG_OK;
