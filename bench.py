@@ -971,8 +971,10 @@ def main():
                      "counts -> the m x 2G doubles grouped_alt_freq returns: 12 Cpad B read + 16 G B written per locus"),
             valu_roof("fst_hudson", "tpg_fst_hudson_gemm_kernel (totals as three masked G x M x G products)", 12.0 * P * m,
                       "priced at SURVEY.md 8d's ~12 flop per pair-locus; the kernel itself does 3 * 2 * 64^2 flop per locus"),
-            valu_roof("fst_wc84", "tpg_fst_wc84_tab_kernel<8> (totals, reciprocals tabulated by valid-allele count)", 45.0 * P * m,
-                      "priced at SURVEY.md 8d's ~45 flop per pair-locus; the kernel issues ~27 FP64 instructions per pair-locus"),
+            valu_roof("fst_wc84", "tpg_fst_wc84_tile_kernel (totals, 3 x 2 tiles of populations per thread, reciprocals tabulated by "
+                      "valid-allele count)", 45.0 * P * m,
+                      "priced at SURVEY.md 8d's ~45 flop per pair-locus; the kernel issues 22 FP64 (27 VALU) instructions and 3.67 "
+                      "16-byte LDS reads per pair-locus: LDS bandwidth and VALU issue within 10 % of each other"),
             mfma_roof("loadings_mfma", "tpg_loadings_mfma_kernel (v = Z'u/d)", 2.0 * n * m_pca * 6 * k,
                       "u split into 6 int8 digits: 2 N M 6k ops; HBM side N M / 4 + 4 * 32 ceil(6k/32) B per locus"),
             hbm_roof("pairwise_epilogue", "tpg_pairwise_epilogue_kernel", (20.0 * n * (n + 64) / 2 + 24.0 * n * n) / max(1, world),

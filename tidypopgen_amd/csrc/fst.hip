@@ -530,6 +530,202 @@ __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64
     }
 }
 
+// The same for MANY pairs (more than 256) of at most 64 populations: a thread owns a TILE of FSTW_TR x FSTW_TC populations =
+// up to 6 pairs instead of 8 unrelated pairs.  The kernel above is bound by LDS bandwidth AND close to its VALU bound
+// (rocprofv3 --pmc at 51 populations: 1.2e8 ds_read_b128 x 8 cycles / 256 CUs = 3.8 of the kernel's 3.97 million cycles, 7.6e8
+// VALU x 4 / 1 024 SIMDs = 3.0): six 16-byte reads per pair and locus, four of them the pair's two populations, and 38 VALU
+// instructions of which 24 are the FP64 arithmetic.  Here
+//   * a tile reads its 3 + 2 populations ONCE per locus -- 1.67 reads per pair -- and only the two table reads stay per
+//     pair: 3.67 reads instead of 6.  The tiles come from the host (any list of pairs: a tile holds the listed pairs that fall
+//     into it, -1 elsewhere; all pairs of 51 populations: 242 tiles = one workgroup of four full waves, 88 % of their slots
+//     used; 4 x 2 tiles need 194 registers and leave a CU with six waves: 2.4 ms);
+//   * every LDS address is a per-lane pointer that advances by two loci per iteration + an IMMEDIATE offset (the layout is a
+//     compile-time constant: tables of 512 entries first, 16 loci x 64 populations after them), where the kernel above
+//     adds a loop-dependent offset to every one of its addresses in the VALU;
+//   * a population is staged as {32 n, p} and {32 H, 1 / n}: 32 (n_1 + n_2) IS the byte offset of the pair's table entry
+//     (16 bytes per valid allele), and the powers of two cancel exactly against the table's 1 / (32 nt): no doubling, no
+//     shift, the same roundings;
+//   * "is the denominator a number" is decided per WAVE and locus (one ballot of the six comparisons): the common case
+//     adds without v_cndmask (4 per pair).
+// 26 VALU instructions per pair and locus instead of 38.  Per pair the arithmetic, its order, and the order of the loci are
+// those of the kernel above: the sums are identical bit for bit.
+#define FSTW_TR 3
+#define FSTW_TC 2
+#define FSTW_TASK_INTS (2 + FSTW_TR * FSTW_TC)  // {first row population, first column population, pair index x 6}
+#define FSTT_KMAX 511                            // table entries 0 .. 511 valid alleles of a pair
+#define FSTT_LB 16
+#define FSTT_TAB2 (512 * 16)
+#define FSTT_SA (2 * 512 * 16)                   // {32 n, p} [locus][population]
+#define FSTT_SB (FSTT_SA + FSTT_LB * 64 * 16)    // {32 H, 1 / n}
+#define FSTT_LDS (FSTT_SB + FSTT_LB * 64 * 16)
+__global__ __launch_bounds__(256, 3) void tpg_fst_wc84_tile_kernel(FstSrc src, int64_t m, int G, int kmax,
+                                                                   const int32_t* __restrict__ tasks, int ntask, int P,
+                                                                   double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) char shb[FSTT_LDS];
+  constexpr int NPT = FSTW_TR * FSTW_TC, LB = FSTT_LB, GS = 64;
+  for (int A = threadIdx.x; A <= kmax; A += 256) {
+    const double nt = 0.5 * (double)A, nb1 = 0.5 * nt - 1.0;
+    const double r = 1.0 / nt, sv = 1.0 / nb1;
+    double* t = (double*)shb + (size_t)A * 2;
+    t[0] = r * 0.03125;  // against the staged 32 n, 32 H
+    t[1] = (0.5 * (nt - 1.0)) * r;
+    double* t2 = (double*)(shb + FSTT_TAB2) + (size_t)A * 2;
+    t2[0] = (0.5 * nt) * sv;
+    t2[1] = (0.25 * (nt * nt)) * sv;
+  }
+  const int task = blockIdx.y * 256 + threadIdx.x;
+  const bool active = task < ntask;
+  int pidx[NPT];
+  uint32_t ro[FSTW_TR], co[FSTW_TC];  // byte offsets of the tile's populations inside a locus' staged row
+  double sum_num[NPT], sum_den[NPT];
+  {
+    const int r0 = active ? tasks[task * FSTW_TASK_INTS] : 0, c0 = active ? tasks[task * FSTW_TASK_INTS + 1] : 0;
+#pragma unroll
+    for (int i = 0; i < FSTW_TR; i++) ro[i] = (uint32_t)min(r0 + i, G - 1) * 16u;
+#pragma unroll
+    for (int j = 0; j < FSTW_TC; j++) co[j] = (uint32_t)min(c0 + j, G - 1) * 16u;
+#pragma unroll
+    for (int k = 0; k < NPT; k++) {
+      pidx[k] = active ? tasks[task * FSTW_TASK_INTS + 2 + k] : -1;
+      sum_num[k] = 0.0; sum_den[k] = 0.0;
+    }
+  }
+  const int kmax16 = kmax * 16;
+  const int64_t nchunks = (m + LB - 1) / LB;
+  constexpr int SLOTS = LB * GS / 256;  // staged (locus, population) slots per thread
+  int pn1[SLOTS], pn2[SLOTS], pnv[SLOTS];
+  auto fetch = [&](int64_t ch) {
+    const int64_t plane = src.Mpad * src.Cpad;
+#pragma unroll
+    for (int i = 0; i < SLOTS; i++) {
+      pn1[i] = 0; pn2[i] = 0; pnv[i] = 0;
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < LB * G && ch < nchunks) {
+        const int64_t j = ch * LB + idx / G;
+        if (j < m) {
+          const int64_t o = j * src.Cpad + idx % G;
+          pn1[i] = src.cnt[o]; pn2[i] = src.cnt[plane + o]; pnv[i] = src.cnt[2 * plane + o];
+        }
+      }
+    }
+  };
+  // one locus of the tile: the row populations at pr[] + OFF, the column populations at pc[] + OFF
+  // (LDS pointers by their address space: as generic pointers kept in arrays across the loop they become 64-bit FLAT loads)
+  typedef __attribute__((address_space(3))) const char lchar;
+  typedef __attribute__((address_space(3))) const v2d lv2d;
+  auto locus = [&](lchar* const* pr, lchar* const* pc, auto off) {
+#pragma clang fp contract(fast)  // (as in the kernel above)
+    constexpr int OFF = decltype(off)::value;
+    v4d R[FSTW_TR], Cc[FSTW_TC];  // {32 n, p, 32 H, 1 / n}
+#pragma unroll
+    for (int i = 0; i < FSTW_TR; i++) {
+      const v2d a = *(lv2d*)(pr[i] + OFF), b = *(lv2d*)(pr[i] + OFF + (FSTT_SB - FSTT_SA));
+      R[i] = v4d{a[0], a[1], b[0], b[1]};
+    }
+#pragma unroll
+    for (int j = 0; j < FSTW_TC; j++) {
+      const v2d a = *(lv2d*)(pc[j] + OFF), b = *(lv2d*)(pc[j] + OFF + (FSTT_SB - FSTT_SA));
+      Cc[j] = v4d{a[0], a[1], b[0], b[1]};
+    }
+    double av[NPT], dv[NPT];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < FSTW_TR; i++)
+#pragma unroll
+      for (int j = 0; j < FSTW_TC; j++) {
+        const int k = i * FSTW_TC + j;
+        const v4d s1 = R[i], s2 = Cc[j];
+        // 16 bytes per valid allele of the pair: 32 (n1 + n2), an exact small integer in FP64
+        const int A16 = min(__double2int_rz(s1[0] + s2[0]), kmax16);
+        const v2d ta = *(const v2d*)(shb + A16), tb = *(const v2d*)(shb + A16 + FSTT_TAB2);
+        const v4d t = v4d{ta[0], ta[1], tb[0], tb[1]};
+        const double p_bar = fma(s2[1], s2[0], s1[1] * s1[0]) * t[0], h_bar = (s1[2] + s2[2]) * t[0];
+        const double d = s1[1] - s2[1], d2 = d * d;
+        const double half_s2 = (d2 * (s1[0] * s2[0])) * (t[0] * t[0]);
+        const double core = fma(-p_bar, p_bar, p_bar) - half_s2;
+        const double X = t[3] * (s1[3] * s2[3]);
+        const double a = fma(-X, fma(-0.25, h_bar, core), 0.5 * d2);
+        const double b = t[2] * fma(-t[1], h_bar, core);
+        const double den = fma(0.5, h_bar, a + b);
+        av[k] = a; dv[k] = den;
+        ok = ok && den == den;
+      }
+    if (__all(ok)) {  // (an unused slot of the tile sums what nobody reads)
+#pragma unroll
+      for (int k = 0; k < NPT; k++) { sum_num[k] += av[k]; sum_den[k] += dv[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NPT; k++)
+        if (dv[k] == dv[k]) { sum_num[k] += av[k]; sum_den[k] += dv[k]; }  // a NaN numerator makes the denominator NaN too
+    }
+  };
+  fetch(blockIdx.x);
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t j0 = ch * LB;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SLOTS; i++) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < LB * G) {
+        // src/grouped_summaries_dip_pseudo_cpp.cpp:40-56 on the counts (diploids): n = 2 valid, freq, het_obs
+        const double vn = (double)(2 * pnv[i]);
+        const double vp = (double)(pn1[i] + 2 * pn2[i]) / vn, vh = (double)(2 * pn1[i]) / vn;  // 0 / 0 = NaN: no valid genotype
+        const double ni = 0.5 * vn;
+        const uint32_t q = (uint32_t)((idx / G) * GS + idx % G);
+        *(v2d*)(shb + FSTT_SA + q * 16u) = v2d{32.0 * ni, vp};
+        *(v2d*)(shb + FSTT_SB + q * 16u) = v2d{32.0 * (vh * ni), 1.0 / ni};
+      }
+    }
+    __syncthreads();
+    fetch(ch + gridDim.x);
+    const int lmax = (int)((m - j0) < LB ? (m - j0) : LB);
+    if (!active) continue;
+    lchar *pr[FSTW_TR], *pc[FSTW_TC];
+#pragma unroll
+    for (int i = 0; i < FSTW_TR; i++) pr[i] = (lchar*)(shb + FSTT_SA + ro[i]);
+#pragma unroll
+    for (int j = 0; j < FSTW_TC; j++) pc[j] = (lchar*)(shb + FSTT_SA + co[j]);
+    int l = 0;
+    for (; l + 2 <= lmax; l += 2) {
+      locus(pr, pc, std::integral_constant<int, 0>{});
+      locus(pr, pc, std::integral_constant<int, GS * 16>{});
+#pragma unroll
+      for (int i = 0; i < FSTW_TR; i++) pr[i] += 2 * GS * 16;
+#pragma unroll
+      for (int j = 0; j < FSTW_TC; j++) pc[j] += 2 * GS * 16;
+    }
+    if (l < lmax) locus(pr, pc, std::integral_constant<int, 0>{});
+  }
+#pragma unroll
+  for (int k = 0; k < NPT; k++)
+    if (pidx[k] >= 0) {
+      part[((int64_t)blockIdx.x * P + pidx[k]) * 2] = sum_num[k];
+      part[((int64_t)blockIdx.x * P + pidx[k]) * 2 + 1] = sum_den[k];
+    }
+}
+
+// the pairs (0-based populations, row = first, column = second of a pair) cut into tiles of FSTW_TR x FSTW_TC populations
+static void fst_wc84_tiles(const std::vector<int32_t>& p0, int P, std::vector<int32_t>& tasks) {
+  std::map<std::pair<int, int>, std::vector<size_t>> where;  // tile -> its tasks (more than one if a pair is listed twice)
+  tasks.clear();
+  for (int pi = 0; pi < P; pi++) {
+    const int g1 = p0[(size_t)2 * pi], g2 = p0[(size_t)2 * pi + 1];
+    const int rb = g1 / FSTW_TR, cb = g2 / FSTW_TC, slot = (g1 % FSTW_TR) * FSTW_TC + g2 % FSTW_TC;
+    auto& list = where[{rb, cb}];
+    size_t t = (size_t)-1;
+    for (size_t cand : list)
+      if (tasks[cand * FSTW_TASK_INTS + 2 + slot] < 0) { t = cand; break; }
+    if (t == (size_t)-1) {
+      t = tasks.size() / FSTW_TASK_INTS;
+      tasks.resize(tasks.size() + FSTW_TASK_INTS, -1);
+      tasks[t * FSTW_TASK_INTS] = rb * FSTW_TR;
+      tasks[t * FSTW_TASK_INTS + 1] = cb * FSTW_TC;
+      list.push_back(t);
+    }
+    tasks[t * FSTW_TASK_INTS + 2 + slot] = pi;
+  }
+}
+
 // flag[0] = 1 if some freq_ref entry is not exactly 1 - freq_alt (NaN matches NaN)
 __global__ void tpg_freq_ref_check_kernel(const double* __restrict__ p, const double* __restrict__ q, int64_t total,
                                           int* __restrict__ flag) {
@@ -613,6 +809,23 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
     const int64_t nch = ceil_div(m, lb_tab);
     const int nbt = (int)std::max<int64_t>(1, std::min<int64_t>(nch, (int64_t)nblocks));
     dim3 grid((unsigned)nbt, (unsigned)ypass);
+    // many pairs: a thread takes a tile of populations (tpg_fst_wc84_tile_kernel); TPG_FST_TILES=0: 8 unrelated pairs (A/B)
+    static const bool no_tiles = getenv("TPG_FST_TILES") && atoi(getenv("TPG_FST_TILES")) == 0;
+    InBuf tb;
+    int ntask = 0;
+    const bool tiles = ppt == 8 && !no_tiles && G <= 64 && kmax <= FSTT_KMAX && lb_tab == FSTT_LB;
+    if (tiles) {
+      std::vector<int32_t> tasks;
+      fst_wc84_tiles(p0, P, tasks);
+      ntask = (int)(tasks.size() / FSTW_TASK_INTS);
+      rc = tb.init(ctx, tasks.data(), sizeof(int32_t) * tasks.size());
+    }
+    if (rc == TPG_OK && ntask > 0) {
+      const int nbt2 = (int)std::max<int64_t>(1, std::min<int64_t>(nch, (int64_t)nblocks));
+      dim3 tgrid((unsigned)nbt2, (unsigned)ceil_div(ntask, 256));
+      TPG_LAUNCH(ctx, "fst_wc84", tpg_fst_wc84_tile_kernel, tgrid, dim3(256), 0, src, m, G, kmax, tb.dev<int32_t>(), ntask, P,
+                 d_part);
+    } else if (rc == TPG_OK) {
 #define FSTW_LAUNCH(PP, GSV)                                                                                                    \
   do {                                                                                                                          \
     (void)hipFuncSetAttribute((const void*)tpg_fst_wc84_tab_kernel<PP, GSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_tab); \
@@ -624,8 +837,10 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
     else if (G <= 64) FSTW_LAUNCH(1, 64);
     else FSTW_LAUNCH(1, 0);
 #undef FSTW_LAUNCH
-    TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 16)), dim3(256), 0, d_part, nbt, P,
-               ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
+    }
+    if (rc == TPG_OK)
+      TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_reduce_kernel, dim3((unsigned)ceil_div(P, 16)), dim3(256), 0, d_part, nbt, P,
+                 ot.dev<double>(), osn.dev<double>(), osd.dev<double>());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { tpg_set_error("fst kernels: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
   } else if (rc == TPG_OK) {
