@@ -589,6 +589,42 @@ def test_fst_vs_oracle(tpg, n, m, G, method):
                 tpg.pairwise_fst_nei87_loop(pairs, pf["n"], pf["het_obs"], pf["freq_alt"], bad)
 
 
+def test_wc84_totals_tiles_any_pair_list(tpg):
+    """More than 256 pairs of at most 64 populations take the tiled totals kernel (tpg_fst_wc84_tile_kernel: a thread owns a
+    3 x 2 tile of populations): a pair list in any order, with (g2, g1) orientations and repeated pairs, an empty population,
+    a population without a valid genotype at a locus, a last chunk of odd length -- against sums of the oracle's by-locus
+    numerators and denominators."""
+    import math
+
+    n, m, G = 330, 1237, 31  # 1 237 = 77 chunks of 16 loci + 5
+    Xb = orc.synth_fbm(23, n, m, npop=G - 1, miss=0.04)
+    gid = (np.arange(n) % (G - 1)).astype(np.int32)  # population G - 1 is empty
+    Xb[gid == 3, 7] = 3  # missing
+    rng = np.random.default_rng(23)
+    allp = tpg.combn2(G)
+    cols = rng.permutation(allp.shape[1])[:420]
+    pairs = allp[:, cols].copy()
+    flip = rng.random(pairs.shape[1]) < 0.3
+    pairs[:, flip] = pairs[::-1, flip]
+    pairs = np.ascontiguousarray(np.concatenate([pairs, pairs[:, :9]], axis=1))  # nine pairs listed twice
+    X = tpg.FBM.from_numpy(Xb)
+    got = tpg.pairwise_pop_fst(X, None, None, gid, G, method="WC84", pairwise_combn=pairs, sums=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pf = orc.grouped_summaries_dip_pseudo_cpp(Xb, None, None, gid, G, np.full(n, 2.0))
+        ref = orc.pairwise_fst_wc84_loop(pairs, pf["n"], pf["freq_alt"], pf["het_obs"], True, True)
+    num, den = np.asarray(ref["Fst_by_locus_num"]), np.asarray(ref["Fst_by_locus_den"])
+    P = pairs.shape[1]
+    sn = np.array([math.fsum(num[~np.isnan(den[:, k]), k]) for k in range(P)])
+    sd = np.array([math.fsum(den[~np.isnan(den[:, k]), k]) for k in range(P)])
+    ok = sd != 0  # (pairs with the empty population have no locus at all)
+    assert ok.sum() > 380 and (~ok).sum() > 0
+    assert np.allclose(got["sum_num"][ok], sn[ok], rtol=1e-10, atol=1e-12)
+    assert np.allclose(got["sum_den"][ok], sd[ok], rtol=1e-10, atol=1e-12)
+    assert np.all(got["sum_den"][~ok] == 0)
+    assert np.array_equal(got["sum_num"][-9:], got["sum_num"][:9])  # the repeated pairs
+    X.free()
+
+
 def test_fst_pseudohaploid_hudson_only(tpg):
     n, m, G = 120, 900, 4
     fbm = orc.synth_fbm(61, n, m, npop=G, miss=0.05)
