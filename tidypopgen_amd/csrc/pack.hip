@@ -116,6 +116,11 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
 // T0 / T1 may be NULL (the view gets no T layout: tpg_view_need_T makes it from L if it is ever wanted); T4 (may be
 // NULL) = the FP4 operand layout of view 0 for the pairwise kernel (pairwise.hip), written instead of being expanded
 // from T later: every T word goes out as the two T4 words of the same lane.
+#ifndef PACK_NSUB
+#define PACK_NSUB 2  // individual chunks per workgroup, all their loads issued up front
+#endif
+typedef uint32_t pk_u4 __attribute__((ext_vector_type(4)));
+typedef pk_u4 pk_u4a8 __attribute__((aligned(8)));
 template <int NV>
 __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __restrict__ fbm, int64_t nrow,
                                                             const int32_t* __restrict__ cols, uint8_t* lut_and_flag,
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
   // 1-D grid, individual chunk fastest: neighbouring workgroups read neighbouring pieces of the same 128 columns
   // (columns are only 8-byte aligned, so the pieces share cache lines and DRAM pages).  A workgroup does NSUB
   // individual chunks one after the other with all their loads issued up front (16 x 8 B in flight per thread).
-  constexpr int NSUB = 2;
+  constexpr int NSUB = PACK_NSUB;
   const int64_t QB = (Q + NSUB - 1) / NSUB;
   const int64_t bj = blockIdx.x / QB;          // locus group (kg)
   const int64_t bi0 = (blockIdx.x % QB) * NSUB;  // first individual chunk (q)
@@ -174,8 +179,14 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
       if (j < m && bi0 + sub < Q) {
         const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
         const uint8_t* p = fbm + i0 + src_col * nrow;
-        if (i0 + 8 <= n) va[sub][it] = *reinterpret_cast<const uint2*>(p);
-        if (i0 + 16 <= n) vb[sub][it] = *reinterpret_cast<const uint2*>(p + 8);
+        // (columns are 8-byte aligned only; the hardware takes a 16-byte load at any dword address: half the load instructions)
+        if (i0 + 16 <= n) {
+          const pk_u4 t = *reinterpret_cast<const pk_u4a8*>(p);
+          va[sub][it] = make_uint2(t[0], t[1]);
+          vb[sub][it] = make_uint2(t[2], t[3]);
+        } else if (i0 + 8 <= n) {
+          va[sub][it] = *reinterpret_cast<const uint2*>(p);
+        }
       }
     }
   }
@@ -261,7 +272,7 @@ int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, con
   if (fbm->bed_bpl == 0 && d_rows == nullptr && (fbm->nrow & 7) == 0 && (((uintptr_t)fbm->d_bytes) & 7) == 0 &&
       !getenv("TPG_PACK_GENERIC")) {
     TPG_REQUIRE(v->KG * v->Q < 2147483647ll, TPG_EINVAL, "view too large for the pack grid");
-    const dim3 g1((unsigned)(v->KG * ((v->Q + 1) / 2)));
+    const dim3 g1((unsigned)(v->KG * ((v->Q + PACK_NSUB - 1) / PACK_NSUB)));
     if (v2)
       TPG_LAUNCH(ctx, "pack2", tpg_pack_fast_kernel<2>, g1, dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
                  v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)v2->T, (uint32_t*)v2->L,
