@@ -88,7 +88,10 @@ int tpg_prof_resolve(tpg_ctx* ctx);
 // gramcls.hip: S' = sum_j w_j g_i g_k' (n x n, column-major, both triangles) into d_K by weight classes; *done = false
 // (nothing written) when the weights take too many distinct values for that to pay.  d_what (may be NULL): the weight
 // actually used for every locus (its class representative, within 2^-47 of w_j)
-int tpg_gram_classes(tpg_ctx* ctx, const struct tpg_view* v, const double* d_w, double* d_what, double* d_K, bool* done);
+// centred_ok: the caller applies the double centring H K H afterwards, so terms r_i + r_k + const may be left out of S'
+// (gramcls.hip: the centred operand layout of the mixed-fold kernel)
+int tpg_gram_classes(tpg_ctx* ctx, const struct tpg_view* v, const double* d_w, double* d_what, double* d_K, bool* done,
+                     bool centred_ok);
 // The same over the ranks of a communicator, with whole weight classes per rank: `v` holds this rank's loci (counts: its
 // m x 4 genotype counts, scale: its binomial scales), the packed columns are exchanged so that rank r ends up with ALL loci
 // of the allele-count range it owns, and d_K receives S' of those classes (the sum over the ranks is S' of the panel).

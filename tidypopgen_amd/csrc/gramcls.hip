@@ -218,6 +218,14 @@ struct GclsSrc {
   int64_t sb, sq, sh1;
 };
 
+// CEN (tpg_gcls_gram2_kernel<VT, true> only): a source dword packs the codes of BOTH blocks of the pair -- low two bits of
+// a nibble: the dosage code of a locus of block 2 bp, as before (P & 0x33333333 = FP4 dosage / 2); high two bits: a locus
+// of block 2 bp + 1 as its CENTRED dosage g - 1, coded 3 / 0 / 1 so that P & 0xCCCCCCCC is the FP4 value -2 / 0 / +2 -- and
+// the kernel makes an operand word with ONE v_and_b32 instead of a shift and an AND (4 instead of 6 VALU per MFMA).  A
+// padding locus of the odd block is 0 = "dosage 1".  What the products of the odd blocks lack, w (g_i + g_k - 1) summed over
+// their loci, is r_i + r_k + const: the double centring of the PCA removes exactly such terms, so this layout is only used
+// where that centring follows (tpg_gram_classes' centred_ok).
+template <bool CEN>
 __global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(GclsSrc S, int64_t Q,
                                                                const int32_t* __restrict__ src, int64_t nblocks,
                                                                int64_t rs2, uint4* __restrict__ T2g) {
@@ -235,6 +243,8 @@ __global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(GclsSrc S, int64_t
     for (int hb = 0; hb < 2; hb++) {
       const int64_t b = 2 * bp + hb;
       const int32_t j = b < nblocks ? src[b * 64 + lane] : -1;
+      const unsigned long long valid = __ballot(j >= 0);  // bit l: locus l of this block exists
+      (void)valid;
       uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
       if (j >= 0) {
         const uint4* p = S.base + (int64_t)(j >> S.sh) * S.sa + (int64_t)(j & S.msk) * S.sb + q * S.sq;
@@ -262,8 +272,23 @@ __global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(GclsSrc S, int64_t
           const uint32_t m3 = acc & (acc >> 1) & 0x11111111u;  // code 3 -> 0
           nib[d] = acc & ~(m3 | (m3 << 1));
         }
-        out[s][2 * hb] = nib[0] | (nib[1] << 2);
-        out[s][2 * hb + 1] = nib[2] | (nib[3] << 2);
+        if constexpr (CEN) {
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            if (hb == 0) {
+              out[s][d] = nib[d];
+            } else {  // g - 1 on the loci that exist: (code + 3) & 3 per nibble (no carry leaves a nibble: code <= 2)
+              uint32_t vb = (uint32_t)(valid >> (32 * ho + 8 * d)) & 0xFFu;  // loci 32 ho + 8 d + e, e = bit e
+              vb = (vb | (vb << 12)) & 0x000F000Fu;
+              vb = (vb | (vb << 6)) & 0x03030303u;
+              vb = (vb | (vb << 3)) & 0x11111111u;
+              out[s][d] |= ((nib[d] + 3u * vb) & 0x33333333u) << 2;
+            }
+          }
+        } else {
+          out[s][2 * hb] = nib[0] | (nib[1] << 2);
+          out[s][2 * hb + 1] = nib[2] | (nib[3] << 2);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -443,7 +468,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define GCLS2_D 2
 #endif
 // VT: the block table through one vector load per loop body + v_readlane_b32 instead of one scalar load per block (see 3c)
-template <bool VT>
+// CEN: operands in the centred layout of tpg_gcls_gather_kernel<true> (one v_and_b32 per operand word; the odd block of a
+// pair takes the high halves of the nibbles, values +-2, with the block scales 2^-1 where the even block has 2^+1)
+#define MFMA_G4S2_ODD(a, b, c) \
+  __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tpg_g8(a), tpg_g8(b), (c), 4, 4, 0, (int)0x7E7E7E7E, 0, (int)0x7E7E7E7E)
+template <bool VT, bool CEN = false>
 __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __restrict__ T2g, int64_t nblocks, int64_t rs2, int nrtv,
                                                                 const ulonglong2* __restrict__ wblk,
                                                                 const int2* __restrict__ order, int64_t nun, int S,
@@ -547,8 +576,12 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
                 v4u X[GA + GB];
 #pragma unroll
                 for (int t = 0; t < GA + GB; t++) {
-                  const uint32_t w0 = R[C][t][2 * hb], w1 = R[C][t][2 * hb + 1];
-                  X[t] = v4u{w0 & 0x33333333u, (w0 >> 2) & 0x33333333u, w1 & 0x33333333u, (w1 >> 2) & 0x33333333u};
+                  if constexpr (CEN) {
+                    X[t] = R[C][t] & (hb == 0 ? 0x33333333u : 0xCCCCCCCCu);
+                  } else {
+                    const uint32_t w0 = R[C][t][2 * hb], w1 = R[C][t][2 * hb + 1];
+                    X[t] = v4u{w0 & 0x33333333u, (w0 >> 2) & 0x33333333u, w1 & 0x33333333u, (w1 >> 2) & 0x33333333u};
+                  }
                 }
                 if (st & 2) {  // the class that ended with the previous block: dev += (w_c - w_{c+1}) * P_c
                   const v2f dl = v2f{pdelta, pdelta};
@@ -562,8 +595,13 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
                     });
                   }
                 }
+                if (CEN && hb == 1) {
 #pragma unroll
-                for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2(X[p / GB], X[GA + p % GB], acc[p]);
+                  for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2_ODD(X[p / GB], X[GA + p % GB], acc[p]);
+                } else {
+#pragma unroll
+                  for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2(X[p / GB], X[GA + p % GB], acc[p]);
+                }
                 st = 0;
                 const uint32_t fl = (uint32_t)wf.x & 3u;
                 if ((fl & 2u) || b == bl) {  // group end: the FP64 fold, then everything starts from zero
@@ -896,7 +934,7 @@ static double gcls_cost_classes(int64_t nunits, int64_t nruns, int64_t nblocks, 
 }
 
 static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, const GclsSrc& src, const double* d_w, double* d_what,
-                             double* d_K, bool force, bool* done) {
+                             double* d_K, bool force, bool* done, bool centred_ok) {
   *done = false;
   if (m >= (1ll << 31) - 64 || (getenv("TPG_GRAM_DIGITS") && !force)) return TPG_OK;
   GclsBufs B;
@@ -968,6 +1006,10 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   int ncu8 = ctx->num_cu / 8 * 8;
   if (ncu8 < 8) ncu8 = 8;
   const bool f64 = body ? false : gcls_fold64(nruns, nblocks);
+  // the centred operand layout (tpg_gcls_gather_kernel<true>): the default two-waves mixed-fold kernel only, and only where
+  // the caller double-centres the result (the omitted terms are r_i + r_k + const); TPG_GRAM_CENTER=0: never (A/B)
+  static const bool no_cen = getenv("TPG_GRAM_CENTER") && atoi(getenv("TPG_GRAM_CENTER")) == 0;
+  const bool cen = centred_ok && !no_cen && !f64 && !body && kern3 != 1;
   const int nblk_grid = one_wave ? ncu8 : 2 * ncu8;  // two workgroups per CU = two waves per SIMD
   const int nwaves = 4 * nblk_grid;
   int S = 2;
@@ -1016,8 +1058,12 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   {
     const int64_t tasks = Q * rs2;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(tasks, 4), (int64_t)ctx->num_cu * 16);
-    TPG_LAUNCH(ctx, "gcls_gather", tpg_gcls_gather_kernel, dim3(grid), dim3(256), 0, src, Q, (const int32_t*)d_src, nblocks, rs2,
-               d_T2g);
+    if (cen)
+      TPG_LAUNCH(ctx, "gcls_gather", tpg_gcls_gather_kernel<true>, dim3(grid), dim3(256), 0, src, Q, (const int32_t*)d_src, nblocks,
+                 rs2, d_T2g);
+    else
+      TPG_LAUNCH(ctx, "gcls_gather", tpg_gcls_gather_kernel<false>, dim3(grid), dim3(256), 0, src, Q, (const int32_t*)d_src, nblocks,
+                 rs2, d_T2g);
   }
   if (f64)
     TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T2g, nblocks,
@@ -1043,6 +1089,10 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
     if (kern3 == 1) {
       (void)hipFuncSetAttribute((const void*)tpg_gcls_gram2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
       TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram2_kernel<false>, dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
+                 (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
+    } else if (cen) {
+      (void)hipFuncSetAttribute((const void*)tpg_gcls_gram2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
+      TPG_LAUNCH(ctx, "pca_gram_classes", (tpg_gcls_gram2_kernel<true, true>), dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
                  (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
     } else {
       (void)hipFuncSetAttribute((const void*)tpg_gcls_gram2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
@@ -1078,7 +1128,8 @@ __global__ __launch_bounds__(256) void tpg_gcls_l2lm_kernel(const uint4* __restr
   }
 }
 
-int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double* d_what, double* d_K, bool* done) {
+int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double* d_what, double* d_K, bool* done,
+                     bool centred_ok) {
   *done = false;
   if (getenv("TPG_GRAM_DIGITS")) return TPG_OK;
   const int64_t n_lt = 4 * v->KG;
@@ -1087,7 +1138,7 @@ int tpg_gram_classes(tpg_ctx* ctx, const tpg_view* v, const double* d_w, double*
   TPG_LAUNCH(ctx, "gcls_l2lm", tpg_gcls_l2lm_kernel, dim3((unsigned)std::min<int64_t>(n_lt * ((v->Q + 3) / 4), (int64_t)ctx->num_cu * 32)),
              dim3(256), 0, (const uint4*)v->L, v->Q, n_lt, d_LM);
   const GclsSrc src{d_LM, 0, 2 * v->Q, 0, 0, 2, 1};
-  const int rc = gram_classes_core(ctx, v->n, v->Q, v->m, src, d_w, d_what, d_K, false, done);
+  const int rc = gram_classes_core(ctx, v->n, v->Q, v->m, src, d_w, d_what, d_K, false, done, centred_ok);
   tpg_pfree(d_LM);  // stream-ordered
   return rc;
 }
@@ -1297,7 +1348,7 @@ int tpg_gram_classes_exchanged(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, 
   hipLaunchKernelGGL(tpg_gclx_weights_kernel, dim3(512), dim3(256), 0, ctx->stream, (const uint4*)d_recv, Q, m_in, d_w);
   const GclsSrc src{d_recv, 0, recq, 0, 0, 2, 1};
   bool ok = false;
-  TPG_TRY(gram_classes_core(ctx, n, Q, m_in, src, d_w, nullptr, d_K, true, &ok));
+  TPG_TRY(gram_classes_core(ctx, n, Q, m_in, src, d_w, nullptr, d_K, true, &ok, true));  // (the caller double-centres: pca.hip)
   TPG_REQUIRE(ok, TPG_EHIP, "class Gram of the exchanged loci was not computed");
   *done = true;
   return TPG_OK;

@@ -789,7 +789,7 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
     GHIP(tpg_pmalloc((void**)&d_w, sizeof(double) * (size_t)m));
     if (e == hipSuccess) {
       TPG_LAUNCH(ctx, "pca_weights", tpg_pca_weights_kernel, dim3(1024), dim3(256), 0, d_scale, m, d_w);
-      rc = tpg_gram_classes(ctx, v, d_w, d_what, d_K, &by_classes);
+      rc = tpg_gram_classes(ctx, v, d_w, d_what, d_K, &by_classes, own_center);
       if (rc == TPG_OK && by_classes)
         TPG_LAUNCH(ctx, "pca_weights", tpg_pca_wc_kernel, dim3(1024), dim3(256), 0, (const double*)d_what, d_center, m, d_wc);
     }
