@@ -1,7 +1,7 @@
 // tests/host/host_pieces.cpp -- self-checking driver for the host-only pieces of libtpg_hip.so (tidypopgen_amd/csrc/host/*.h),
 // built WITHOUT HIP by tests/test_host_sanitizers.py with -fsanitize=address,undefined and (the transport) -fsanitize=thread:
 // the CPU-side equivalent of the reference's valgrind job (.github/workflows/R-CMD-check-valgrind.yaml:50-51).
-//   host_pieces eig | bands | relfilter | nibpack | inproc [threads] | inproc_mismatch
+//   host_pieces eig | bands | relfilter | nibpack | fsttiles | inproc [threads] | inproc_mismatch
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,6 +14,7 @@
 #define TPG_HOST_NO_CLONES 1  // one plain build of the QL (function multiversioning and sanitizers do not mix everywhere)
 #include "host/host_bands.h"
 #include "host/host_eig.h"
+#include "host/host_fsttiles.h"
 #include "host/host_inproc.h"
 #include "host/host_nibpack.h"
 #include "host/host_relfilter.h"
@@ -286,6 +287,45 @@ static int test_nibpack() {
   return 0;
 }
 
+// the pair list of pairwise_pop_fst cut into tiles of populations: every listed pair in exactly one slot of the right tile,
+// whatever the order, the orientation and the repeats of the list
+static int test_fsttiles() {
+  for (int G : {2, 3, 7, 51, 64}) {
+    for (int kind = 0; kind < 3; kind++) {
+      std::vector<int32_t> p0;
+      for (int a = 0; a < G; a++)
+        for (int b = a + 1; b < G; b++) {
+          if (kind == 1 && urand() < 0.5) continue;                     // a subset
+          const bool flip = kind == 2 && urand() < 0.4;                 // (g2, g1)
+          p0.push_back(flip ? b : a);
+          p0.push_back(flip ? a : b);
+          if (kind == 2 && urand() < 0.05) { p0.push_back(a); p0.push_back(b); }  // listed twice
+        }
+      const int P = (int)(p0.size() / 2);
+      std::vector<int32_t> tasks;
+      fst_wc84_tiles(p0, P, tasks);
+      CHECK(tasks.size() % FSTW_TASK_INTS == 0, "task record size");
+      std::vector<int> seen((size_t)P, 0);
+      for (size_t t = 0; t < tasks.size() / FSTW_TASK_INTS; t++) {
+        const int32_t* T = &tasks[t * FSTW_TASK_INTS];
+        CHECK(T[0] % FSTW_TR == 0 && T[1] % FSTW_TC == 0 && T[0] >= 0 && T[1] >= 0, "tile origin");
+        int used = 0;
+        for (int k = 0; k < FSTW_TR * FSTW_TC; k++) {
+          const int pi = T[2 + k];
+          if (pi < 0) continue;
+          CHECK(pi < P, "pair index %d out of %d", pi, P);
+          CHECK(p0[(size_t)2 * pi] == T[0] + k / FSTW_TC && p0[(size_t)2 * pi + 1] == T[1] + k % FSTW_TC, "pair %d in the wrong slot", pi);
+          seen[(size_t)pi]++;
+          used++;
+        }
+        CHECK(used > 0, "empty tile");
+      }
+      for (int pi = 0; pi < P; pi++) CHECK(seen[(size_t)pi] == 1, "pair %d placed %d times (G = %d, kind %d)", pi, seen[(size_t)pi], G, kind);
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "";
   int rc = 2;
@@ -295,7 +335,8 @@ int main(int argc, char** argv) {
   else if (what == "inproc") rc = test_inproc(argc > 2 ? atoi(argv[2]) : 4);
   else if (what == "inproc_mismatch") rc = test_inproc_mismatch();
   else if (what == "nibpack") rc = test_nibpack();
-  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | nibpack | inproc [threads] | inproc_mismatch\n");
+  else if (what == "fsttiles") rc = test_fsttiles();
+  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | nibpack | fsttiles | inproc [threads] | inproc_mismatch\n");
   if (rc == 0) printf("ok %s\n", what.c_str());
   return rc;
 }

@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "devfrag.h"
+#include "host/host_fsttiles.h"
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define FST_NAN __longlong_as_double(0x7FF8000000000000ll)
@@ -549,9 +550,8 @@ __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64
 //     adds without v_cndmask (4 per pair).
 // 26 VALU instructions per pair and locus instead of 38.  Per pair the arithmetic, its order, and the order of the loci are
 // those of the kernel above: the sums are identical bit for bit.
-#define FSTW_TR 3
-#define FSTW_TC 2
-#define FSTW_TASK_INTS (2 + FSTW_TR * FSTW_TC)  // {first row population, first column population, pair index x 6}
+// FSTW_TR x FSTW_TC = 3 x 2 populations; a task record = {first row population, first column population, pair index x 6}:
+// host/host_fsttiles.h (fst_wc84_tiles cuts the pair list into them)
 #define FSTT_KMAX 511                            // table entries 0 .. 511 valid alleles of a pair
 #define FSTT_LB 16
 #define FSTT_TAB2 (512 * 16)
@@ -702,28 +702,6 @@ __global__ __launch_bounds__(256, 3) void tpg_fst_wc84_tile_kernel(FstSrc src, i
       part[((int64_t)blockIdx.x * P + pidx[k]) * 2] = sum_num[k];
       part[((int64_t)blockIdx.x * P + pidx[k]) * 2 + 1] = sum_den[k];
     }
-}
-
-// the pairs (0-based populations, row = first, column = second of a pair) cut into tiles of FSTW_TR x FSTW_TC populations
-static void fst_wc84_tiles(const std::vector<int32_t>& p0, int P, std::vector<int32_t>& tasks) {
-  std::map<std::pair<int, int>, std::vector<size_t>> where;  // tile -> its tasks (more than one if a pair is listed twice)
-  tasks.clear();
-  for (int pi = 0; pi < P; pi++) {
-    const int g1 = p0[(size_t)2 * pi], g2 = p0[(size_t)2 * pi + 1];
-    const int rb = g1 / FSTW_TR, cb = g2 / FSTW_TC, slot = (g1 % FSTW_TR) * FSTW_TC + g2 % FSTW_TC;
-    auto& list = where[{rb, cb}];
-    size_t t = (size_t)-1;
-    for (size_t cand : list)
-      if (tasks[cand * FSTW_TASK_INTS + 2 + slot] < 0) { t = cand; break; }
-    if (t == (size_t)-1) {
-      t = tasks.size() / FSTW_TASK_INTS;
-      tasks.resize(tasks.size() + FSTW_TASK_INTS, -1);
-      tasks[t * FSTW_TASK_INTS] = rb * FSTW_TR;
-      tasks[t * FSTW_TASK_INTS + 1] = cb * FSTW_TC;
-      list.push_back(t);
-    }
-    tasks[t * FSTW_TASK_INTS + 2 + slot] = pi;
-  }
 }
 
 // flag[0] = 1 if some freq_ref entry is not exactly 1 - freq_alt (NaN matches NaN)

@@ -187,8 +187,11 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
 #pragma unroll
           for (int t = 0; t < TA; t++) RA[g][t][s] = LD(pa[t] + (ig * 2 + s) * 64);
           RB[g][s] = LD(pb0 + (ig * 2 + s) * 64);
+          // block by block, in the order the loop issues them: hipcc's wait-count pass merges the loop entry with the back
+          // edge, and with the two blocks of a group interleaved here the loop's second wait of every group became
+          // vmcnt(4) instead of vmcnt(8) -- the prefetch one block shallower than the slots allow (see tpg_pairwise_set_kernel)
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (NG > 3) __builtin_amdgcn_sched_barrier(0);  // slot by slot (see tpg_pairwise_set_kernel)
       }
       Frag3 P[2][TA + 1];
 #pragma unroll
