@@ -921,10 +921,12 @@ def main():
             mfma_roof("pca_gram_classes", "tpg_gcls_gram2_kernel / tpg_gcls_gram_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 "
                       "dosages from 2-bit codes)", 1.0 * n * n * m_pca,
                       "PCA Gram by weight classes: ONE unweighted symmetric product = N^2 M / 2 MACs on exact FP4 dosages "
-                      "(2-bit codes over the L2 -> CU path, expanded to FP4 nibbles in registers: 6 VALU per MFMA); a class "
+                      "(2-bit codes over the L2 -> CU path, made FP4 operand words by one v_and_b32 each: the odd block of a "
+                      "block pair is stored as centred dosages in the high halves of the nibbles, 4 VALU per MFMA); a class "
                       "end is 8 v_pk_fma_f32 per 32 x 32 tile (small weight differences of a group of neighbouring classes, "
-                      "summation by parts), a group end the FP64 fold; 64 x 64 wave tiles, two waves per SIMD; bound by operand "
-                      "latency on the L2 -> CU path (MFMA pipe 28 % busy, s_waitcnt 28 %), not by issue any more",
+                      "summation by parts), a group end the FP64 fold; 64 x 64 wave tiles, two waves per SIMD; each wave waits "
+                      "for a dependency most of the time (MFMA pipe 35 % busy, 10.4 VALU-class instructions per MFMA, "
+                      "s_waitcnt 23 %: profiles/r04_pmc_one_step.json)",
                       peak=10000.0),
         ]
         roofs = [r for r in roofs if r]

@@ -72,5 +72,5 @@ json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc_one_step.json"), 
 json.dump({"workload": "5000 x 1000000 per GPU, 51 populations, k = 20", "source": f"profiles/{tag}_pmc_one_step.json",
            "hbm_bytes_per_launch": traffic}, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 for k, o in out.items():
-    if any(s in k for s in ("pairwise_kernel", "gram_kernel", "gram2_kernel", "gcls", "t4_expand", "pack_fast", "fst_kernel", "grouped_counts")):
+    if any(s in k for s in ("pairwise_kernel", "gram_kernel", "gram2_kernel", "gcls", "t4_expand", "pack_fast", "fst_kernel", "wc84", "grouped_counts")):
         print(k, json.dumps({a: (round(b, 4) if isinstance(b, float) else b) for a, b in o["derived"].items()}))
