@@ -872,23 +872,45 @@ __global__ __launch_bounds__(256, WPE) void tpg_gcls_gram3_kernel(const uint4* _
   }
 }
 
-// 4. the S slabs of every unit, added in split order, into both triangles of K (n x n, column-major)
+// 4. the S slabs of every unit, added in split order, into both triangles of K (n x n, column-major).  A wave takes one
+// 32 x 32 tile of the unit: it sums the slabs in MFMA register order (512 contiguous bytes per wave and slab), turns the
+// tile through LDS, and writes it twice with 32 lanes on 256 contiguous bytes -- K[i, k] along i and K[k, i] along k.
+// (Written straight from register order, K[i + k n] had the lanes of a wave on 64 different columns: 8-byte pieces 40 KB
+// apart, SQ_WAIT_ANY 93 %.)
 __global__ __launch_bounds__(256) void tpg_gcls_assemble_kernel(const double* __restrict__ slabs, const int2* __restrict__ order,
                                                                 int64_t nun, int S, int n, double* __restrict__ K) {
+  __shared__ double tile[GP][32][33];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  static_assert(GP == 4, "one wave per tile of the unit");
   for (int64_t u = blockIdx.x; u < nun; u += gridDim.x) {
     const int2 ij = order[u];
-    for (int q = wv; q < GP * 16; q += 4) {
-      const int p = q >> 4, reg = q & 15;
-      const int ti = GA * ij.x + p / GB, tk = GB * ij.y + p % GB;
-      if (tk < ti) continue;
-      const int i = 32 * ti + tpg_cd_row(reg, lane), k = 32 * tk + (lane & 31);
-      if (i >= n || k >= n) continue;
-      double v = 0;
-      for (int s = 0; s < S; s++) v += slabs[((int64_t)s * nun + u) * GCLS_SLAB + (p * 16 + reg) * 64 + lane];
-      K[i + (int64_t)k * n] = v;
-      K[k + (int64_t)i * n] = v;
+    const int p = wv;
+    const int ti = GA * ij.x + p / GB, tk = GB * ij.y + p % GB;
+    if (tk < ti) continue;  // (wave-uniform; no barrier below: a wave only ever reads what it wrote)
+    double v[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) v[reg] = 0.0;
+    for (int s = 0; s < S; s++) {
+      const double* sl = slabs + ((int64_t)s * nun + u) * GCLS_SLAB + (p * 16) * 64 + lane;
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) v[reg] += sl[reg * 64];
     }
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) tile[p][tpg_cd_row(reg, lane)][lane & 31] = v[reg];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int a = lane & 31, h = lane >> 5;
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {
+      const int c = 2 * it + h;
+      // K[i, k] with the lanes along i (rows of the tile), then K[k, i] with the lanes along k (its columns)
+      const int i1 = 32 * ti + a, k1 = 32 * tk + c;
+      if (i1 < n && k1 < n) K[i1 + (int64_t)k1 * n] = tile[p][a][c];
+      const int i2 = 32 * ti + c, k2 = 32 * tk + a;
+      if (i2 < n && k2 < n) K[k2 + (int64_t)i2 * n] = tile[p][c][a];
+    }
+    __builtin_amdgcn_wave_barrier();  // the tile is rewritten in the next round
   }
 }
 
