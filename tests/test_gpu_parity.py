@@ -119,6 +119,29 @@ def test_packed_upload_roundtrip(tpg, monkeypatch):
     X.free()
 
 
+def test_prof_only_times_the_listed_launches(tpg):
+    """tpg_prof_only: HIP events only around the launches named (what bench.py's timed region uses), all of them again
+    after prof_only(None)."""
+    ctx = tpg.default_context()
+    X = tpg.FBM.from_numpy(orc.synth_fbm(5, 200, 3000, npop=3))
+    try:
+        ctx.prof_enable(True)
+        ctx.prof_only(["loci_counts"])
+        ctx.prof_reset()
+        tpg.loci_alt_freq(X)
+        only = ctx.prof_dump()
+        assert set(only) == {"loci_counts"} and only["loci_counts"][0] >= 1
+        ctx.prof_only(None)
+        ctx.prof_reset()
+        tpg.loci_alt_freq(X)
+        every = ctx.prof_dump()
+        assert "loci_counts" in every and len(every) > 1
+    finally:
+        ctx.prof_only(None)
+        ctx.prof_enable(False)
+        X.free()
+
+
 def test_small_transfers_through_the_mailbox(tpg, monkeypatch):
     """Small host <-> device transfers go through coherent pinned memory by one-workgroup kernels (runtime.hip:
     tpg_push_small / tpg_fetch_small): every size class, unaligned sizes (which take the copy engine), and more pushes in
