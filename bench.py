@@ -971,8 +971,10 @@ def main():
                      "MFMA time at C4)"),
             hbm_roof("grouped_finalize", "tpg_grouped_finalize_kernel", (12.0 * Cpad + 16.0 * G) * m,
                      "counts -> the m x 2G doubles grouped_alt_freq returns: 12 Cpad B read + 16 G B written per locus"),
-            valu_roof("fst_hudson", "tpg_fst_hudson_gemm_kernel (totals as three masked G x M x G products)", 12.0 * P * m,
-                      "priced at SURVEY.md 8d's ~12 flop per pair-locus; the kernel itself does 3 * 2 * 64^2 flop per locus"),
+            valu_roof("fst_hudson", "tpg_fst_hudson_gemm_kernel (totals as three masked G x M x G products on v_mfma_f64_16x16x4_f64)",
+                      12.0 * P * m,
+                      "priced at SURVEY.md 8d's ~12 flop per pair-locus against the FP64 VALU peak (the FP64 MFMA has the same rate on "
+                      "this part); the kernel itself does 3 * 2 * 64^2 flop per locus (16-wide tiles pad 51 populations to 64)"),
             valu_roof("fst_wc84", "tpg_fst_wc84_tile_kernel (totals, 3 x 2 tiles of populations per thread, reciprocals tabulated by "
                       "valid-allele count)", 45.0 * P * m,
                       "priced at SURVEY.md 8d's ~45 flop per pair-locus; the kernel issues 22 FP64 (27 VALU) instructions and 3.67 "

@@ -256,31 +256,41 @@ __global__ __launch_bounds__(256) void tpg_fst_reduce_kernel(const double* __res
 // statement): the totals agree to ~1e-14 relative.
 #define FSTG_T 64   // populations per tile side
 #define FSTG_LB 16  // loci per staged chunk (32 KiB of LDS: four workgroups per CU hide one another's staging)
+// MF: the three products on the FP64 matrix cores (v_mfma_f64_16x16x4_f64: 16 x 16 pairs x 4 loci in 32 cycles, twice the
+// FP64 VALU rate, and a lane feeds it ONE double per operand where the VALU form reads 16 doubles for 48 FMAs -- that form
+// is bound by LDS bandwidth: 27 M ds_read_b128 + 40 M conflict cycles against 1.32 M cycles per launch at 51 populations).
+// A wave owns 16 row populations x all 64 column populations: 4 column tiles x 3 products = 12 accumulators, per 4 loci
+// 2 + 8 ds_read_b64 and 12 MFMAs.  Rows of the staged arrays are FSTG_RS = 80 doubles apart (32 dwords modulo the 64
+// banks), so that the four loci a wave instruction reads fall on disjoint banks.
+#define FSTG_RS_MFMA 80
+template <bool MF>
 __global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_kernel(FstSrc src, int64_t m, int G, int ntile, int kmax,
                                                                   double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* ra = sh;                          // [l][64] a of the row populations
-  double* rc = sh + FSTG_LB * FSTG_T;       // c of the row populations
-  double* cb = sh + 2 * FSTG_LB * FSTG_T;   // b of the column populations
+  constexpr int RS = MF ? FSTG_RS_MFMA : FSTG_T;  // row stride of the staged arrays
+  double* ra = sh;                      // [l][RS] a of the row populations
+  double* rc = sh + FSTG_LB * RS;       // c of the row populations
+  double* cb = sh + 2 * FSTG_LB * RS;   // b of the column populations
   const int tR = blockIdx.y / ntile, tC = blockIdx.y % ntile;
   const bool diag = tR == tC;
-  double* cc = diag ? rc : sh + 3 * FSTG_LB * FSTG_T;  // c of the column populations
+  double* cc = diag ? rc : sh + 3 * FSTG_LB * RS;  // c of the column populations
   // 1 / A and 1 / (A - 1) for A valid alleles (class counts: A is a small integer), by IEEE divisions once per workgroup:
   // the per-population staging then needs no division (freq = alt * (1 / A) differs from alt / A by at most an ulp; the
   // by-locus path, which must be bit-identical to the reference, divides)
-  double* inv = sh + 4 * FSTG_LB * FSTG_T;
+  double* inv = sh + 4 * FSTG_LB * RS;
   for (int A = threadIdx.x; A <= kmax; A += 256) { inv[2 * A] = 1.0 / (double)A; inv[2 * A + 1] = 1.0 / ((double)A - 1.0); }
   // thread grid TG x TG of 4 x 4 blocks, TG = populations of this tile / 4 rounded up: with 51 populations 13 x 13 = 169
   // threads work (three waves) instead of 256 on a padded 64 x 64 tile
   const int gR = min(FSTG_T, G - tR * FSTG_T), gC = min(FSTG_T, G - tC * FSTG_T);
   const int TGy = (gR + 3) / 4, TGx = (gC + 3) / 4;
-  const bool work = (int)threadIdx.x < TGy * TGx;
+  const bool work = MF || (int)threadIdx.x < TGy * TGx;
   const int ty = work ? threadIdx.x / TGx : 0, tx = work ? threadIdx.x % TGx : 0;
-  double AB[4][4], CB[4][4], CC[4][4];
+  double AB[4][4], CB[4][4], CC[4][4];  // VALU form: a 4 x 4 block of pairs; MFMA form: [column tile][C/D register]
 #pragma unroll
   for (int r = 0; r < 4; r++)
 #pragma unroll
     for (int c = 0; c < 4; c++) { AB[r][c] = 0.0; CB[r][c] = 0.0; CC[r][c] = 0.0; }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
   const int64_t nchunks = (m + FSTG_LB - 1) / FSTG_LB;
   // class counts of diploids (kmax > 0): the three counts of this thread's (locus, population) slots of the NEXT chunk are
   // fetched into registers before the products of the current one, so that their latency hides behind the FMAs
@@ -320,10 +330,11 @@ __global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_kernel(FstSrc src, in
           const double e = (vp * (1 - vp)) * inv[2 * A + 1];
           if (e == e) { a = vp * vp - e; b = 1.0; c = vp; }
         }
-        if (side) { cb[rem] = b; cc[rem] = c; }
+        const int srem = (rem / FSTG_T) * RS + rem % FSTG_T;
+        if (side) { cb[srem] = b; cc[srem] = c; }
         else {
-          ra[rem] = a; rc[rem] = c;
-          if (diag) cb[rem] = b;
+          ra[srem] = a; rc[srem] = c;
+          if (diag) cb[srem] = b;
         }
       }
     } else {
@@ -340,16 +351,30 @@ __global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_kernel(FstSrc src, in
           const double e = (vp * (1 - vp)) / (vn - 1);  // src/pairwise_fst_hudson_loop.cpp:28-29
           if (vp == vp && e == e) { a = vp * vp - e; b = 1.0; c = vp; }
         }
-        if (side) { cb[rem] = b; cc[rem] = c; }
+        const int srem = l * RS + gl;
+        if (side) { cb[srem] = b; cc[srem] = c; }
         else {
-          ra[rem] = a; rc[rem] = c;
-          if (diag) cb[rem] = b;
+          ra[srem] = a; rc[srem] = c;
+          if (diag) cb[srem] = b;
         }
       }
     }
     __syncthreads();
     if (kmax > 0) fetch(ch + gridDim.x);
-    if (work) {
+    if constexpr (MF) {
+      // A = x[locus l + kq][row population 16 wv + r16], B = y[locus l + kq][column population 16 ct + r16]
+#pragma unroll
+      for (int l = 0; l < FSTG_LB; l += 4) {
+        const double av = ra[(l + kq) * RS + 16 * wv + r16], cv = rc[(l + kq) * RS + 16 * wv + r16];
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) {
+          const double bv = cb[(l + kq) * RS + 16 * ct + r16], dv = cc[(l + kq) * RS + 16 * ct + r16];
+          *(v4d*)AB[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, *(v4d*)AB[ct], 0, 0, 0);
+          *(v4d*)CB[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv, bv, *(v4d*)CB[ct], 0, 0, 0);
+          *(v4d*)CC[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv, dv, *(v4d*)CC[ct], 0, 0, 0);
+        }
+      }
+    } else if (work) {
 #pragma unroll 2
       for (int l = 0; l < FSTG_LB; l++) {
         const v4d a4 = *(const v4d*)&ra[l * FSTG_T + 4 * ty], c4 = *(const v4d*)&rc[l * FSTG_T + 4 * ty];
@@ -368,6 +393,18 @@ __global__ __launch_bounds__(256) void tpg_fst_hudson_gemm_kernel(FstSrc src, in
   // partial sums of this workgroup: [block x][tile][product][row][col]
   if (!work) return;
   double* o = part + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 3) * FSTG_T * FSTG_T;
+  if constexpr (MF) {  // C/D: column = lane & 15, row = (lane >> 4) + 4 reg
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int q = (16 * wv + kq + 4 * reg) * FSTG_T + 16 * ct + r16;
+        o[q] = AB[ct][reg];
+        o[FSTG_T * FSTG_T + q] = CB[ct][reg];
+        o[2 * FSTG_T * FSTG_T + q] = CC[ct][reg];
+      }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -749,10 +786,18 @@ static int run_fst(tpg_ctx* ctx, int method, FstSrc src, int64_t m, int G, const
     double* d_full = d_gp + (size_t)cells * (size_t)nbx;
     // reciprocals by table when the source is the class counts of diploids and the table fits (kmax valid alleles at most)
     const int kq = (src.cnt && !src.has_hap && kmax > 0 && kmax <= 4096) ? kmax : 0;
-    const size_t shg = sizeof(double) * (4 * FSTG_LB * FSTG_T + 2 * ((size_t)kq + 1));
-    (void)hipFuncSetAttribute((const void*)tpg_fst_hudson_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shg);
-    TPG_LAUNCH(ctx, "fst_hudson", tpg_fst_hudson_gemm_kernel, dim3((unsigned)nbx, (unsigned)(ntile * ntile)), dim3(256), shg, src, m, G,
-               ntile, kq, d_gp);
+    // TPG_FST_HUDSON_VALU=1: the three products on the FP64 VALU (A/B; rounds 3 and 4)
+    static const bool valu = getenv("TPG_FST_HUDSON_VALU") && atoi(getenv("TPG_FST_HUDSON_VALU")) != 0;
+    const size_t shg = sizeof(double) * (4 * FSTG_LB * (valu ? FSTG_T : FSTG_RS_MFMA) + 2 * ((size_t)kq + 1));
+    if (valu) {
+      (void)hipFuncSetAttribute((const void*)tpg_fst_hudson_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shg);
+      TPG_LAUNCH(ctx, "fst_hudson", tpg_fst_hudson_gemm_kernel<false>, dim3((unsigned)nbx, (unsigned)(ntile * ntile)), dim3(256), shg,
+                 src, m, G, ntile, kq, d_gp);
+    } else {
+      (void)hipFuncSetAttribute((const void*)tpg_fst_hudson_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shg);
+      TPG_LAUNCH(ctx, "fst_hudson", tpg_fst_hudson_gemm_kernel<true>, dim3((unsigned)nbx, (unsigned)(ntile * ntile)), dim3(256), shg,
+                 src, m, G, ntile, kq, d_gp);
+    }
     TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_hudson_gemm_reduce_kernel, dim3((unsigned)ceil_div(cells, 256), FSTG_SL), dim3(256), 0,
                (const double*)d_gp, nbx, cells, d_full);
     TPG_LAUNCH(ctx, "fst_reduce", tpg_fst_hudson_gemm_final_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, (const double*)d_full,
