@@ -180,8 +180,8 @@ __global__ void tpg_gcls_block_table_kernel(const unsigned long long* __restrict
 __global__ void tpg_gcls_block_table2_kernel(const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ blk_start,
                                              const uint32_t* __restrict__ nblk, int nr, int64_t nblocks, int gmax, int gq,
                                              ulonglong2* __restrict__ wblk) {
-  // (four entries after the last block: empty blocks of the last class without a flag, which pad the list to a multiple of
-  // four for tpg_gcls_gram4_kernel)
+  // (entries after the last block: empty blocks of the last class without a flag -- tpg_gcls_gram2_kernel works in whole
+  // block pairs and reads the entry of the block that pads an odd list)
   if (blockIdx.x == 0 && threadIdx.x < 4) wblk[nblocks + threadIdx.x] = make_ulonglong2(ukeys[nr - 1], 0ull);
   for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < nblocks; b += (int64_t)gridDim.x * blockDim.x) {
     const int r = tpg_gcls_find_run(blk_start, nr, (uint32_t)b);
@@ -471,6 +471,17 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define GCLS2_D 2
 #endif
 // VT: the block table through one vector load per loop body + v_readlane_b32 instead of one scalar load per block (see 3c)
+// The scalar stream of the loop is kept LEAN on purpose.  Two experiments (operand loads removed: 10.4 -> 8.75 ms; class-end
+// and fold flags ignored: 10.3 -> 7.8 ms; neither leaves less than 2.4 x the MFMA time) said that what the waves wait for is
+// mostly their OWN instruction stream: a wave issues one instruction per four cycles, whatever its kind, and per block (4 MFMAs
+// = 128 cycles of the pipe) the first form of this loop spent 16 - 24 VALU, 22 SALU, 4 branches and half a dozen s_waitcnt /
+// s_nop.  So: 32-bit block indices (as 64-bit values `b < bend` was a VALU compare of two uniform values + a branch on VCC,
+// every increment an s_add_u32 + s_addc_u32); K ranges in whole block pairs over a list whose padding block is empty and
+// flagless (no range test per block); fixed tile bases in SGPRs + ONE lane offset per pair (a v_lshl_or_b32 where a pointer
+// per tile cost an s_add_u32 + s_addc_u32 each); ONE test of the two flag bits per block with everything behind it out of
+// line (__builtin_expect: the FP64 fold no longer sits in the loop body); the fold of the range end after the loop instead of
+// a comparison in every block.  10.4 -> 9.2 ms with the same results (a rewrite from scratch on these lines spilled 358
+// registers and ran at 43 ms: at 256 registers the allocator decides, so the existing loop was trimmed instead).
 // CEN: operands in the centred layout of tpg_gcls_gather_kernel<true> (one v_and_b32 per operand word; the odd block of a
 // pair takes the high halves of the nibbles, values +-2, with the block scales 2^-1 where the even block has 2^+1)
 #define MFMA_G4S2_ODD(a, b, c) \
@@ -499,7 +510,9 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
     // block pairs [p0, p1), blocks [2 p0, bend): 32-bit (the class path stops below 2^31 loci), so that the range tests of
     // the loop are scalar compares -- as 64-bit values `b < bend` was a VALU compare of two uniform values and a branch on VCC
     const int p0 = __builtin_amdgcn_readfirstlane((int)((npairs * ks) / S)), p1 = __builtin_amdgcn_readfirstlane((int)((npairs * (ks + 1)) / S));
-    const int bend = 2 * p1 < (int)nblocks ? 2 * p1 : (int)nblocks;
+    // (whole pairs: the block after an odd number of blocks is empty in T2g and has a flagless entry in the table, so
+    // no block of the loop needs a range test)
+    const int bend = 2 * p1;
     // the tiles' rows of T2g from pair p0 on: fixed bases in SGPRs; a pair is one 32-bit lane offset (a v_lshl_add_u32 per
     // pair where a pointer per tile cost an s_add_u32 + s_addc_u32 each; the host keeps a K range below 2^21 pairs)
     const char* pt[GA + GB];
@@ -569,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
 #pragma unroll
             for (int hb = 0; hb < 2; hb++) {
               const int b = 2 * pr + hb;
-              if (b < bend) {
+              {
                 ulonglong2 wf;
                 if constexpr (VT) {
                   wf.x = ((unsigned long long)tx1[2 * C + hb] << 32) | tx0[2 * C + hb];
@@ -668,184 +681,6 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
           }
         });
       }
-    }
-    double* slab = slabs + ((int64_t)ks * nun + u) * GCLS_SLAB + lane;
-#pragma unroll
-    for (int p = 0; p < GP; p++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) slab[(p * 16 + i) * 64] = p < 2 ? o[p][i] : olds[((p - 2) * 16 + i) * 64];
-  }
-}
-
-// 3b'. The same kernel with a LEAN scalar stream.  Two experiments on the kernel above (operand loads removed: 10.4 -> 8.75 ms;
-// class-end / fold flags ignored: 10.3 -> 7.8 ms; neither leaves less than 2.4 x the MFMA time) say that what its waves wait
-// for is mostly their OWN instruction stream: a wave issues one instruction per four cycles, whatever its kind, and per block
-// (4 MFMAs = 128 cycles of the pipe) the loop above spends 16 - 24 VALU, 22 SALU, 4 branches and half a dozen s_waitcnt / s_nop:
-// 64-bit block indices (s_add_u32 + s_addc_u32, and `b < bend` as a VALU compare of two uniform values followed by a branch on
-// VCC), a pointer per tile advanced in SGPRs, three flag tests with s_cselect / s_or chains.  Here: 32-bit indices; K ranges
-// in whole iterations of the loop (two block pairs) over a block list padded to a multiple of four (padding blocks are empty,
-// their table entries have no flag: no range test inside the loop, no tail after it); one uniform pair counter under fixed
-// SGPR bases (one v_lshl_add_u32 per pair instead of an s_add_u32 + s_addc_u32 per tile); one test of the two flag bits per
-// block, the rest behind it; the fold of the range end after the loop.
-template <bool CEN>
-__global__ __launch_bounds__(256, 2) void tpg_gcls_gram4_kernel(const uint4* __restrict__ T2g, int nblocks4, int64_t rs2, int nrtv,
-                                                                const ulonglong2* __restrict__ wblk,
-                                                                const int2* __restrict__ order, int64_t nun, int S,
-                                                                double* __restrict__ slabs) {
-  extern __shared__ double olds_raw[];  // [wave][tile 2, 3][register][lane]
-  constexpr int WPE = 2, NT = GA + GB;
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* olds = olds_raw + (size_t)wv * (2 * 16 * 64) + lane;
-  const int hgrid = gridDim.x / WPE, half = (int)blockIdx.x / hgrid, bx = (int)blockIdx.x % hgrid;
-  const int xcd = bx & 7, cidx = bx >> 3, cpx = hgrid >> 3;
-  const int SH = S / WPE;  // splits per half (the host makes S even)
-  const int npairs = nblocks4 >> 1;  // even
-  typedef uint32_t v3u __attribute__((ext_vector_type(3)));
-  for (int64_t round = 0;; round++) {
-    const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
-    if (un >= nun * SH) break;
-    const int ks = half * SH + (int)(un / nun);
-    const int64_t u = un % nun;
-    const int2 ijv = order[u];
-    const int2 ij = make_int2(__builtin_amdgcn_readfirstlane(ijv.x), __builtin_amdgcn_readfirstlane(ijv.y));
-    // block pairs [p0, p1): whole iterations of the loop below (two pairs; the host pads the block list to a multiple of four)
-    const int p0 = __builtin_amdgcn_readfirstlane(2 * (int)(((int64_t)(npairs >> 1) * ks) / S));
-    const int p1 = __builtin_amdgcn_readfirstlane(2 * (int)(((int64_t)(npairs >> 1) * (ks + 1)) / S));
-
-    double o[2][16];
-    v2f dev[GP][8];
-    v16f acc[GP];
-#pragma unroll
-    for (int p = 0; p < GP; p++) {
-#pragma unroll
-      for (int i = 0; i < 16; i++) acc[p][i] = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; i++) dev[p][i] = v2f{0.f, 0.f};
-    }
-#pragma unroll
-    for (int p = 0; p < 2; p++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) { o[p][i] = 0.0; olds[(p * 16 + i) * 64] = 0.0; }
-
-    if (p0 < p1) {
-      // the tiles' rows of T2g from pair p0 on: fixed bases in SGPRs, one 32-bit lane offset that moves 1 KiB per pair
-      const char* pt[NT];
-#pragma unroll
-      for (int t = 0; t < GA; t++) pt[t] = (const char*)(T2g + ((int64_t)min(GA * ij.x + t, nrtv - 1) * rs2 + p0) * 64);
-#pragma unroll
-      for (int t = 0; t < GB; t++) pt[GA + t] = (const char*)(T2g + ((int64_t)min(GB * ij.y + t, nrtv - 1) * rs2 + p0) * 64);
-      int kf = 0;  // the pair being FETCHED, relative to p0 (SGPR)
-      const int klast = p1 - 1 - p0;
-      v4u R[2][NT];
-      auto LDP = [&](int slot) {
-        uint32_t off = (uint32_t)lane * 16u + (uint32_t)kf * 1024u;
-        asm("" : "+v"(off));
-#pragma unroll
-        for (int t = 0; t < NT; t++) R[slot][t] = *(const v4u*)(pt[t] + off);
-        kf = min(kf + 1, klast);  // (past the range: the last pair again, never used)
-      };
-      // the table entries of the blocks from 2 p0 on, four per vector load (lane l: block first + l)
-      const uint32_t tlast = (uint32_t)(2 * p1 - 1) * 16u;
-      auto LDT = [&](int first_block) {
-        uint32_t tb = ((uint32_t)first_block + (uint32_t)lane) * 16u;
-        tb = min(tb, tlast);
-        return *(const v3u*)((const char*)wblk + tb);
-      };
-      const unsigned long long wend = wblk[2 * p1 - 1].x & ~3ull;  // the class weight of the last block: the fold after the loop
-      v3u TB = LDT(2 * p0);
-      LDP(0);
-      bool pend = false;   // the block before ended a class inside its group: dev += pdelta * sums before this block's MFMAs
-      float pdelta = 0.f;  // w_c - w_{c+1}
-
-      // out += w * sums + dev; sums and dev start again from zero (the FP64 fold of tpg_gcls_gram2_kernel)
-      auto fold = [&](double w) {
-        tpg_static_for<4>([&](auto hh) {
-          constexpr int h = decltype(hh)::value, pr_ = h >> 1, pl_ = 2 + (h >> 1), e0 = (h & 1) * 8;
-          double t[8];
-#pragma unroll
-          for (int e = 0; e < 8; e++) t[e] = olds[((pl_ - 2) * 16 + e0 + e) * 64];
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            const int i = e0 + e;
-            o[pr_][i] = __builtin_fma((double)acc[pr_][i], w, o[pr_][i]) + (double)dev[pr_][i >> 1][i & 1];
-            acc[pr_][i] = 0.f;
-          }
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            const int i = e0 + e;
-            olds[((pl_ - 2) * 16 + i) * 64] = __builtin_fma((double)acc[pl_][i], w, t[e]) + (double)dev[pl_][i >> 1][i & 1];
-            acc[pl_][i] = 0.f;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; e++) dev[pr_][(e0 >> 1) + e] = dev[pl_][(e0 >> 1) + e] = v2f{0.f, 0.f};
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      };
-      // one block: hb = 0 / 1 of the pair in slot C; x0, x1, y0 = its table entry (SGPRs)
-      auto block = [&](auto Cc, auto Hh, uint32_t x0, uint32_t x1, uint32_t y0) {
-        constexpr int C = decltype(Cc)::value, hb = decltype(Hh)::value;
-        v4u X[NT];
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-          if constexpr (CEN) {
-            X[t] = R[C][t] & (hb == 0 ? 0x33333333u : 0xCCCCCCCCu);
-          } else {
-            const uint32_t w0 = R[C][t][2 * hb], w1 = R[C][t][2 * hb + 1];
-            X[t] = v4u{w0 & 0x33333333u, (w0 >> 2) & 0x33333333u, w1 & 0x33333333u, (w1 >> 2) & 0x33333333u};
-          }
-        }
-        if (pend) {
-          const v2f dl = v2f{pdelta, pdelta};
-#pragma unroll
-          for (int p = 0; p < GP; p++)
-            tpg_static_for<8>([&](auto ii) {
-              constexpr int i = decltype(ii)::value;
-              dev[p][i] = __builtin_elementwise_fma(dl, __builtin_shufflevector(acc[p], acc[p], 2 * i, 2 * i + 1), dev[p][i]);
-            });
-          pend = false;
-        }
-        if (CEN && hb == 1) {
-#pragma unroll
-          for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2_ODD(X[p / GB], X[GA + p % GB], acc[p]);
-        } else {
-#pragma unroll
-          for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2(X[p / GB], X[GA + p % GB], acc[p]);
-        }
-        if (x0 & 3u) {  // rare: one class end per ~4 blocks, one group end per ~40
-          if (x0 & 2u) {
-            fold(__longlong_as_double((long long)(((unsigned long long)x1 << 32) | (x0 & ~3u))));
-          } else {
-            pend = true;
-            pdelta = __uint_as_float(y0);
-          }
-        }
-      };
-      auto entry = [&](int k, uint32_t& x0, uint32_t& x1, uint32_t& y0) {
-        x0 = (uint32_t)__builtin_amdgcn_readlane((int)TB[0], k);
-        x1 = (uint32_t)__builtin_amdgcn_readlane((int)TB[1], k);
-        y0 = (uint32_t)__builtin_amdgcn_readlane((int)TB[2], k);
-      };
-      using I0 = std::integral_constant<int, 0>;
-      using I1 = std::integral_constant<int, 1>;
-      int pp = p0;
-      for (; pp + 2 <= p1; pp += 2) {
-        uint32_t x0[4], x1[4], y0[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) entry(k, x0[k], x1[k], y0[k]);
-        __builtin_amdgcn_sched_barrier(0);
-        TB = LDT(2 * pp + 4);
-        LDP(1);
-        __builtin_amdgcn_sched_barrier(0);
-        block(I0{}, I0{}, x0[0], x1[0], y0[0]);
-        block(I0{}, I1{}, x0[1], x1[1], y0[1]);
-        LDP(0);
-        block(I1{}, I0{}, x0[2], x1[2], y0[2]);
-        block(I1{}, I1{}, x0[3], x1[3], y0[3]);
-      }
-      // the end of the range: whatever the sums hold belongs to the class of the last block (a class end that is still
-      // pending is part of it: folding with w_c itself needs no difference)
-      fold(__longlong_as_double((long long)wend));
     }
     double* slab = slabs + ((int64_t)ks * nun + u) * GCLS_SLAB + lane;
 #pragma unroll
@@ -1240,8 +1075,6 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   // the caller double-centres the result (the omitted terms are r_i + r_k + const); TPG_GRAM_CENTER=0: never (A/B)
   static const bool no_cen = getenv("TPG_GRAM_CENTER") && atoi(getenv("TPG_GRAM_CENTER")) == 0;
   const bool cen = centred_ok && !no_cen && !f64 && !body && kern3 != 1;
-  // TPG_GRAM_KERNEL=40: tpg_gcls_gram4_kernel (a K range of a split must stay below 2^21 pairs: its lane offsets are 32-bit)
-  const bool lean = kern3 == 40 && !f64 && !body && nblocks / 2 / 2 + 2 < (1 << 21);
   const int nblk_grid = one_wave ? ncu8 : 2 * ncu8;  // two workgroups per CU = two waves per SIMD
   const int nwaves = 4 * nblk_grid;
   int S = 2;
@@ -1266,8 +1099,7 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   TPG_HIP(B.get(&d_src, (size_t)nblocks * 64));
   if (f64) TPG_HIP(B.get(&d_wblk, (size_t)nblocks));
   else TPG_HIP(B.get(&d_wblk2, (size_t)nblocks + 4));
-  // row-tile stride of T2g: a uint4 per lane and PAIR of blocks (the lean kernel: a multiple of four blocks)
-  const int64_t rs2 = lean ? (nblocks + 3) / 4 * 2 : (nblocks + 1) / 2;
+  const int64_t rs2 = (nblocks + 1) / 2;  // row-tile stride of T2g: a uint4 per lane and PAIR of blocks
   TPG_HIP(B.get(&d_T2g, (size_t)(4 * Q) * (size_t)rs2 * 64));
   TPG_HIP(B.get(&d_order, (size_t)nun));
   TPG_HIP(B.get(&d_slabs, (size_t)S * (size_t)nun * GCLS_SLAB));
@@ -1324,17 +1156,6 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
       (void)hipFuncSetAttribute((const void*)tpg_gcls_gram2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
       TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram2_kernel<false>, dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
                  (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
-    } else if (lean) {  // the lean scalar stream (tpg_gcls_gram4_kernel): whole block pairs, 32-bit indices
-      const int nblocks2 = (int)(2 * rs2);
-      if (cen) {
-        (void)hipFuncSetAttribute((const void*)tpg_gcls_gram4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
-        TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram4_kernel<true>, dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
-                   (const uint4*)d_T2g, nblocks2, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
-      } else {
-        (void)hipFuncSetAttribute((const void*)tpg_gcls_gram4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
-        TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram4_kernel<false>, dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
-                   (const uint4*)d_T2g, nblocks2, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
-      }
     } else if (cen) {
       (void)hipFuncSetAttribute((const void*)tpg_gcls_gram2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS2_LDS_BYTES);
       TPG_LAUNCH(ctx, "pca_gram_classes", (tpg_gcls_gram2_kernel<true, true>), dim3((unsigned)nblk_grid), dim3(256), GCLS2_LDS_BYTES,
