@@ -145,18 +145,21 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
     const int2 ijt = order[un % nun];
     const int I = __builtin_amdgcn_readfirstlane(ijt.x), jt = __builtin_amdgcn_readfirstlane(ijt.y);
     const int64_t tp0 = tpg_pw_unit_index(nst, I, jt) + rowpad[I];
-    const int64_t k0 = kg_begin + (kgs * ks) / S, k1 = kg_begin + (kgs * (ks + 1)) / S;
+    // 32-bit group indices (a view has fewer than 2^25 groups): scalar range tests, one s_add_i32 per step
+    const int k0 = __builtin_amdgcn_readfirstlane((int)(kg_begin + (kgs * ks) / S));
+    const int k1 = __builtin_amdgcn_readfirstlane((int)(kg_begin + (kgs * (ks + 1)) / S));
 
     // A row tiles past the last one with data (the last super-tile may be partial; the view holds 4 ceil(n / 128)
     // row tiles) read tile 0 instead and get zero plane masks: zero products
-    const uint4* pa[TA];
+    // (fixed bases at group k0 in SGPRs; a block is one 32-bit lane offset: a wave-unit never spans 2^22 blocks)
+    const char* pa[TA];
     bool there[TA];
 #pragma unroll
     for (int t = 0; t < TA; t++) {
       there[t] = TA * I + t < nct;
-      pa[t] = T4 + ((int64_t)(there[t] ? TA * I + t : 0) * KG * 2) * 64;
+      pa[t] = (const char*)(T4 + (((int64_t)(there[t] ? TA * I + t : 0) * KG + k0) * 2) * 64);
     }
-    const uint4* pb0 = T4 + ((int64_t)jt * KG * 2) * 64;
+    const char* pb0 = (const char*)(T4 + (((int64_t)jt * KG + k0) * 2) * 64);
 
     v16f cV[TA], cD[TA], cH[TA], cHV[TA], cVH[TA];
 #pragma unroll
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       for (int r = 0; r < 16; r++) { cV[t][r] = 0.f; cD[t][r] = 0.f; cH[t][r] = 0.f; cHV[t][r] = 0.f; cVH[t][r] = 0.f; }
 
     if (k0 < k1) {
-      const int64_t kl = k1 - 1;
+      const int kl = k1 - 1;
       // three rotating load slots (current group, next, two ahead): the K loop is unrolled by three so that no
       // slot is copied -- a copy at the end of a group waits for the loads issued at its start, which cuts the
       // prefetch distance to one group.  Groups past k1 run with zero A planes.
@@ -174,19 +177,20 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       v4u RA[NG][TA][2], RB[NG][2];
       // wave-uniform base (SGPRs) + one 32-bit lane offset: global_load_dwordx4 v, v_off, s[base]; the empty asm keeps
       // hipcc from folding the lane into loop-invariant 64-bit VGPR pointers (a v_lshl_add_u64 per load)
-      auto LD = [&](const uint4* p) {
-        uint32_t off = (uint32_t)lane * 16u;
+      auto OFF = [&](int ig, int s) {  // block s of group ig, relative to group k0
+        uint32_t off = (uint32_t)lane * 16u + (uint32_t)((ig - k0) * 2 + s) * 1024u;
         asm("" : "+v"(off));
-        return *(const v4u*)((const char*)p + off);
+        return off;
       };
 #pragma unroll
       for (int g = 0; g < NG - 1; g++) {
-        const int64_t ig = k0 + g < k1 ? k0 + g : kl;
+        const int ig = k0 + g < k1 ? k0 + g : kl;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
+          const uint32_t off = OFF(ig, s);
 #pragma unroll
-          for (int t = 0; t < TA; t++) RA[g][t][s] = LD(pa[t] + (ig * 2 + s) * 64);
-          RB[g][s] = LD(pb0 + (ig * 2 + s) * 64);
+          for (int t = 0; t < TA; t++) RA[g][t][s] = *(const v4u*)(pa[t] + off);
+          RB[g][s] = *(const v4u*)(pb0 + off);
           // block by block, in the order the loop issues them: hipcc's wait-count pass merges the loop entry with the back
           // edge, and with the two blocks of a group interleaved here the loop's second wait of every group became
           // vmcnt(4) instead of vmcnt(8) -- the prefetch one block shallower than the slots allow (see tpg_pairwise_set_kernel)
@@ -198,17 +202,18 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       for (int t = 0; t < TA; t++)
         P[0][t] = tpg_planes(RA[0][t][0], there[t] ? TPG_NIB_V : 0u, there[t] ? TPG_NIB_D : 0u, there[t] ? TPG_NIB_H : 0u);
       P[0][TA] = tpg_planes(RB[0][0], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
-      auto group = [&](auto Cc, auto Nn, auto Mm, int64_t kg) {
+      auto group = [&](auto Cc, auto Nn, auto Mm, int kg) {
         constexpr int C = decltype(Cc)::value, N = decltype(Nn)::value, M = decltype(Mm)::value;
-        const int64_t i2 = kg + NG - 1 < k1 ? kg + NG - 1 : kl;
+        const int i2 = kg + NG - 1 < k1 ? kg + NG - 1 : kl;
         const bool live = kg < k1, live1 = kg + 1 < k1;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
           const int cur = s & 1, nx = cur ^ 1;
           // the loads of the group after next: the first block of every tile in step 0, the second in step 1
+          const uint32_t off = OFF(i2, s);
 #pragma unroll
-          for (int t = 0; t < TA; t++) RA[M][t][s] = LD(pa[t] + (i2 * 2 + s) * 64);
-          RB[M][s] = LD(pb0 + (i2 * 2 + s) * 64);
+          for (int t = 0; t < TA; t++) RA[M][t][s] = *(const v4u*)(pa[t] + off);
+          RB[M][s] = *(const v4u*)(pb0 + off);
           // planes of the next K step: the second block of this group, or the first of the next group
 #pragma unroll
           for (int t = 0; t < TA; t++) {
@@ -242,13 +247,13 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       using I2 = std::integral_constant<int, 2>;
       using I3 = std::integral_constant<int, 3>;
       if constexpr (NG == 3) {
-        for (int64_t kg = k0; kg < k1; kg += 3) {
+        for (int kg = k0; kg < k1; kg += 3) {
           group(I0{}, I1{}, I2{}, kg);
           group(I1{}, I2{}, I0{}, kg + 1);
           group(I2{}, I0{}, I1{}, kg + 2);
         }
       } else {
-        for (int64_t kg = k0; kg < k1; kg += 4) {
+        for (int kg = k0; kg < k1; kg += 4) {
           group(I0{}, I1{}, I3{}, kg);
           group(I1{}, I2{}, I0{}, kg + 1);
           group(I2{}, I3{}, I1{}, kg + 2);
@@ -311,7 +316,7 @@ __device__ __forceinline__ Frag3 tpg_planes_of(v4u w, uint32_t mv, uint32_t md, 
 }
 
 template <typename F, int... Ss>
-__device__ __forceinline__ void tpg_unrolled_steps(F& step, int64_t kb, std::integer_sequence<int, Ss...>) {
+__device__ __forceinline__ void tpg_unrolled_steps(F& step, int kb, std::integer_sequence<int, Ss...>) {
   (step(std::integral_constant<int, Ss>{}, kb + Ss), ...);
 }
 
@@ -337,14 +342,18 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
     const int ks = (int)(un / nun);
     const int2 ij = order[un % nun];
     const int I = __builtin_amdgcn_readfirstlane(ij.x), J = __builtin_amdgcn_readfirstlane(ij.y);
-    const int64_t kb0 = kb_begin + (kbs * ks) / S, kb1 = kb_begin + (kbs * (ks + 1)) / S;
+    // 32-bit block indices (a view has fewer than 2^26 blocks): the range tests of the loop are scalar compares, not VALU
+    // compares of two uniform 64-bit values, and an index step is one s_add_i32
+    const int kb0 = __builtin_amdgcn_readfirstlane((int)(kb_begin + (kbs * ks) / S));
+    const int kb1 = __builtin_amdgcn_readfirstlane((int)(kb_begin + (kbs * (ks + 1)) / S));
     // row tiles of the wave: RA A tiles (rows of the output), RB B tiles (columns).  A tile past the last one with data
     // reads tile 0 instead; what it yields is never stored
-    const uint4* pt[NT];
+    // (fixed bases at block kb0 in SGPRs; a block is one 32-bit lane offset: a wave-unit never spans 2^22 blocks)
+    const char* pt[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const int tile = t < RA ? RA * I + t : RB * J + (t - RA);
-      pt[t] = T4 + ((int64_t)(tile < nct ? tile : 0) * KG * 2) * 64;
+      pt[t] = (const char*)(T4 + ((int64_t)(tile < nct ? tile : 0) * KG * 2 + kb0) * 64);
     }
     v16f cV[RA][RB], cD[RA][RB], cH[RA][RB], cHV[RA][RB], cVH[RA][RB];
 #pragma unroll
@@ -355,18 +364,17 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
         for (int r = 0; r < 16; r++) { cV[a][b][r] = 0.f; cD[a][b][r] = 0.f; cH[a][b][r] = 0.f; cHV[a][b][r] = 0.f; cVH[a][b][r] = 0.f; }
 
     if (kb0 < kb1) {
-      const int64_t kl = kb1 - 1;
+      const int kl = kb1 - 1;
       v4u R[NS][NT];
-      auto LD = [&](const uint4* p) {
-        uint32_t off = (uint32_t)lane * 16u;
+      auto LDB = [&](v4u* slot, int b) {  // block b of the NT tiles
+        uint32_t off = (uint32_t)lane * 16u + (uint32_t)(b - kb0) * 1024u;
         asm("" : "+v"(off));
-        return *(const v4u*)((const char*)p + off);
+#pragma unroll
+        for (int t = 0; t < NT; t++) slot[t] = *(const v4u*)(pt[t] + off);
       };
 #pragma unroll
       for (int s = 0; s < NS - 1; s++) {
-        const int64_t b = kb0 + s < kb1 ? kb0 + s : kl;
-#pragma unroll
-        for (int t = 0; t < NT; t++) R[s][t] = LD(pt[t] + b * 64);
+        LDB(R[s], kb0 + s < kb1 ? kb0 + s : kl);
         // in THIS order: hipcc's wait-count pass merges the loop's entry state with its back edge, so a prologue that
         // loads the slot the first step needs last costs a vmcnt(0) at the top of every loop body
         __builtin_amdgcn_sched_barrier(0);
@@ -374,12 +382,10 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
       Frag3 P[2][NT];
 #pragma unroll
       for (int t = 0; t < NT; t++) P[0][t] = tpg_planes_of<MASK>(R[0][t], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
-      auto step = [&](auto Sc, int64_t kb) {
+      auto step = [&](auto Sc, int kb) {
         constexpr int s = decltype(Sc)::value, cur = s & 1, nx = cur ^ 1, sl = (s + 1) % NS, ld = (s + NS - 1) % NS;
         // the slot whose planes were taken in the previous step is free: block kb + NS - 1
-        const int64_t bl = kb + NS - 1 < kb1 ? kb + NS - 1 : kl;
-#pragma unroll
-        for (int t = 0; t < NT; t++) R[ld][t] = LD(pt[t] + bl * 64);
+        LDB(R[ld], kb + NS - 1 < kb1 ? kb + NS - 1 : kl);
         // planes of the next block (zero A planes past the K range: the tail of the last unrolled body adds nothing)
         const bool live1 = kb + 1 < kb1;
 #pragma unroll
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      for (int64_t kb = kb0; kb < kb1; kb += U) tpg_unrolled_steps(step, kb, std::make_integer_sequence<int, U>{});
+      for (int kb = kb0; kb < kb1; kb += U) tpg_unrolled_steps(step, kb, std::make_integer_sequence<int, U>{});
     }
     // integer sums (<= 2^24 loci per wave-unit): exact in int32.  Tiles on or above the diagonal only.
 #pragma unroll
