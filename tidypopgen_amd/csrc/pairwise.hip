@@ -202,10 +202,13 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       for (int t = 0; t < TA; t++)
         P[0][t] = tpg_planes(RA[0][t][0], there[t] ? TPG_NIB_V : 0u, there[t] ? TPG_NIB_D : 0u, there[t] ? TPG_NIB_H : 0u);
       P[0][TA] = tpg_planes(RB[0][0], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
-      auto group = [&](auto Cc, auto Nn, auto Mm, int kg) {
+      // TAIL = false: a group of the main loop, whose groups kg and kg + 1 lie inside the K range: no plane mask depends on
+      // the position (the masks of an absent A tile are loop-invariant SGPRs); TAIL = true: the last, partial body
+      auto group = [&](auto Cc, auto Nn, auto Mm, auto Tl, int kg) {
         constexpr int C = decltype(Cc)::value, N = decltype(Nn)::value, M = decltype(Mm)::value;
+        constexpr bool TAIL = decltype(Tl)::value;
         const int i2 = kg + NG - 1 < k1 ? kg + NG - 1 : kl;
-        const bool live = kg < k1, live1 = kg + 1 < k1;
+        const bool live = !TAIL || kg < k1, live1 = !TAIL || kg + 1 < k1;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
           const int cur = s & 1, nx = cur ^ 1;
@@ -246,18 +249,26 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
       using I3 = std::integral_constant<int, 3>;
+      using TF = std::false_type;
+      using TT = std::true_type;
       if constexpr (NG == 3) {
-        for (int kg = k0; kg < k1; kg += 3) {
-          group(I0{}, I1{}, I2{}, kg);
-          group(I1{}, I2{}, I0{}, kg + 1);
-          group(I2{}, I0{}, I1{}, kg + 2);
+        int kg = k0;
+        for (; kg + 4 <= k1; kg += 3) {  // groups kg .. kg + 3 inside the range (a step looks one group ahead)
+          group(I0{}, I1{}, I2{}, TF{}, kg);
+          group(I1{}, I2{}, I0{}, TF{}, kg + 1);
+          group(I2{}, I0{}, I1{}, TF{}, kg + 2);
+        }
+        for (; kg < k1; kg += 3) {
+          group(I0{}, I1{}, I2{}, TT{}, kg);
+          group(I1{}, I2{}, I0{}, TT{}, kg + 1);
+          group(I2{}, I0{}, I1{}, TT{}, kg + 2);
         }
       } else {
         for (int kg = k0; kg < k1; kg += 4) {
-          group(I0{}, I1{}, I3{}, kg);
-          group(I1{}, I2{}, I0{}, kg + 1);
-          group(I2{}, I3{}, I1{}, kg + 2);
-          group(I3{}, I0{}, I2{}, kg + 3);
+          group(I0{}, I1{}, I3{}, TT{}, kg);
+          group(I1{}, I2{}, I0{}, TT{}, kg + 1);
+          group(I2{}, I3{}, I1{}, TT{}, kg + 2);
+          group(I3{}, I0{}, I2{}, TT{}, kg + 3);
         }
       }
     }
