@@ -913,8 +913,9 @@ def main():
         roofs = [
             mfma_roof("pairwise_mfma", "tpg_pairwise_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 operands)", 5.0 * n * n * m,
                       "fused IBS+KING+AS/GRM: 3 symmetric + 1 general product = 2.5 N^2 M MACs on exact FP4 planes "
-                      "(0.5 / 1 / +-2 with block scales, integer sums in FP32 below 2^24); peak = dense FP4, "
-                      "the bare instruction loop reaches 7.7 of it at the clock the chip holds (tools/ubench_mfma_fp4.hip)",
+                      "(0.5 / 1 / +-2 with block scales, integer sums in FP32 below 2^24); peak = dense FP4 at 2.4 GHz; the MFMA pipe is "
+                      "89 % busy at the 1.87 - 2.05 GHz the chip holds under this kernel (profiles/r04_pmc_one_step.json), the bare "
+                      "instruction loop reaches 7.7 POP/s (tools/ubench_mfma_fp4.hip)",
                       peak=10000.0),
             mfma_roof("pca_gram_mfma", "tpg_pca_gram_kernel (v_mfma_i32_32x32x32_i8)", 4.0 * n * n * m_pca,
                       "PCA Gram: 4 weight digits x symmetric int8 product = 4 * N^2 M / 2 MACs"),
@@ -925,8 +926,8 @@ def main():
                       "block pair is stored as centred dosages in the high halves of the nibbles, 4 VALU per MFMA); a class "
                       "end is 8 v_pk_fma_f32 per 32 x 32 tile (small weight differences of a group of neighbouring classes, "
                       "summation by parts), a group end the FP64 fold; 64 x 64 wave tiles, two waves per SIMD; each wave waits "
-                      "for a dependency most of the time (MFMA pipe 35 % busy, 10.4 VALU-class instructions per MFMA, "
-                      "s_waitcnt 23 %: profiles/r04_pmc_one_step.json)",
+                      "for its own instruction stream and its dependencies (MFMA pipe 42 % busy, 8.4 VALU-class instructions per MFMA, "
+                      "s_waitcnt 27 %: profiles/r04_pmc_one_step.json)",
                       peak=10000.0),
         ]
         roofs = [r for r in roofs if r]
