@@ -7,6 +7,8 @@
 // takes tpg_pack_fast_kernel below.  HBM-bound: reads n*m bytes, writes n*m/2 bytes.  Replaces the per-block
 // byte decode loops of the reference (src/snp_ibs.cpp:45-55, src/snp_king.cpp:45-58, src/snp_as.cpp:44-53 and
 // the SubBMCode256Acc accessor in src/alt_freq_dip_pseudo_cpp.cpp:15-16).
+#include <type_traits>
+
 #include "common.h"
 #include "devfrag.h"
 #include "synth_common.h"
@@ -190,12 +192,26 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
       }
     }
   }
+  // One decision per WAVE instead of two divergent tests per dword (64 conv() calls per thread: ~700 v_cmp / s_and_saveexec /
+  // s_cbranch_execz / s_or_b64 around 224 v_perm_b32): if no byte this wave loaded is >= 8 -- every genotype panel --
+  // every dword takes the v_perm_b32 and the "code the table does not map" flag is looked at once at the end (a view with
+  // that flag set is refused by the caller, so what its words hold does not matter).
+  uint32_t anyw = 0;
+#pragma unroll
+  for (int sub = 0; sub < NSUB; sub++)
+#pragma unroll
+    for (int it = 0; it < 4; it++) anyw |= va[sub][it].x | va[sub][it].y | vb[sub][it].x | vb[sub][it].y;
+  const bool fastw = __builtin_amdgcn_ballot_w64((anyw & 0xF8F8F8F8u) != 0) == 0;  // wave-uniform
+  uint32_t cacc[NV];
+#pragma unroll
+  for (int vw = 0; vw < NV; vw++) cacc[vw] = 0;
 #pragma unroll
   for (int sub = 0; sub < NSUB; sub++) {
   const int64_t bi = bi0 + sub;
   if (bi >= Q) break;
   if (sub) __syncthreads();  // the previous chunk's readers are done with `codes`
-  {
+  auto phase1 = [&](auto fastc) {
+    constexpr bool FAST = decltype(fastc)::value;
     const int64_t i0 = bi * TILE + 16 * c16;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
@@ -206,15 +222,28 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
         uint8_t* codes = codes_all + vw * TILE * TILE;
         uint32_t* L = vw ? L1 : L0;
         uint32_t c[4] = {0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u};
-        if (inside && i0 + 8 <= n) { c[0] = conv(va[sub][it].x, vw); c[1] = conv(va[sub][it].y, vw); }
-        if (inside && i0 + 16 <= n) { c[2] = conv(vb[sub][it].x, vw); c[3] = conv(vb[sub][it].y, vw); }
+        if constexpr (FAST) {
+          const uint32_t w[4] = {va[sub][it].x, va[sub][it].y, vb[sub][it].x, vb[sub][it].y};
+          const bool h0 = inside && i0 + 8 <= n, h1 = inside && i0 + 16 <= n;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t cq = __builtin_amdgcn_perm(hi_[vw], lo_[vw], w[q]);
+            c[q] = (q < 2 ? h0 : h1) ? cq : 0x03030303u;
+            cacc[vw] |= c[q];
+          }
+        } else {
+          if (inside && i0 + 8 <= n) { c[0] = conv(va[sub][it].x, vw); c[1] = conv(va[sub][it].y, vw); }
+          if (inside && i0 + 16 <= n) { c[2] = conv(vb[sub][it].x, vw); c[3] = conv(vb[sub][it].y, vw); }
+        }
         *reinterpret_cast<uint4*>(codes + l * TILE + ((16 * c16 + 32 * (l >> 4)) & 127)) = make_uint4(c[0], c[1], c[2], c[3]);
         const int64_t lt = bj * 4 + (l >> 5);
         const int lane = (l & 31) + 32 * (c16 & 1);
         L[((lt * Q + bi) * 64 + lane) * 4 + (c16 >> 1)] = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
       }
     }
-  }
+  };
+  if (fastw) phase1(std::true_type{});
+  else phase1(std::false_type{});
   __syncthreads();
   {
     const int wv = tid >> 6, t = tid & 63;
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
   }  // sub
 #pragma unroll
   for (int vw = 0; vw < NV; vw++)
-    if (bad_[vw]) atomicOr((unsigned int*)(lut_and_flag + vw * (256 + 16) + 256), 1u);
+    if (bad_[vw] || (cacc[vw] & 0x80808080u)) atomicOr((unsigned int*)(lut_and_flag + vw * (256 + 16) + 256), 1u);
 }
 
 // d_lut: one (v2 == NULL) or two consecutive {256-byte table, 16-byte flag area} records
