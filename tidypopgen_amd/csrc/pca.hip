@@ -964,7 +964,12 @@ extern "C" int tpg_pca_gram_add(tpg_ctx* ctx, const tpg_view* v, const double* c
 // part[split][row + c n] = sum_{k in split} K[row + k n] * Q[k + c n]   (c < b <= 64)
 // FP64 MFMA (v_mfma_f64_16x16x4_f64): one wave owns 16 rows x 64 columns (4 accumulator tiles), so every
 // element of K is read exactly once per product; the workgroup's 4 waves share the 64-deep slice of Q
-// staged in LDS.  A = K[row0 + (l & 15)][k + (l >> 4)], B = Q[k + (l >> 4)][col + (l & 15)];
+// staged in LDS.  A = K[row0 + (l & 15)][k], B = Q[k][col + (l & 15)] with k = 16 (l >> 4) + u in MFMA step u of a chunk
+// (any assignment of the chunk's 64 k to (step, lane quarter) is as good as another: the sum runs over all of them), so a
+// lane's sixteen K values of a chunk are CONTIGUOUS in a row of K -- read as K[k + row n] (K is symmetric): one 128-byte
+// line per lane in eight 16-byte loads, no predicates (indices past n are clamped: such a row is never stored, such a k
+// meets a zero row of the Q slice), where sixteen 8-byte loads 4 n doubles apart, each under its own bounds test, made
+// this kernel 126 address computations and 80 exec-mask branches per 64 MFMAs.
 // C/D: col = l & 15, row = (l >> 4) + 4 reg.
 __global__ __launch_bounds__(256) void tpg_symm_apply_kernel(const double* __restrict__ K, int n,
                                                              const double* __restrict__ Q, int b, int S,
@@ -984,14 +989,32 @@ __global__ __launch_bounds__(256) void tpg_symm_apply_kernel(const double* __res
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0, 0, 0, 0};
   double av[16], qv[16];
+  typedef double sa_v2d __attribute__((ext_vector_type(2)));
+  typedef sa_v2d sa_v2d_a8 __attribute__((aligned(8)));  // (a row of K starts on an 8-byte boundary only when n is odd)
+  const double* Krow = K + (int64_t)(row < n ? row : n - 1) * n;
   auto fetch = [&](int ch) {  // K values of this lane and this thread's 16 entries of the Q slice, chunk ch
     const int k0 = ch * 64;
+    const int kb = k0 + 16 * kq;
+    if (kb + 16 <= n) {  // (false only in the last chunk)
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        const sa_v2d t = *(const sa_v2d_a8*)(Krow + kb + u);
+        av[u] = t[0]; av[u + 1] = t[1];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; u++) av[u] = Krow[kb + u < n ? kb + u : n - 1];
+    }
+    // the Q slice: column wv + 4 u (wave-uniform), row k0 + lane: zero past n and past b, both tests scalar but for the last chunk
+    const int wvu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool inside = k0 + 64 <= n || k0 + lane < n;
+    const double* Qk = Q + (k0 + lane < n ? k0 + lane : n - 1);
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-      const int k = k0 + 4 * u + kq;
-      av[u] = (row < n && k < n) ? K[row + (int64_t)k * n] : 0.0;
-      const int idx = threadIdx.x + 256 * u, kk = idx & 63, c = idx >> 6;
-      qv[u] = (k0 + kk < n && c < b) ? Q[(k0 + kk) + (int64_t)c * n] : 0.0;
+      const int c = wvu + 4 * u;
+      double t = 0.0;
+      if (c < b) t = Qk[(int64_t)c * n];
+      qv[u] = inside ? t : 0.0;
     }
   };
   if (cbeg < cend) {
@@ -1010,7 +1033,7 @@ __global__ __launch_bounds__(256) void tpg_symm_apply_kernel(const double* __res
     for (int u = 0; u < 16; u++) {
 #pragma unroll
       for (int ct = 0; ct < 4; ct++)
-        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], qs[cur][4 * u + kq][ct * 16 + r16], acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], qs[cur][16 * kq + u][ct * 16 + r16], acc[ct], 0, 0, 0);
     }
     if (ch + 1 < cend) {
 #pragma unroll
@@ -1199,6 +1222,7 @@ struct EigWork {
     S = 1;
     const int row_blocks = (n + 63) / 64;
     while (row_blocks * S < 4 * ctx->num_cu && S < 32 && n / (S * 2) >= 64) S *= 2;
+    if (getenv("TPG_EIG_S")) S = std::max(1, atoi(getenv("TPG_EIG_S")));  // (experiments)
     // A'B over chunks of rows: a workgroup per 32 (64) rows, so that a product on a few thousand rows is one short round
     // of many workgroups instead of a long loop in a few
     rows_per_chunk = n <= 4096 ? 32 : 64;
