@@ -198,6 +198,11 @@ typedef float gc_v16f __attribute__((ext_vector_type(16)));
 #define GC_MFMA(a, b, c, sa) \
   __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((gc_v8i){(int)(a)[0], (int)(a)[1], (int)(a)[2], (int)(a)[3], 0, 0, 0, 0}, \
                                                   (gc_v8i){(int)(b).x, (int)(b).y, (int)(b).z, (int)(b).w, 0, 0, 0, 0}, (c), 4, 4, 0, (sa), 0, 0x7F7F7F7F)
+__device__ __forceinline__ int64_t tpg_gc_uniform64(int64_t x) {  // a wave-uniform value the compiler keeps in SGPRs
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 template <int GT>
 __global__ __launch_bounds__(256, 3) void tpg_grouped_counts_kernel(const uint4* __restrict__ L,
                                                                     const uint4* __restrict__ OH, int64_t n_lt,
@@ -217,33 +222,44 @@ __global__ __launch_bounds__(256, 3) void tpg_grouped_counts_kernel(const uint4*
       for (int g = 0; g < GT; g++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[p][t][g][r] = 0.f;
-  const uint4* pa[GC_NLT];
+  // (wave-uniform bases in SGPRs + a 32-bit lane offset per group: 32-bit group indices, no 64-bit per-lane pointers)
+  const int Qi = (int)Q;
+  const int64_t lt0u = tpg_gc_uniform64(lt0);
+  const char* pa[GC_NLT];
 #pragma unroll
-  for (int t = 0; t < GC_NLT; t++) pa[t] = L + ((lt0 + t < n_lt ? lt0 + t : 0) * Q) * 64 + lane;  // past the end: a copy
+  for (int t = 0; t < GC_NLT; t++) pa[t] = (const char*)(L + ((lt0u + t < n_lt ? lt0u + t : 0) * Q) * 64);  // past the end: a copy
+  auto LDG = [&](const char* p, int q) {
+    uint32_t off = (uint32_t)lane * 16u + (uint32_t)q * 1024u;
+    asm("" : "+v"(off));
+    return *(const uint4*)(p + off);
+  };
   // this wave's share of a group's 2 * GT one-hot fragments: items wv, wv + 4, ... (fragment (S, g) of group q sits at
   // OH[((q * 2 + S) * GT_total + gt0 + g) * 64 + lane])
   constexpr int NIT = (2 * GT + 3) / 4;
-  const uint4* po = OH + (int64_t)gt0 * 64 + lane;
-  auto frag = [&](int64_t q, int it) { return po[((q * 2 + it / GT) * GT_total + it % GT) * 64]; };
+  const char* po = (const char*)(OH + (int64_t)gt0 * 64);
+  auto frag = [&](int q, int it) {
+    uint32_t off = (uint32_t)lane * 16u + (uint32_t)(((q * 2 + it / GT) * GT_total + it % GT)) * 1024u;
+    return *(const uint4*)(po + off);
+  };
   // genotype blocks of groups q .. q + GC_D - 1 in GC_D rotating register slots (the HBM stream is fetched GC_D - 1 groups
   // ahead; the loop is unrolled by GC_D so that no slot is copied -- a copy would wait for the load just issued)
   uint4 R[GC_D][GC_NLT], on[NIT];
 #pragma unroll
   for (int d = 0; d < GC_D - 1; d++)
 #pragma unroll
-    for (int t = 0; t < GC_NLT; t++) R[d][t] = pa[t][(d < Q ? d : Q - 1) * 64];
+    for (int t = 0; t < GC_NLT; t++) R[d][t] = LDG(pa[t], d < Qi ? d : Qi - 1);
 #pragma unroll
   for (int j = 0; j < NIT; j++) {
     const int it = wv + 4 * j;
     if (it < 2 * GT) ohb[0][it][lane] = frag(0, it);
   }
   tpg_lds_barrier();
-  auto group = [&](auto Cc, auto Mm, int64_t q) {
+  auto group = [&](auto Cc, auto Mm, int q) {
     constexpr int C = decltype(Cc)::value, M = decltype(Mm)::value;
-    const int64_t qn = q + 1 < Q ? q + 1 : q, qn2 = q + GC_D - 1 < Q ? q + GC_D - 1 : Q - 1;
-    const int cur = (int)(q & 1);
+    const int qn = q + 1 < Qi ? q + 1 : q, qn2 = q + GC_D - 1 < Qi ? q + GC_D - 1 : Qi - 1;
+    const int cur = q & 1;
 #pragma unroll
-    for (int t = 0; t < GC_NLT; t++) R[M][t] = pa[t][qn2 * 64];
+    for (int t = 0; t < GC_NLT; t++) R[M][t] = LDG(pa[t], qn2);
 #pragma unroll
     for (int j = 0; j < NIT; j++) {
       const int it = wv + 4 * j;
@@ -282,10 +298,10 @@ __global__ __launch_bounds__(256, 3) void tpg_grouped_counts_kernel(const uint4*
     }
     tpg_lds_barrier();
   };
-  for (int64_t q = 0; q < Q; q += GC_D)  // Q is the same for every wave: all of them meet every barrier
+  for (int q = 0; q < Qi; q += GC_D)  // Q is the same for every wave: all of them meet every barrier
     gc_static_for<GC_D>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
-      if (q + k < Q) group(std::integral_constant<int, k>{}, std::integral_constant<int, (k + GC_D - 1) % GC_D>{}, q + k);
+      if (q + k < Qi) group(std::integral_constant<int, k>{}, std::integral_constant<int, (k + GC_D - 1) % GC_D>{}, q + k);
     });
 #pragma unroll
   for (int t = 0; t < GC_NLT; t++) {
