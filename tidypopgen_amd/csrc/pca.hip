@@ -1740,6 +1740,11 @@ __global__ __launch_bounds__(256) void tpg_uq_colsum_kernel(const double* __rest
 // and was bound by that (1.6 ms).  The A side is the code bytes themselves (no missing values here, see the Gram
 // kernel).
 #define LD_NLT 2
+__device__ __forceinline__ int64_t tpg_uniform64_pca(int64_t x) {  // a wave-uniform value the compiler keeps in SGPRs
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 template <int CTP>
 __global__ __launch_bounds__(256, 2) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
                                                                    const uint4* __restrict__ UD, int64_t n_lt,
@@ -1755,30 +1760,38 @@ __global__ __launch_bounds__(256, 2) void tpg_loadings_mfma_kernel(const uint4* 
     for (int c = 0; c < CTP; c++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[t][c][r] = 0;
-  const uint4* pa[LD_NLT];
+  // (wave-uniform bases in SGPRs + a 32-bit lane offset per group, 32-bit group indices: no 64-bit per-lane pointers)
+  const int Qi = (int)Q;
+  const int64_t lt0u = tpg_uniform64_pca(lt0);
+  const char* pa[LD_NLT];
 #pragma unroll
-  for (int t = 0; t < LD_NLT; t++) pa[t] = L + ((lt0 + t < n_lt ? lt0 + t : 0) * Q) * 64 + lane;  // past the end: a copy
+  for (int t = 0; t < LD_NLT; t++) pa[t] = (const char*)(L + ((lt0u + t < n_lt ? lt0u + t : 0) * Q) * 64);  // past the end: a copy
+  auto LDG = [&](const char* p, int blk) {
+    uint32_t off = (uint32_t)lane * 16u + (uint32_t)blk * 1024u;
+    asm("" : "+v"(off));
+    return *(const uint4*)(p + off);
+  };
   uint4 a[LD_NLT], a1[LD_NLT], a2[LD_NLT];  // the genotype stream is fetched two groups ahead
 #pragma unroll
-  for (int t = 0; t < LD_NLT; t++) { a[t] = pa[t][0]; a1[t] = pa[t][(Q > 1 ? 1 : 0) * 64]; }
+  for (int t = 0; t < LD_NLT; t++) { a[t] = LDG(pa[t], 0); a1[t] = LDG(pa[t], Qi > 1 ? 1 : 0); }
   // this wave's share of a group's fragments: items wv, wv + 4, ... of the 4 * CTP (K step, column tile) pairs
-  const uint4* pu = UD + ct0 * 64 + lane;  // fragment (ks, c) = pu[(ks * CT + c) * 64]
+  const char* pu = (const char*)(UD + ct0 * 64);  // fragment (ks, c) = block ks * CT + c
   uint4 un[CTP];
 #pragma unroll
   for (int j = 0; j < CTP; j++) {
     const int it = wv + 4 * j;
-    ubuf[0][it][lane] = pu[((int64_t)(it / CTP) * CT + it % CTP) * 64];
+    ubuf[0][it][lane] = LDG(pu, (it / CTP) * CT + it % CTP);
   }
   tpg_lds_barrier();
-  for (int64_t q = 0; q < Q; q++) {
-    const int64_t qn = q + 1 < Q ? q + 1 : q, qn2 = q + 2 < Q ? q + 2 : Q - 1;
-    const int cur = (int)(q & 1);
+  for (int q = 0; q < Qi; q++) {
+    const int qn = q + 1 < Qi ? q + 1 : q, qn2 = q + 2 < Qi ? q + 2 : Qi - 1;
+    const int cur = q & 1;
 #pragma unroll
-    for (int t = 0; t < LD_NLT; t++) a2[t] = pa[t][qn2 * 64];
+    for (int t = 0; t < LD_NLT; t++) a2[t] = LDG(pa[t], qn2);
 #pragma unroll
     for (int j = 0; j < CTP; j++) {
       const int it = wv + 4 * j;
-      un[j] = pu[((qn * 4 + it / CTP) * CT + it % CTP) * 64];
+      un[j] = LDG(pu, (qn * 4 + it / CTP) * CT + it % CTP);
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
