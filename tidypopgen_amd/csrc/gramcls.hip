@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram_kernel(const uint4* __re
 // hides the scalar bookkeeping and the load latency of a single wave.)
 typedef float v2f __attribute__((ext_vector_type(2)));
 // cost model of this kernel (microseconds per wave and 32 x 32 tile): per class, per block
-#define GCLS2_T_CLASS 0.05
-#define GCLS2_T_BLOCK 0.079
+#define GCLS2_T_CLASS 0.045  // (refitted at the end of round 4: 9.2 ms for 4 728 classes in 17 888 blocks at n = 5 000)
+#define GCLS2_T_BLOCK 0.067
 #define GCLS2_LDS_BYTES (4 * 2 * 16 * 64 * 8)
 #ifndef GCLS2_D
 #define GCLS2_D 2
@@ -1078,8 +1078,8 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   const int nblk_grid = one_wave ? ncu8 : 2 * ncu8;  // two workgroups per CU = two waves per SIMD
   const int nwaves = 4 * nblk_grid;
   int S = 2;
-  // + the sort, the gather (2.0 us per 1000 loci at n = 5 000: it scales with n m) and the assemble pass
-  const double cost_cls = gcls_cost_classes(nun, nruns, nblocks, nwaves, &S) + 650.0 + 2.0e-3 * (double)m * ((double)n / 5000.0);
+  // + the sort, the locus-major copy and the gather (1.25 us per 1000 loci at n = 5 000: they scale with n m)
+  const double cost_cls = gcls_cost_classes(nun, nruns, nblocks, nwaves, &S) + 350.0 + 1.25e-3 * (double)m * ((double)n / 5000.0);
   // the digit kernel: 32 x 128 wave tiles, 64 int8 MFMAs (~1.0 us) per 128 loci, 4 row tiles x super-tiles of 4
   const int64_t nun_dig = (int64_t)nrtv * ceil_div((int64_t)nrtv, 4) / 2 + nrtv;
   const double cost_dig = (double)ceil_div(nun_dig, (int64_t)(4 * ncu8)) * ((double)ceil_div(m, 128) * 1.0) + 65.0;
