@@ -208,7 +208,7 @@ __global__ void tpg_gcls_block_table2_kernel(const unsigned long long* __restric
 // through LDS, and lane (r, ho) of output row tile s ends up with the 32 dosages of individual 32 (4q + s) + r at the
 // loci 32 ho .. 32 ho + 31 of each block: one uint4 = {P0, P1 of block 2 bp, P0, P1 of block 2 bp + 1}, a source dword
 // P packing 16 codes as nibbles [c_odd | c_even], so that P & 0x33333333 and (P >> 2) & 0x33333333 are FP4 operand
-// words of value dosage / 2.  Missing / padding -> 0.  (Which locus sits on which nibble is immaterial: both MFMA
+// words of value dosage / 2.  Padding -> 0; the view holds no missing value (checked by both callers of the class path).  (Which locus sits on which nibble is immaterial: both MFMA
 // operands come from this layout.)
 // Where the 16-byte pieces of a locus live (uint4 units): piece (j, q, h) at base + (j >> sh) * sa + (j & msk) * sb +
 // q * sq + h * sh1.  A view's L layout: 32 loci per 1-KiB block, {5, Q * 64, 31, 1, 64, 32}; records received from other
@@ -272,8 +272,7 @@ __global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(GclsSrc S, int64_t
           uint32_t acc = 0;
 #pragma unroll
           for (int e = 0; e < 8; e++) acc = (__builtin_amdgcn_alignbit(ws[e], ws[e], rot[e]) & (3u << (4 * e))) | acc;
-          const uint32_t m3 = acc & (acc >> 1) & 0x11111111u;  // code 3 -> 0
-          nib[d] = acc & ~(m3 | (m3 << 1));
+          nib[d] = acc;  // (codes 0 / 1 / 2 only: every caller has refused a view with a missing value before it gets here)
         }
         if constexpr (CEN) {
 #pragma unroll
