@@ -51,6 +51,12 @@ static int test_eig() {
       std::vector<double> th, X;
       host_sym_eig(H, n, th, X);
       CHECK((int)th.size() == n && (int)X.size() == n * n, "sizes");
+      {  // eigenvalues only: the same values bit for bit
+        std::vector<double> th2, X2;
+        host_sym_eig(H, n, th2, X2, false);
+        CHECK(X2.empty() && th2.size() == th.size(), "values-only sizes");
+        for (int j = 0; j < n; j++) CHECK(th2[j] == th[j], "values-only eigenvalue %d differs (n = %d)", j, n);
+      }
       double hmax = 0;
       for (double v : H) hmax = std::max(hmax, fabs(v));
       for (int j = 0; j < n; j++) {

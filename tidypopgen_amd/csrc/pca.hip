@@ -1421,12 +1421,12 @@ static int eig_topk(tpg_ctx* ctx, const double* d_K, int n, int k, double* lambd
         H[i + (size_t)j * act] = sy;
         H[j + (size_t)i * act] = sy;
       }
-    host_sym_eig(H, act, theta, X);
-    st.mark("host_sym_eig");
     // The random start block has no converged pair and the filter works on any basis of the subspace: its first
     // Rayleigh-Ritz step only supplies the Ritz VALUES (the filter's interval), so the rotation to Ritz vectors and the
-    // residuals (three products, a Gram matrix and a host round trip) are left out
+    // residuals (three products, a Gram matrix and a host round trip) are left out -- and so are the eigenvectors of H
     const bool first = it == 0 && b < n;  // (a block that spans the whole space is exact at once)
+    host_sym_eig(H, act, theta, X, !first);
+    st.mark("host_sym_eig");
     std::vector<double> RR;
     if (first) {
       lam1 = fabs(theta[0]) > 0 ? fabs(theta[0]) : 1.0;
