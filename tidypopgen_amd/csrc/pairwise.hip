@@ -1333,10 +1333,15 @@ void tpg_resident_release(tpg_ctx* ctx) {  // called by tpg_ctx_destroy and tpg_
 // The two count matrices of one increment_* entry point as int32, both triangles, column-major: half the bytes of the
 // double outputs of tpg_pairwise_counts on their way to the host.  which 0: IBS = V + D + H, 2 V; 1: KING numerator
 // D - V + A + A', A; 2: D (+ quirk), V.  Same tile walk as tpg_pairwise_epilogue_kernel.
+// OA / OB = int32_t, or uint16_t where a block is short enough for its counts (+ bias for a signed one) to fit 16 bits: a
+// block of the R drivers is 26 843 loci, so IBS and its valid count (<= 2 x loci), N_Aa (<= loci) and the allele-sharing
+// numerator (|D| <= loci, biased by 32 768) and denominator travel as 16 bits -- half the bytes again; the KING numerator
+// (|x| <= 2 x loci) stays int32.
+template <typename OA, typename OB>
 __global__ __launch_bounds__(256) void tpg_pairwise_counts2_i32_kernel(const int32_t* __restrict__ acc,
                                                                        const int64_t* __restrict__ rowpad, int nst, int n,
-                                                                       int which, int quirk, int32_t* __restrict__ oA,
-                                                                       int32_t* __restrict__ oB) {
+                                                                       int which, int quirk, OA* __restrict__ oA, int biasA,
+                                                                       OB* __restrict__ oB) {
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (ti > tj) return;
   __shared__ int sp[5][32][33];
@@ -1352,9 +1357,9 @@ __global__ __launch_bounds__(256) void tpg_pairwise_counts2_i32_kernel(const int
   auto emit = [&](int row, int col, int64_t idx, bool mirrored) {
     const int V = sp[0][row][col], D = sp[1][row][col], H = sp[2][row][col];
     const int Aij = mirrored ? sp[4][row][col] : sp[3][row][col], Aji = mirrored ? sp[3][row][col] : sp[4][row][col];
-    if (which == 0) { oA[idx] = V + D + H; oB[idx] = 2 * V; }
-    else if (which == 1) { oA[idx] = D - V + Aij + Aji; oB[idx] = Aij; }
-    else { oA[idx] = D + quirk; oB[idx] = V; }
+    if (which == 0) { oA[idx] = (OA)(V + D + H + biasA); oB[idx] = (OB)(2 * V); }
+    else if (which == 1) { oA[idx] = (OA)(D - V + Aij + Aji + biasA); oB[idx] = (OB)Aij; }
+    else { oA[idx] = (OA)(D + quirk + biasA); oB[idx] = (OB)V; }
   };
 #pragma unroll
   for (int e = 0; e < 4; e++) {
@@ -1406,34 +1411,57 @@ static int add_counts_to_caller(tpg_ctx* ctx, int which, const tpg_pairwise* pw,
     TPG_HIP(hipHostMalloc((void**)&r->stage, sizeof(int32_t) * 2 * nn, hipHostMallocDefault));
     r->stage_ints = 2 * nn;
   }
-  int32_t* d_out = nullptr;
-  TPG_HIP(tpg_pmalloc((void**)&d_out, sizeof(int32_t) * 2 * nn));
+  // widths on the wire: 16 bits where the block's bounds allow it (see the kernel); TPG_INCREMENT_I32=1: always int32 (A/B)
+  static const bool wide = getenv("TPG_INCREMENT_I32") && atoi(getenv("TPG_INCREMENT_I32")) != 0;
+  const int64_t bound = 2 * pw->loci + pw->as_pad_quirk;  // of |IBS|, |valid|, |KING numerator|; N_Aa, |D|, V <= loci + quirk
+  const bool a16 = !wide && (which == 0 ? bound <= 65535 : which == 2 ? pw->loci + pw->as_pad_quirk <= 32767 : false);
+  const bool b16 = !wide && (which == 0 ? bound <= 65535 : pw->loci <= 65535);
+  const int biasA = (a16 && which == 2) ? 32768 : 0;
+  const size_t bytesA = nn * (a16 ? 2 : 4), bytesB = nn * (b16 ? 2 : 4);
+  uint8_t* d_out = nullptr;
+  TPG_HIP(tpg_pmalloc((void**)&d_out, bytesA + bytesB));
   const unsigned nt = (unsigned)ceil_div(pw->n, 32);
   hipEvent_t evA = nullptr;
   hipError_t e = hipEventCreateWithFlags(&evA, hipEventDisableTiming);
   if (e == hipSuccess) {
-    TPG_LAUNCH(ctx, "pairwise_counts_i32", tpg_pairwise_counts2_i32_kernel, dim3(nt, nt), dim3(256), 0, (const int32_t*)pw->acc,
-               (const int64_t*)pw->rowpad, (int)pw->nst, (int)pw->n, which, (int)pw->as_pad_quirk, d_out, d_out + nn);
+    ProfScope ps(ctx, "pairwise_counts_i32");
+    const dim3 grid(nt, nt);
+#define CNT2(TA_, TB_)                                                                                                        \
+  hipLaunchKernelGGL((tpg_pairwise_counts2_i32_kernel<TA_, TB_>), grid, dim3(256), 0, ctx->stream, (const int32_t*)pw->acc,   \
+                     (const int64_t*)pw->rowpad, (int)pw->nst, (int)pw->n, which, (int)pw->as_pad_quirk, (TA_*)d_out, biasA,  \
+                     (TB_*)(d_out + bytesA))
+    if (a16 && b16) CNT2(uint16_t, uint16_t);
+    else if (b16) CNT2(int32_t, uint16_t);
+    else if (a16) CNT2(uint16_t, int32_t);
+    else CNT2(int32_t, int32_t);
+#undef CNT2
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(r->stage, d_out, sizeof(int32_t) * nn, hipMemcpyDeviceToHost, ctx->stream);
+  uint8_t* stage = (uint8_t*)r->stage;
+  if (e == hipSuccess) e = hipMemcpyAsync(stage, d_out, bytesA, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipEventRecord(evA, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(r->stage + nn, d_out + nn, sizeof(int32_t) * nn, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(stage + bytesA, d_out + bytesA, bytesB, hipMemcpyDeviceToHost, ctx->stream);
   tpg_pfree(d_out);  // stream-ordered
+  auto add = [&](double* dst, const uint8_t* src, bool is16, int bias) {
+    team([&](int t) {
+      const size_t k0 = nn * (size_t)t / (size_t)NT, k1 = nn * (size_t)(t + 1) / (size_t)NT;
+      if (is16) {
+        const uint16_t* q = (const uint16_t*)src;
+        for (size_t k = k0; k < k1; k++) dst[k] += (double)((int)q[k] - bias);
+      } else {
+        const int32_t* q = (const int32_t*)src;
+        for (size_t k = k0; k < k1; k++) dst[k] += (double)q[k];
+      }
+    });
+  };
   if (e == hipSuccess) e = hipEventSynchronize(evA);
   if (e == hipSuccess) {
-    const int32_t* sa = r->stage;
-    team([&](int t) {
-      for (size_t k = nn * (size_t)t / (size_t)NT; k < nn * (size_t)(t + 1) / (size_t)NT; k++) A[k] += (double)sa[k];
-    });
+    add(A, stage, a16, biasA);
     e = hipStreamSynchronize(ctx->stream);
   }
   if (evA) (void)hipEventDestroy(evA);
   if (e != hipSuccess) { tpg_set_error("increment: counts to the caller: %s", hipGetErrorString(e)); return TPG_EHIP; }
-  const int32_t* sb = r->stage + nn;
-  team([&](int t) {
-    for (size_t k = nn * (size_t)t / (size_t)NT; k < nn * (size_t)(t + 1) / (size_t)NT; k++) B[k] += (double)sb[k];
-  });
+  add(B, stage + bytesA, b16, 0);
   return TPG_OK;
 }
 
