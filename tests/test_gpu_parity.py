@@ -452,6 +452,27 @@ def test_increment_mirrors(tpg):
     tpg.resident_drop()
 
 
+@pytest.mark.parametrize("m", [30000, 33000, 70000])
+def test_increment_wire_widths(tpg, m):
+    """The count matrices of a block come down as 16 bits where the block's bounds allow it (IBS, its valid count and N_Aa up
+    to 32 767 / 65 535 loci, the allele-sharing numerator biased by 32 768), as int32 otherwise: blocks on both sides of every
+    bound, monomorphic individuals that drive the sums to the bounds, against the oracle."""
+    n = 40
+    fbm = orc.synth_fbm(77, n, m, npop=2, miss=0.01)
+    fbm[0, :] = 2; fbm[1, :] = 2; fbm[2, :] = 0; fbm[3, :] = 1  # IBS(0,1) = 2 m, D(0,2) = -m, A(3,*) large
+    rows = np.arange(1, n + 1, dtype=np.int32)
+    cols = np.arange(1, m + 1, dtype=np.int32)
+    for inc_t, inc_o in ((tpg.increment_ibs_counts, orc.increment_ibs_counts),
+                         (tpg.increment_king_numerator, orc.increment_king_numerator),
+                         (tpg.increment_as_counts, orc.increment_as_counts)):
+        A = np.full((n, n), 5.0, order="F"); B = np.full((n, n), -2.0, order="F")
+        Ao = A.copy(order="F"); Bo = B.copy(order="F")
+        inc_t(A, B, fbm, rows, cols)
+        inc_o(Ao, Bo, fbm, rows, cols)
+        assert np.array_equal(A, Ao) and np.array_equal(B, Bo)
+    tpg.resident_drop()
+
+
 def test_increment_mirrors_resident_block_loop(tpg):
     """The R block loop unchanged (R/snp_ibs.R:69-82): FBM uploaded once, accumulators resident, one flush at the end.
     Accumulators that already hold values (a second pass over more loci) are incremented, not overwritten."""
