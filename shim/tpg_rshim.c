@@ -157,6 +157,11 @@ static mapped_file* map_file(const char* path, size_t bytes, int writable, int64
   void* p = mmap(NULL, bytes, writable ? (PROT_READ | PROT_WRITE) : PROT_READ, MAP_SHARED, fd, 0);
   close(fd);
   if (p == MAP_FAILED) Rf_error("mmap of '%s' failed", path);
+#ifdef MADV_POPULATE_WRITE
+  /* an accumulator is written in full by the first call that uses it: one batched populate (Linux 5.14) instead of a write
+     fault per page of a shared file mapping from the adding threads (49 000 per matrix at n = 5 000) */
+  if (writable) (void)madvise(p, bytes, MADV_POPULATE_WRITE);
+#endif
   mapped_file** nf = (mapped_file**)realloc(g_files, sizeof(mapped_file*) * (size_t)(g_nfiles + 1));
   mapped_file* f = nf ? (mapped_file*)calloc(1, sizeof(mapped_file)) : NULL;
   char* pc = f ? strdup(path) : NULL;
