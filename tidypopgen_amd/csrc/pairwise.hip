@@ -41,6 +41,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -1442,26 +1443,42 @@ static int add_counts_to_caller(tpg_ctx* ctx, int which, const tpg_pairwise* pw,
   if (e == hipSuccess) e = hipEventRecord(evA, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(stage + bytesA, d_out + bytesA, bytesB, hipMemcpyDeviceToHost, ctx->stream);
   tpg_pfree(d_out);  // stream-ordered
-  auto add = [&](double* dst, const uint8_t* src, bool is16, int bias) {
-    team([&](int t) {
-      const size_t k0 = nn * (size_t)t / (size_t)NT, k1 = nn * (size_t)(t + 1) / (size_t)NT;
-      if (is16) {
-        const uint16_t* q = (const uint16_t*)src;
-        for (size_t k = k0; k < k1; k++) dst[k] += (double)((int)q[k] - bias);
-      } else {
-        const int32_t* q = (const int32_t*)src;
-        for (size_t k = k0; k < k1; k++) dst[k] += (double)q[k];
-      }
-    });
+  auto add = [&](int t, double* dst, const uint8_t* src, bool is16, int bias) {
+    const size_t k0 = nn * (size_t)t / (size_t)NT, k1 = nn * (size_t)(t + 1) / (size_t)NT;
+    if (is16) {
+      const uint16_t* q = (const uint16_t*)src;
+      for (size_t k = k0; k < k1; k++) dst[k] += (double)((int)q[k] - bias);
+    } else {
+      const int32_t* q = (const int32_t*)src;
+      for (size_t k = k0; k < k1; k++) dst[k] += (double)q[k];
+    }
   };
-  if (e == hipSuccess) e = hipEventSynchronize(evA);
-  if (e == hipSuccess) {
-    add(A, stage, a16, biasA);
-    e = hipStreamSynchronize(ctx->stream);
-  }
+  // ONE team for both matrices (starting sixteen threads is ~0.8 ms, and this runs once per block of the R loop): a thread
+  // adds its stripe of the first matrix when that has arrived, of the second when the stream is drained; thread 0 does the
+  // waiting.  state: 0 nothing yet, 1 the first matrix is in the staging buffer, 2 both, -1 a transfer failed
+  std::atomic<int> state{0};
+  if (e != hipSuccess) state.store(-1);
+  team([&](int t) {
+    if (t == 0 && state.load() == 0) {
+      hipError_t w = hipEventSynchronize(evA);
+      if (w != hipSuccess) { e = w; state.store(-1); }
+      else state.store(1);
+    }
+    int sv;
+    while ((sv = state.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+    if (sv < 0) return;
+    add(t, A, stage, a16, biasA);
+    if (t == 0) {
+      hipError_t w = hipStreamSynchronize(ctx->stream);
+      if (w != hipSuccess) { e = w; state.store(-1); }
+      else state.store(2);
+    }
+    while ((sv = state.load(std::memory_order_acquire)) == 1) std::this_thread::yield();
+    if (sv < 0) return;
+    add(t, B, stage + bytesA, b16, 0);
+  });
   if (evA) (void)hipEventDestroy(evA);
   if (e != hipSuccess) { tpg_set_error("increment: counts to the caller: %s", hipGetErrorString(e)); return TPG_EHIP; }
-  add(B, stage + bytesA, b16, 0);
   return TPG_OK;
 }
 
