@@ -22,7 +22,7 @@ ms, v = t(lambda: tpg.View(X, None, None, code256=None)); print(f"view: {ms:.2f}
 ms, _ = t(lambda: (pw.zero(), pw.accumulate(v, products=tpg.PW_FOR_IBS))); print(f"zero + accumulate: {ms:.2f} ms")
 for label, src in (("anonymous memory", a), ("fresh file mapping", None)):
     if src is None:
-        d = tempfile.mkdtemp(dir="gpurun_out" if os.path.isdir("gpurun_out") else None)
+        d = tempfile.mkdtemp(dir="/tmp")
         f = os.path.join(d, "g.bk"); a.T.tofile(f)  # column-major bytes
         src = np.memmap(f, dtype=np.uint8, mode="r", shape=(n, m * nb), order="F")
     for flush in (True, False):
@@ -35,5 +35,6 @@ for label, src in (("anonymous memory", a), ("fresh file mapping", None)):
             times.append((time.perf_counter() - t0) * 1e3)
         if not flush:
             tpg.increment_flush()
-        print(f"{label}, flush={flush}: first call {times[0]:.2f} ms, then {np.mean(times[1:]):.2f} ms per block")
+        print(f"{label}, flush={flush}: first call {times[0]:.2f} ms, then {np.mean(times[1:]):.2f} ms per block (median {np.median(times[1:]):.2f})")
     tpg.resident_drop()
+import shutil; del src; shutil.rmtree(d, ignore_errors=True)
