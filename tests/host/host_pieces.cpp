@@ -1,7 +1,7 @@
 // tests/host/host_pieces.cpp -- self-checking driver for the host-only pieces of libtpg_hip.so (tidypopgen_amd/csrc/host/*.h),
 // built WITHOUT HIP by tests/test_host_sanitizers.py with -fsanitize=address,undefined and (the transport) -fsanitize=thread:
 // the CPU-side equivalent of the reference's valgrind job (.github/workflows/R-CMD-check-valgrind.yaml:50-51).
-//   host_pieces eig | bands | relfilter | nibpack | fsttiles | inproc [threads] | inproc_mismatch
+//   host_pieces eig | bands | relfilter | nibpack | fsttiles | bits2 | inproc [threads] | inproc_mismatch
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,6 +18,7 @@
 #include "host/host_inproc.h"
 #include "host/host_nibpack.h"
 #include "host/host_relfilter.h"
+#include "host/host_bits2.h"
 
 static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
 static double urand() {  // splitmix64 -> [0, 1)
@@ -332,6 +333,24 @@ static int test_fsttiles() {
   return 0;
 }
 
+// the 16 x 16 transposition of 2-bit fields against its definition, and the byte permute against v_perm_b32's table
+static int test_bits2() {
+  CHECK(tpg_byte_perm(0x77665544u, 0x33221100u, 0x07040300u) == 0x77443300u, "byte permute");
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  for (int rep = 0; rep < 2000; rep++) {
+    uint32_t W[16], T[16];
+    for (int k = 0; k < 16; k++) {
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      W[k] = T[k] = (uint32_t)(st >> 32);
+    }
+    tpg_transpose16_2bit(T);
+    for (int k = 0; k < 16; k++)
+      for (int p = 0; p < 16; p++)
+        CHECK(((T[p] >> (2 * k)) & 3u) == ((W[k] >> (2 * p)) & 3u), "transposition: word %d field %d (rep %d)", k, p, rep);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "";
   int rc = 2;
@@ -342,7 +361,8 @@ int main(int argc, char** argv) {
   else if (what == "inproc_mismatch") rc = test_inproc_mismatch();
   else if (what == "nibpack") rc = test_nibpack();
   else if (what == "fsttiles") rc = test_fsttiles();
-  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | nibpack | fsttiles | inproc [threads] | inproc_mismatch\n");
+  else if (what == "bits2") rc = test_bits2();
+  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | nibpack | fsttiles | bits2 | inproc [threads] | inproc_mismatch\n");
   if (rc == 0) printf("ok %s\n", what.c_str());
   return rc;
 }

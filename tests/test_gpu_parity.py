@@ -1115,6 +1115,9 @@ def test_pca_gram_weight_classes_equal_digits_and_numpy(tpg, n, m):
             assert np.array_equal(Kc, Kc.T)
             assert np.abs(Kc - ref).max() <= tol * sc
             assert np.array_equal(tpg.pca_gram(v, center, scale), Kc)  # run-to-run identical (ordered slab sums)
+            for qw in ("1", "2", "4"):  # the gather's chunks of 128 individuals per task: the same operand layout
+                with _env(TPG_GATHER_QW=qw):
+                    assert np.array_equal(tpg.pca_gram(v, center, scale), Kc)
     with _env(TPG_GRAM_DIGITS="1", TPG_GRAM_CLASSES=None):
         Kd = tpg.pca_gram(v, center, scale)
     assert np.abs(Kd - ref).max() <= 1e-6 * sc    # 2^-24 weight rounding

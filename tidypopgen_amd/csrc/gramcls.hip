@@ -41,6 +41,7 @@
 
 #include "common.h"
 #include "devfrag.h"
+#include "host/host_bits2.h"  // tpg_transpose16_2bit
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -228,76 +229,138 @@ struct GclsSrc {
 // padding locus of the odd block is 0 = "dosage 1".  What the products of the odd blocks lack, w (g_i + g_k - 1) summed over
 // their loci, is r_i + r_k + const: the double centring of the PCA removes exactly such terms, so this layout is only used
 // where that centring follows (tpg_gram_classes' centred_ok).
-template <bool CEN>
+//
+// One wave = one task (QW chunks q of 128 individuals, block pair); per chunk 128 loci x 128 individuals, 4 KiB in and out.
+// Lane l fetches the 32 QW bytes of locus l of either block (the next task's are in flight while this one is turned) and, chunk
+// after chunk, puts eight dwords (16 individuals each) into LDS rows of 64 loci; then every lane owns ONE 16 x 16
+// tile of 2-bit codes (block hb, row tile s, half hs, 16 loci g): four ds_read_b128, the register transposition of
+// host/host_bits2.h (96 instructions for 256 genotypes; picking two bits at a time took 512), sixteen ds_write_b32 that hand
+// the words to the lanes of the operand layout.  A transposed word IS an operand dword -- 16 loci of one individual, the
+// kernels take P & 0x33333333 and (P >> 2) & 0x33333333 -- and the order of the loci inside a block is free as long as every
+// individual uses the same one: dword 2 hb + t of lane (r, ho) holds loci 16 (2 ho + t) + k of block hb at field k.
+#define GSH_ROW 68                 // source rows: 64 loci + 4 (a tile's four 16-byte reads meet no other tile's bank)
+#define GSH_HS 140                 // result rows of 8 dwords per individual: 16 individuals + 12 dwords
+#define GSH_WORDS (4 * 2 * GSH_HS) // per wave; the 16 source rows (1088 dwords) live in the same place
+template <bool CEN, int QW>
 __global__ __launch_bounds__(256) void tpg_gcls_gather_kernel(GclsSrc S, int64_t Q,
                                                                const int32_t* __restrict__ src, int64_t nblocks,
                                                                int64_t rs2, uint4* __restrict__ T2g) {  // rs2 pairs per row tile, all written
-  __shared__ __attribute__((aligned(16))) uint32_t sh[4][2][4][64];  // [wave][source half][s][locus]
+  __shared__ __attribute__((aligned(16))) uint32_t shm[4][GSH_WORDS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int r = lane & 31, ho = lane >> 5, hs = r >> 4, shf = tpg_elem_shift(r & 15);
-  uint32_t rot[8];
+  uint32_t* sh = shm[wv];
+  // this lane's tile in the transposition: row x = (hb * 2 + hs) * 4 + s of the source, loci 16 g .. 16 g + 15
+  const int g = lane & 3, x = lane >> 2, t_s = x & 3, t_hs = (x >> 2) & 1, t_hb = x >> 3;
+  const uint4* rd_src = (const uint4*)(sh + x * GSH_ROW + 16 * g);
+  uint32_t* wr_dst = sh + t_s * (2 * GSH_HS) + t_hs * GSH_HS + (g >> 1) * 4 + 2 * t_hb + (g & 1);  // + 8 * individual
+  // this lane in the operand layout: individual r of a row tile, loci 32 ho .. 32 ho + 31
+  const int r = lane & 31, ho = lane >> 5;
+  const uint4* rd_dst = (const uint4*)(sh + (r >> 4) * GSH_HS + (r & 15) * 8 + ho * 4);  // + s * 2 * GSH_HS
+  const uint32_t uQ = (uint32_t)((Q + QW - 1) / QW), ntask = uQ * (uint32_t)rs2, step = gridDim.x * 4u;  // (the host has checked Q rs2 < 2^31)
+  auto load_j = [&](uint32_t task, int32_t (&j)[2]) {
+    j[0] = j[1] = -1;
+    if (task < ntask) {
+      const int64_t bp = task / uQ;
 #pragma unroll
-  for (int e = 0; e < 8; e++) rot[e] = (uint32_t)(shf - 4 * e) & 31u;
-  const int64_t npairs = rs2;  // (pairs past (nblocks + 1) / 2 are written as empty blocks)
-  for (int64_t task = (int64_t)blockIdx.x * 4 + wv; task < Q * npairs; task += (int64_t)gridDim.x * 4) {
-    const int64_t q = task % Q, bp = task / Q;
-    uint32_t out[4][4];  // [s][word]
+      for (int hb = 0; hb < 2; hb++)
+        if (2 * bp + hb < nblocks) j[hb] = src[(2 * bp + hb) * 64 + lane];
+    }
+  };
+  auto load_d = [&](uint32_t task, const int32_t (&j)[2], uint4 (&w)[QW][2][2]) {
+    const int64_t q0 = (int64_t)(task % uQ) * QW;
 #pragma unroll
     for (int hb = 0; hb < 2; hb++) {
-      const int64_t b = 2 * bp + hb;
-      const int32_t j = b < nblocks ? src[b * 64 + lane] : -1;
-      const unsigned long long valid = __ballot(j >= 0);  // bit l: locus l of this block exists
-      (void)valid;
-      uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
-      if (j >= 0) {
-        const uint4* p = S.base + (int64_t)(j >> S.sh) * S.sa + (int64_t)(j & S.msk) * S.sb + q * S.sq;
-        w0 = p[0];
-        w1 = p[S.sh1];
-      }
-      sh[wv][0][0][lane] = w0.x; sh[wv][0][1][lane] = w0.y; sh[wv][0][2][lane] = w0.z; sh[wv][0][3][lane] = w0.w;
-      sh[wv][1][0][lane] = w1.x; sh[wv][1][1][lane] = w1.y; sh[wv][1][2][lane] = w1.z; sh[wv][1][3][lane] = w1.w;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const uint4* rd = (const uint4*)&sh[wv][hs][s][32 * ho];
-        uint32_t nib[4];
+      for (int qi = 0; qi < QW; qi++) w[qi][hb][0] = w[qi][hb][1] = make_uint4(0, 0, 0, 0);
+      if (j[hb] >= 0) {
+        const uint4* p = S.base + (int64_t)(j[hb] >> S.sh) * S.sa + (int64_t)(j[hb] & S.msk) * S.sb + q0 * S.sq;
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-          const uint4 a = rd[2 * d], c = rd[2 * d + 1];
-          const uint32_t ws[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-          // this lane's individual sits at bits [shf, shf + 1] of every word: a rotation brings them to nibble e
-          // (v_alignbit_b32), v_and_or_b32 drops them into place: two instructions per genotype
-          uint32_t acc = 0;
-#pragma unroll
-          for (int e = 0; e < 8; e++) acc = (__builtin_amdgcn_alignbit(ws[e], ws[e], rot[e]) & (3u << (4 * e))) | acc;
-          nib[d] = acc;  // (codes 0 / 1 / 2 only: every caller has refused a view with a missing value before it gets here)
-        }
-        if constexpr (CEN) {
-#pragma unroll
-          for (int d = 0; d < 4; d++) {
-            if (hb == 0) {
-              out[s][d] = nib[d];
-            } else {  // g - 1 on the loci that exist: (code + 3) & 3 per nibble (no carry leaves a nibble: code <= 2)
-              uint32_t vb = (uint32_t)(valid >> (32 * ho + 8 * d)) & 0xFFu;  // loci 32 ho + 8 d + e, e = bit e
-              vb = (vb | (vb << 12)) & 0x000F000Fu;
-              vb = (vb | (vb << 6)) & 0x03030303u;
-              vb = (vb | (vb << 3)) & 0x11111111u;
-              out[s][d] |= ((nib[d] + 3u * vb) & 0x33333333u) << 2;
-            }
+        for (int qi = 0; qi < QW; qi++)
+          if (qi == 0 || q0 + qi < Q) {
+            w[qi][hb][0] = p[qi * S.sq];
+            w[qi][hb][1] = p[qi * S.sq + S.sh1];
           }
-        } else {
-          out[s][2 * hb] = nib[0] | (nib[1] << 2);
-          out[s][2 * hb + 1] = nib[2] | (nib[3] << 2);
-        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  uint32_t task = blockIdx.x * 4u + wv;
+  int32_t j0[2], j1[2];
+  uint4 w[QW][2][2];
+  load_j(task, j0);
+  load_d(task, j0, w);
+  load_j(task + step, j1);
+  for (; task < ntask; task += step) {
+    uint4 wn[QW][2][2];  // the next task's bytes and the indices of the one after it are on their way while this one is turned
+    int32_t j2[2];
+    load_d(task + step, j1, wn);
+    load_j(task + 2 * step, j2);
+    const int64_t q0 = (int64_t)(task % uQ) * QW, bp = task / uQ;
+    const unsigned long long valid = __ballot(j0[1] >= 0);  // bit l: locus l of the odd block exists
+    (void)valid;
+    uint32_t v55[2] = {0, 0};
+    if constexpr (CEN) {  // bit 2 k of v55[t]: locus 16 (2 ho + t) + k of the odd block exists
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        uint32_t vb = (uint32_t)(valid >> (32 * ho + 16 * t)) & 0xFFFFu;
+        vb = (vb | (vb << 8)) & 0x00FF00FFu;
+        vb = (vb | (vb << 4)) & 0x0F0F0F0Fu;
+        vb = (vb | (vb << 2)) & 0x33333333u;
+        v55[t] = (vb | (vb << 1)) & 0x55555555u;
+      }
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++)
-      T2g[((4 * q + s) * rs2 + bp) * 64 + lane] = make_uint4(out[s][0], out[s][1], out[s][2], out[s][3]);
+    for (int qi = 0; qi < QW; qi++) {
+    const int64_t q = q0 + qi;
+    if (qi && q >= Q) break;
+#pragma unroll
+    for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+      for (int hs = 0; hs < 2; hs++) {
+        uint32_t* row = sh + ((hb * 2 + hs) * 4) * GSH_ROW + lane;
+        row[0] = w[qi][hb][hs].x; row[GSH_ROW] = w[qi][hb][hs].y; row[2 * GSH_ROW] = w[qi][hb][hs].z; row[3 * GSH_ROW] = w[qi][hb][hs].w;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t W[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint4 a = rd_src[i];
+      W[4 * i] = a.x; W[4 * i + 1] = a.y; W[4 * i + 2] = a.z; W[4 * i + 3] = a.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (one wave, one LDS queue: the stores below cannot pass these loads)
+    __builtin_amdgcn_wave_barrier();
+    tpg_transpose16_2bit(W);
+#pragma unroll
+    for (int p = 0; p < 16; p++) wr_dst[8 * ((p >> 2) + 4 * (p & 3))] = W[p];  // field p of a source dword = individual p / 4 + 4 (p % 4) (tpg_elem_shift)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      uint4 o = rd_dst[s * (2 * GSH_HS / 4)];  // {even block t = 0, 1; odd block t = 0, 1}
+      if constexpr (CEN) {
+        const uint32_t A[2] = {o.x, o.y}, B[2] = {o.z, o.w};
+        uint32_t out[4];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          // g - 1 on the loci that exist, as the code (c + 3) & 3: low bit = ~c0, high bit = ~c0 & ~c1
+          const uint32_t nb = ~B[t], lo = nb & v55[t], hi = (nb >> 1) & lo, bc = lo | (hi << 1);
+          out[2 * t] = (A[t] & 0x33333333u) | ((bc & 0x33333333u) << 2);
+          out[2 * t + 1] = ((A[t] >> 2) & 0x33333333u) | (bc & 0xCCCCCCCCu);
+        }
+        o = make_uint4(out[0], out[1], out[2], out[3]);
+      }
+      T2g[((4 * q + s) * rs2 + bp) * 64 + lane] = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int hb = 0; hb < 2; hb++) {
+#pragma unroll
+      for (int qi = 0; qi < QW; qi++) { w[qi][hb][0] = wn[qi][hb][0]; w[qi][hb][1] = wn[qi][hb][1]; }
+      j0[hb] = j1[hb]; j1[hb] = j2[hb];
+    }
   }
 }
 
@@ -1122,13 +1185,15 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   }
   {
     const int64_t tasks = Q * rs2;
+    if (tasks >= ((int64_t)1 << 31)) return TPG_OK;  // (not done: the caller's digit kernel; 2^31 tasks are 2^43 genotypes)
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(tasks, 4), (int64_t)ctx->num_cu * 16);
-    if (cen)
-      TPG_LAUNCH(ctx, "gcls_gather", tpg_gcls_gather_kernel<true>, dim3(grid), dim3(256), 0, src, Q, (const int32_t*)d_src, nblocks,
-                 rs2, d_T2g);
-    else
-      TPG_LAUNCH(ctx, "gcls_gather", tpg_gcls_gather_kernel<false>, dim3(grid), dim3(256), 0, src, Q, (const int32_t*)d_src, nblocks,
-                 rs2, d_T2g);
+    // chunks of 128 individuals per task: a lane reads 32 QW contiguous bytes of its locus (0.69 / 0.61 / 0.60 ms for 1 / 2 / 4
+    // at 5 000 x 1 000 000: fewer, longer random reads); TPG_GATHER_QW for the comparison
+    const int qw = getenv("TPG_GATHER_QW") ? atoi(getenv("TPG_GATHER_QW")) : Q >= 4 ? 4 : Q >= 2 ? 2 : 1;
+#define GATHER_GO(C, W) TPG_LAUNCH(ctx, "gcls_gather", (tpg_gcls_gather_kernel<C, W>), dim3(grid), dim3(256), 0, src, Q, (const int32_t*)d_src, nblocks, rs2, d_T2g)
+    if (cen) { if (qw == 4) GATHER_GO(true, 4); else if (qw == 2) GATHER_GO(true, 2); else GATHER_GO(true, 1); }
+    else { if (qw == 4) GATHER_GO(false, 4); else if (qw == 2) GATHER_GO(false, 2); else GATHER_GO(false, 1); }
+#undef GATHER_GO
   }
   if (f64)
     TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T2g, nblocks,
