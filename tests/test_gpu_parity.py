@@ -1115,6 +1115,11 @@ def test_pca_gram_weight_classes_equal_digits_and_numpy(tpg, n, m):
             assert np.array_equal(Kc, Kc.T)
             assert np.abs(Kc - ref).max() <= tol * sc
             assert np.array_equal(tpg.pca_gram(v, center, scale), Kc)  # run-to-run identical (ordered slab sums)
+            if fold64 == "0":  # the one-wave-per-SIMD form of the mixed fold (an A/B kept in the library), plain and interleaved
+                for kern in ("14", "34"):
+                    with _env(TPG_GRAM_KERNEL=kern):
+                        K1 = tpg.pca_gram(v, center, scale)
+                        assert np.array_equal(K1, K1.T) and np.abs(K1 - ref).max() <= tol * sc
             for qw in ("1", "2", "4"):  # the gather's chunks of 128 individuals per task: the same operand layout
                 with _env(TPG_GATHER_QW=qw):
                     assert np.array_equal(tpg.pca_gram(v, center, scale), Kc)

@@ -111,7 +111,7 @@ __global__ void tpg_gcls_group_pad_kernel(const unsigned long long* __restrict__
   }
 }
 
-// Block table of tpg_gcls_gram3_kernel over the padded layout: entry as in tpg_gcls_block_table2_kernel (x = weight | flags,
+// Block table of tpg_gcls_gram1w_kernel over the padded layout: entry as in tpg_gcls_block_table2_kernel (x = weight | flags,
 // y = bits of (float)(w_c - w_{c+1})); flag 1 = last block of a class that is not the last of its group; flag 2 = FP64 fold
 // after this block -- the last (possibly empty) block of a group, or a block whose index is GCLS3_GRUN - 1 modulo GCLS3_GRUN
 // (integer sums stay exact: 4 * 64 * 16 320 < 2^23): always the last block of a body, GCLS3_GRUN being a multiple of 8, 10, 12.
@@ -752,167 +752,146 @@ __global__ __launch_bounds__(256, 2) void tpg_gcls_gram2_kernel(const uint4* __r
   }
 }
 
-// 3c. the mixed-precision fold at ONE wave per SIMD, built like the pairwise kernel (pairwise.hip): what two waves per SIMD
-// buy the kernel above is that one wave's loads and folds hide behind the other's MFMAs -- with ONE block pair of prefetch
-// each (a third operand slot does not fit 256 registers beside three sets of sums), which leaves the MFMA pipe 28 % busy
-// and the waves waiting for operands 29 % of the time.  Here a wave has the whole register file of its SIMD and nobody to
-// hide behind, so everything is explicit:
+// 3c. the mixed-precision fold at ONE wave per SIMD (TPG_GRAM_KERNEL=14 / 34; the A/B of DESIGN.md 3.2, not a path anything
+// takes): what two waves per SIMD buy the kernel above is that one wave's loads and folds hide behind the other's MFMAs.
+// Here a wave has the whole register file of its SIMD and nobody to hide behind, so everything is explicit:
 //   * operands go through NS rotating register slots (one 16-byte load per lane = a PAIR of blocks), fetched NS - 1 pairs
 //     ahead of their use; the prologue issues them slot by slot (sched_barrier) so that hipcc's wait-count pass, which merges
 //     the loop entry with the back edge, does not put a vmcnt(0) at the top of every loop body (pairwise.hip);
-//   * the 2-bit -> FP4 expansion of block b + 1 is done while the MFMAs of block b issue (an MFMA whose operands were
-//     written by the VALU just before it waits for them: tools/ubench_mfma_dep.hip);
-//   * a class end is not folded when its last block has been issued -- that would wait for its MFMAs to drain -- but as
-//     the first thing of the NEXT block;
 //   * group ends fall between two bodies of the unrolled loop by construction (tpg_gcls_group_pad_kernel pads every group to
-//     a multiple of 2 NS blocks), so the FP64 fold exists once, not in every step, and the steps have two variants only;
+//     a multiple of 2 NS blocks), so the FP64 fold exists once, not in every step;
 //   * the FP64 result lives in LDS (32 KiB per wave, 128 KiB per workgroup, one workgroup per CU): touched at group
 //     ends only, and an LDS read-modify-write is cheaper than moving 128 registers through AGPRs;
 //   * the block table comes through ONE vector load per body, issued a body ahead and taken apart into SGPRs
 //     (v_readlane_b32) at the top of the body.  (Scalar loads return out of order, so each use is an s_waitcnt lgkmcnt(0):
 //     with one wave per SIMD a full scalar-load latency per block -- 1 750 cycles per block, 44 ms, measured; a load under a
 //     condition, or a loaded register copied into another, makes hipcc drain every load in flight.)
+//   * the lean scalar stream of the two-waves kernel: 32-bit indices, fixed tile bases in SGPRs + one lane offset that
+//     advances by a pair, no range tests (the padded layout ends on a whole body, T2g has a slack of NS pairs behind it),
+//     flags and class differences in SGPRs; the centred operand layout (CEN);
+//   * IL: a step written tile by tile -- MFMA of tile p, then the operand words of fragment p of the NEXT block (4 v_and_b32)
+//     -- and pinned in that order (sched_barrier + an empty asm on the words: left alone hipcc makes them in the next block,
+//     in front of its four MFMAs, and the pipe idles while the wave issues VALU); the class end of the block before
+//     (32 v_pk_fma_f32) sits in front of the step behind ONE scalar branch, and only `dev` changes behind it -- with the
+//     MFMAs inside two variants of the step hipcc gave each variant its own accumulators, ran BOTH sets of MFMAs and merged
+//     them with 32 v_mov_b64 per block (20.7 ms, 1.65 x the MFMAs by SQ_INSTS_MFMA).
+// Measured at 5 000 x 1 000 000 in one job with the two-waves kernel (9.13 ms): 9.36 ms interleaved, 9.93 ms not, whatever
+// the slots (3 / 4 / 5) and the K split (4 ... 24); round 3's first form of it (100 instructions per block) 12.8 - 13.4.
+// PMC: 7.9 VALU-class instructions per MFMA, the wave issues VALU 55 % of its cycles, waits (vmcnt) 26 %, everything else
+// 19 %; MFMA pipe 42 % busy -- the figure of the two-waves kernel -- L2 hit rate 77 % against 85 % (22.8 GB HBM-side).
+// (The same pipelined kernel at TWO waves per SIMD, its FP64 result half in LDS and half read-modify-written in the unit's
+// slab: 13.9 ms, 60 GB of slab traffic; DESIGN.md 3.2.  Two lessons from it live on as comments in the kernels: an address
+// that went through an integer is FLAT to hipcc unless cast to address_space(1), and ONE flat access in a loop turns every
+// vmcnt wait of the loop into vmcnt(0); 64-bit per-lane addresses get hoisted out of loops and spill.)
 // Slabs and the assemble pass are those of the kernel above; K ranges start on multiples of NS pairs.
-// WPE = 2: the same kernel at TWO waves per SIMD (grid = 2 x one workgroup per CU, 256 registers per wave, S even: the two
-// halves of the grid take different halves of the K range, as in tpg_gcls_gram2_kernel).  Its steps need 221 registers with
-// three operand slots -- where the two-waves kernel above keeps half of the FP64 result in registers and has room for two
-// slots and no pipelining -- because the FP64 result has left the register file altogether: tiles 0, 1 in LDS (16 KiB per
-// wave), tiles 2, 3 accumulated in the unit's own slab in HBM (a read-modify-write of 16 KiB per group end: 24 GB over the
-// kernel against 117 GB of operands, mostly L2 hits).
-#define GCLS3_LDS_TILES(WPE) ((WPE) == 1 ? GP : 2)
-#define GCLS3_LDS_BYTES_W(WPE) (4 * GCLS3_LDS_TILES(WPE) * 16 * 64 * 8)
-template <int NS, int WPE>
-__global__ __launch_bounds__(256, WPE) void tpg_gcls_gram3_kernel(const uint4* __restrict__ T2g, int64_t nblocks, int64_t rs2, int nrtv,
-                                                                     const ulonglong2* __restrict__ wblk,
-                                                                     const int2* __restrict__ order, int64_t nun, int S,
-                                                                     double* __restrict__ slabs) {
+#define GCLS3_LDS_BYTES (4 * GP * 16 * 64 * 8)
+template <int NS, bool CEN, bool IL>
+__global__ __launch_bounds__(256, 1) void tpg_gcls_gram1w_kernel(const uint4* __restrict__ T2g, int64_t nblocks, int64_t rs2, int nrtv,
+                                                                  const ulonglong2* __restrict__ wblk,
+                                                                  const int2* __restrict__ order, int64_t nun, int S,
+                                                                  double* __restrict__ slabs) {
   extern __shared__ double olds_raw[];  // [wave][tile][register][lane]
-  constexpr int NT = GA + GB, BODY = 2 * NS, LT = GCLS3_LDS_TILES(WPE);  // LT result tiles in LDS, the others in the slab
+  constexpr int NT = GA + GB, BODY = 2 * NS;
+  static_assert(NT == GP, "a step expands fragment p beside the MFMA of tile p");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* olds = olds_raw + (size_t)wv * (LT * 16 * 64) + lane;
-  const int hgrid = gridDim.x / WPE, half = (int)blockIdx.x / hgrid, bx = (int)blockIdx.x % hgrid;
-  const int xcd = bx & 7, cidx = bx >> 3, cpx = hgrid >> 3;
-  const int SH = S / WPE;  // splits per half of the grid
-  const int64_t nbodies = (nblocks + BODY - 1) / BODY;
+  double* olds = olds_raw + (size_t)wv * (GP * 16 * 64) + lane;
+  const int bx = (int)blockIdx.x, xcd = bx & 7, cidx = bx >> 3, cpx = (int)gridDim.x >> 3;
+  const int nbodies = (int)(nblocks / BODY);  // (the padded layout: every group, so the whole list, ends on a body)
+  typedef __attribute__((address_space(1))) const char gchar;
+  typedef __attribute__((address_space(1))) const v4u gv4u;
   for (int64_t round = 0;; round++) {
     const int64_t un = ((round * 8 + xcd) * cpx + cidx) * 4 + wv;
-    if (un >= nun * SH) break;
-    const int ks = half * SH + (int)(un / nun);
+    if (un >= nun * S) break;
+    const int ks = (int)(un / nun);
     const int64_t u = un % nun;
     const int2 ijv = order[u];
     const int2 ij = make_int2(__builtin_amdgcn_readfirstlane(ijv.x), __builtin_amdgcn_readfirstlane(ijv.y));
-    // whole bodies (NS block pairs) per split
-    const int64_t p0 = tpg_uniform64(NS * ((nbodies * ks) / S)), p1 = tpg_uniform64(NS * ((nbodies * (ks + 1)) / S));
-    const int64_t bend = 2 * p1 < nblocks ? 2 * p1 : nblocks;  // blocks [2 p0, bend)
-    const uint4* pt[NT];
+    const int p0 = __builtin_amdgcn_readfirstlane(NS * (int)(((int64_t)nbodies * ks) / S));
+    const int p1 = __builtin_amdgcn_readfirstlane(NS * (int)(((int64_t)nbodies * (ks + 1)) / S));
+    gchar* pt[NT];  // the unit's four row tiles at pair p0
 #pragma unroll
-    for (int t = 0; t < GA; t++) pt[t] = T2g + ((int64_t)min(GA * ij.x + t, nrtv - 1) * rs2) * 64;
+    for (int t = 0; t < GA; t++) pt[t] = (gchar*)tpg_uniform64((int64_t)(T2g + ((int64_t)min(GA * ij.x + t, nrtv - 1) * rs2 + p0) * 64));
 #pragma unroll
-    for (int t = 0; t < GB; t++) pt[GA + t] = T2g + ((int64_t)min(GB * ij.y + t, nrtv - 1) * rs2) * 64;
-
-    // the unit's slab: a uniform base (SGPRs) + the lane's 32-bit offset, made opaque wherever it is used -- as 64-bit lane
-    // addresses hipcc hoists five of them out of the loops and, at two waves per SIMD, spills them
-    // (an address that went through an integer is FLAT to hipcc unless told otherwise -- and one flat access in the loop turns
-    // every vmcnt wait of the steps into vmcnt(0))
-    typedef __attribute__((address_space(1))) char gchar;
-    typedef __attribute__((address_space(1))) double gdouble;
-    gchar* const slab_u = (gchar*)tpg_uniform64((int64_t)(slabs + ((int64_t)ks * nun + u) * GCLS_SLAB));
-    auto slab_at = [&](int p, int i, uint32_t so) { return (gdouble*)(slab_u + (p * 16 + i) * 512 + so); };
+    for (int t = 0; t < GB; t++) pt[GA + t] = (gchar*)tpg_uniform64((int64_t)(T2g + ((int64_t)min(GB * ij.y + t, nrtv - 1) * rs2 + p0) * 64));
     v2f dev[GP][8];
     v16f acc[GP];
 #pragma unroll
     for (int p = 0; p < GP; p++) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        acc[p][i] = 0.f;
-        if (p < LT) olds[(p * 16 + i) * 64] = 0.0;
-      }
+      for (int i = 0; i < 16; i++) { acc[p][i] = 0.f; olds[(p * 16 + i) * 64] = 0.0; }
 #pragma unroll
       for (int i = 0; i < 8; i++) dev[p][i] = v2f{0.f, 0.f};
     }
-    bool slab_fresh = true;  // nothing has been added to the slab's own tiles yet: the first fold writes instead of adding
-    // out += w * sums + dev; sums and dev start again from zero.  Four elements at a time: the fold is rare, what matters is
-    // that it needs few registers (every temporary it holds is a register the steps lose to spills)
+    // out += w * sums + dev; sums and dev start again from zero (four elements at a time: few temporaries)
     auto fold = [&](double w) {
-      uint32_t so = (uint32_t)lane * 8u;
-      asm volatile("" : "+v"(so));
 #pragma unroll
       for (int p = 0; p < GP; p++)
         tpg_static_for<4>([&](auto qq) {
           constexpr int q = decltype(qq)::value;
           double t[4];
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            if (p < LT) t[e] = olds[(p * 16 + 4 * q + e) * 64];
-            else t[e] = slab_fresh ? 0.0 : *slab_at(p, 4 * q + e, so);
-          }
+          for (int e = 0; e < 4; e++) t[e] = olds[(p * 16 + 4 * q + e) * 64];
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const int i = 4 * q + e;
-            const double r = __builtin_fma((double)acc[p][i], w, t[e]) + (double)dev[p][i >> 1][i & 1];
-            if (p < LT) olds[(p * 16 + i) * 64] = r;
-            else *slab_at(p, i, so) = r;
+            olds[(p * 16 + i) * 64] = __builtin_fma((double)acc[p][i], w, t[e]) + (double)dev[p][i >> 1][i & 1];
             acc[p][i] = 0.f;
           }
           dev[p][2 * q] = v2f{0.f, 0.f};
           dev[p][2 * q + 1] = v2f{0.f, 0.f};
           __builtin_amdgcn_sched_barrier(0);
         });
-      slab_fresh = false;
     };
-
     if (p0 < p1) {
-      const int64_t pl = (bend + 1) / 2 - 1, bl = bend - 1;  // last pair that holds a block, last block
       v4u R[NS][NT];
-      auto LD = [&](const uint4* p) {
-        uint32_t off = (uint32_t)lane * 16u;
-        asm("" : "+v"(off));
-        return *(const v4u*)((const char*)p + off);
+      uint32_t voff = (uint32_t)lane * 16u;  // this lane's 16 bytes of the NEXT pair to fetch, relative to pair p0
+      auto LDP = [&](v4u (&slot)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) slot[t] = *(gv4u*)(pt[t] + voff);
+        voff += 1024u;
       };
-      // lane l: the table entry of block first_block + l (past the range: the last block's)
-      // (three dwords: with a fourth, dead, register in the tuple hipcc parks the loads' lane offset in it and waits for
-      // the table load -- for every load in flight -- right after issuing it)
+      // lane l: the table entry of block first + l (three dwords: with a fourth, dead, register in the tuple hipcc parks the loads' lane offset in it and waits for the table load)
       typedef uint32_t v3u __attribute__((ext_vector_type(3)));
-      // (32-bit lane arithmetic: the 64-bit lane index is one more pair of registers alive across the loop)
-      const uint32_t bl32 = (uint32_t)bl;
-      auto LDT = [&](int64_t first_block) {
+      typedef __attribute__((address_space(1))) const v3u gv3u;
+      const uint32_t blast = (uint32_t)(nblocks - 1);
+      gchar* const wb = (gchar*)tpg_uniform64((int64_t)wblk);
+      auto LDT = [&](int first_block) {
         uint32_t bb = (uint32_t)first_block + (uint32_t)lane;
-        bb = (bb < bl32 ? bb : bl32) * 16u;
-        return *(const v3u*)((const char*)wblk + bb);
+        bb = (bb < blast ? bb : blast) * 16u;
+        return *(gv3u*)(wb + bb);
       };
       v3u TB = LDT(2 * p0);
       __builtin_amdgcn_sched_barrier(0);
       tpg_static_for<NS - 1>([&](auto dd) {
-        constexpr int d = decltype(dd)::value;
-        const int64_t pc = p0 + d < pl ? p0 + d : pl;
-#pragma unroll
-        for (int t = 0; t < NT; t++) R[d][t] = LD(pt[t] + pc * 64);
-        __builtin_amdgcn_sched_barrier(0);  // in this order (see above)
+        LDP(R[decltype(dd)::value]);
+        __builtin_amdgcn_sched_barrier(0);  // slot by slot (see above)
       });
-      // FP4 operand words of one block: half hb of a slot; a block past the range gives zeros
-      auto expand = [&](const v4u& r, int hb, uint32_t m) {
-        const uint32_t w0 = r[2 * hb], w1 = r[2 * hb + 1];
-        return v4u{w0 & m, (w0 >> 2) & m, w1 & m, (w1 >> 2) & m};
+      // operand words of one block: half hb of a slot
+      auto expand = [&](const v4u& r, auto Hh) {
+        constexpr int hb = decltype(Hh)::value;
+        if constexpr (CEN) {
+          return r & (hb == 0 ? 0x33333333u : 0xCCCCCCCCu);
+        } else {
+          const uint32_t w0 = r[2 * hb], w1 = r[2 * hb + 1];
+          return v4u{w0 & 0x33333333u, (w0 >> 2) & 0x33333333u, w1 & 0x33333333u, (w1 >> 2) & 0x33333333u};
+        }
       };
       v4u X[2][NT];
 #pragma unroll
-      for (int t = 0; t < NT; t++) X[0][t] = expand(R[0][t], 0, 0x33333333u);
+      for (int t = 0; t < NT; t++) X[0][t] = expand(R[0][t], std::integral_constant<int, 0>{});
       bool pend = false;   // the block before ended a class inside its group: dev += pdelta * sums before this block's MFMAs
       float pdelta = 0.f;  // w_c - w_{c+1}
       uint32_t fl[BODY], dl[BODY], wlo = 0, whi = 0;  // this body's table entries, in SGPRs
 
-      auto step = [&](auto Cc, auto Hh, int64_t pr) {
+      auto step = [&](auto Cc, auto Hh) {
         constexpr int C = decltype(Cc)::value, hb = decltype(Hh)::value, cur = hb, nx = hb ^ 1;
         constexpr int M = (C + NS - 1) % NS;                        // the slot the pair before this one left
         constexpr int SN = hb == 0 ? C : (C + 1) % NS, HN = hb ^ 1;  // slot and half of the NEXT block
-        const int64_t b = 2 * pr + hb;
-        if constexpr (hb == 0) {
-          const int64_t pn = pr + NS - 1, pc = pn < pl ? pn : pl;
-#pragma unroll
-          for (int t = 0; t < NT; t++) R[M][t] = LD(pt[t] + pc * 64);
-        }
-        if (pend) {
+        if constexpr (hb == 0) LDP(R[M]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pend) {  // (one branch per block, and only `dev` changes behind it: with the MFMAs inside two variants of the step
+                     // hipcc gave each variant its own accumulators and merged them with 32 v_mov_b64 per block)
           const v2f dlt = v2f{pdelta, pdelta};
 #pragma unroll
           for (int p = 0; p < GP; p++)
@@ -922,58 +901,53 @@ __global__ __launch_bounds__(256, WPE) void tpg_gcls_gram3_kernel(const uint4* _
             });
         }
         __builtin_amdgcn_sched_barrier(0);
-        const uint32_t mn = b + 1 < bend ? 0x33333333u : 0u;
-#pragma unroll
-        for (int t = 0; t < NT; t++) X[nx][t] = expand(R[SN][t], HN, mn);
-#pragma unroll
-        for (int p = 0; p < GP; p++) acc[p] = MFMA_G4S2(X[cur][p / GB], X[cur][GA + p % GB], acc[p]);
-#pragma unroll
-        for (int q = 0; q < GP; q++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-          if (hb == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pend = (fl[2 * C + hb] & 1u) != 0 && b < bl;  // (the last block of the range is folded in FP64 below)
+        tpg_static_for<GP>([&](auto pp_) {
+          constexpr int p = decltype(pp_)::value;
+          if constexpr (CEN && hb == 1) acc[p] = MFMA_G4S2_ODD(X[cur][p / GB], X[cur][GA + p % GB], acc[p]);
+          else acc[p] = MFMA_G4S2(X[cur][p / GB], X[cur][GA + p % GB], acc[p]);
+          X[nx][p] = expand(R[SN][p], std::integral_constant<int, HN>{});
+          if constexpr (IL) {
+            asm volatile("" : "+v"(X[nx][p]));  // HERE, in the shadow of the MFMA (left alone, the words are made in the next block, where they are used)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        pend = (fl[2 * C + hb] & 1u) != 0;
         pdelta = __uint_as_float(dl[2 * C + hb]);
       };
-      for (int64_t pp = p0; pp < p1; pp += NS) {
+      for (int pp = p0; pp < p1; pp += NS) {
         // this body's table entries -> SGPRs, then the load of the next body's into the same register
 #pragma unroll
         for (int k = 0; k < BODY; k++) {
           fl[k] = (uint32_t)__builtin_amdgcn_readlane((int)TB[0], k);
           dl[k] = (uint32_t)__builtin_amdgcn_readlane((int)TB[2], k);
         }
-        wlo = (uint32_t)__builtin_amdgcn_readlane((int)TB[0], BODY - 1);
+        wlo = fl[BODY - 1];
         whi = (uint32_t)__builtin_amdgcn_readlane((int)TB[1], BODY - 1);
         __builtin_amdgcn_sched_barrier(0);
         TB = LDT(2 * (pp + NS));
         __builtin_amdgcn_sched_barrier(0);
         tpg_static_for<NS>([&](auto cc) {
-          step(cc, std::integral_constant<int, 0>{}, pp + decltype(cc)::value);
-          step(cc, std::integral_constant<int, 1>{}, pp + decltype(cc)::value);
+          step(cc, std::integral_constant<int, 0>{});
+          step(cc, std::integral_constant<int, 1>{});
         });
-        // a group (or 16 320 blocks) ends with this body's last block: the FP64 fold, here and nowhere else
-        if ((wlo & 2u) && 2 * (pp + NS) - 1 < bl) {
+        // a group (or GCLS3_GRUN blocks) ends with this body's last block: the FP64 fold, here and nowhere else
+        if (__builtin_expect((wlo & 2u) != 0 && pp + NS < p1, 0)) {
           fold(__longlong_as_double((long long)(((uint64_t)whi << 32) | (wlo & ~3u))));
           pend = false;
         }
       }
-      // the end of the range: whatever the sums hold belongs to the class of the last block
+      // the end of the range: whatever the sums hold belongs to the class of the last block (a class end pending there is
+      // part of it: with w_c itself no difference is needed)
       {
-        const ulonglong2 e = wblk[bl];
+        const ulonglong2 e = wblk[2 * (int64_t)p1 - 1];
         fold(__longlong_as_double((long long)(e.x & ~3ull)));
       }
     }
-    uint32_t so = (uint32_t)lane * 8u;
-    asm volatile("" : "+v"(so));
+    double* slab = slabs + ((int64_t)ks * nun + u) * GCLS_SLAB + lane;
 #pragma unroll
     for (int p = 0; p < GP; p++)
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        if (p < LT) *slab_at(p, i, so) = olds[(p * 16 + i) * 64];
-        else if (slab_fresh) *slab_at(p, i, so) = 0.0;  // an empty K range: nothing was folded
-      }
+      for (int i = 0; i < 16; i++) slab[(p * 16 + i) * 64] = olds[(p * 16 + i) * 64];
   }
 }
 
@@ -1082,13 +1056,13 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   const size_t t_bytes = std::max(t_sort, std::max(t_rle, t_scan));
   TPG_HIP(B.get((uint8_t**)&d_tmp, t_bytes));
   long long totals[2] = {0, 0};
-  // TPG_GRAM_KERNEL=3 / 4: the one-wave-per-SIMD form of the mixed fold with that many operand slots (tpg_gcls_gram3_kernel,
-  // a measured negative result kept for the A/B: 12.8 - 13.4 ms against 10.6 - 10.8): every group of classes is padded to
-  // whole bodies of its unrolled loop.  TPG_GRAM_KERNEL=1: the two-waves kernel with its block table by scalar loads.
+  // TPG_GRAM_KERNEL=14 / 34: the one-wave-per-SIMD form of the mixed fold (tpg_gcls_gram1w_kernel, four operand slots; 34 =
+  // steps interleaved tile by tile; a measured A/B: 9.9 / 9.4 ms against 9.1): every group of classes is padded to whole bodies
+  // of its unrolled loop.  TPG_GRAM_KERNEL=1: the two-waves kernel with its block table by scalar loads.
   const int kern3 = getenv("TPG_GRAM_KERNEL") ? atoi(getenv("TPG_GRAM_KERNEL")) : 0;
-  // 23 / 24: the same kernel at two waves per SIMD with 3 / 4 slots (its FP64 result in LDS + the slab)
-  const int body = kern3 == 3 || kern3 == 4 ? 2 * kern3 : kern3 >= 23 && kern3 <= 25 ? 2 * (kern3 - 20) : 0;
-  const bool one_wave = kern3 == 3 || kern3 == 4;
+  const bool lean_il = kern3 == 34, lean1 = kern3 == 14 || lean_il;
+  const int body = lean1 ? 8 : 0;
+  const bool one_wave = lean1;
   const int gmax = getenv("TPG_GRAM_GMAX") ? std::max(1, atoi(getenv("TPG_GRAM_GMAX"))) : GCLS_GMAX;
   const int gq = getenv("TPG_GRAM_GQ") ? std::min(40, std::max(1, atoi(getenv("TPG_GRAM_GQ")))) : GCLS_GQ;
   uint32_t* d_sblk = nullptr;
@@ -1136,7 +1110,7 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   // the centred operand layout (tpg_gcls_gather_kernel<true>): the default two-waves mixed-fold kernel only, and only where
   // the caller double-centres the result (the omitted terms are r_i + r_k + const); TPG_GRAM_CENTER=0: never (A/B)
   static const bool no_cen = getenv("TPG_GRAM_CENTER") && atoi(getenv("TPG_GRAM_CENTER")) == 0;
-  const bool cen = centred_ok && !no_cen && !f64 && !body && kern3 != 1;
+  const bool cen = centred_ok && !no_cen && !f64 && (!body || lean1) && kern3 != 1;
   const int nblk_grid = one_wave ? ncu8 : 2 * ncu8;  // two workgroups per CU = two waves per SIMD
   const int nwaves = 4 * nblk_grid;
   int S = 2;
@@ -1162,7 +1136,7 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   if (f64) TPG_HIP(B.get(&d_wblk, (size_t)nblocks));
   else TPG_HIP(B.get(&d_wblk2, (size_t)nblocks + 4));
   const int64_t rs2 = (nblocks + 1) / 2;  // row-tile stride of T2g: a uint4 per lane and PAIR of blocks
-  TPG_HIP(B.get(&d_T2g, (size_t)(4 * Q) * (size_t)rs2 * 64));
+  TPG_HIP(B.get(&d_T2g, (size_t)(4 * Q) * (size_t)rs2 * 64 + 8 * 64));  // (+ 8 pairs: tpg_gcls_gram1w_kernel fetches NS - 1 pairs past a range)
   TPG_HIP(B.get(&d_order, (size_t)nun));
   TPG_HIP(B.get(&d_slabs, (size_t)S * (size_t)nun * GCLS_SLAB));
   TPG_HIP(tpg_h2d_async(ctx, d_order, order.data(), sizeof(int2) * (size_t)nun));
@@ -1199,21 +1173,17 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
     TPG_LAUNCH(ctx, "pca_gram_classes", tpg_gcls_gram_kernel, dim3((unsigned)nblk_grid), dim3(256), 0, (const uint4*)d_T2g, nblocks,
                rs2, nrtv, (const unsigned long long*)d_wblk, (const int2*)d_order, nun, S, d_slabs);
   else if (body) {
-    auto launch3 = [&](auto ns, auto wpe) {
-      constexpr int NS = decltype(ns)::value, WPE = decltype(wpe)::value;
-      (void)hipFuncSetAttribute((const void*)tpg_gcls_gram3_kernel<NS, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GCLS3_LDS_BYTES_W(WPE));
-      TPG_LAUNCH(ctx, "pca_gram_classes", (tpg_gcls_gram3_kernel<NS, WPE>), dim3((unsigned)nblk_grid), dim3(256),
-                 GCLS3_LDS_BYTES_W(WPE), (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2,
-                 (const int2*)d_order, nun, S, d_slabs);
+    auto launch1 = [&](auto ns, auto cn, auto il) {
+      constexpr int NS = decltype(ns)::value;
+      constexpr bool CN = decltype(cn)::value, IL = decltype(il)::value;
+      (void)hipFuncSetAttribute((const void*)tpg_gcls_gram1w_kernel<NS, CN, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, GCLS3_LDS_BYTES);
+      TPG_LAUNCH(ctx, "pca_gram_classes", (tpg_gcls_gram1w_kernel<NS, CN, IL>), dim3((unsigned)nblk_grid), dim3(256), GCLS3_LDS_BYTES,
+                 (const uint4*)d_T2g, nblocks, rs2, nrtv, (const ulonglong2*)d_wblk2, (const int2*)d_order, nun, S, d_slabs);
     };
-    using W1 = std::integral_constant<int, 1>;
-    using W2 = std::integral_constant<int, 2>;
-    if (kern3 == 3) launch3(std::integral_constant<int, 3>{}, W1{});
-    else if (kern3 == 4) launch3(std::integral_constant<int, 4>{}, W1{});
-    else if (kern3 == 23) launch3(std::integral_constant<int, 3>{}, W2{});
-    else if (kern3 == 24) launch3(std::integral_constant<int, 4>{}, W2{});
-    else launch3(std::integral_constant<int, 5>{}, W2{});
+    TPG_REQUIRE(nblocks % body == 0, TPG_EHIP, "class layout does not end on a body");
+    const std::integral_constant<int, 4> ns;
+    if (cen) { if (lean_il) launch1(ns, std::true_type{}, std::true_type{}); else launch1(ns, std::true_type{}, std::false_type{}); }
+    else { if (lean_il) launch1(ns, std::false_type{}, std::true_type{}); else launch1(ns, std::false_type{}, std::false_type{}); }
   } else {
     // TPG_GRAM_KERNEL=1: the block table by scalar loads, one per block (rounds 2 and 3; A/B)
     if (kern3 == 1) {

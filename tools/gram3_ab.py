@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Class Gram: the one-wave-per-SIMD pipelined kernel (TPG_GRAM_KERNEL=3 / 4 / 5 = slots) against the two-waves-per-SIMD
-kernel: time and agreement.  tools/gram3_ab.py [n] [m] [S values...]"""
+"""Class Gram: the lean one-wave-per-SIMD kernel (TPG_GRAM_KERNEL=14, 34 = interleaved steps) against the two-waves-per-SIMD
+kernel (2 = the default, 1 = its block table by scalar loads): time and agreement.  tools/gram3_ab.py [n] [m] [S values...]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -20,7 +20,7 @@ v = tpg.View(X, None, cols, code256=np.ascontiguousarray(tpg.CODE_IMPUTE_PRED))
 center, scale = tpg.pca_center_scale(v)
 os.environ["TPG_GRAM_FOLD64"] = "0"
 ref = None
-for kern in (os.environ.get("GRAM_AB_KERNELS") or "1,2,3,4,23,24").split(","):
+for kern in (os.environ.get("GRAM_AB_KERNELS") or "1,2,14,34").split(","):
     for S in Ss:
         if kern == "2":  # the default: two waves per SIMD, block table through vector loads
             os.environ.pop("TPG_GRAM_KERNEL", None)

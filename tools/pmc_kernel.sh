@@ -18,7 +18,7 @@ for f in glob.glob(sys.argv[1] + "/p*/*/*_counter_collection.csv"):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); nd[(k, f)].add(r["Dispatch_Id"])
 for k, c in sorted(acc.items()):
-    if not any(s in k for s in ("pairwise_kernel", "pairwise_set_kernel", "gram_kernel", "gram2_kernel", "gram3_kernel", "gcls", "wc84", "hudson", "pack_fast")): continue
+    if not any(s in k for s in ("pairwise_kernel", "pairwise_set_kernel", "gram_kernel", "gram2_kernel", "gram3_kernel", "gram1w_kernel", "gcls", "wc84", "hudson", "pack_fast")): continue
     d = max(len(v) for (kk, f), v in nd.items() if kk == k)
     print(k, "dispatches", d)
     for n, v in sorted(c.items()): print("   %-28s %.4g per launch" % (n, v / d))
