@@ -33,7 +33,7 @@ avg_ns = {}
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         avg_ns[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
-WIDE = ("tpg_pairwise_kernel", "tpg_pairwise_set_kernel", "tpg_pca_gram_kernel", "tpg_gcls_gram_kernel", "tpg_gcls_gram2_kernel", "tpg_gcls_gram3_kernel")
+WIDE = ("tpg_pairwise_kernel", "tpg_pairwise_set_kernel", "tpg_pca_gram_kernel", "tpg_gcls_gram_kernel", "tpg_gcls_gram2_kernel", "tpg_gcls_gram1w_kernel")
 out, traffic = {}, {}
 for k, c in sorted(acc.items()):
     d = disp[k]
