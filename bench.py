@@ -961,8 +961,8 @@ def main():
             hbm_roof("t4_expand", "tpg_t4_expand_kernel", 0.75 * n * m,
                      "2-bit T layout -> FP4 operand nibbles of the pairwise kernel: N M / 4 read + N M / 2 written"),
             hbm_roof("gcls_gather", "tpg_gcls_gather_kernel", 0.5 * n * m_pca,
-                     "class-sorted 2-bit operand layout of the PCA Gram: N M / 4 read (16-byte pieces of the L layout, i.e. a "
-                     "quarter of every 64-byte sector fetched) + N M / 4 written"),
+                     "class-sorted 2-bit operand layout of the PCA Gram: N M / 4 read (128 contiguous bytes per locus of the "
+                     "locus-major copy, loci in class order) + N M / 4 written; 16 x 16 tiles of 2-bit codes transposed in registers"),
             hbm_roof("loci_counts", "tpg_loci_counts_kernel", 0.25 * n * m + 16.0 * m,
                      "per-locus genotype counts: N M / 4 read + 16 B per locus written"),
             hbm_roof("grouped_counts", "tpg_grouped_counts_kernel (FP4 MFMA one-hot contraction)",
