@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256) void tpg_pack_kernel(const uint8_t* __restrict
 #ifndef PACK_NSUB
 #define PACK_NSUB 2  // individual chunks per workgroup, all their loads issued up front
 #endif
+__device__ __forceinline__ int64_t tpg_pack_uniform64(int64_t x) {  // a wave-uniform value the compiler keeps in SGPRs
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 typedef uint32_t pk_u4 __attribute__((ext_vector_type(4)));
 typedef pk_u4 pk_u4a8 __attribute__((aligned(8)));
 template <int NV>
@@ -129,8 +133,19 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
                                                             int64_t n, int64_t m, int64_t Q, int64_t KG,
                                                             uint32_t* __restrict__ T0, uint32_t* __restrict__ L0,
                                                             uint32_t* __restrict__ T1, uint32_t* __restrict__ L1,
-                                                            uint32_t* __restrict__ T4) {
-  __shared__ __attribute__((aligned(16))) uint8_t smem[NV * (256 + 16) + NV * TILE * TILE];
+                                                            uint32_t* __restrict__ T4, int xcd_map) {
+  // dynamic: the tables + one TILE x TILE array of code bytes per view that gets a T or T4 layout (tpg_pack_lds_bytes).  A view
+  // with L only -- the imputed view of the bench's pair -- needs no pass through LDS at all, and with 17 instead of 33 KiB a CU
+  // holds six workgroups instead of four: the kernel is bound by the bytes it has in flight, not by HBM or the VALU
+  // (rocprofv3 --pmc: the waves issue VALU 11 % of their cycles; FETCH_SIZE at the algorithmic 5.0 GB with the XCD map)
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  bool need_[NV];
+  int slot_[NV];
+#pragma unroll
+  for (int vw = 0; vw < NV; vw++) {
+    need_[vw] = vw ? T1 != nullptr : (T0 != nullptr || T4 != nullptr);
+    slot_[vw] = vw ? (need_[0] ? 1 : 0) : 0;
+  }
   // lut_and_flag: NV tables of 256 bytes, each followed by its 16-byte flag area
   uint8_t* codes_all = smem + NV * (256 + 16);  // codes[view][locus][(individual + 32 * (locus >> 4)) & 127]
   const int tid = threadIdx.x;
@@ -139,8 +154,14 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
   // individual chunks one after the other with all their loads issued up front (16 x 8 B in flight per thread).
   constexpr int NSUB = PACK_NSUB;
   const int64_t QB = (Q + NSUB - 1) / NSUB;
-  const int64_t bj = blockIdx.x / QB;          // locus group (kg)
-  const int64_t bi0 = (blockIdx.x % QB) * NSUB;  // first individual chunk (q)
+  int64_t bj = blockIdx.x / QB;            // locus group (kg)
+  int64_t bi0 = (blockIdx.x % QB) * NSUB;  // first individual chunk (q)
+  if (xcd_map) {  // workgroup b runs on XCD b % 8: the chunks of one locus group stay on one XCD, whose L2 then holds the lines two of them share
+    const int64_t k = blockIdx.x >> 3;
+    bj = (k / QB) * 8 + (blockIdx.x & 7);
+    bi0 = (k % QB) * NSUB;
+    if (bj >= KG) return;
+  }
 #pragma unroll
   for (int vw = 0; vw < NV; vw++) smem[vw * (256 + 16) + tid] = lut_and_flag[vw * (256 + 16) + tid];
   __syncthreads();
@@ -210,17 +231,25 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
   const int64_t bi = bi0 + sub;
   if (bi >= Q) break;
   if (sub) __syncthreads();  // the previous chunk's readers are done with `codes`
-  auto phase1 = [&](auto fastc) {
-    constexpr bool FAST = decltype(fastc)::value;
+  // FULL (wave-uniform, with FAST): every thread of the wave is inside the view with all its 16 individuals -- no selects, and
+  // every address is a base that was made once (uniform part in SGPRs, the thread's part a 32-bit offset) + an immediate:
+  // written the plain way, the L store alone cost five 64-bit VALU operations per word.
+  auto phase1 = [&](auto fastc, auto fullc) {
+    constexpr bool FAST = decltype(fastc)::value, FULL = decltype(fullc)::value;
     const int64_t i0 = bi * TILE + 16 * c16;
+    const int l0 = tid >> 3;  // locus l = l0 + 32 it, so l >> 5 = it, l & 31 = l0, l >> 4 = (l0 >> 4) + 2 it
+    const uint32_t rot0 = (uint32_t)(16 * c16 + 32 * (l0 >> 4)) & 127u;
+    const uint32_t cb[2] = {(uint32_t)l0 * TILE + rot0, (uint32_t)l0 * TILE + (rot0 ^ 64u)};  // `codes` offset of it even / odd
+    const uint32_t loff = (uint32_t)(l0 + 32 * (c16 & 1)) * 16u + (uint32_t)(c16 >> 1) * 4u;  // inside a 1-KiB L block
+    typedef __attribute__((address_space(1))) char gchar;
+    typedef __attribute__((address_space(1))) uint32_t gu32;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
-      const int l = (tid >> 3) + 32 * it;
+      const int l = l0 + 32 * it;
       const bool inside = bj * TILE + l < m;
 #pragma unroll
       for (int vw = 0; vw < NV; vw++) {
-        uint8_t* codes = codes_all + vw * TILE * TILE;
-        uint32_t* L = vw ? L1 : L0;
+        uint8_t* codes = codes_all + slot_[vw] * TILE * TILE;
         uint32_t c[4] = {0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u};
         if constexpr (FAST) {
           const uint32_t w[4] = {va[sub][it].x, va[sub][it].y, vb[sub][it].x, vb[sub][it].y};
@@ -228,29 +257,31 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const uint32_t cq = __builtin_amdgcn_perm(hi_[vw], lo_[vw], w[q]);
-            c[q] = (q < 2 ? h0 : h1) ? cq : 0x03030303u;
-            cacc[vw] |= c[q];
+            c[q] = FULL || (q < 2 ? h0 : h1) ? cq : 0x03030303u;
           }
+          cacc[vw] |= (c[0] | c[1]) | (c[2] | c[3]);
         } else {
           if (inside && i0 + 8 <= n) { c[0] = conv(va[sub][it].x, vw); c[1] = conv(va[sub][it].y, vw); }
           if (inside && i0 + 16 <= n) { c[2] = conv(vb[sub][it].x, vw); c[3] = conv(vb[sub][it].y, vw); }
         }
-        *reinterpret_cast<uint4*>(codes + l * TILE + ((16 * c16 + 32 * (l >> 4)) & 127)) = make_uint4(c[0], c[1], c[2], c[3]);
-        const int64_t lt = bj * 4 + (l >> 5);
-        const int lane = (l & 31) + 32 * (c16 & 1);
-        L[((lt * Q + bi) * 64 + lane) * 4 + (c16 >> 1)] = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
+        if (need_[vw]) *reinterpret_cast<uint4*>(codes + cb[it & 1] + it * 32 * TILE) = make_uint4(c[0], c[1], c[2], c[3]);
+        gchar* Lb = (gchar*)tpg_pack_uniform64((int64_t)((vw ? L1 : L0) + ((bj * 4 + it) * Q + bi) * 256));  // L block (lt = 4 bj + it, bi)
+        *(gu32*)(Lb + loff) = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
       }
     }
   };
-  if (fastw) phase1(std::true_type{});
-  else phase1(std::false_type{});
+  // (wave-uniform) all 64 threads x 4 loci of this wave inside the view with 16 individuals each
+  const bool fullw = __builtin_amdgcn_ballot_w64(!(bj * TILE + (tid >> 3) + 96 < m && bi * TILE + 16 * c16 + 16 <= n)) == 0;
+  if (fastw && fullw) phase1(std::true_type{}, std::true_type{});
+  else if (fastw) phase1(std::true_type{}, std::false_type{});
+  else phase1(std::false_type{}, std::false_type{});
   __syncthreads();
   {
     const int wv = tid >> 6, t = tid & 63;
     const int g = t >> 3, iqq = t & 7;  // loci 16 g .. 16 g + 15, individuals 32 wv + 4 iqq .. + 3
 #pragma unroll
     for (int vw = 0; vw < NV; vw++) {
-    const uint8_t* codes = codes_all + vw * TILE * TILE;
+    const uint8_t* codes = codes_all + slot_[vw] * TILE * TILE;
     uint32_t* T = vw ? T1 : T0;
     uint32_t* T4v = vw ? nullptr : T4;
     if (!T && !T4v) continue;
@@ -258,31 +289,55 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
 #pragma unroll
     for (int e = 0; e < 16; e++)
       d[e] = *reinterpret_cast<const uint32_t*>(codes + (16 * g + e) * TILE + ((32 * wv + 4 * iqq + 32 * g) & 127));
-    uint32_t W[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t x0 = d[4 * k], x1 = d[4 * k + 1], x2 = d[4 * k + 2], x3 = d[4 * k + 3];
-      const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
-      const uint32_t t2 = __builtin_amdgcn_perm(x3, x2, 0x05010400u), t3 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
-      W[0] |= __builtin_amdgcn_perm(t2, t0, 0x05040100u) << (2 * k);
-      W[1] |= __builtin_amdgcn_perm(t2, t0, 0x07060302u) << (2 * k);
-      W[2] |= __builtin_amdgcn_perm(t3, t1, 0x05040100u) << (2 * k);
-      W[3] |= __builtin_amdgcn_perm(t3, t1, 0x07060302u) << (2 * k);
-    }
     const int64_t rt = bi * 4 + wv;
+    typedef __attribute__((address_space(1))) char gchar2;
     if (T) {
+      uint32_t W[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t x0 = d[4 * k], x1 = d[4 * k + 1], x2 = d[4 * k + 2], x3 = d[4 * k + 3];
+        const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+        const uint32_t t2 = __builtin_amdgcn_perm(x3, x2, 0x05010400u), t3 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+        W[0] |= __builtin_amdgcn_perm(t2, t0, 0x05040100u) << (2 * k);
+        W[1] |= __builtin_amdgcn_perm(t2, t0, 0x07060302u) << (2 * k);
+        W[2] |= __builtin_amdgcn_perm(t3, t1, 0x05040100u) << (2 * k);
+        W[3] |= __builtin_amdgcn_perm(t3, t1, 0x07060302u) << (2 * k);
+      }
       uint32_t* dst = T + ((rt * KG + bj) * 64 + 4 * iqq + 32 * (g & 1)) * 4 + (g >> 1);
 #pragma unroll
       for (int b = 0; b < 4; b++) dst[b * 4] = W[b];
-    }
-    if (T4v) {  // T word s = g >> 1 of lane l -> words 2 (s & 1), 2 (s & 1) + 1 of lane l in T4 block 2 kg + (s >> 1)
+      if (T4v) {  // T word s = g >> 1 of lane l -> words 2 (s & 1), 2 (s & 1) + 1 of lane l in T4 block 2 kg + (s >> 1)
+        const int sT = g >> 1;
+        uint32_t* dst4 = T4v + (((rt * KG + bj) * 2 + (sT >> 1)) * 64 + 4 * iqq + 32 * (g & 1)) * 4 + 2 * (sT & 1);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          uint32_t lo, hi;
+          tpg_t4_words(W[b], lo, hi);
+          *reinterpret_cast<uint2*>(dst4 + b * 4) = make_uint2(lo, hi);
+        }
+      }
+    } else {
+      // T4 only (the bench's raw view): the transposed code bytes go through the nibble table as they are -- the T word they
+      // would be OR-ed into is never made (16 v_perm_b32 + 8 v_lshl_or_b32 where the detour took 16 + 52)
+      uint32_t N[4][4];  // [k][b]
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t x0 = d[4 * k], x1 = d[4 * k + 1], x2 = d[4 * k + 2], x3 = d[4 * k + 3];
+        const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+        const uint32_t t2 = __builtin_amdgcn_perm(x3, x2, 0x05010400u), t3 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+        N[k][0] = (uint32_t)tpg_lut(TPG_NIB_LUT, __builtin_amdgcn_perm(t2, t0, 0x05040100u));
+        N[k][1] = (uint32_t)tpg_lut(TPG_NIB_LUT, __builtin_amdgcn_perm(t2, t0, 0x07060302u));
+        N[k][2] = (uint32_t)tpg_lut(TPG_NIB_LUT, __builtin_amdgcn_perm(t3, t1, 0x05040100u));
+        N[k][3] = (uint32_t)tpg_lut(TPG_NIB_LUT, __builtin_amdgcn_perm(t3, t1, 0x07060302u));
+      }
       const int sT = g >> 1;
-      uint32_t* dst4 = T4v + (((rt * KG + bj) * 2 + (sT >> 1)) * 64 + 4 * iqq + 32 * (g & 1)) * 4 + 2 * (sT & 1);
+      gchar2* B4 = (gchar2*)tpg_pack_uniform64((int64_t)(T4v + ((rt * KG + bj) * 2) * 256));  // the two T4 blocks of (rt, kg)
+      const uint32_t o4 = (uint32_t)(sT >> 1) * 1024u + (uint32_t)(4 * iqq + 32 * (g & 1)) * 16u + (uint32_t)(sT & 1) * 8u;
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        uint32_t lo, hi;
-        tpg_t4_words(W[b], lo, hi);
-        *reinterpret_cast<uint2*>(dst4 + b * 4) = make_uint2(lo, hi);
+        typedef uint32_t pk_u2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) pk_u2 gu2;
+        *(gu2*)(B4 + o4 + b * 16) = pk_u2{N[0][b] | (N[1][b] << 4), N[2][b] | (N[3][b] << 4)};
       }
     }
     }  // view
@@ -300,16 +355,18 @@ int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, con
   dim3 grid((unsigned)v->KG, (unsigned)v->Q);
   if (fbm->bed_bpl == 0 && d_rows == nullptr && (fbm->nrow & 7) == 0 && (((uintptr_t)fbm->d_bytes) & 7) == 0 &&
       !getenv("TPG_PACK_GENERIC")) {
-    TPG_REQUIRE(v->KG * v->Q < 2147483647ll, TPG_EINVAL, "view too large for the pack grid");
-    const dim3 g1((unsigned)(v->KG * ((v->Q + PACK_NSUB - 1) / PACK_NSUB)));
+    TPG_REQUIRE((v->KG + 8) * v->Q < 2147483647ll, TPG_EINVAL, "view too large for the pack grid");
+    const int xmap = getenv("TPG_PACK_XCD") ? atoi(getenv("TPG_PACK_XCD")) : 1;
+    const dim3 g1((unsigned)((xmap ? (v->KG + 7) / 8 * 8 : v->KG) * ((v->Q + PACK_NSUB - 1) / PACK_NSUB)));
+    auto lds_bytes = [&](int nv, bool t_a, bool t_b) { return (size_t)nv * (256 + 16) + (size_t)((t_a ? 1 : 0) + (t_b ? 1 : 0)) * TILE * TILE; };
     if (v2)
-      TPG_LAUNCH(ctx, "pack2", tpg_pack_fast_kernel<2>, g1, dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
+      TPG_LAUNCH(ctx, "pack2", tpg_pack_fast_kernel<2>, g1, dim3(256), lds_bytes(2, v->T || v->T4, v2->T != nullptr), fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
                  v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)v2->T, (uint32_t*)v2->L,
-                 (uint32_t*)v->T4);
+                 (uint32_t*)v->T4, xmap);
     else
-      TPG_LAUNCH(ctx, "pack", tpg_pack_fast_kernel<1>, g1, dim3(256), 0, fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
+      TPG_LAUNCH(ctx, "pack", tpg_pack_fast_kernel<1>, g1, dim3(256), lds_bytes(1, v->T || v->T4, false), fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
                  v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                 (uint32_t*)v->T4);
+                 (uint32_t*)v->T4, xmap);
     TPG_CHECK_LAUNCH();
     return TPG_OK;
   }
