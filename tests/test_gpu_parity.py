@@ -746,6 +746,39 @@ def test_pca_vs_oracle(tpg, n, m, G, k):
     assert tpg.square_frobenius(X, None, cols, o["center"], o["scale"]) == pytest.approx(o["square_frobenius"], rel=1e-12)
 
 
+def test_pca_loadings_entry_point_and_small_context_calls(tpg):
+    """tpg_pca_loadings on its own (v = Z' u / d, the second sweep of big_SVD: the driver reaches it through the PCA, a caller
+    with its own u may not), on a caller's stream (tpg_ctx_set_stream), and the two one-line queries of the ABI."""
+    n, m, k = 150, 2100, 7
+    g = orc.synth_fbm(5, n, m, npop=3, miss=0.0)
+    g = g[:, (g.sum(0) > 0) & (g.sum(0) < 2 * n)]
+    X = _X(tpg, g)
+    v = tpg.View(X)
+    center, scale = tpg.pca_center_scale(v)
+    rng = np.random.default_rng(3)
+    U, _ = np.linalg.qr(rng.standard_normal((n, k)))
+    d = np.linspace(9.0, 2.0, k)
+    want = ((g.astype(float) - center) / scale).T @ U / d
+    got = tpg.pca_loadings(v, center, scale, U, d)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+    import torch
+    st = torch.cuda.Stream()
+    ctx = tpg.default_context()
+    ctx.set_stream(st.cuda_stream)
+    try:
+        again = tpg.pca_loadings(v, center, scale, U, d)
+        ctx.sync()
+    finally:
+        ctx.set_stream(None)
+    assert np.array_equal(again, got)
+    assert tpg.Pairwise.buffer_bytes(n) >= 5 * 4 * n * (n + 1) // 2  # five int32 planes over the tiles of one triangle
+    try:
+        uid = tpg.Comm.unique_id()
+    except RuntimeError:
+        uid = None  # no RCCL on this box: the library says so instead of handing out a made-up id
+    assert uid is None or (len(uid) == 128 and any(uid))
+
+
 def test_pca_errors_like_big_svd(tpg):
     fbm = orc.synth_fbm(72, 50, 300, npop=2, miss=0.05)
     X = tpg.FBM.from_numpy(fbm)
