@@ -586,7 +586,8 @@ __global__ __launch_bounds__(256) void tpg_fst_wc84_tab_kernel(FstSrc src, int64
 //   * "is the denominator a number" is decided per WAVE and locus (one ballot of the six comparisons): the common case
 //     adds without v_cndmask (4 per pair).
 // 26 VALU instructions per pair and locus instead of 38.  Per pair the arithmetic, its order, and the order of the loci are
-// those of the kernel above: the sums are identical bit for bit.
+// those of the kernel above; the staged frequency is a product with the table's 1 / n instead of a quotient (one ulp), so the
+// sums agree with that kernel's to 1e-16, not bit for bit.
 // FSTW_TR x FSTW_TC = 3 x 2 populations; a task record = {first row population, first column population, pair index x 6}:
 // host/host_fsttiles.h (fst_wc84_tiles cuts the pair list into them)
 #define FSTT_KMAX 511                            // table entries 0 .. 511 valid alleles of a pair
@@ -627,7 +628,6 @@ __global__ __launch_bounds__(256, 3) void tpg_fst_wc84_tile_kernel(FstSrc src, i
       sum_num[k] = 0.0; sum_den[k] = 0.0;
     }
   }
-  const int kmax16 = kmax * 16;
   const int64_t nchunks = (m + LB - 1) / LB;
   constexpr int SLOTS = LB * GS / 256;  // staged (locus, population) slots per thread
   int pn1[SLOTS], pn2[SLOTS], pnv[SLOTS];
@@ -636,11 +636,11 @@ __global__ __launch_bounds__(256, 3) void tpg_fst_wc84_tile_kernel(FstSrc src, i
 #pragma unroll
     for (int i = 0; i < SLOTS; i++) {
       pn1[i] = 0; pn2[i] = 0; pnv[i] = 0;
-      const int idx = threadIdx.x + 256 * i;
-      if (idx < LB * G && ch < nchunks) {
-        const int64_t j = ch * LB + idx / G;
+      // slot = (locus (threadIdx.x >> 6) + 4 i, population threadIdx.x & 63): no division by G, and a wave reads one locus' row
+      if ((int)(threadIdx.x & 63u) < G && ch < nchunks) {
+        const int64_t j = ch * LB + (threadIdx.x >> 6) + 4 * i;
         if (j < m) {
-          const int64_t o = j * src.Cpad + idx % G;
+          const int64_t o = j * src.Cpad + (threadIdx.x & 63u);
           pn1[i] = src.cnt[o]; pn2[i] = src.cnt[plane + o]; pnv[i] = src.cnt[2 * plane + o];
         }
       }
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256, 3) void tpg_fst_wc84_tile_kernel(FstSrc src, i
         const int k = i * FSTW_TC + j;
         const v4d s1 = R[i], s2 = Cc[j];
         // 16 bytes per valid allele of the pair: 32 (n1 + n2), an exact small integer in FP64
-        const int A16 = min(__double2int_rz(s1[0] + s2[0]), kmax16);
+        const int A16 = __double2int_rz(s1[0] + s2[0]);  // <= 16 kmax (the staging clamps n)
         const v2d ta = *(const v2d*)(shb + A16), tb = *(const v2d*)(shb + A16 + FSTT_TAB2);
         const v4d t = v4d{ta[0], ta[1], tb[0], tb[1]};
         const double p_bar = fma(s2[1], s2[0], s1[1] * s1[0]) * t[0], h_bar = (s1[2] + s2[2]) * t[0];
@@ -702,15 +702,19 @@ __global__ __launch_bounds__(256, 3) void tpg_fst_wc84_tile_kernel(FstSrc src, i
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SLOTS; i++) {
-      const int idx = threadIdx.x + 256 * i;
-      if (idx < LB * G) {
-        // src/grouped_summaries_dip_pseudo_cpp.cpp:40-56 on the counts (diploids): n = 2 valid, freq, het_obs
-        const double vn = (double)(2 * pnv[i]);
-        const double vp = (double)(pn1[i] + 2 * pn2[i]) / vn, vh = (double)(2 * pn1[i]) / vn;  // 0 / 0 = NaN: no valid genotype
-        const double ni = 0.5 * vn;
-        const uint32_t q = (uint32_t)((idx / G) * GS + idx % G);
+      if ((int)(threadIdx.x & 63u) < G) {
+        // src/grouped_summaries_dip_pseudo_cpp.cpp:40-56 on the counts (diploids): n = 2 valid, freq, het_obs -- without a
+        // division: 1 / n is the table's own 1 / nt at 2 n valid alleles (32 t[0], exact), freq = alleles * (0.5 / n) (one ulp
+        // from the quotient: these are the totals, 1e-11 is the contract), and H = het_obs * n IS the heterozygote count
+        // (kmax = 4 x the largest population: n <= kmax / 4 whenever the counts belong to these populations; the clamp is what
+        // keeps the pair's table offset 32 (n1 + n2) inside the table if they do not, instead of a test per pair and locus)
+        const int nv = min(pnv[i], kmax >> 2);
+        const double rn = 32.0 * *(const double*)(shb + (uint32_t)nv * 32u);  // 1 / n; n = 0: inf, and 0 * inf = NaN below, as 0 / 0 was
+        const double ni = (double)nv;
+        const double vp = (double)(pn1[i] + 2 * pn2[i]) * (0.5 * rn);
+        const uint32_t q = threadIdx.x + 256u * (uint32_t)i;
         *(v2d*)(shb + FSTT_SA + q * 16u) = v2d{32.0 * ni, vp};
-        *(v2d*)(shb + FSTT_SB + q * 16u) = v2d{32.0 * (vh * ni), 1.0 / ni};
+        *(v2d*)(shb + FSTT_SB + q * 16u) = v2d{32.0 * (double)pn1[i], rn};
       }
     }
     __syncthreads();
