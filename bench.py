@@ -957,7 +957,7 @@ def main():
             hbm_roof("pack", "tpg_pack_fast_kernel<1>", 1.5 * n * m, "FBM bytes -> two 2-bit layouts: N M read + N M / 2 written"),
             hbm_roof("pack2", "tpg_pack_fast_kernel<2>", 2.0 * n * m,
                      "FBM bytes -> the raw AND the imputed view from one read: N M read + N M written (L of both views, "
-                     "N M / 4 each, + the FP4 operand layout T4 of the raw view, N M / 2); FETCH_SIZE = the algorithmic 5.0 GB; a "
+                     "N M / 4 each, + the FP4 operand layout T4 of the raw view, N M / 2); FETCH_SIZE of the kernel alone = the algorithmic 5.0 GB; a "
                      "plain device-to-device copy of 5 GB gets 4.5 TB/s on this part (tools/copy_probe.py), a pure read 6.0"),
             hbm_roof("t4_expand", "tpg_t4_expand_kernel", 0.75 * n * m,
                      "2-bit T layout -> FP4 operand nibbles of the pairwise kernel: N M / 4 read + N M / 2 written"),
