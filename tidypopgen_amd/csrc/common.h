@@ -158,6 +158,12 @@ struct tpg_view {
   // methods of one analysis all use the same grouping): reused while the class vector is unchanged
   mutable GroupedCounts gc_cache;
   mutable std::vector<int32_t> gc_cls;
+  // per-locus genotype counts as the fast pack kernel left them (it has every code in registers anyway): for each chunk of
+  // 256 individuals and each locus one dword {codes with bit 0 set, with bit 1 set, with both} in fields of 10 bits,
+  // lc_part[chunk * lc_row + locus]; tpg_launch_loci_counts adds the chunks up instead of reading the L layout again
+  uint32_t* lc_part = nullptr;
+  int lc_chunks = 0;
+  int64_t lc_row = 0;
 };
 
 // tile-packed int32 accumulators of the pairwise kernel: per unit (super-tile I of TPG_PW_TA row tiles, 32-column

@@ -3,7 +3,8 @@
 //  * tpg_loci_counts_kernel: genotype counts per locus (n0,n1,n2,nNA).  One wave per 32-locus
 //    tile streams that tile's Q contiguous 1-KiB blocks with 16-B coalesced loads; lane (r,h)
 //    owns locus r and popcounts its own dwords, so the only cross-lane step is one lane^32
-//    exchange at the end.  HBM-bound: n/4 bytes per locus in, 16 B out.
+//    exchange at the end.  HBM-bound: n/4 bytes per locus in, 16 B out.  (A view made by the fast pack kernel carries
+//    per-chunk counts from the pack itself: tpg_loci_counts_sum_kernel adds those up and L is not read.)
 //  * tpg_grouped_counts_kernel: per locus x class counts as an int8 MFMA contraction over
 //    individuals, D[locus][class] = sum_i plane[i][locus] * onehot[i][class] for the planes
 //    {het, hom-alt, valid}.  Exact in int32, arbitrary class assignment, no atomics.
@@ -56,7 +57,30 @@ __global__ __launch_bounds__(256) void tpg_loci_counts_kernel(const uint4* __res
   }
 }
 
+// the same counts from what the fast pack kernel left beside the layouts (tpg_view::lc_part): per locus the sum over the
+// chunks of 256 individuals of {codes with bit 0 set, with bit 1 set, with both}, 4 B per chunk and locus instead of n / 4
+__global__ __launch_bounds__(256) void tpg_loci_counts_sum_kernel(const uint32_t* __restrict__ part, int chunks, int64_t row,
+                                                                  int64_t n, int64_t m, int4* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  int lo = 0, hi = 0, both = 0;
+  for (int c = 0; c < chunks; c++) {
+    const uint32_t w = part[(int64_t)c * row + j];
+    lo += (int)(w & 1023u);
+    hi += (int)((w >> 10) & 1023u);
+    both += (int)(w >> 20);
+  }
+  const int n1 = lo - both, n2 = hi - both;
+  out[j] = make_int4((int)n - n1 - n2 - both, n1, n2, both);
+}
+
 int tpg_launch_loci_counts(tpg_ctx* ctx, const tpg_view* v, int32_t* d_counts) {
+  if (v->lc_part) {
+    TPG_LAUNCH(ctx, "loci_counts", tpg_loci_counts_sum_kernel, dim3((unsigned)ceil_div(v->m, 256)), dim3(256), 0,
+               (const uint32_t*)v->lc_part, v->lc_chunks, v->lc_row, v->n, v->m, (int4*)d_counts);
+    TPG_CHECK_LAUNCH();
+    return TPG_OK;
+  }
   const int64_t n_lt = v->KG * 4;
   TPG_LAUNCH(ctx, "loci_counts", tpg_loci_counts_kernel, dim3((unsigned)ceil_div(n_lt, 4)), dim3(256), 0,
              (const uint4*)v->L, n_lt, v->Q, v->n, v->m, (int4*)d_counts);

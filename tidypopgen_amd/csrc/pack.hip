@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
                                                             int64_t n, int64_t m, int64_t Q, int64_t KG,
                                                             uint32_t* __restrict__ T0, uint32_t* __restrict__ L0,
                                                             uint32_t* __restrict__ T1, uint32_t* __restrict__ L1,
-                                                            uint32_t* __restrict__ T4, int xcd_map) {
+                                                            uint32_t* __restrict__ T4, int xcd_map,
+                                                            uint32_t* __restrict__ P0, uint32_t* __restrict__ P1) {
   // dynamic: the tables + one TILE x TILE array of code bytes per view that gets a T or T4 layout (tpg_pack_lds_bytes).  A view
   // with L only -- the imputed view of the bench's pair -- needs no pass through LDS at all, and with 17 instead of 33 KiB a CU
   // holds six workgroups instead of four: the kernel is bound by the bytes it has in flight, not by HBM or the VALU
@@ -226,6 +227,14 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
   uint32_t cacc[NV];
 #pragma unroll
   for (int vw = 0; vw < NV; vw++) cacc[vw] = 0;
+  // genotype counts of this thread's 16 (then, over the chunks, 32) individuals per locus and view, three 10-bit fields:
+  // codes with bit 0 set, with bit 1 set, with both (tpg_view::lc_part)
+  uint32_t cnt3[NV][4];
+#pragma unroll
+  for (int vw = 0; vw < NV; vw++)
+#pragma unroll
+    for (int it = 0; it < 4; it++) cnt3[vw][it] = 0;
+  const bool cnt_on = P0 != nullptr;
 #pragma unroll
   for (int sub = 0; sub < NSUB; sub++) {
   const int64_t bi = bi0 + sub;
@@ -266,7 +275,14 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
         }
         if (need_[vw]) *reinterpret_cast<uint4*>(codes + cb[it & 1] + it * 32 * TILE) = make_uint4(c[0], c[1], c[2], c[3]);
         gchar* Lb = (gchar*)tpg_pack_uniform64((int64_t)((vw ? L1 : L0) + ((bj * 4 + it) * Q + bi) * 256));  // L block (lt = 4 bj + it, bi)
-        *(gu32*)(Lb + loff) = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
+        const uint32_t lw = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
+        *(gu32*)(Lb + loff) = lw;
+        if (cnt_on) {  // (the padding code 3 of individuals past n, loci past m, is not a genotype: masked out)
+          uint32_t wc = lw;
+          if constexpr (!FULL) wc = (inside && i0 + 16 <= n) ? lw : (inside && i0 + 8 <= n) ? (lw & 0x0F0F0F0Fu) : 0u;
+          cnt3[vw][it] += (uint32_t)__popc(wc & 0x55555555u) | ((uint32_t)__popc(wc & 0xAAAAAAAAu) << 10) |
+                          ((uint32_t)__popc(wc & (wc >> 1) & 0x55555555u) << 20);
+        }
       }
     }
   };
@@ -346,6 +362,21 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
 #pragma unroll
   for (int vw = 0; vw < NV; vw++)
     if (bad_[vw] || (cacc[vw] & 0x80808080u)) atomicOr((unsigned int*)(lut_and_flag + vw * (256 + 16) + 256), 1u);
+  if (cnt_on) {  // the eight threads of a locus (16 individuals each) are eight neighbouring lanes
+    const int64_t Mp = KG * TILE;
+#pragma unroll
+    for (int vw = 0; vw < NV; vw++) {
+      uint32_t* P = vw ? P1 : P0;
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        uint32_t pk = cnt3[vw][it];
+        pk += (uint32_t)__shfl_xor((int)pk, 1);
+        pk += (uint32_t)__shfl_xor((int)pk, 2);
+        pk += (uint32_t)__shfl_xor((int)pk, 4);
+        if (c16 == 0) P[(bi0 / NSUB) * Mp + bj * TILE + (tid >> 3) + 32 * it] = pk;
+      }
+    }
+  }
 }
 
 // d_lut: one (v2 == NULL) or two consecutive {256-byte table, 16-byte flag area} records
@@ -358,15 +389,31 @@ int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, con
     TPG_REQUIRE((v->KG + 8) * v->Q < 2147483647ll, TPG_EINVAL, "view too large for the pack grid");
     const int xmap = getenv("TPG_PACK_XCD") ? atoi(getenv("TPG_PACK_XCD")) : 1;
     const dim3 g1((unsigned)((xmap ? (v->KG + 7) / 8 * 8 : v->KG) * ((v->Q + PACK_NSUB - 1) / PACK_NSUB)));
+    // per-chunk genotype counts beside the layouts (tpg_view::lc_part; TPG_PACK_COUNTS=0: not, the counts kernel reads L)
+    static const bool counts_on = !(getenv("TPG_PACK_COUNTS") && atoi(getenv("TPG_PACK_COUNTS")) == 0);
+    const int64_t qb = (v->Q + PACK_NSUB - 1) / PACK_NSUB;
+    static_assert(PACK_NSUB * 8 * 16 < 1024, "a 10-bit field holds the counts of a chunk: NSUB x 8 threads x 16 individuals");
+    if (counts_on)
+      for (tpg_view* w : {v, v2}) {
+        if (!w || w->lc_part) continue;
+        if (tpg_pmalloc((void**)&w->lc_part, sizeof(uint32_t) * (size_t)qb * (size_t)w->KG * TILE) != hipSuccess) { w->lc_part = nullptr; continue; }
+        w->lc_chunks = (int)qb;
+        w->lc_row = w->KG * TILE;
+      }
+    uint32_t* lp0 = v->lc_part && (!v2 || v2->lc_part) ? v->lc_part : nullptr;
+    uint32_t* lp1 = lp0 && v2 ? v2->lc_part : nullptr;
+    if (!lp0)
+      for (tpg_view* w : {v, v2})
+        if (w && w->lc_part) { tpg_pfree(w->lc_part); w->lc_part = nullptr; w->lc_chunks = 0; }
     auto lds_bytes = [&](int nv, bool t_a, bool t_b) { return (size_t)nv * (256 + 16) + (size_t)((t_a ? 1 : 0) + (t_b ? 1 : 0)) * TILE * TILE; };
     if (v2)
       TPG_LAUNCH(ctx, "pack2", tpg_pack_fast_kernel<2>, g1, dim3(256), lds_bytes(2, v->T || v->T4, v2->T != nullptr), fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
                  v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)v2->T, (uint32_t*)v2->L,
-                 (uint32_t*)v->T4, xmap);
+                 (uint32_t*)v->T4, xmap, lp0, lp1);
     else
       TPG_LAUNCH(ctx, "pack", tpg_pack_fast_kernel<1>, g1, dim3(256), lds_bytes(1, v->T || v->T4, false), fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
                  v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                 (uint32_t*)v->T4, xmap);
+                 (uint32_t*)v->T4, xmap, lp0, lp1);
     TPG_CHECK_LAUNCH();
     return TPG_OK;
   }

@@ -957,6 +957,7 @@ extern "C" void tpg_view_free(tpg_view* v) {
   if (v->T) tpg_pfree(v->T);
   if (v->L) tpg_pfree(v->L);
   if (v->T4) tpg_pfree(v->T4);
+  if (v->lc_part) tpg_pfree(v->lc_part);
   delete v;
 }
 extern "C" int64_t tpg_view_n(const tpg_view* v) { return v ? v->n : 0; }
