@@ -964,8 +964,9 @@ def main():
             hbm_roof("gcls_gather", "tpg_gcls_gather_kernel", 0.5 * n * m_pca,
                      "class-sorted 2-bit operand layout of the PCA Gram: N M / 4 read (128 contiguous bytes per locus of the "
                      "locus-major copy, loci in class order) + N M / 4 written; 16 x 16 tiles of 2-bit codes transposed in registers"),
-            hbm_roof("loci_counts", "tpg_loci_counts_kernel", 0.25 * n * m + 16.0 * m,
-                     "per-locus genotype counts: N M / 4 read + 16 B per locus written"),
+            hbm_roof("loci_counts", "tpg_loci_counts_sum_kernel", 4.0 * ((((n + 127) // 128) + 1) // 2) * m + 16.0 * m,
+                     "per-locus genotype counts from the dwords the pack kernel leaves per chunk of 256 individuals and locus "
+                     "(4 B x chunks per locus read + 16 B written; the N M / 4 bytes of the L layout are not read again)"),
             hbm_roof("grouped_counts", "tpg_grouped_counts_kernel (FP4 MFMA one-hot contraction)",
                      0.25 * n * m + 12.0 * Cpad * m,
                      "grouped counts: N M / 4 read once + 3 int32 count planes of Cpad classes per locus written "
