@@ -267,7 +267,9 @@ __global__ __launch_bounds__(256, 3) void tpg_grouped_counts_kernel(const uint4*
   };
   // genotype blocks of groups q .. q + GC_D - 1 in GC_D rotating register slots (the HBM stream is fetched GC_D - 1 groups
   // ahead; the loop is unrolled by GC_D so that no slot is copied -- a copy would wait for the load just issued)
-  uint4 R[GC_D][GC_NLT], on[NIT];
+  // the one-hot fragments of group q' wait in register slot q' & 1, fetched TWO groups ahead of the barrier behind which they
+  // are used (one group ahead they had not arrived when the group's MFMAs were done: the wave waited, three others with it)
+  uint4 R[GC_D][GC_NLT], on[2][NIT];
 #pragma unroll
   for (int d = 0; d < GC_D - 1; d++)
 #pragma unroll
@@ -275,19 +277,23 @@ __global__ __launch_bounds__(256, 3) void tpg_grouped_counts_kernel(const uint4*
 #pragma unroll
   for (int j = 0; j < NIT; j++) {
     const int it = wv + 4 * j;
-    if (it < 2 * GT) ohb[0][it][lane] = frag(0, it);
+    if (it < 2 * GT) {
+      ohb[0][it][lane] = frag(0, it);
+      on[1][j] = frag(Qi > 1 ? 1 : 0, it);
+    }
   }
   tpg_lds_barrier();
   auto group = [&](auto Cc, auto Mm, int q) {
     constexpr int C = decltype(Cc)::value, M = decltype(Mm)::value;
-    const int qn = q + 1 < Qi ? q + 1 : q, qn2 = q + GC_D - 1 < Qi ? q + GC_D - 1 : Qi - 1;
+    static_assert(GC_D % 2 == 0, "the slot of a group's fragments is its parity, known at compile time in the unrolled loop");
+    const int qn2 = q + GC_D - 1 < Qi ? q + GC_D - 1 : Qi - 1, qo2 = q + 2 < Qi ? q + 2 : Qi - 1;
     const int cur = q & 1;
 #pragma unroll
     for (int t = 0; t < GC_NLT; t++) R[M][t] = LDG(pa[t], qn2);
 #pragma unroll
     for (int j = 0; j < NIT; j++) {
       const int it = wv + 4 * j;
-      if (it < 2 * GT) on[j] = frag(qn, it);
+      if (it < 2 * GT) on[C & 1][j] = frag(qo2, it);
     }
 #pragma unroll
     for (int S = 0; S < 2; S++) {
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256, 3) void tpg_grouped_counts_kernel(const uint4*
 #pragma unroll
     for (int j = 0; j < NIT; j++) {
       const int it = wv + 4 * j;
-      if (it < 2 * GT) ohb[cur ^ 1][it][lane] = on[j];
+      if (it < 2 * GT) ohb[cur ^ 1][it][lane] = on[(C & 1) ^ 1][j];
     }
     tpg_lds_barrier();
   };
