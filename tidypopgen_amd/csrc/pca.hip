@@ -1745,6 +1745,14 @@ __device__ __forceinline__ int64_t tpg_uniform64_pca(int64_t x) {  // a wave-uni
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+template <int C, class F>
+__device__ __forceinline__ void tpg_pca_static_for(F&& f) {
+  if constexpr (C > 0) {
+    tpg_pca_static_for<C - 1>(f);
+    f(std::integral_constant<int, C - 1>{});
+  }
+}
+
 template <int CTP>
 __global__ __launch_bounds__(256, 2) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
                                                                    const uint4* __restrict__ UD, int64_t n_lt,
@@ -1771,52 +1779,65 @@ __global__ __launch_bounds__(256, 2) void tpg_loadings_mfma_kernel(const uint4* 
     asm("" : "+v"(off));
     return *(const uint4*)(p + off);
   };
-  uint4 a[LD_NLT], a1[LD_NLT], a2[LD_NLT];  // the genotype stream is fetched two groups ahead
+  // The genotype stream goes through LD_D rotating register slots, fetched LD_D - 1 groups ahead, and the digit fragments of
+  // group q' wait in slot q' & 1, fetched TWO groups ahead of the barrier behind which they are used; the loop is unrolled by
+  // LD_D so that every slot is a compile-time index (copying a register that a load has just been issued into -- the
+  // a = a1, a1 = a2 of the first form of this loop -- makes the wave wait for that load: SQ_WAIT_ANY 52 %).
+  constexpr int LD_D = 4;
+  static_assert(LD_D % 2 == 0, "the slot of a group's digit fragments is its parity");
+  uint4 AR[LD_D][LD_NLT];
 #pragma unroll
-  for (int t = 0; t < LD_NLT; t++) { a[t] = LDG(pa[t], 0); a1[t] = LDG(pa[t], Qi > 1 ? 1 : 0); }
+  for (int d = 0; d < LD_D - 1; d++)
+#pragma unroll
+    for (int t = 0; t < LD_NLT; t++) AR[d][t] = LDG(pa[t], d < Qi ? d : Qi - 1);
   // this wave's share of a group's fragments: items wv, wv + 4, ... of the 4 * CTP (K step, column tile) pairs
   const char* pu = (const char*)(UD + ct0 * 64);  // fragment (ks, c) = block ks * CT + c
-  uint4 un[CTP];
+  uint4 un[2][CTP];
+  auto ufrag = [&](int q, int j) {
+    const int it = wv + 4 * j;
+    return LDG(pu, (q * 4 + it / CTP) * CT + it % CTP);
+  };
 #pragma unroll
   for (int j = 0; j < CTP; j++) {
-    const int it = wv + 4 * j;
-    ubuf[0][it][lane] = LDG(pu, (it / CTP) * CT + it % CTP);
+    ubuf[0][wv + 4 * j][lane] = ufrag(0, j);
+    un[1][j] = ufrag(Qi > 1 ? 1 : 0, j);
   }
   tpg_lds_barrier();
-  for (int q = 0; q < Qi; q++) {
-    const int qn = q + 1 < Qi ? q + 1 : q, qn2 = q + 2 < Qi ? q + 2 : Qi - 1;
+  auto group = [&](auto Cc, auto Mm, int q) {
+    constexpr int C = decltype(Cc)::value, M = decltype(Mm)::value;
+    const int qa = q + LD_D - 1 < Qi ? q + LD_D - 1 : Qi - 1, qu = q + 2 < Qi ? q + 2 : Qi - 1;
     const int cur = q & 1;
 #pragma unroll
-    for (int t = 0; t < LD_NLT; t++) a2[t] = LDG(pa[t], qn2);
+    for (int t = 0; t < LD_NLT; t++) AR[M][t] = LDG(pa[t], qa);
 #pragma unroll
-    for (int j = 0; j < CTP; j++) {
-      const int it = wv + 4 * j;
-      un[j] = LDG(pu, (qn * 4 + it / CTP) * CT + it % CTP);
-    }
+    for (int j = 0; j < CTP; j++) un[C & 1][j] = ufrag(qu, j);
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       v4i fg[LD_NLT];
 #pragma unroll
       for (int t = 0; t < LD_NLT; t++) {
-        const uint32_t w = s == 0 ? a[t].x : s == 1 ? a[t].y : s == 2 ? a[t].z : a[t].w;
+        const uint32_t w = s == 0 ? AR[C][t].x : s == 1 ? AR[C][t].y : s == 2 ? AR[C][t].z : AR[C][t].w;
 #pragma unroll
         for (int k = 0; k < 4; k++) fg[t][k] = (int)tpg_codes(w, k);
       }
 #pragma unroll
       for (int c = 0; c < CTP; c++) {
-        const uint4 b = ubuf[cur][s * CTP + c][lane];
-        v4i fb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+        const uint4 bq = ubuf[cur][s * CTP + c][lane];
+        v4i fb = {(int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w};
 #pragma unroll
         for (int t = 0; t < LD_NLT; t++) acc[t][c] = MFMA_I8(fg[t], fb, acc[t][c]);
       }
     }
-#pragma unroll
-    for (int t = 0; t < LD_NLT; t++) { a[t] = a1[t]; a1[t] = a2[t]; }
     // the other buffer was last read in group q - 1, which every wave left through the barrier below
 #pragma unroll
-    for (int j = 0; j < CTP; j++) ubuf[cur ^ 1][wv + 4 * j][lane] = un[j];
+    for (int j = 0; j < CTP; j++) ubuf[cur ^ 1][wv + 4 * j][lane] = un[(C & 1) ^ 1][j];
     tpg_lds_barrier();
-  }
+  };
+  for (int q = 0; q < Qi; q += LD_D)  // Q is the same for every wave: all of them meet every barrier
+    tpg_pca_static_for<LD_D>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      if (q + k < Qi) group(std::integral_constant<int, k>{}, std::integral_constant<int, (k + LD_D - 1) % LD_D>{}, q + k);
+    });
 #pragma unroll
   for (int t = 0; t < LD_NLT; t++) {
     if (lt0 + t >= n_lt) break;
