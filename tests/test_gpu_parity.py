@@ -746,6 +746,27 @@ def test_pca_vs_oracle(tpg, n, m, G, k):
     assert tpg.square_frobenius(X, None, cols, o["center"], o["scale"]) == pytest.approx(o["square_frobenius"], rel=1e-12)
 
 
+@pytest.mark.parametrize("n,m", [(8, 1), (24, 130), (104, 257), (136, 64), (264, 1000), (520, 333), (200, 129)])
+def test_loci_counts_from_the_pack_equal_counts_over_L(tpg, n, m):
+    """Per-locus genotype counts: the fast pack kernel (FBM rows a multiple of 8, all rows in file order) leaves per-chunk counts
+    beside the layouts and tpg_loci_counts adds them up; a view of a row subset takes the kernel over the L layout.  Both against
+    numpy: ragged last chunks of 8 / 16 individuals, a last locus group of one locus, a column subset, the pair of views."""
+    rng = np.random.default_rng(n * 1000 + m)
+    g = rng.integers(0, 4, size=(n, m)).astype(np.uint8)  # 3 = missing
+    X = tpg.FBM.from_numpy(g)
+    want = np.stack([(g == c).sum(0) for c in range(4)], axis=1).astype(np.int32)
+    v = tpg.View(X)
+    assert np.array_equal(tpg.loci_counts(v), want)
+    a, b = tpg.View.pair(X, None, None, tpg.CODE_012, tpg.CODE_IMPUTE_PRED)
+    assert np.array_equal(tpg.loci_counts(a), want) and np.array_equal(tpg.loci_counts(b), want)
+    if m > 2:
+        cols = np.sort(rng.choice(m, size=max(1, m // 2), replace=False)).astype(np.int32) + 1
+        assert np.array_equal(tpg.loci_counts(tpg.View(X, None, cols)), want[cols - 1])
+    rows = (np.arange(0, n, 2) + 1).astype(np.int32)  # a row subset: the generic pack kernel, counts over L
+    wr = np.stack([(g[::2] == c).sum(0) for c in range(4)], axis=1).astype(np.int32)
+    assert np.array_equal(tpg.loci_counts(tpg.View(X, rows, None)), wr)
+
+
 def test_pca_loadings_entry_point_and_small_context_calls(tpg):
     """tpg_pca_loadings on its own (v = Z' u / d, the second sweep of big_SVD: the driver reaches it through the PCA, a caller
     with its own u may not), on a caller's stream (tpg_ctx_set_stream), and the two one-line queries of the ABI."""
