@@ -1219,9 +1219,13 @@ struct EigWork {
   // tpg_push_small / tpg_fetch_small): no copy engine and no stream synchronisation anywhere in the iteration
   double* xdev = nullptr;
   int init() {
-    S = 1;
+    // K splits: ONE round of workgroups (two fit a CU: 66 KiB of LDS each) -- at n = 5 000, 79 row blocks x 6 splits = 474
+    // of 512 places, 89.5 us per product; 16 splits (2.5 rounds, the last half empty) 94.6, 13 splits (two rounds and three
+    // workgroups) 108 (tools/eig_s_scan.py)
     const int row_blocks = (n + 63) / 64;
-    while (row_blocks * S < 4 * ctx->num_cu && S < 32 && n / (S * 2) >= 64) S *= 2;
+    S = 1;
+    while (row_blocks * S < 4 * ctx->num_cu && S < 32 && n / (S * 2) >= 64) S *= 2;  // (short ranges: 1 000 rows take 4)
+    S = std::max(1, std::min((int)S, 2 * ctx->num_cu / row_blocks));
     if (getenv("TPG_EIG_S")) S = std::max(1, atoi(getenv("TPG_EIG_S")));  // (experiments)
     // A'B over chunks of rows: a workgroup per 32 (64) rows, so that a product on a few thousand rows is one short round
     // of many workgroups instead of a long loop in a few

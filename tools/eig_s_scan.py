@@ -7,7 +7,7 @@ import tidypopgen_amd as tpg
 n, m = 5000, 200000
 ctx = tpg.default_context(); ctx.prof_enable(True)
 X = tpg.FBM.synth(3, n, m, npop=51, imputed_bytes=True)
-for S in (0, 4, 8, 16, 32):
+for S in [int(x) for x in sys.argv[1:]] or (0, 4, 8, 16, 32):
     if S: os.environ["TPG_EIG_S"] = str(S)
     for rep in range(2):
         ctx.prof_reset()
