@@ -633,6 +633,108 @@ def test_fst_vs_oracle(tpg, n, m, G, method):
                 tpg.pairwise_fst_nei87_loop(pairs, pf["n"], pf["het_obs"], pf["freq_alt"], bad)
 
 
+
+def _fst_case(tpg, fbm, gid, G, method, pairs=None, tot_rtol=1e-11):
+    """all outputs of pairwise_pop_fst for one panel against the oracle: by-locus values and numerators / denominators bit for
+    bit, totals (both the by-locus call's and the totals-only kernels') and the sums=True path within tot_rtol"""
+    import math
+
+    n = fbm.shape[0]
+    X = tpg.FBM.from_numpy(fbm)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pf = orc.grouped_summaries_dip_pseudo_cpp(fbm, None, None, gid, G, np.full(n, 2.0))
+        allp = orc.combn2(G) if pairs is None else pairs
+        if method == "Hudson":
+            o = orc.pairwise_fst_hudson_loop(allp, pf["n"], pf["freq_alt"], pf["freq_ref"], True, True)
+            o_loc = orc.pairwise_fst_hudson_loop(allp, pf["n"], pf["freq_alt"], pf["freq_ref"], True, False)
+        elif method == "WC84":
+            o = orc.pairwise_fst_wc84_loop(allp, pf["n"], pf["freq_alt"], pf["het_obs"], True, True)
+            o_loc = orc.pairwise_fst_wc84_loop(allp, pf["n"], pf["freq_alt"], pf["het_obs"], True, False)
+        else:
+            o = orc.pairwise_fst_nei87_loop(allp, pf["n"], pf["het_obs"], pf["freq_alt"], pf["freq_ref"], True, True)
+            o_loc = orc.pairwise_fst_nei87_loop(allp, pf["n"], pf["het_obs"], pf["freq_alt"], pf["freq_ref"], True, False)
+    num, den = np.asarray(o["Fst_by_locus_num"]), np.asarray(o["Fst_by_locus_den"])
+    P = allp.shape[1]
+    # the correctly rounded sums over the loci the reference keeps (src/pairwise_fst_hudson_loop.cpp:43-52: a locus is
+    # dropped when its numerator or denominator is NaN)
+    keep = ~(np.isnan(num) | np.isnan(den))
+    sn = np.array([math.fsum(num[keep[:, k], k]) for k in range(P)])
+    sd = np.array([math.fsum(den[keep[:, k], k]) for k in range(P)])
+    scale_n = np.array([math.fsum(np.abs(num[keep[:, k], k])) for k in range(P)])  # the numerators of a pair can cancel
+    with np.errstate(invalid="ignore", divide="ignore"):
+        o_tot = sn / sd
+        tot_tol = tot_rtol * scale_n / np.abs(sd) + 1e-300
+
+    def same_tot(got):
+        assert np.array_equal(np.isnan(got), np.isnan(o_tot))
+        fin = ~np.isnan(o_tot)
+        assert np.all(np.abs(got[fin] - o_tot[fin]) <= tot_tol[fin])
+
+    kw = dict(method=method, pairwise_combn=pairs)
+    t = tpg.pairwise_pop_fst(X, None, None, gid, G, by_locus=True, **kw)
+    assert np.array_equal(t["fst_locus"], np.asarray(o_loc["fst_locus"]), equal_nan=True)
+    same_tot(t["fst_tot"])
+    nd = tpg.pairwise_pop_fst(X, None, None, gid, G, return_num_dem=True, **kw)
+    assert np.array_equal(nd["Fst_by_locus_num"], num, equal_nan=True)
+    assert np.array_equal(nd["Fst_by_locus_den"], den, equal_nan=True)
+    t_fast = tpg.pairwise_pop_fst(X, None, None, gid, G, **kw)["fst_tot"]  # totals-only kernels
+    same_tot(t_fast)
+    s = tpg.pairwise_pop_fst(X, None, None, gid, G, sums=True, **kw)
+    assert np.all(np.abs(s["sum_num"] - sn) <= tot_rtol * scale_n + 1e-300)
+    assert np.allclose(s["sum_den"], sd, rtol=tot_rtol, atol=0)
+    X.free()
+
+
+@pytest.mark.parametrize("G", [64, 65, 130, 300])
+@pytest.mark.parametrize("method", ["Hudson", "WC84", "Nei87"])
+def test_fst_many_small_populations(tpg, G, method):
+    """More than 64 populations leave the 64-population kernels (csrc/fst.hip run_fst: the WC84 tile / table kernels at a
+    stride of 64, the Hudson products in 4 x 4 tiles of 16): G = 64 is the last case on them, 65 the first off, 130 and 300
+    (8 385 / 44 850 pairs) take the many-pairs passes; population G - 1 has ONE individual (n = 2 alleles: n - 1 = 1,
+    WC84's n_c and Nei87's harmonic mean at their smallest), population G - 2 two."""
+    m = 301 if G < 300 else 130
+    n = 3 * (G - 2) + 3
+    fbm = orc.synth_fbm(77 + G, n, m, npop=min(G, 51), miss=0.06)
+    gid = np.concatenate([np.repeat(np.arange(G - 2), 3), [G - 2, G - 2, G - 1]]).astype(np.int32)
+    fbm[gid == 5, 11] = 3      # a population without a valid genotype at a locus
+    fbm[:, 17] = 2             # a monomorphic locus
+    _fst_case(tpg, fbm, gid, G, method)
+
+
+@pytest.mark.parametrize("G,n", [(2, 5000), (5, 5000), (3, 700)])
+@pytest.mark.parametrize("method", ["Hudson", "WC84", "Nei87"])
+def test_fst_large_populations(tpg, G, n, method):
+    """Populations of 2 500 / 1 000 individuals: a pair's valid alleles reach 10 000 / 4 000, past the Hudson reciprocal
+    table (4 096) and the WC84 tile kernel's FSTT_KMAX (511), and at G = 2 past what the WC84 table holds in LDS; (3, 700):
+    populations of 233 -- inside the tables' range but past the tile kernel's."""
+    m = 1500
+    fbm = orc.synth_fbm(91 + G, n, m, npop=G, miss=0.03)
+    gid = (np.arange(n) % G).astype(np.int32)
+    _fst_case(tpg, fbm, gid, G, method)
+
+
+def test_global_stats_many_populations(tpg):
+    n, m, G = 520, 700, 130
+    fbm = orc.synth_fbm(131, n, m, npop=51, miss=0.1)
+    gid = (np.arange(n) % G).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    o_loc = orc.pop_global_stats(fbm, None, None, gid, G, by_locus=True)
+    t_loc = tpg.pop_global_stats(X, None, None, gid, G, by_locus=True)
+    fin = np.isfinite(o_loc)
+    assert np.array_equal(np.isnan(t_loc), np.isnan(o_loc)) and np.array_equal(np.isinf(t_loc), np.isinf(o_loc))
+    assert np.allclose(t_loc[fin], o_loc[fin], rtol=1e-12, atol=1e-13)
+    assert np.allclose(tpg.pop_global_stats(X, None, None, gid, G), orc.pop_global_stats(fbm, None, None, gid, G),
+                       rtol=1e-11, atol=1e-13, equal_nan=True)
+    v = tpg.View(X)
+    assert np.array_equal(tpg.grouped_genotype_counts(v, gid, G), orc.grouped_genotype_counts(fbm, None, None, gid, G))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sa = tpg.grouped_summaries_dip_pseudo_cpp(v, gid, G, np.full(n, 2.0))
+        sb = orc.grouped_summaries_dip_pseudo_cpp(fbm, None, None, gid, G, np.full(n, 2.0))
+    for k in sb:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+    X.free()
+
+
 def test_wc84_totals_tiles_any_pair_list(tpg):
     """More than 256 pairs of at most 64 populations take the tiled totals kernel (tpg_fst_wc84_tile_kernel: a thread owns a
     3 x 2 tile of populations): a pair list in any order, with (g2, g1) orientations and repeated pairs, an empty population,

@@ -156,6 +156,64 @@ def test_many_individuals_indexing():
     assert np.allclose(r["v"].T @ r["v"], np.eye(5), atol=1e-7)
 
 
+def test_forty_thousand_individuals_indexing():
+    """N = 40 000 (1 250 row tiles, 261 000 pairwise units, 16 GB of int32 slabs, 12.8 GB per N x N double output): 32-bit lane
+    offsets, unit tables and epilogue indexing far past anything the bench reaches.  One output matrix is on the host at a
+    time.  (a) the full results contain, as a sub-matrix, the results of the same analysis on every 7th individual alone;
+    (b) 64 individuals spread over the first, a middle and the last (partial) row tile against the CPU oracle."""
+    import tidypopgen_amd as tpg
+    from oracle import oracle as orc
+
+    n, m, G = 40_000, 1_024, 40
+    X = tpg.FBM.synth(17, n, m, npop=G, miss=0.03)
+    rows = np.arange(1, n + 1, 7, dtype=np.int32)
+    pick = np.unique(np.concatenate([np.arange(0, 20), np.arange(20_000, 20_022), np.arange(n - 22, n)]))
+    fb = X.to_numpy()
+    sub_fbm = np.ascontiguousarray(fb[pick])
+    assert np.array_equal(sub_fbm, orc.synth_fbm(17, n, m, npop=G, miss=0.03)[pick])
+    del fb
+    full = tpg.Pairwise(X.ctx, n)
+    full.accumulate(tpg.View(X, code256=None))
+    sub = tpg.Pairwise(X.ctx, len(rows))
+    sub.accumulate(tpg.View(X, rows, None, code256=None))
+    small = tpg.Pairwise(X.ctx, len(pick))
+    small.accumulate(tpg.View(X, (pick + 1).astype(np.int32), None, code256=None))
+    o_ibs = orc.snp_ibs(sub_fbm, type="raw_counts")
+    ix, px = np.ix_(rows - 1, rows - 1), np.ix_(pick, pick)
+    cs, cp = sub.counts(), small.counts()
+    assert np.array_equal(cp["ibs"], o_ibs["ibs"]) and np.array_equal(cp["ibs_valid"], o_ibs["valid_n"])
+    for name in ("ibs", "ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den"):
+        cf = full.counts((name,))[name]
+        assert np.array_equal(cf[ix], cs[name]), name
+        assert np.array_equal(cf[px], cp[name]), name
+        if name != "n_Aa_i":
+            i = np.arange(0, n, 997)
+            assert np.array_equal(cf[i, :], cf[:, i].T), name  # both triangles written
+        del cf
+    del cs, cp
+    o_king = orc.snp_king(sub_fbm)
+    o_as = orc.snp_allele_sharing(sub_fbm)
+    for name, ref in (("king", o_king), ("allele_sharing", o_as)):
+        ef = full.epilogues((name,), m=m)[name]
+        es = sub.epilogues((name,), m=m)[name]
+        assert np.array_equal(ef[ix], es, equal_nan=True), name
+        assert np.allclose(ef[px], ref, rtol=1e-12, atol=0, equal_nan=True), name
+        del ef, es
+    full.free(); sub.free(); small.free()
+    # the per-locus and grouped sweeps at this N (157 chunks of 256 individuals per locus)
+    gid = (np.arange(n) % G).astype(np.int32)
+    v = tpg.View(X)
+    cnt = tpg.loci_counts(v)
+    fb = X.to_numpy()
+    for c in range(3):
+        assert np.array_equal(cnt[:, c], (fb == c).sum(axis=0))
+    ga = tpg.grouped_alt_freq_dip_pseudo_cpp(v, gid, G, np.full(n, 2.0), True)
+    gb = orc.grouped_alt_freq_dip_pseudo_cpp(fb, None, None, gid, G, np.full(n, 2.0), True)
+    assert np.array_equal(ga, gb, equal_nan=True)
+    del fb
+    X.free()
+
+
 def test_bench_size_properties():
     """BASELINE configs 3-5 (5 000 x 1 000 000, 51 populations): results pinned by properties that need no CPU pass
     over the panel -- additivity over locus blocks (bit-exact for counts, 1e-12 for Fst sums), and the SVD identity
