@@ -61,10 +61,14 @@ class Step:
 
         self.tpg, self.api, self.lib = tpg, api, tpg._lib.lib
         self.args, self.rank, self.world = args, rank, world
-        share_gpu = os.environ.get("TPG_BENCH_SHARE_GPU") == "1"  # rehearsal: several ranks on one GPU, gloo transport
+        # rehearsals on one GPU: "1" = the ranks share device 0 and exchange through the host transport over gloo; "rccl" = they
+        # share device 0 and call the nccl* entry points of the library TPG_RCCL_LIBRARY names (tests/host/mock_rccl.cpp --
+        # RCCL itself refuses two ranks on one device)
+        share = os.environ.get("TPG_BENCH_SHARE_GPU", "")
+        share_gpu = share == "1"
         # a launcher may hand every rank ONE visible device (HIP_VISIBLE_DEVICES narrowed per rank) or all of them
         ndev = tpg.device_count()
-        if share_gpu or (ndev == 1 and world > 1):
+        if share_gpu or share == "rccl" or (ndev == 1 and world > 1):
             device = 0
         elif local_rank < ndev:
             device = local_rank
@@ -100,6 +104,10 @@ class Step:
             elif comm is None:
                 raise RuntimeError(err)
             self.comm = comm
+            if self.transport == "rccl" and world > 1:
+                self.transport = comm.transport().replace("rccl: ", "rccl (") + ")"  # names the library that was loaded
+                if share == "rccl":
+                    self.transport += ", all ranks on ONE GPU (rehearsal of the nccl call sites)"
         n, G = args.n, args.pops
         if args.scaling == "strong":
             self.m_total = args.m
@@ -800,7 +808,7 @@ def launch_ranks(args):
     import subprocess
 
     n = args.gpus
-    if os.environ.get("TPG_BENCH_SHARE_GPU") != "1":  # rehearsal mode puts every rank on device 0
+    if os.environ.get("TPG_BENCH_SHARE_GPU") not in ("1", "rccl"):  # rehearsal modes put every rank on device 0
         import torch
 
         have = torch.cuda.device_count()

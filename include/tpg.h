@@ -74,6 +74,7 @@ int tpg_prof_dump(tpg_ctx* ctx, char* buf, size_t cap);
 /* plain device buffers for callers without their own allocator (outputs may be device memory) */
 int tpg_dev_alloc(tpg_ctx* ctx, size_t bytes, void** out);
 void tpg_dev_free(void* p);
+/* both copies are complete when the call returns, whatever the size (the context's stream has been waited for) */
 int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
 int tpg_dev_from_host(tpg_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
 
@@ -317,6 +318,9 @@ int tpg_comm_init_rank(tpg_ctx* ctx, int nranks, int rank, const uint8_t* id128,
 int tpg_comm_init_host(tpg_ctx* ctx, int nranks, int rank,
                        int (*allreduce)(void* user, void* buf, int64_t count, int dtype), void* user, tpg_comm** out);
 void tpg_comm_destroy(tpg_comm* comm);
+/* which transport the communicator's collectives run over: "none" (one rank), "host callback" (tpg_comm_init_host), or
+ * "rccl: <library name as loaded>" (librccl.so.1 unless TPG_RCCL_LIBRARY names another) */
+const char* tpg_comm_transport(const tpg_comm* comm);
 int tpg_comm_rank(const tpg_comm* comm);
 int tpg_comm_size(const tpg_comm* comm);
 /* loci [begin, end) of `rank`: contiguous, boundaries on multiples of 128 loci, sizes differ by at most 128 */
@@ -397,6 +401,9 @@ int tpg_pca_random_svd(tpg_ctx* ctx, const tpg_view* v, int k, double tol, doubl
  * matrix of its loci (tpg_pca_gram, additive over loci), the N x N partials are summed (one all-reduce),
  * then tpg_sym_eig_topk gives lambda[k] (descending) and U (n x k) of the summed matrix and
  * tpg_pca_loadings the rows of v = Z'u/d that belong to the rank's loci (d = sqrt(lambda)). */
+/* K: BOTH triangles filled and bitwise symmetric (K[i + j n] == K[j + i n]; what tpg_pca_gram / tpg_pca_gram_add write): the
+ * products K Q read K by rows or by columns, whichever is faster, so a matrix that is symmetric only to rounding, or has one
+ * triangle filled, gives the eigenpairs of neither. */
 int tpg_sym_eig_topk(tpg_ctx* ctx, const double* K, int64_t n, int k, double* lambda, double* U);
 int tpg_pca_loadings(tpg_ctx* ctx, const tpg_view* v, const double* center, const double* scale,
                      const double* U, const double* d, int k, double* vload);

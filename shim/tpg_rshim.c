@@ -98,6 +98,7 @@ typedef struct {
   int64_t mtime_ns;
   uint64_t fingerprint;
   uint64_t stamp; /* g_call of the last increment_* call that used this (writable) mapping */
+  uint64_t dev_id, ino; /* st_dev / st_ino of the file the mapping was made of */
 } mapped_file;
 
 /* an array of POINTERS: a mapped_file* handed out stays valid when the table grows or an entry is forgotten */
@@ -143,12 +144,19 @@ static void forget_file(int k) { /* unmap, free the HBM copy, close the gap in g
 }
 
 static mapped_file* map_file(const char* path, size_t bytes, int writable, int64_t nrow, int64_t ncol) {
+  /* a mapping is reused only while the PATH still names the file it was made of: a backing file unlinked and created again
+     at the same path and size (file.remove() + a new FBM, an explicit backingfile=) is another inode, and adding into the
+     old, unlinked one would leave R reading zeros from the new file without any error */
+  struct stat st;
+  const int have_st = stat(path, &st) == 0;
   for (int k = 0; k < g_nfiles; k++)
-    if (strcmp(g_files[k]->path, path) == 0 && g_files[k]->bytes == bytes && g_files[k]->writable == writable)
-      return g_files[k];
+    if (strcmp(g_files[k]->path, path) == 0 && g_files[k]->bytes == bytes && g_files[k]->writable == writable) {
+      if (have_st && g_files[k]->dev_id == (uint64_t)st.st_dev && g_files[k]->ino == (uint64_t)st.st_ino) return g_files[k];
+      forget_file(k);
+      break;
+    }
   int fd = open(path, writable ? O_RDWR : O_RDONLY);
   if (fd < 0) Rf_error("cannot open backing file '%s'", path);
-  struct stat st;
   if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) {
     close(fd);
     Rf_error("backing file '%s' is smaller than the FBM it should hold", path);
@@ -178,6 +186,8 @@ static mapped_file* map_file(const char* path, size_t bytes, int writable, int64
   f->writable = writable;
   f->nrow = nrow;
   f->ncol = ncol;
+  f->dev_id = (uint64_t)st.st_dev;
+  f->ino = (uint64_t)st.st_ino;
   return f;
 }
 
@@ -542,8 +552,9 @@ SEXP _tidypopgen_tpg_release(void) {
   return R_NilValue;
 }
 
-/* tpg_invalidate(BM): forget the HBM copy of this FBM (only TPG_RSHIM_CACHE=1 keeps one): call it after anything that
- * writes to the FBM -- tpgshim's wrappers of the mutating functions do */
+/* tpg_invalidate(BM): forget the HBM copy of this FBM (only TPG_RSHIM_CACHE=1 keeps one).  The caller's job after anything
+ * that writes to the FBM (gt_impute_simple, gt_set_imputed ...): the tpgshim package exports it as tpg_invalidate() and does
+ * NOT wrap the mutating functions itself; a write that leaves size and mtime alone is otherwise caught by the fingerprint */
 SEXP _tidypopgen_tpg_invalidate(SEXP BM) {
   mapped_file* f = genotype_fbm(BM);
   if (f->dev) {

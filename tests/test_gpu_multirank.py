@@ -364,37 +364,179 @@ def test_multi_on_distinct_gpus_against_oracle(ndev, monkeypatch):
     """tpg.Multi(ndev) on devices 0 .. ndev-1 (ncclCommInitAll, one host thread per device, RCCL between them) against the
     oracle, as test_multi_fst_freq_pca_against_oracle does with one device listed several times; once more with the class
     exchange forced (ncclAllToAllv inside tpg_multi_pca_partial_svd)."""
-    import tidypopgen_amd as tpg
-    from oracle import oracle as orc
+    from tests import multi_cases
 
-    n, m, G, k = 260, 12000, 5, 6
-    fbm = orc.synth_fbm(37, n, m, npop=G, miss=0.04, imputed_bytes=True)
-    gid = (np.arange(n) % G).astype(np.int32)
-    mg = tpg.Multi(ndev)
-    out = mg.pairwise(fbm)
-    assert np.array_equal(out["ibs"], orc.snp_ibs(fbm), equal_nan=True)
-    assert np.array_equal(out["king"], orc.snp_king(fbm), equal_nan=True)
-    as_ = orc.snp_allele_sharing(fbm)
-    assert np.array_equal(out["allele_sharing"], as_, equal_nan=True)
-    assert np.allclose(out["grm"], orc.pairwise_grm(as_), rtol=1e-12, atol=1e-14)
-    only = mg.pairwise(fbm, which=("king", "grm"))  # the {V, D, A} kernel on every device, one reduce-scatter
-    assert np.array_equal(only["king"], out["king"], equal_nan=True) and np.array_equal(only["grm"], out["grm"], equal_nan=True)
-    assert np.array_equal(mg.loci_alt_freq(fbm, None, None, gid, G),
-                          orc.grouped_alt_freq_dip_pseudo_cpp(fbm, None, None, gid, G, np.full(n, 2.0)))
-    for method in ("Hudson", "WC84"):
-        o = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method, by_locus=True)
-        t = mg.pairwise_pop_fst(fbm, None, None, gid, G, method=method, by_locus=True)
-        assert np.array_equal(t["fst_locus"], o["fst_locus"], equal_nan=True), method
-        assert np.allclose(t["fst_tot"], o["fst_tot"], rtol=1e-12, atol=0), method
-    dec = np.where(fbm > 3, fbm - 4, fbm)
-    pc = (np.where((dec.sum(axis=0) > 0) & (dec.sum(axis=0) < 2 * n))[0] + 1).astype(np.int32)
-    o = orc.gt_pca_partialSVD(fbm, None, pc, k=k)
-    for exchange in (False, True):
-        if exchange:
-            monkeypatch.setenv("TPG_GRAM_EXCHANGE", "1")
-        t = mg.gt_pca_partialSVD(fbm, None, pc, k=k)
-        assert np.array_equal(t["center"], o["center"]) and np.array_equal(t["scale"], o["scale"])
-        assert np.allclose(t["d"], o["d"], rtol=1e-6, atol=0)
-        so = o["u"] * o["d"]
-        assert np.max(np.abs(_align_sign(t["u"] * t["d"], so) - so)) <= 1e-6 * np.max(np.abs(so))
-    mg.close()
+    tr = multi_cases.multi_against_oracle(ndev, setenv=monkeypatch.setenv)
+    assert tr.startswith("rccl: librccl"), tr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The nccl* call sites with N > 1 ranks on ONE GPU: tests/host/mock_rccl.cpp stands in for librccl.so (TPG_RCCL_LIBRARY), with
+# rccl.h's semantics -- counts and displacements in elements, the in-place reduce-scatter at sendbuff + rank * recvcount, send
+# and receive counts of the all-to-all checked against each other, every buffer range checked against its allocation, every
+# rank checked to be in the SAME collective.  What the skipped tests above would be the first to run on hardware runs here
+# today; what the mock cannot show is in its header (stream ordering, RCCL's own kernels, xGMI).
+@pytest.fixture(scope="module")
+def mock_rccl():
+    from tests import multi_cases
+
+    return multi_cases.build_mock_rccl()
+
+
+def test_mock_rccl_semantics_and_misuse_detection(mock_rccl):
+    """The mock itself, driven directly (two rank threads, device buffers from the library's allocator): sums, the in-place
+    reduce-scatter, an all-to-all with ragged counts -- and the mistakes it exists to catch at comm.hip's call sites:
+    displacements given in bytes, a receive count that differs from the peer's send count, a reduce-scatter whose recvbuff
+    overlaps sendbuff anywhere else than at rank * recvcount, a rank in another collective than its peers."""
+    import ctypes as C
+    import threading
+
+    import tidypopgen_amd as tpg
+    from tidypopgen_amd import api
+
+    lib = C.CDLL(mock_rccl)
+    lib.ncclGetErrorString.restype = C.c_char_p
+    ctx = tpg.Context(0)
+    R, W = 2, 1000
+    tlib = tpg._lib.lib
+
+    def dalloc(nbytes):
+        p = C.c_void_p()
+        tpg._lib.check(tlib.tpg_dev_alloc(ctx.h, C.c_size_t(nbytes), C.byref(p)))
+        return p
+
+    def put(p, a):
+        tpg._lib.check(tlib.tpg_dev_from_host(ctx.h, p, api._ptr(a), C.c_size_t(a.nbytes)))
+        tpg._lib.check(tlib.tpg_ctx_sync(ctx.h))
+
+    def get(p, a):
+        tpg._lib.check(tlib.tpg_dev_to_host(ctx.h, api._ptr(a), p, C.c_size_t(a.nbytes)))
+        return a
+
+    def two_ranks(body):
+        cs = (C.c_void_p * R)()
+        assert lib.ncclCommInitAll(cs, C.c_int(R), (C.c_int * R)(0, 0)) == 0
+        out, err = [None] * R, []
+
+        def run(r):
+            try:
+                out[r] = body(r, C.c_void_p(cs[r]))
+            except Exception as e:  # noqa: BLE001
+                err.append(repr(e))
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(R)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for c in cs:
+            lib.ncclCommDestroy(C.c_void_p(c))
+        assert not err, err
+        return out
+
+    lock = threading.Lock()  # the context's staging helpers are used by one host thread at a time
+
+    def good(r, comm):
+        rng = np.random.default_rng(100 + r)
+        mine = rng.integers(-1000, 1000, R * W).astype(np.int32)
+        x = rng.standard_normal(77)
+        # ragged: rank r sends B + 3 + r + 2 d words to d (B large enough that displacements in BYTES leave the allocation,
+        # which the library's pool rounds up to whole MiB)
+        B = 70_000
+        scnt = np.array([B + 3 + r + 2 * dd for dd in range(R)], dtype=np.uint64)
+        soff = np.concatenate([[0], np.cumsum(scnt)[:-1]]).astype(np.uint64)
+        rcnt = np.array([B + 3 + s_ + 2 * r for s_ in range(R)], dtype=np.uint64)
+        roff = np.concatenate([[0], np.cumsum(rcnt)[:-1]]).astype(np.uint64)
+        send = np.arange(int(scnt.sum()), dtype=np.uint64) + np.uint64(10_000_000 * r)
+        with lock:
+            d, dx, ds_, dr_ = dalloc(mine.nbytes), dalloc(x.nbytes), dalloc(send.nbytes), dalloc(8 * int(rcnt.sum()))
+            put(d, mine); put(dx, x); put(ds_, send)
+        rc = lib.ncclReduceScatter(d, C.c_void_p(d.value + 4 * W * r), C.c_size_t(W), C.c_int(2), C.c_int(0), comm, None)
+        assert rc == 0, lib.ncclGetErrorString(rc)
+        assert lib.ncclAllReduce(dx, dx, C.c_size_t(77), C.c_int(8), C.c_int(0), comm, None) == 0
+        rc = lib.ncclAllToAllv(ds_, api._ptr(scnt), api._ptr(soff), dr_, api._ptr(rcnt), api._ptr(roff), C.c_int(5), comm, None)
+        assert rc == 0, lib.ncclGetErrorString(rc)
+        with lock:
+            res = dict(mine=mine, after=get(d, np.zeros(R * W, dtype=np.int32)), x=x, xsum=get(dx, np.zeros(77)), send=send, scnt=scnt,
+                       soff=soff, got=get(dr_, np.zeros(int(rcnt.sum()), dtype=np.uint64)), rcnt=rcnt, roff=roff)
+        # misuse 1: displacements in bytes (every rank makes the same mistake) -> the pieces leave the allocation
+        res["bytes_rc"] = lib.ncclAllToAllv(ds_, api._ptr(scnt), api._ptr(soff * np.uint64(8)), dr_, api._ptr(rcnt),
+                                            api._ptr(roff * np.uint64(8)), C.c_int(5), comm, None)
+        return res
+
+    res = two_ranks(good)
+    tot = sum(res[r]["mine"].astype(np.int64) for r in range(R))
+    for r in range(R):
+        a = res[r]
+        assert np.array_equal(a["after"][W * r:W * (r + 1)], tot[W * r:W * (r + 1)])      # my chunk: the sum
+        other = np.ones(R * W, dtype=bool)
+        other[W * r:W * (r + 1)] = False
+        assert np.array_equal(a["after"][other], a["mine"][other])                          # the rest: untouched
+        assert np.array_equal(a["xsum"], res[0]["x"] + res[1]["x"])
+        for s_ in range(R):
+            b = res[s_]
+            piece = b["send"][int(b["soff"][r]):int(b["soff"][r]) + int(b["scnt"][r])]
+            assert np.array_equal(a["got"][int(a["roff"][s_]):int(a["roff"][s_]) + int(a["rcnt"][s_])], piece)
+        assert a["bytes_rc"] != 0
+
+    def mismatch(r, comm):  # misuse 2: rank 1 expects one word more from rank 0 than rank 0 sends
+        scnt, soff = np.array([4, 4], dtype=np.uint64), np.array([0, 4], dtype=np.uint64)
+        rcnt, roff = np.array([4 + (r == 1), 4], dtype=np.uint64), np.array([0, 5], dtype=np.uint64)
+        with lock:
+            ds_, dr_ = dalloc(8 * 8), dalloc(8 * 10)
+        return lib.ncclAllToAllv(ds_, api._ptr(scnt), api._ptr(soff), dr_, api._ptr(rcnt), api._ptr(roff), C.c_int(5), comm, None)
+
+    assert all(rc != 0 for rc in two_ranks(mismatch))
+
+    def overlap(r, comm):  # misuse 3: in place at the WRONG chunk (rank r writes chunk 1 - r)
+        with lock:
+            d = dalloc(4 * R * W)
+        return lib.ncclReduceScatter(d, C.c_void_p(d.value + 4 * W * (1 - r)), C.c_size_t(W), C.c_int(2), C.c_int(0), comm, None)
+
+    assert all(rc != 0 for rc in two_ranks(overlap))
+
+    def different_ops(r, comm):  # a rank in another collective than its peers: on hardware, the classic hang
+        with lock:
+            d = dalloc(4 * R * W)
+        if r == 0:
+            return lib.ncclAllReduce(d, d, C.c_size_t(W), C.c_int(2), C.c_int(0), comm, None)
+        return lib.ncclReduceScatter(d, C.c_void_p(d.value + 4 * W), C.c_size_t(W), C.c_int(2), C.c_int(0), comm, None)
+
+    assert all(rc != 0 for rc in two_ranks(different_ops))
+    ctx.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("ndev", [2, 8])
+def test_mock_rccl_multi_against_oracle(mock_rccl, ndev):
+    """tpg.Multi with device 0 listed ndev times and TPG_MULTI_FORCE_RCCL=1: ncclCommInitAll, then ndev rank threads through
+    ncclReduceScatter (in place at rank offsets, band-padded slabs), the FP64 / int32 ncclAllReduce calls, and -- with the class
+    exchange forced -- ncclAllToAllv with the library's element counts and displacements; results against the oracle.  A child
+    process, because the library loads its RCCL once per process."""
+    r = subprocess.run([sys.executable, "-m", "tests.multi_cases", str(ndev)], cwd=ROOT, capture_output=True, text=True, timeout=800,
+                       env=dict(os.environ, TPG_RCCL_LIBRARY=mock_rccl, TPG_MULTI_FORCE_RCCL="1"))
+    assert r.returncode == 0 and "MOCK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("nproc,exchange,scaling", [(2, False, "strong"), (2, True, "strong"), (4, True, "strong"), (2, False, "weak")])
+def test_mock_rccl_rank_processes_equal_one_gpu(tmp_path, mock_rccl, nproc, exchange, scaling):
+    """`bench.py --gpus N --digest` with one PROCESS per rank, all on device 0, over the mock (TPG_BENCH_SHARE_GPU=rccl):
+    tpg_comm_unique_id -> broadcast -> ncclCommInitRank, the reduce-scatter of the pairwise slabs, the Fst / Gram / GRM-mean
+    all-reduces, tpg_comm_agree's status words and (exchange) ncclAllToAllv -- the digest must equal the 1-GPU digest with the
+    tolerances of the gloo rehearsal, and the line must say which library the collectives ran over."""
+    d1, dn = str(tmp_path / "one.json"), str(tmp_path / "n.json")
+    snps = 60000
+    common = ["--steps", "1", "--warmup", "0", "--indiv", "700", "--pops", "9", "--k", "8", "--no-cpu-baseline",
+              "--no-end-to-end", "--no-standalone", "--scaling", scaling]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    _run([sys.executable, "bench.py", "--gpus", "1", "--digest", d1, "--snps", str(snps)] + common, {})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(nproc), "--digest", dn, "--snps",
+                        str(snps if scaling == "strong" else snps // nproc)] + common, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900, env=dict(env, MASTER_ADDR="127.0.0.1", TPG_BENCH_SHARE_GPU="rccl", TPG_RCCL_LIBRARY=mock_rccl,
+                                                        **({"TPG_GRAM_EXCHANGE": "1"} if exchange else {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == nproc
+    assert "libmock_rccl.so" in line["config"]["collectives"] and "ONE GPU" in line["config"]["collectives"], line["config"]["collectives"]
+    if exchange:
+        assert "all-to-all" in line["config"]["pca_gram_path"], line["config"]["pca_gram_path"]
+    _digests_match(json.load(open(d1)), json.load(open(dn)), exchange)

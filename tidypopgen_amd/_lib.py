@@ -46,6 +46,8 @@ vp = C.c_void_p
 
 lib.tpg_last_error.restype = C.c_char_p
 lib.tpg_version.restype = C.c_char_p
+lib.tpg_comm_transport.restype = C.c_char_p
+lib.tpg_comm_transport.argtypes = [C.c_void_p]
 lib.tpg_pairwise_buffer_bytes.restype = C.c_size_t
 lib.tpg_pairwise_buffer_bytes.argtypes = [C.c_int64]
 lib.tpg_view_n.restype = C.c_int64
@@ -89,7 +91,7 @@ SYMBOLS = [
     "tpg_pairwise_set_as_pad_quirk", "tpg_as_pad_quirk_blocks", "tpg_increment_defer", "tpg_increment_flush", "tpg_resident_drop",
     "tpg_increment_as_note_narrow_block", "tpg_filter_high_relatedness", "tpg_pca_random_svd",
     "tpg_fbm256_valid_prod", "tpg_comm_unique_id", "tpg_comm_init_rank", "tpg_comm_init_host", "tpg_comm_destroy",
-    "tpg_comm_rank", "tpg_comm_size", "tpg_shard_loci", "tpg_comm_allreduce_f64", "tpg_pairwise_buffer_bytes_sharded",
+    "tpg_comm_rank", "tpg_comm_size", "tpg_comm_transport", "tpg_shard_loci", "tpg_comm_allreduce_f64", "tpg_pairwise_buffer_bytes_sharded",
     "tpg_pairwise_create_sharded", "tpg_pairwise_reduce", "tpg_pairwise_band", "tpg_pairwise_band_of", "tpg_pairwise_epilogues_sharded",
     "tpg_pca_partial_svd_sharded", "tpg_multi_create", "tpg_multi_destroy", "tpg_multi_ndev", "tpg_multi_ctx", "tpg_multi_comm", "tpg_multi_pairwise",
     "tpg_multi_grouped_alt_freq", "tpg_multi_pop_fst", "tpg_multi_pca_partial_svd",

@@ -416,6 +416,10 @@ class Comm:
         check(lib.tpg_comm_allreduce_f64(self.ctx.h, self.h, _ptr(buf), C.c_int64(int(count))))
         return buf
 
+    def transport(self) -> str:
+        """'none', 'host callback' or 'rccl: <library as loaded>'"""
+        return lib.tpg_comm_transport(self.h).decode()
+
     def close(self):
         if self.h:
             lib.tpg_comm_destroy(self.h)
@@ -462,6 +466,10 @@ class Multi:
         dv = _i32(devices)
         check(lib.tpg_multi_create(C.c_int(ndev), _ptr(dv), C.byref(h)))
         self.h, self.ndev = h, ndev
+
+    def transport(self) -> str:
+        """transport of the device threads' communicators: 'none', 'host callback' or 'rccl: <library as loaded>'"""
+        return lib.tpg_comm_transport(C.c_void_p(lib.tpg_multi_comm(self.h, C.c_int(0)))).decode()
 
     def pairwise(self, X_bytes, ind_row=None, ind_col=None, which=("ibs", "king", "allele_sharing", "grm"),
                  ibs_type: str = "proportion") -> dict:

@@ -45,17 +45,23 @@ struct RcclApi {
 };
 
 static RcclApi g_rccl;
+static std::string g_rccl_path;  // the name the library was loaded by
 static std::string g_rccl_why;  // why the load failed (dlerror() text, read once: a second dlerror() returns NULL)
 static std::once_flag g_rccl_once;
 
 static void rccl_load() {
   RcclApi& api = g_rccl;
+  // TPG_RCCL_LIBRARY=<path>: load THAT library and nothing else (tests/host/mock_rccl.cpp: the nccl* call sites below with
+  // N > 1 ranks on a one-GPU box, where RCCL refuses a device listed twice; tpg_comm_transport says which library ran)
+  const char* forced = getenv("TPG_RCCL_LIBRARY");
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* nm : names) {
+    if (forced && forced[0]) nm = forced;
     api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-    if (api.handle) break;
+    if (api.handle) { g_rccl_path = nm; break; }
     const char* why = dlerror();
     g_rccl_why = why ? why : "not found";
+    if (forced && forced[0]) break;
   }
   if (!api.handle) return;
 #define RSYM(field, sym)                                                                          \
@@ -188,6 +194,15 @@ extern "C" void tpg_comm_destroy(tpg_comm* comm) {
     }
   }
   comm_delete(comm);
+}
+
+// "none" (one rank: every exchange is the identity), "host callback" (rehearsal), or "rccl: <library as loaded>"
+extern "C" const char* tpg_comm_transport(const tpg_comm* comm) {
+  static thread_local std::string s;
+  if (!comm || (!comm->nccl && !comm->host_fn)) return "none";
+  if (comm->host_fn) return "host callback";
+  s = "rccl: " + g_rccl_path;
+  return s.c_str();
 }
 
 extern "C" int tpg_comm_rank(const tpg_comm* comm) { return comm ? comm->rank : 0; }
@@ -454,7 +469,10 @@ extern "C" int tpg_multi_create(int ndev, const int* devices, tpg_multi** out) {
   }
   std::vector<ncclComm_t> nc((size_t)ndev, nullptr);
   bool host_transport = getenv("TPG_MULTI_HOST_TRANSPORT") && getenv("TPG_MULTI_HOST_TRANSPORT")[0] == '1';
-  for (int i = 0; i < ndev; i++)
+  // a device listed twice: RCCL refuses it, the device threads exchange in process -- unless TPG_MULTI_FORCE_RCCL=1 says the
+  // loaded library takes it (the mock of the tests does: ncclCommInitAll and every nccl* call site then run with ndev ranks)
+  const bool force_rccl = getenv("TPG_MULTI_FORCE_RCCL") && getenv("TPG_MULTI_FORCE_RCCL")[0] == '1';
+  for (int i = 0; i < ndev && !force_rccl; i++)
     for (int j = 0; j < i; j++)
       if (devs[(size_t)i] == devs[(size_t)j]) host_transport = true;
   if (ndev > 1 && host_transport) {

@@ -540,14 +540,22 @@ extern "C" int tpg_pairwise_reduce(tpg_ctx* ctx, tpg_comm* comm, tpg_pairwise* p
   TPG_REQUIRE(!pw->reduced, TPG_EINVAL, "already reduced: zero the accumulators first");
   // the locus count behind the overflow guard is the total over the ranks: known BEFORE the sums are exchanged, so that
   // a panel that is too long is refused with the accumulators intact instead of after they have wrapped
-  double loci = (double)pw->loci;
-  if (comm->nranks > 1 || comm->nccl) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, &loci, 1));
+  // With it travels, per product, the number of ranks that did NOT accumulate it since their last zero: the sums of a product
+  // are complete only if every rank added it (`have` is rank-local; a rank that ran all five products must not pass pw_need
+  // for IBS / KING when another contributed {V, D} alone).
+  const int bits[4] = {TPG_PW_V, TPG_PW_D, TPG_PW_H, TPG_PW_A};
+  double word[5] = {(double)pw->loci, 0, 0, 0, 0};
+  for (int b = 0; b < 4; b++) word[1 + b] = (pw->have & bits[b]) ? 0.0 : 1.0;
+  if (comm->nranks > 1 || comm->nccl) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, word, 5));
+  const double loci = word[0];
   TPG_REQUIRE(loci <= (double)TPG_PW_MAX_LOCI, TPG_EUNSUPPORTED, "%.0f loci over all ranks overflow the int32 pair counts", loci);
   {
     ProfScope ps(ctx, "pairwise_reduce_scatter");
     TPG_TRY(tpg_comm_reduce_scatter_i32(comm, pw->acc, pw->chunk_units * TPG_PW_TILE_INTS));
   }
   pw->loci = (int64_t)loci;
+  for (int b = 0; b < 4; b++)
+    if (word[1 + b] > 0) pw->have &= ~bits[b];
   pw->reduced = true;
   return TPG_OK;
 }
@@ -750,8 +758,8 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
   // the kernels that exist: {V, D}, {V, D, H}, {V, D, A}, all five; anything else takes the smallest one that covers it
   int set = products | TPG_PW_V | TPG_PW_D;
   if ((set & TPG_PW_H) && (set & TPG_PW_A)) set = TPG_PW_ALL;
-  pw->loci += col_end - col_begin;
-  pw->have &= set;
+  // (pw->loci and pw->have are committed at the end, once every launch has been accepted: a failed accumulate must not leave
+  // them claiming work that never ran)
   // the FP4 operand form of the view: written by the pack kernel (tpg_view_create_pair) or made here on first use
   if (!v->T4) {
     TPG_TRY(tpg_view_need_T(ctx, v));
@@ -787,6 +795,8 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
   }
 #undef PW_SET
   TPG_CHECK_LAUNCH();
+  pw->loci += col_end - col_begin;
+  pw->have &= set;
   return TPG_OK;
 }
 

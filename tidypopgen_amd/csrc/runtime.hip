@@ -326,11 +326,10 @@ extern "C" int tpg_dev_to_host(tpg_ctx* ctx, void* host_dst, const void* dev_src
 extern "C" int tpg_dev_from_host(tpg_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && dev_dst && host_src, TPG_EINVAL, "null argument");
-  if (bytes <= tpg_ctx::MAIL_PUSH_MAX) {  // (the caller's buffer is free at return; the copy is in stream order)
-    TPG_HIP(tpg_push_small(ctx, dev_dst, host_src, bytes));
-    return TPG_OK;
-  }
-  TPG_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // public entry point: COMPLETE at return for every size (a caller may consume the buffer from a stream of its own, and a
+  // copy error belongs to this call); the library's own small inputs take tpg_h2d_async, which is only stream-ordered
+  if (bytes <= tpg_ctx::MAIL_PUSH_MAX) TPG_HIP(tpg_push_small(ctx, dev_dst, host_src, bytes));
+  else TPG_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   TPG_HIP(hipStreamSynchronize(ctx->stream));
   return TPG_OK;
 }
@@ -620,9 +619,15 @@ static uint8_t* nib_stage_acquire() {
   if (hipHostMalloc((void**)&p, NIB_CHUNK, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   return p;
 }
+// at most two buffers stay pinned between uploads (the main context's and a pipeline's uploader thread's); a burst of
+// concurrent uploads hands the others back to the system (the two are the process's, like the HIP runtime's own pools: freeing
+// them from a static destructor would race the runtime's teardown)
 static void nib_stage_release(uint8_t* p) {
-  std::lock_guard<std::mutex> lk(g_nib_mu);
-  g_nib_free.push_back(p);
+  {
+    std::lock_guard<std::mutex> lk(g_nib_mu);
+    if (g_nib_free.size() < 2) { g_nib_free.push_back(p); return; }
+  }
+  (void)hipHostFree(p);
 }
 
 static hipError_t tpg_upload_packed(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes) {
@@ -630,7 +635,8 @@ static hipError_t tpg_upload_packed(tpg_ctx* ctx, uint8_t* dst, const uint8_t* s
   if (!pinned) return tpg_upload(ctx, dst, src, bytes);  // no pinned memory to be had: the plain copy
   struct Back { uint8_t* p; ~Back() { nib_stage_release(p); } } back{pinned};
   uint8_t* d_stage = nullptr;
-  hipError_t e = tpg_pmalloc((void**)&d_stage, NIB_CHUNK);  // two halves, like the pinned buffer
+  // two halves, like the pinned buffer; a payload of one chunk needs its own packed size only
+  hipError_t e = tpg_pmalloc((void**)&d_stage, bytes <= NIB_CHUNK ? std::max<size_t>(bytes / 2, 16) : NIB_CHUNK);
   if (e != hipSuccess) { (void)hipGetLastError(); return tpg_upload(ctx, dst, src, bytes); }  // HBM is that full: the plain copy
   hipEvent_t ev[2] = {nullptr, nullptr};
   for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
