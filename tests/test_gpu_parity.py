@@ -347,7 +347,7 @@ def test_pairwise_counts_bit_exact_and_epilogues(tpg, monkeypatch, n, m, miss, v
     assert np.array_equal(pw.epilogues(which=("grm",))["grm"], ep["grm"], equal_nan=True)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 13, 14, 16])  # 13 ... 16: operands shared through LDS (3 ... 6 stages)
 @pytest.mark.parametrize("which", ["as", "ibs", "king"])
 @pytest.mark.parametrize("n,m,miss", [(1, 1, 0.0), (65, 129, 0.05), (130, 700, 0.3), (333, 5001, 0.1), (500, 8000, 0.02)])
 def test_pairwise_product_sets_bit_exact(tpg, monkeypatch, n, m, miss, which, variant):

@@ -332,7 +332,9 @@ __device__ __forceinline__ void tpg_unrolled_steps(F& step, int kb, std::integer
   (step(std::integral_constant<int, Ss>{}, kb + Ss), ...);
 }
 
-template <int RA, int RB, int MASK, int NS>
+// DBG (timing experiments only, wrong sums; TPG_PW_VARIANT=21 / 22): 1 = the loads of the loop removed (the slots keep what the
+// prologue fetched), 2 = the plane masks of the loop removed as well (the MFMAs run on the first block's planes)
+template <int RA, int RB, int MASK, int NS, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* __restrict__ T4, int64_t KG,
                                                                      int64_t kb_begin, int64_t kb_end, int nst, int nct,
                                                                      const int2* __restrict__ order, int64_t nun, int S,
@@ -393,17 +395,20 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
       }
       Frag3 P[2][NT];
 #pragma unroll
-      for (int t = 0; t < NT; t++) P[0][t] = tpg_planes_of<MASK>(R[0][t], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
+      for (int t = 0; t < NT; t++) {
+        P[0][t] = tpg_planes_of<MASK>(R[0][t], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
+        if constexpr (DBG == 2) P[1][t] = tpg_planes_of<MASK>(R[1][t], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
+      }
       auto step = [&](auto Sc, int kb) {
         constexpr int s = decltype(Sc)::value, cur = s & 1, nx = cur ^ 1, sl = (s + 1) % NS, ld = (s + NS - 1) % NS;
         // the slot whose planes were taken in the previous step is free: block kb + NS - 1
-        LDB(R[ld], kb + NS - 1 < kb1 ? kb + NS - 1 : kl);
+        if constexpr (DBG == 0) LDB(R[ld], kb + NS - 1 < kb1 ? kb + NS - 1 : kl);
         // planes of the next block (zero A planes past the K range: the tail of the last unrolled body adds nothing)
         const bool live1 = kb + 1 < kb1;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
           const bool keep = t >= RA || live1;
-          P[nx][t] = tpg_planes_of<MASK>(R[sl][t], keep ? TPG_NIB_V : 0u, keep ? TPG_NIB_D : 0u, keep ? TPG_NIB_H : 0u);
+          if constexpr (DBG < 2) P[nx][t] = tpg_planes_of<MASK>(R[sl][t], keep ? TPG_NIB_V : 0u, keep ? TPG_NIB_D : 0u, keep ? TPG_NIB_H : 0u);
         }
 #pragma unroll
         for (int a = 0; a < RA; a++)
@@ -432,6 +437,197 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
 #pragma unroll
       for (int b = 0; b < RB; b++) {
         const int rt = RA * I + a, ct = RB * J + b;
+        if (rt < nct && ct < nct && ct >= rt) {
+          const int I3 = rt / TA, a3 = rt - TA * I3;
+          int32_t* slab = acc_out + (tpg_pw_unit_index(nst, I3, ct) + rowpad[I3]) * TPG_PW_TILE_INTS + a3 * 16 * 64 + lane;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            if constexpr (PS::pV) atomicAdd(slab + 0 * TPG_PW_PLANE_INTS + r * 64, (int)cV[a][b][r]);
+            if constexpr (PS::pD) atomicAdd(slab + 1 * TPG_PW_PLANE_INTS + r * 64, (int)cD[a][b][r]);
+            if constexpr (PS::pH) atomicAdd(slab + 2 * TPG_PW_PLANE_INTS + r * 64, (int)cH[a][b][r]);
+            if constexpr (PS::pA) atomicAdd(slab + 3 * TPG_PW_PLANE_INTS + r * 64, (int)cHV[a][b][r]);
+            if constexpr (PS::pA) atomicAdd(slab + 4 * TPG_PW_PLANE_INTS + r * 64, (int)cVH[a][b][r]);
+          }
+        }
+      }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// The product-set kernels with the operands SHARED by the four waves of a workgroup (round 5).  tpg_pairwise_set_kernel is
+// bound on the L2 -> CU path (every wave fetches its own RA + RB fragments per 64 loci: 146 - 195 GB per launch, 16 TB/s: what
+// the 8 XCDs deliver), not on the matrix cores.  Here a workgroup of 2 x 2 waves owns a (64 RA) x (64 RB) block of pairs; the
+// 2 RA + 2 RB fragments of a 64-locus block cross the L2 -> CU path ONCE (half the bytes per MFMA) by LDS-DMA
+// (global_load_lds_dwordx4: one 1-KiB fragment per wave instruction, no VGPR, no VALU, no ds_write), every wave issuing a
+// quarter of them, into a ring of NST stages in LDS; a wave reads its RA + RB fragments from the ring (ds_read_b128,
+// lane-linear: conflict-free) one block ahead of its MFMAs.  One s_barrier per block: behind it block b + 1 is complete in LDS
+// and the stage of block b is free for block b + NST.  Every stage is its OWN __shared__ array and the loop is unrolled over
+// the ring, so that hipcc's wait-count pass can tell the LDS-DMA into one stage from the reads of another (alias scopes per
+// LDS variable): a single array would make every ds_read wait for every DMA in flight, vmcnt(0), i.e. no prefetch at all.
+// Same T4 operands, same slabs, same atomics as the other kernels.
+template <typename F, int... Is>
+__device__ __forceinline__ void tpg_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void tpg_static_for(F&& f) {
+  tpg_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// s_waitcnt immediate of gfx9: vmcnt in bits [3:0] and [15:14], expcnt [6:4] and lgkmcnt [11:8] left at "do not wait"
+constexpr int tpg_waitcnt_vm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | (((n >> 4) & 3) << 14); }
+#define SGB_DS_READ 0x100
+
+template <int RA, int RB, int MASK, int NST>
+__global__ __launch_bounds__(256, 1) void tpg_pairwise_wg_kernel(const uint4* __restrict__ T4, int64_t KG, int64_t kb_begin,
+                                                                    int64_t kb_end, int nst, int nct, const int2* __restrict__ order,
+                                                                    int64_t nun, int S, const int64_t* __restrict__ rowpad,
+                                                                    int32_t* __restrict__ acc_out) {
+  using PS = PwSet<MASK>;
+  constexpr int NFW = 2 * RA + 2 * RB;           // fragments of the workgroup per 64 loci
+  constexpr int NLD = NFW / 4;                   // ... of which a wave fetches this many
+  static_assert(NFW % 4 == 0, "the fragments of a block are dealt evenly to the four waves");
+  constexpr int NT = RA + RB;                    // fragments a wave consumes per 64 loci
+  constexpr int NM = RA * RB * PS::NP;           // MFMAs per wave and 64 loci
+  constexpr int NV = NT * 4 * PS::NPL;           // plane masks per wave and 64 loci
+  constexpr int STB = NFW * 1024;                // bytes of a stage
+  typedef char __attribute__((address_space(3)))* lds_t;
+  typedef const char __attribute__((address_space(1)))* glb_t;
+  // one LDS variable per stage (see above); the unrolled step picks its stage at compile time
+  __shared__ __attribute__((aligned(16))) char st0[STB], st1[STB], st2[STB], st3[NST > 3 ? STB : 16], st4[NST > 4 ? STB : 16],
+      st5[NST > 5 ? STB : 16];
+  static_assert(NST >= 4 && NST <= 6, "4 to 6 stages");
+  auto stage = [&](auto Sc) -> lds_t {
+    constexpr int s = decltype(Sc)::value;
+    if constexpr (s == 0) return (lds_t)st0;
+    else if constexpr (s == 1) return (lds_t)st1;
+    else if constexpr (s == 2) return (lds_t)st2;
+    else if constexpr (s == 3) return (lds_t)st3;
+    else if constexpr (s == 4) return (lds_t)st4;
+    else return (lds_t)st5;
+  };
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wa = wv >> 1, wb = wv & 1;
+  const int64_t kbs = kb_end - kb_begin;
+  const int xcd = blockIdx.x & 7, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+  const int sc1 = TPG_SC_ONE, sc2 = TPG_SC_TWO, sch = TPG_SC_HALF;
+  for (int64_t round = 0;; round++) {
+    const int64_t un = (round * 8 + xcd) * cpx + cidx;  // one unit per WORKGROUP
+    if (un >= nun * S) break;
+    const int ks = (int)(un / nun);
+    const int2 ij = order[un % nun];
+    const int I = __builtin_amdgcn_readfirstlane(ij.x), J = __builtin_amdgcn_readfirstlane(ij.y);
+    const int kb0 = __builtin_amdgcn_readfirstlane((int)(kb_begin + (kbs * ks) / S));
+    const int kb1 = __builtin_amdgcn_readfirstlane((int)(kb_begin + (kbs * (ks + 1)) / S));
+    // fragment f of the workgroup: f < 2 RA: A row tile 2 RA I + f; else B row tile 2 RB J + (f - 2 RA).  A tile past the last
+    // one with data reads tile 0 instead; what it yields is never stored.  Wave wv fetches fragments NLD wv .. NLD wv + NLD - 1.
+    glb_t src[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; q++) {
+      const int f = NLD * wv + q;
+      const int tile = f < 2 * RA ? 2 * RA * I + f : 2 * RB * J + (f - 2 * RA);
+      src[q] = (glb_t)(T4 + ((int64_t)(tile < nct ? tile : 0) * KG * 2 + kb0) * 64);
+    }
+    v16f cV[RA][RB], cD[RA][RB], cH[RA][RB], cHV[RA][RB], cVH[RA][RB];
+#pragma unroll
+    for (int a = 0; a < RA; a++)
+#pragma unroll
+      for (int b = 0; b < RB; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { cV[a][b][r] = 0.f; cD[a][b][r] = 0.f; cH[a][b][r] = 0.f; cHV[a][b][r] = 0.f; cVH[a][b][r] = 0.f; }
+
+    if (kb0 < kb1) {
+      const int kl = kb1 - 1;
+      // the previous unit's last reads of the ring are behind every wave before anything is written into it again
+      __builtin_amdgcn_s_barrier();
+      auto DMA = [&](auto Sc, int b) {  // this wave's share of block b -> stage Sc
+        uint32_t off = (uint32_t)lane * 16u + (uint32_t)(b - kb0) * 1024u;
+        asm("" : "+v"(off));
+        lds_t dst = stage(Sc);
+#pragma unroll
+        for (int q = 0; q < NLD; q++)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src[q] + off),
+                                           (void __attribute__((address_space(3)))*)(dst + (NLD * wv + q) * 1024), 16, 0, 0);
+      };
+      auto RD = [&](auto Sc, v4u* w) {  // this wave's RA + RB fragments out of stage Sc
+        lds_t base = stage(Sc);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const int f = t < RA ? RA * wa + t : 2 * RA + RB * wb + (t - RA);
+          w[t] = *(const v4u __attribute__((address_space(3)))*)(base + f * 1024 + lane * 16);
+        }
+      };
+      // prologue: blocks kb0 .. kb0 + NST - 1 on their way (clamped to the last block of the range: the counts below rely on
+      // every step issuing its loads)
+      tpg_static_for<NST>([&](auto Sc) {
+        constexpr int s = decltype(Sc)::value;
+        DMA(Sc, kb0 + s < kb1 ? kb0 + s : kl);
+      });
+      // The ring is read TWO blocks ahead of the MFMAs, the planes are masked ONE block ahead: right behind the barrier all four
+      // waves read at once (24 KiB per block: ~100 cycles of the LDS array + its latency), and with the reads one block ahead
+      // the first plane mask of a step -- and every MFMA behind it: a wave issues in order -- waited for them (9.0 - 9.3 ms
+      // against 8.4 for the kernel without LDS; measured).  W[q] holds block kb0 + q (mod 2).
+      // vmcnt counts this wave's DMAs in order: blocks kb0, kb0 + 1 have landed when at most NLD (NST - 2) younger ones fly
+      __builtin_amdgcn_s_waitcnt(tpg_waitcnt_vm(NLD * (NST - 2)));
+      __builtin_amdgcn_s_barrier();
+      v4u W[2][NT];
+      RD(std::integral_constant<int, 0>{}, W[0]);
+      RD(std::integral_constant<int, 1>{}, W[1]);
+      Frag3 P[2][NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) P[0][t] = tpg_planes_of<MASK>(W[0][t], TPG_NIB_V, TPG_NIB_D, TPG_NIB_H);
+      auto step = [&](auto Sc, auto Cc, int kb) {  // block kb: stage s, planes in P[cur]; block kb + 1: words in W[cur ^ 1]
+        constexpr int s = decltype(Sc)::value, cur = decltype(Cc)::value, nx = cur ^ 1, s2 = (s + 2) % NST;
+        // my pieces of block kb + 2 have landed (younger DMAs: blocks kb + 3 .. kb + NST - 1); behind the barrier everybody's
+        // have, and everybody has read block kb (two steps ago): its stage takes block kb + NST
+        __builtin_amdgcn_s_waitcnt(tpg_waitcnt_vm(NLD * (NST - 3)));
+        __builtin_amdgcn_s_barrier();
+        DMA(Sc, kb + NST < kb1 ? kb + NST : kl);
+        const bool live1 = kb + 1 < kb1;  // past the K range: zero A planes, the tail of the last unrolled body adds nothing
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const bool keep = t >= RA || live1;
+          P[nx][t] = tpg_planes_of<MASK>(W[nx][t], keep ? TPG_NIB_V : 0u, keep ? TPG_NIB_D : 0u, keep ? TPG_NIB_H : 0u);
+        }
+        // (W[cur] held block kb: masked a step ago)
+        RD(std::integral_constant<int, s2>{}, W[cur]);
+#pragma unroll
+        for (int a = 0; a < RA; a++)
+#pragma unroll
+          for (int b = 0; b < RB; b++) {
+            if constexpr (PS::pV) cV[a][b] = MFMA_F4(P[cur][a].v, P[cur][RA + b].v, cV[a][b], sc1, sc1);
+            if constexpr (PS::pD) cD[a][b] = MFMA_F4(P[cur][a].d, P[cur][RA + b].d, cD[a][b], sch, sch);
+            if constexpr (PS::pH) cH[a][b] = MFMA_F4(P[cur][a].h, P[cur][RA + b].h, cH[a][b], sc2, sc2);
+            if constexpr (PS::pA) cHV[a][b] = MFMA_F4(P[cur][a].h, P[cur][RA + b].v, cHV[a][b], sc2, sc1);
+            if constexpr (PS::pA) cVH[a][b] = MFMA_F4(P[cur][a].v, P[cur][RA + b].h, cVH[a][b], sc1, sc2);
+          }
+        // the DMAs and the ring reads spread over the first MFMAs, the plane masks between all of them
+        __builtin_amdgcn_sched_group_barrier(SGB_VMEM_READ, NLD, 0);
+#pragma unroll
+        for (int q = 0; q < NM; q++) {
+          __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(SGB_VALU, (NV + NM - 1) / NM + 1, 0);
+          // (the first masks wait for the words read a step ago, lgkmcnt(0): no read of THIS step may stand in front of them)
+          if (q >= 1 && q <= NT) __builtin_amdgcn_sched_group_barrier(SGB_DS_READ, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      constexpr int U = (NST % 2 == 0) ? NST : 2 * NST;  // stages and plane sets both come round
+      for (int kb = kb0; kb < kb1; kb += U)
+        tpg_static_for<U>([&](auto Uc) {
+          constexpr int u = decltype(Uc)::value;
+          // (a body of 2 NST steps walks the ring twice: the stage of step u is u mod NST, its plane set u & 1)
+          step(std::integral_constant<int, u % NST>{}, std::integral_constant<int, u & 1>{}, kb + u);
+        });
+      // drain: nothing of this unit is in flight when the next one (or the end of the kernel) comes
+      __builtin_amdgcn_s_waitcnt(tpg_waitcnt_vm(0));
+    }
+#pragma unroll
+    for (int a = 0; a < RA; a++)
+#pragma unroll
+      for (int b = 0; b < RB; b++) {
+        const int rt = 2 * RA * I + RA * wa + a, ct = 2 * RB * J + RB * wb + b;
         if (rt < nct && ct < nct && ct >= rt) {
           const int I3 = rt / TA, a3 = rt - TA * I3;
           int32_t* slab = acc_out + (tpg_pw_unit_index(nst, I3, ct) + rowpad[I3]) * TPG_PW_TILE_INTS + a3 * 16 * 64 + lane;
@@ -678,7 +874,7 @@ static int pw_ksplit(int64_t nun, int64_t steps, int64_t min_steps_per_unit, int
   return bestS;
 }
 
-template <int RA, int RB, int MASK, int NS>
+template <int RA, int RB, int MASK, int NS, int DBG = 0>
 static int pw_launch_set(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t kg0, int64_t kg1, const char* name) {
   const int2* d_order = nullptr;
   int64_t nun = 0;
@@ -692,9 +888,33 @@ static int pw_launch_set(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int6
     const int64_t c1 = std::min(kg1, c0 + 8 * max_groups);
     const int64_t kgs = c1 - c0;
     // per 64-locus block: NM MFMAs at ~18 ns; flush: 16 atomic wave-instructions per accumulator tile (12 us for 15)
-    const int S = pw_ksplit(nun, 2 * kgs, 16, ceil_div(kgs, max_groups), nwaves, 0.0183 * NM, 0.8 * NM);
+    int S = pw_ksplit(nun, 2 * kgs, 16, ceil_div(kgs, max_groups), nwaves, 0.0183 * NM, 0.8 * NM);
+    if (const char* e = getenv("TPG_PW_KSPLIT")) S = std::max<int>((int)ceil_div(kgs, max_groups), atoi(e));
     if (getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] %s: %d x %d tiles, %lld units, S = %d\n", name, RA, RB, (long long)nun, S);
-    TPG_LAUNCH(ctx, name, (tpg_pairwise_set_kernel<RA, RB, MASK, NS>), dim3((unsigned)nblk), dim3(256), 0,
+    TPG_LAUNCH(ctx, name, (tpg_pairwise_set_kernel<RA, RB, MASK, NS, DBG>), dim3((unsigned)nblk), dim3(256), 0,
+               (const uint4*)v->T4, v->KG, 2 * c0, 2 * c1, (int)pw->nst, (int)ceil_div(pw->n, 32), d_order, nun, S,
+               (const int64_t*)pw->rowpad, pw->acc);
+  }
+  return TPG_OK;
+}
+
+// the workgroup form: units are (64 RA) x (64 RB) blocks of pairs, one per workgroup; TPG_PW_KSPLIT=<S> overrides the K split
+template <int RA, int RB, int MASK, int NST>
+static int pw_launch_wg(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t kg0, int64_t kg1, const char* name) {
+  const int2* d_order = nullptr;
+  int64_t nun = 0;
+  TPG_TRY(pw_order_for(ctx, pw, 2 * RA, 2 * RB, &d_order, &nun));
+  constexpr int NM = RA * RB * PwSet<MASK>::NP;
+  const int64_t max_groups = 131072;  // 2^24 loci per unit: FP32 sums of integers stay exact
+  int nblk = ctx->num_cu / 8 * 8;
+  if (nblk < 8) nblk = 8;
+  for (int64_t c0 = kg0; c0 < kg1; c0 += 8 * max_groups) {
+    const int64_t c1 = std::min(kg1, c0 + 8 * max_groups);
+    const int64_t kgs = c1 - c0;
+    int S = pw_ksplit(nun, 2 * kgs, 16, ceil_div(kgs, max_groups), nblk, 0.0183 * NM, 0.8 * NM);
+    if (const char* e = getenv("TPG_PW_KSPLIT")) S = std::max<int>((int)ceil_div(kgs, max_groups), atoi(e));
+    if (getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] %s: workgroups of %d x %d tiles, %lld units, S = %d\n", name, 2 * RA, 2 * RB, (long long)nun, S);
+    TPG_LAUNCH(ctx, name, (tpg_pairwise_wg_kernel<RA, RB, MASK, NST>), dim3((unsigned)nblk), dim3(256), 0,
                (const uint4*)v->T4, v->KG, 2 * c0, 2 * c1, (int)pw->nst, (int)ceil_div(pw->n, 32), d_order, nun, S,
                (const int64_t*)pw->rowpad, pw->acc);
   }
@@ -777,8 +997,21 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
   // 96 x 64 9.8, 64 x 64 11.8; {V, D, H} 64 x 64 with 5 / 4 / 3 / 6 / 7 slots 13.6 / 14.3 / 22.6 / 13.9 / 14.0, 96 x 32 15.7;
   // {V, D, A} 64 x 64 with 5 / 4 / 3 / 6 slots 16.2 / 16.5 / 23.5 / 16.4, 128 x 32 17.9, 96 x 32 17.8; all five through
   // this template (96 x 32, 4 ... 7 slots) 20.2 - 21.8 against 19.5 for the kernel above with its two-block groups
-  if (set == TPG_PW_FOR_AS) {
-    if (var == 1) PW_SET(4, 2, TPG_PW_FOR_AS, 4, "pairwise_mfma_as");
+#define PW_WG(RA, RB, MASK, NST, name) TPG_TRY((pw_launch_wg<RA, RB, MASK, NST>(ctx, pw, v, kg0, kg1, name)))
+  if (set == TPG_PW_FOR_AS && var >= 10) {        // operands shared through LDS (round 5): 14 / 15 / 16 = 4 / 5 / 6 stages
+    if (var == 15) PW_WG(4, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
+    else if (var == 16) PW_WG(4, 2, TPG_PW_FOR_AS, 6, "pairwise_mfma_as");
+    else PW_WG(4, 2, TPG_PW_FOR_AS, 4, "pairwise_mfma_as");
+  } else if (set == TPG_PW_FOR_IBS && var >= 10) {
+    if (var == 16) PW_WG(2, 2, TPG_PW_FOR_IBS, 6, "pairwise_mfma_ibs");
+    else PW_WG(2, 2, TPG_PW_FOR_IBS, 4, "pairwise_mfma_ibs");
+  } else if (set == TPG_PW_FOR_KING && var >= 10) {
+    if (var == 16) PW_WG(2, 2, TPG_PW_FOR_KING, 6, "pairwise_mfma_king");
+    else PW_WG(2, 2, TPG_PW_FOR_KING, 4, "pairwise_mfma_king");
+  } else if (set == TPG_PW_FOR_AS) {
+    if (var == 21) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 5, 1>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));       // timing only
+    else if (var == 22) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 5, 2>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));  // timing only
+    else if (var == 1) PW_SET(4, 2, TPG_PW_FOR_AS, 4, "pairwise_mfma_as");
     else if (var == 2) PW_SET(3, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
     else PW_SET(4, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
   } else if (set == TPG_PW_FOR_IBS) {
@@ -794,6 +1027,7 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
     else TPG_TRY(pw_launch_all(ctx, pw, v, kg0, kg1));
   }
 #undef PW_SET
+#undef PW_WG
   TPG_CHECK_LAUNCH();
   pw->loci += col_end - col_begin;
   pw->have &= set;
