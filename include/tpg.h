@@ -97,6 +97,11 @@ int tpg_fbm_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t ncol, int64
  * to).  n / m are the line counts of the .fam / .bim files.  `bytes` is the payload after the 3-byte magic. */
 int tpg_fbm_open_bed(tpg_ctx* ctx, const char* path, int64_t n, int64_t m, tpg_fbm** out);
 int tpg_fbm_from_bed_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t n, int64_t m, tpg_fbm** out);
+/* the same store filled block of SNPs by block of SNPs (the .bed form of tpg_fbm_alloc / tpg_fbm_upload_cols: a block of SNPs
+ * is one contiguous piece of the payload, ceil(n / 4) bytes per SNP): an uploader thread with a context of its own feeds
+ * block b + 1 while views of block b are packed and analysed */
+int tpg_fbm_alloc_bed(tpg_ctx* ctx, int64_t n, int64_t m, tpg_fbm** out);
+int tpg_fbm_upload_bed_snps(tpg_ctx* ctx, tpg_fbm* fbm, const uint8_t* host_snps, int64_t snp0, int64_t nsnps);
 int tpg_fbm_to_host(tpg_ctx* ctx, const tpg_fbm* fbm, uint8_t* bytes);
 void tpg_fbm_free(tpg_fbm* fbm);
 

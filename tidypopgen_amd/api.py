@@ -184,6 +184,21 @@ class FBM:
         return cls(ctx, h, n, m, code256)
 
     @classmethod
+    def alloc_bed(cls, n: int, m: int, ctx: Optional[Context] = None, code256=None) -> "FBM":
+        """HBM for a .bed store whose SNPs arrive block by block (upload_bed_snps)"""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib.tpg_fbm_alloc_bed(ctx.h, C.c_int64(n), C.c_int64(m), C.byref(h)))
+        return cls(ctx, h, n, m, code256)
+
+    def upload_bed_snps(self, host_bytes, snp0: int, nsnps: int, ctx: Optional[Context] = None):
+        """SNPs [snp0, snp0 + nsnps) <- nsnps * ceil(n / 4) payload bytes (e.g. a slice of a numpy memmap of the .bed behind
+        its 3-byte magic); another Context (another stream) runs the upload beside kernels of this store's own context"""
+        a = np.asarray(host_bytes)
+        assert a.dtype == np.uint8 and a.flags.c_contiguous and a.size == nsnps * ((self.nrow + 3) // 4)
+        check(lib.tpg_fbm_upload_bed_snps((ctx or self.ctx).h, self.h, _ptr(a), C.c_int64(snp0), C.c_int64(nsnps)))
+
+    @classmethod
     def synth(cls, seed: int, nrow: int, ncol: int, j0: int = 0, npop: int = 51, miss: float = 0.02,
               imputed_bytes: bool = False, ctx: Optional[Context] = None, code256=None) -> "FBM":
         ctx = ctx or default_context()

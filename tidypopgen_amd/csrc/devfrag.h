@@ -21,9 +21,43 @@ __device__ __forceinline__ int tpg_lut(uint32_t lut, uint32_t codes) {
   return (int)__builtin_amdgcn_perm(0u, lut, codes);
 }
 
-// FP4 operand nibble of the pairwise kernel (pairwise.hip): bit 0 heterozygous, bit 1 typed, bit 2 homozygous, bit 3
-// dosage 0.  2-bit code -> nibble: dosage 0 -> 0xE, 1 -> 0x3, 2 -> 0x6, missing -> 0
-#define TPG_NIB_LUT 0x0006030Eu
+// FP4 operand nibble of the pairwise kernel (pairwise.hip): one magnitude bit per operand plane -- 0x1 = FP4 0.5, 0x2 = 1.0,
+// 0x4 = 2.0 -- for heterozygous (h), typed (v) and homozygous (d), bit 3 = the sign of d (dosage 0).  Which plane takes which
+// magnitude does not change a single sum (the E8M0 block scales undo it: TPG_T4_SC_*), only the bit patterns the matrix cores
+// multiply -- and their clock under the MFMAs is a POWER limit that depends on those (tools/pw_power_probe.py), so the
+// assignment is a compile-time choice that was measured (TPG_T4_ENC, tools/enc_ab.py): 0 = h 0.5, v 1, d 2 (rounds 2 - 4).
+#ifndef TPG_T4_ENC
+#define TPG_T4_ENC 0
+#endif
+#if TPG_T4_ENC == 0
+#define TPG_T4_MH 1u
+#define TPG_T4_MV 2u
+#define TPG_T4_MD 4u
+#elif TPG_T4_ENC == 1
+#define TPG_T4_MH 1u
+#define TPG_T4_MV 4u
+#define TPG_T4_MD 2u
+#elif TPG_T4_ENC == 2
+#define TPG_T4_MH 2u
+#define TPG_T4_MV 1u
+#define TPG_T4_MD 4u
+#elif TPG_T4_ENC == 3
+#define TPG_T4_MH 2u
+#define TPG_T4_MV 4u
+#define TPG_T4_MD 1u
+#elif TPG_T4_ENC == 4
+#define TPG_T4_MH 4u
+#define TPG_T4_MV 1u
+#define TPG_T4_MD 2u
+#else
+#define TPG_T4_MH 4u
+#define TPG_T4_MV 2u
+#define TPG_T4_MD 1u
+#endif
+// 2-bit code -> nibble: dosage 0 -> v | d | sign, 1 -> v | h, 2 -> v | d, missing -> 0  (0x0006030E for TPG_T4_ENC = 0)
+#define TPG_NIB_LUT ((TPG_T4_MV | TPG_T4_MD | 8u) | ((TPG_T4_MV | TPG_T4_MH) << 8) | ((TPG_T4_MV | TPG_T4_MD) << 16))
+// E8M0 block scale (all four bytes equal) that turns a plane of magnitude bit M into 0 / +-1: 0.5 x 2, 1 x 1, 2 x 0.5
+#define TPG_T4_SC(M) ((M) == 1u ? (int)0x80808080 : (M) == 2u ? 0x7f7f7f7f : 0x7e7e7e7e)
 // one T dword (16 codes) -> two T4 dwords (16 nibbles)
 __device__ __forceinline__ void tpg_t4_words(uint32_t w, uint32_t& lo, uint32_t& hi) {
   uint32_t nb[4];

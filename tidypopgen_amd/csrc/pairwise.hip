@@ -53,13 +53,14 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-#define TPG_NIB_V 0x22222222u
-#define TPG_NIB_H 0x11111111u
-#define TPG_NIB_D 0xCCCCCCCCu
-// E8M0 block scales (one byte per 32 contracted elements; all four bytes equal, so the byte select does not matter)
-#define TPG_SC_ONE 0x7f7f7f7f
-#define TPG_SC_TWO 0x80808080
-#define TPG_SC_HALF 0x7e7e7e7e
+#define TPG_NIB_V (TPG_T4_MV * 0x11111111u)
+#define TPG_NIB_H (TPG_T4_MH * 0x11111111u)
+#define TPG_NIB_D ((TPG_T4_MD | 8u) * 0x11111111u)
+// E8M0 block scales (one byte per 32 contracted elements; all four bytes equal, so the byte select does not matter): the
+// kernels' sc1 / sc2 / sch are the scales of the v / h / d planes (1, 2, 1/2 with the encoding of rounds 2 - 4)
+#define TPG_SC_ONE TPG_T4_SC(TPG_T4_MV)
+#define TPG_SC_TWO TPG_T4_SC(TPG_T4_MH)
+#define TPG_SC_HALF TPG_T4_SC(TPG_T4_MD)
 
 __device__ __forceinline__ v8i tpg_w8(v4i a) { return v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0}; }
 // FP4 x FP4 (format code 4), 32 x 32 x 64

@@ -542,9 +542,56 @@ static void xfer_parallel(size_t bytes, F f) {
   for (auto& t : th) t.join();
 }
 
+static uint8_t* nib_stage_acquire();
+static void nib_stage_release(uint8_t* p);
+static constexpr size_t XFER_PIECE = 64u << 20;  // a quarter of the process's pinned staging buffer (NIB_CHUNK)
+
+// device memory -> host memory the caller owns (pageable), large: through the process's pinned staging buffer in four pieces
+// of 64 MiB -- the copy engine fills piece i + 1 ... i + 3 (55 GB/s into pinned memory) while the team of threads moves piece
+// i into the caller's pages, which is also what faults those pages in (no separate pass over them).  The runtime's own path
+// for a pageable destination (round 4: parallel page touch, then one hipMemcpy) moved the bytes at 45 - 53 GB/s but left the
+// runtime with something to undo: the NEXT device -> host copy of the process, or the exit of the thread, stood still for
+// 45 - 48 ms after 1.4 GB had gone down that way (seen with the end-to-end routes' downloads beside the step; bench.py
+// TPG_E2E_TRACE=1).  TPG_DOWNLOAD_PINNED=0: the old path (A/B).
+static hipError_t tpg_download_pinned(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes, bool* done) {
+  *done = false;
+  static const bool off = getenv("TPG_DOWNLOAD_PINNED") && atoi(getenv("TPG_DOWNLOAD_PINNED")) == 0;
+  uint8_t* const pinned = off ? nullptr : nib_stage_acquire();
+  if (!pinned) return hipSuccess;
+  struct Back { uint8_t* p; ~Back() { nib_stage_release(p); } } back{pinned};
+  const size_t H = XFER_PIECE, np = (bytes + H - 1) / H;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+  auto issue = [&](size_t i) -> hipError_t {
+    const size_t a = i * H, len = std::min(bytes - a, H);
+    hipError_t r = hipMemcpyAsync(pinned + (i & 3) * H, src + a, len, hipMemcpyDeviceToHost, ctx->stream);
+    return r == hipSuccess ? hipEventRecord(ev[i & 3], ctx->stream) : r;
+  };
+  for (size_t i = 0; i < np && i < 4 && e == hipSuccess; i++) e = issue(i);
+  for (size_t i = 0; i < np && e == hipSuccess; i++) {
+    e = hipEventSynchronize(ev[i & 3]);
+    if (e != hipSuccess) break;
+    const size_t a = i * H, len = std::min(bytes - a, H);
+    const uint8_t* pin = pinned + (i & 3) * H;
+    xfer_parallel(len, [=](int, size_t lo, size_t hi) { memcpy(dst + a + lo, pin + lo, hi - lo); });
+    if (i + 4 < np) e = issue(i + 4);
+  }
+  if (e != hipSuccess) (void)hipStreamSynchronize(ctx->stream);
+  for (int q = 0; q < 4; q++)
+    if (ev[q]) (void)hipEventDestroy(ev[q]);
+  *done = e == hipSuccess;
+  return e;
+}
+
 // device memory -> host memory the caller owns (pageable)
 hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes <= tpg_ctx::MAIL_FETCH_BYTES) return tpg_fetch_small(ctx, dst, src, bytes);  // (falls back to the copy engine by itself)
+  if (bytes >= (256u << 10)) {
+    bool done = false;
+    const hipError_t e = tpg_download_pinned(ctx, (uint8_t*)dst, (const uint8_t*)src, bytes, &done);
+    if (e != hipSuccess || done) return e;
+  }
   if (bytes >= XFER_BIG) {  // make the pages present (the buffer is about to be overwritten anyway)
     volatile uint8_t* d = (volatile uint8_t*)dst;
     xfer_parallel(bytes, [=](int, size_t lo, size_t hi) { for (size_t o = lo; o < hi; o += 4096) d[o] = 0; });
@@ -688,6 +735,38 @@ static hipError_t tpg_upload_packed(tpg_ctx* ctx, uint8_t* dst, const uint8_t* s
   return e;
 }
 
+// The same pipeline WITHOUT the packing, for bytes that are already dense (a PLINK .bed payload: 2 bits per genotype): the
+// team copies chunk c + 1 of the source (a file mapping: 39 - 46 GB/s when the DMA reads it directly, page faults included)
+// into one half of the pinned buffer while chunk c leaves the other half at the rate of pinned memory (55 - 57 GB/s).
+// TPG_UPLOAD_PINNED=0: the plain chunked copy (A/B).
+static hipError_t tpg_upload_pinned(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes) {
+  static const bool off = getenv("TPG_UPLOAD_PINNED") && atoi(getenv("TPG_UPLOAD_PINNED")) == 0;
+  uint8_t* const pinned = off ? nullptr : nib_stage_acquire();
+  if (!pinned) return tpg_upload(ctx, dst, src, bytes);
+  struct Back { uint8_t* p; ~Back() { nib_stage_release(p); } } back{pinned};
+  const size_t H = NIB_CHUNK / 4;  // 64 MiB pieces, four in the buffer: two copies may be in flight while two are being filled
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+  bool used[4] = {false, false, false, false};
+  int k = 0;
+  for (size_t a = 0; a < bytes && e == hipSuccess; a += H, k = (k + 1) & 3) {
+    const size_t b = std::min(bytes, a + H);
+    uint8_t* pin = pinned + (size_t)k * H;
+    if (used[k]) e = hipEventSynchronize(ev[k]);  // the copy that last read this piece of the pinned buffer is done
+    if (e != hipSuccess) break;
+    xfer_parallel(b - a, [=](int, size_t lo, size_t hi) { memcpy(pin + lo, src + a + lo, hi - lo); });
+    e = hipMemcpyAsync(dst + a, pin, b - a, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev[k], ctx->stream);
+    used[k] = true;
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  else (void)hipStreamSynchronize(ctx->stream);
+  for (int q = 0; q < 4; q++)
+    if (ev[q]) (void)hipEventDestroy(ev[q]);
+  return e;
+}
+
 // bulk FBM bytes: packed on the way when that can pay (large, 16-byte aligned destination) and is not switched off
 static hipError_t tpg_upload_fbm_bytes(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes) {
   static const bool off = getenv("TPG_UPLOAD_PACKED") && atoi(getenv("TPG_UPLOAD_PACKED")) == 0;
@@ -789,9 +868,35 @@ extern "C" int tpg_fbm_from_bed_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t
   const size_t sz = (size_t)bpl * (size_t)m;
   hipError_t e = hipMalloc((void**)&f->d_bytes, sz);
   if (e != hipSuccess) { delete f; tpg_set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e)); return TPG_EHIP; }
-  e = tpg_upload(ctx, f->d_bytes, bytes, sz);
+  e = sz >= XFER_BIG ? tpg_upload_pinned(ctx, f->d_bytes, bytes, sz) : tpg_upload(ctx, f->d_bytes, bytes, sz);
   if (e != hipSuccess) { (void)hipFree(f->d_bytes); delete f; tpg_set_error(".bed upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
   *out = f;
+  return TPG_OK;
+}
+
+// A .bed store whose SNPs arrive block by block (the pipeline of tpg_fbm_alloc / tpg_fbm_upload_cols for the 2-bit payload:
+// a SNP is ceil(n / 4) contiguous bytes, so a block of SNPs is one contiguous piece of the file behind its 3-byte magic)
+extern "C" int tpg_fbm_alloc_bed(tpg_ctx* ctx, int64_t n, int64_t m, tpg_fbm** out) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(n > 0 && m > 0, TPG_EINVAL, "empty .bed (%lld x %lld)", (long long)n, (long long)m);
+  tpg_fbm* f = new tpg_fbm{ctx, nullptr, n, m};
+  f->bed_bpl = (n + 3) / 4;
+  hipError_t e = hipMalloc((void**)&f->d_bytes, (size_t)f->bed_bpl * (size_t)m);
+  if (e != hipSuccess) { delete f; tpg_set_error("hipMalloc failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
+  *out = f;
+  return TPG_OK;
+}
+
+extern "C" int tpg_fbm_upload_bed_snps(tpg_ctx* ctx, tpg_fbm* fbm, const uint8_t* host_snps, int64_t snp0, int64_t nsnps) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && fbm && host_snps, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(fbm->bed_bpl > 0, TPG_EUNSUPPORTED, "not a .bed store (tpg_fbm_upload_cols fills a byte FBM)");
+  TPG_REQUIRE(snp0 >= 0 && nsnps >= 0 && snp0 + nsnps <= fbm->ncol, TPG_EINVAL, "SNPs [%lld, %lld) outside the store",
+              (long long)snp0, (long long)(snp0 + nsnps));
+  const size_t sz = (size_t)nsnps * (size_t)fbm->bed_bpl;
+  uint8_t* dst = fbm->d_bytes + (size_t)snp0 * (size_t)fbm->bed_bpl;
+  TPG_HIP(sz >= XFER_BIG ? tpg_upload_pinned(ctx, dst, host_snps, sz) : tpg_upload(ctx, dst, host_snps, sz));
   return TPG_OK;
 }
 
