@@ -98,6 +98,60 @@ def test_direct_bed_ingest(tpg):
     os.remove(tmp)
 
 
+def _bed_file(fbm, path):
+    """an FBM (bytes 0 / 1 / 2 / 3 = missing) as a PLINK .bed file; odd padding bits of the last byte set to garbage"""
+    n, m = fbm.shape
+    enc = np.array([3, 2, 0, 1], dtype=np.uint8)[fbm]  # FBM byte 0,1,2,3 -> bed code 11,10,00,01
+    pad = np.vstack([enc, np.full(((-n) % 4, m), 2, dtype=np.uint8)])  # (garbage in the unused bit pairs)
+    bed = (pad[0::4] | (pad[1::4] << 2) | (pad[2::4] << 4) | (pad[3::4] << 6)).T.copy()  # (m, bytes per SNP)
+    with open(path, "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]) + bed.tobytes())
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (3, 5), (16, 128), (17, 129), (127, 300), (128, 256), (131, 257), (300, 700), (1030, 2051),
+                                 (5000, 1500)])
+def test_bed_store_fast_pack_equals_the_byte_store(tpg, tmp_path, monkeypatch, n, m):
+    """The .bed payload through the fast pack kernel's own front end (tpg_pack_fast_kernel<NV, true>: one unaligned dword = 16
+    individuals of a SNP, 2-bit fields spread and looked up in registers): every layout it writes against the byte FBM of the
+    same genotypes -- single views (L + T), pairs (L + T4 | L) through the pairwise kernel and the PCA, per-locus counts left
+    behind by the pack, column subsets (the fast path) and row subsets (the generic kernel), n not a multiple of 4 / 16 / 128
+    (padding bits of a SNP's last byte are garbage), and the generic kernel as the A/B (TPG_PACK_BED_GENERIC=1)."""
+    fbm = orc.synth_fbm(83, n, m, npop=min(n, 4), miss=0.07)
+    path = str(tmp_path / "x.bed")
+    _bed_file(fbm, path)
+    Xb, Xf = tpg.FBM.open_bed(path, n, m), tpg.FBM.from_numpy(fbm)
+    cols = (np.random.default_rng(n + m).permutation(m)[: max(1, m // 2)] + 1).astype(np.int32)
+    rows = np.arange(n, 0, -2).astype(np.int32)
+    for gen in ("0", "1"):
+        monkeypatch.setenv("TPG_PACK_BED_GENERIC", gen)
+        assert np.array_equal(tpg.View(Xb).unpack(), fbm)
+        assert np.array_equal(tpg.View(Xb, None, cols).unpack(), fbm[:, cols - 1])
+        assert np.array_equal(tpg.View(Xb, rows, cols).unpack(), fbm[np.ix_(rows - 1, cols - 1)])
+        vb, vf = tpg.View(Xb), tpg.View(Xf)
+        assert np.array_equal(tpg.loci_counts(vb), tpg.loci_counts(vf))  # (from what the pack leaves per chunk)
+        assert np.array_equal(tpg.alt_freq_dip_pseudo_cpp(vb, np.full(n, 2.0), True), orc.alt_freq_dip_pseudo_cpp(fbm, None, None, np.full(n, 2.0), True))
+        # a pair: raw view as L + T4 (pairwise kernel), second view as L
+        code_imp = np.array([0, 1, 2, 0] + [np.nan] * 252)  # "missing imputed as 0": a table that differs from the raw one
+        pa, pb = tpg.View.pair(Xb, None, cols, tpg.CODE_012, code_imp)
+        qa, qb = tpg.View.pair(Xf, None, cols, tpg.CODE_012, code_imp)
+        assert np.array_equal(pa.unpack(), qa.unpack()) and np.array_equal(pb.unpack(), qb.unpack())
+        assert np.array_equal(tpg.loci_counts(pb), tpg.loci_counts(qb))
+        pw_b, pw_f = tpg.Pairwise(Xb.ctx, n), tpg.Pairwise(Xf.ctx, n)
+        pw_b.accumulate(pa); pw_f.accumulate(qa)
+        cb, cf = pw_b.counts(), pw_f.counts()
+        for key in cf:
+            assert np.array_equal(cb[key], cf[key]), key
+        if n >= 16:
+            gid = (np.arange(n) % 3).astype(np.int32)
+            assert np.array_equal(tpg.grouped_alt_freq_dip_pseudo_cpp(pb, gid, 3, np.full(n, 2.0), True),
+                                  tpg.grouped_alt_freq_dip_pseudo_cpp(qb, gid, 3, np.full(n, 2.0), True))
+    # the raw-byte view (code256 = NULL) of a .bed store: L + T4 from a single view
+    vb, vf = tpg.View(Xb, code256=None), tpg.View(Xf, code256=None)
+    pw_b, pw_f = tpg.Pairwise(Xb.ctx, n), tpg.Pairwise(Xf.ctx, n)
+    pw_b.accumulate(vb, products=tpg.PW_FOR_AS); pw_f.accumulate(vf, products=tpg.PW_FOR_AS)
+    assert np.array_equal(pw_b.counts(("as_num", "as_den"))["as_num"], pw_f.counts(("as_num", "as_den"))["as_num"])
+
+
 def test_packed_upload_roundtrip(tpg, monkeypatch):
     """Large FBMs cross PCIe as nibbles (host_nibpack.h + tpg_nib_expand_kernel) and arrive as the bytes they were: genotype
     bytes 0 .. 6, odd sizes (an unpacked tail), and a chunk that holds a byte >= 16 (sent as it is)."""

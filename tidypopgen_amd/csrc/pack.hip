@@ -127,7 +127,13 @@ __device__ __forceinline__ int64_t tpg_pack_uniform64(int64_t x) {  // a wave-un
 }
 typedef uint32_t pk_u4 __attribute__((ext_vector_type(4)));
 typedef pk_u4 pk_u4a8 __attribute__((aligned(8)));
-template <int NV>
+// BED (round 5): the store is a PLINK .bed payload (tpg_fbm::bed_bpl bytes per SNP, 4 genotypes per byte, `nrow` = bed_bpl).
+// Only the front of phase 1 differs: a thread's 16 individuals of a locus are ONE dword (any byte address: a SNP is
+// ceil(n / 4) bytes), byte q of it four individuals; two shift-or-mask steps spread its four 2-bit fields over four
+// bytes, and one v_perm_b32 with the four composed entries table[bigsnpr's byte of .bed code b] turns them into codes.  The
+// generic kernel did this route until now: two passes + a T -> T4 expansion + the counts kernel over L, 5.5 ms more per step
+// at 5 000 x 1 000 000 than the byte FBM.
+template <int NV, bool BED = false>
 __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __restrict__ fbm, int64_t nrow,
                                                             const int32_t* __restrict__ cols, uint8_t* lut_and_flag,
                                                             int64_t n, int64_t m, int64_t Q, int64_t KG,
@@ -174,6 +180,14 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
     hi_[vw] = *reinterpret_cast<const uint32_t*>(smem + vw * (256 + 16) + 4);
     bad_[vw] = false;
   }
+  if constexpr (BED) {  // .bed code b -> the byte bigsnpr would have stored (00, 01, 10, 11 -> 2, 3, 1, 0) -> this view's code
+#pragma unroll
+    for (int vw = 0; vw < NV; vw++) {
+      const uint8_t* lut = smem + vw * (256 + 16);
+      lo_[vw] = (uint32_t)lut[2] | ((uint32_t)lut[3] << 8) | ((uint32_t)lut[1] << 16) | ((uint32_t)lut[0] << 24);
+      hi_[vw] = lo_[vw];
+    }
+  }
   auto conv = [&](uint32_t w, int vw) -> uint32_t {
     const uint8_t* lut = smem + vw * (256 + 16);
     const uint32_t lo = lo_[vw], hi = hi_[vw];
@@ -200,7 +214,20 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
       const int64_t j = bj * TILE + (tid >> 3) + 32 * it;
       va[sub][it] = make_uint2(0, 0);
       vb[sub][it] = make_uint2(0, 0);
-      if (j < m && bi0 + sub < Q) {
+      if constexpr (BED) {
+        if (j < m && bi0 + sub < Q && i0 < n) {
+          const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
+          const uint8_t* p = fbm + (i0 >> 2) + src_col * nrow;  // (nrow = bytes per SNP)
+          typedef uint32_t pk_u1a1 __attribute__((aligned(1)));
+          if ((i0 >> 2) + 4 <= nrow) {
+            va[sub][it].x = *reinterpret_cast<const pk_u1a1*>(p);
+          } else {  // the last bytes of a SNP whose individuals do not fill 16: never past the record
+            uint32_t w = 0;
+            for (int b = 0; (i0 >> 2) + b < nrow; b++) w |= (uint32_t)p[b] << (8 * b);
+            va[sub][it].x = w;
+          }
+        }
+      } else if (j < m && bi0 + sub < Q) {
         const int64_t src_col = cols ? (int64_t)cols[j] - 1 : j;
         const uint8_t* p = fbm + i0 + src_col * nrow;
         // (columns are 8-byte aligned only; the hardware takes a 16-byte load at any dword address: half the load instructions)
@@ -223,7 +250,7 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
   for (int sub = 0; sub < NSUB; sub++)
 #pragma unroll
     for (int it = 0; it < 4; it++) anyw |= va[sub][it].x | va[sub][it].y | vb[sub][it].x | vb[sub][it].y;
-  const bool fastw = __builtin_amdgcn_ballot_w64((anyw & 0xF8F8F8F8u) != 0) == 0;  // wave-uniform
+  const bool fastw = BED || __builtin_amdgcn_ballot_w64((anyw & 0xF8F8F8F8u) != 0) == 0;  // wave-uniform
   uint32_t cacc[NV];
 #pragma unroll
   for (int vw = 0; vw < NV; vw++) cacc[vw] = 0;
@@ -260,7 +287,25 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
       for (int vw = 0; vw < NV; vw++) {
         uint8_t* codes = codes_all + slot_[vw] * TILE * TILE;
         uint32_t c[4] = {0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u};
-        if constexpr (FAST) {
+        if constexpr (FAST && BED) {
+          const uint32_t wb = va[sub][it].x;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            // the four 2-bit fields of byte q, one per byte: individual 4 q + e in byte e (two shift-or-mask steps whose terms do
+            // not overlap; a multiplication by 0x41041 would carry between them)
+            const uint32_t Bq = (wb >> (8 * q)) & 0xFFu, xq = (Bq | (Bq << 12)) & 0x000F000Fu;
+            const uint32_t sel = (xq | (xq << 6)) & 0x03030303u;
+            uint32_t cq = __builtin_amdgcn_perm(hi_[vw], lo_[vw], sel);
+            if constexpr (!FULL) {  // individuals past n (the padding bits of the last byte, or no byte at all), loci past m
+              uint32_t keep = 0;
+#pragma unroll
+              for (int e = 0; e < 4; e++) keep |= (inside && i0 + 4 * q + e < n) ? (0xFFu << (8 * e)) : 0u;
+              cq = (cq & keep) | (0x03030303u & ~keep);
+            }
+            c[q] = cq;
+          }
+          cacc[vw] |= (c[0] | c[1]) | (c[2] | c[3]);
+        } else if constexpr (FAST) {
           const uint32_t w[4] = {va[sub][it].x, va[sub][it].y, vb[sub][it].x, vb[sub][it].y};
           const bool h0 = inside && i0 + 8 <= n, h1 = inside && i0 + 16 <= n;
 #pragma unroll
@@ -279,7 +324,14 @@ __global__ __launch_bounds__(256) void tpg_pack_fast_kernel(const uint8_t* __res
         *(gu32*)(Lb + loff) = lw;
         if (cnt_on) {  // (the padding code 3 of individuals past n, loci past m, is not a genotype: masked out)
           uint32_t wc = lw;
-          if constexpr (!FULL) wc = (inside && i0 + 16 <= n) ? lw : (inside && i0 + 8 <= n) ? (lw & 0x0F0F0F0Fu) : 0u;
+          if constexpr (!FULL && BED) {  // individual i0 + 4 k + b sits at bits 8 b + 2 k of the L word
+            uint32_t vm = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+              for (int b = 0; b < 4; b++) vm |= (inside && i0 + 4 * k + b < n) ? (3u << (8 * b + 2 * k)) : 0u;
+            wc = lw & vm;
+          } else if constexpr (!FULL) wc = (inside && i0 + 16 <= n) ? lw : (inside && i0 + 8 <= n) ? (lw & 0x0F0F0F0Fu) : 0u;
           cnt3[vw][it] += (uint32_t)__popc(wc & 0x55555555u) | ((uint32_t)__popc(wc & 0xAAAAAAAAu) << 10) |
                           ((uint32_t)__popc(wc & (wc >> 1) & 0x55555555u) << 20);
         }
@@ -384,8 +436,9 @@ int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, con
                     const uint8_t* d_lut, tpg_view* v, tpg_view* v2) {
   TPG_REQUIRE(v->KG < 2147483647ll && v->Q <= 65535, TPG_EINVAL, "view too large for the pack grid");
   dim3 grid((unsigned)v->KG, (unsigned)v->Q);
-  if (fbm->bed_bpl == 0 && d_rows == nullptr && (fbm->nrow & 7) == 0 && (((uintptr_t)fbm->d_bytes) & 7) == 0 &&
-      !getenv("TPG_PACK_GENERIC")) {
+  const bool fast_bytes = fbm->bed_bpl == 0 && (fbm->nrow & 7) == 0 && (((uintptr_t)fbm->d_bytes) & 7) == 0;
+  const bool fast_bed = fbm->bed_bpl > 0 && !(getenv("TPG_PACK_BED_GENERIC") && atoi(getenv("TPG_PACK_BED_GENERIC")) != 0);  // (A/B)
+  if ((fast_bytes || fast_bed) && d_rows == nullptr && !getenv("TPG_PACK_GENERIC")) {
     TPG_REQUIRE((v->KG + 8) * v->Q < 2147483647ll, TPG_EINVAL, "view too large for the pack grid");
     const int xmap = getenv("TPG_PACK_XCD") ? atoi(getenv("TPG_PACK_XCD")) : 1;
     const dim3 g1((unsigned)((xmap ? (v->KG + 7) / 8 * 8 : v->KG) * ((v->Q + PACK_NSUB - 1) / PACK_NSUB)));
@@ -406,7 +459,15 @@ int tpg_launch_pack(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* d_rows, con
       for (tpg_view* w : {v, v2})
         if (w && w->lc_part) { tpg_pfree(w->lc_part); w->lc_part = nullptr; w->lc_chunks = 0; }
     auto lds_bytes = [&](int nv, bool t_a, bool t_b) { return (size_t)nv * (256 + 16) + (size_t)((t_a ? 1 : 0) + (t_b ? 1 : 0)) * TILE * TILE; };
-    if (v2)
+    if (v2 && fast_bed)
+      TPG_LAUNCH(ctx, "pack2", (tpg_pack_fast_kernel<2, true>), g1, dim3(256), lds_bytes(2, v->T || v->T4, v2->T != nullptr), fbm->d_bytes, fbm->bed_bpl, d_cols, (uint8_t*)d_lut,
+                 v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)v2->T, (uint32_t*)v2->L,
+                 (uint32_t*)v->T4, xmap, lp0, lp1);
+    else if (fast_bed)
+      TPG_LAUNCH(ctx, "pack", (tpg_pack_fast_kernel<1, true>), g1, dim3(256), lds_bytes(1, v->T || v->T4, false), fbm->d_bytes, fbm->bed_bpl, d_cols, (uint8_t*)d_lut,
+                 v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                 (uint32_t*)v->T4, xmap, lp0, lp1);
+    else if (v2)
       TPG_LAUNCH(ctx, "pack2", tpg_pack_fast_kernel<2>, g1, dim3(256), lds_bytes(2, v->T || v->T4, v2->T != nullptr), fbm->d_bytes, fbm->nrow, d_cols, (uint8_t*)d_lut,
                  v->n, v->m, v->Q, v->KG, (uint32_t*)v->T, (uint32_t*)v->L, (uint32_t*)v2->T, (uint32_t*)v2->L,
                  (uint32_t*)v->T4, xmap, lp0, lp1);

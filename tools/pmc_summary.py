@@ -33,7 +33,11 @@ avg_ns = {}
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         avg_ns[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
-WIDE = ("tpg_pairwise_kernel", "tpg_pairwise_set_kernel", "tpg_pca_gram_kernel", "tpg_gcls_gram_kernel", "tpg_gcls_gram2_kernel", "tpg_gcls_gram1w_kernel")
+# kernels whose global reads are all 16 B per lane (global_load_dwordx4 / LDS-DMA of 16 B): FETCH_SIZE x 2.  The fast pack
+# kernel belongs here since round 4 (commit 6dde6ae: 16-byte loads on its 8-byte-aligned columns; round 4's file still had it
+# at 1.0 and reported half of its 5.0 GB)
+WIDE = ("tpg_pairwise_kernel", "tpg_pairwise_set_kernel", "tpg_pairwise_wg_kernel", "tpg_pca_gram_kernel", "tpg_gcls_gram_kernel",
+        "tpg_gcls_gram2_kernel", "tpg_gcls_gram1w_kernel", "tpg_pack_fast_kernel")
 out, traffic = {}, {}
 for k, c in sorted(acc.items()):
     d = disp[k]
@@ -69,7 +73,15 @@ for k, c in sorted(acc.items()):
         if k.startswith("tpg_gcls_gram_kernel") or k.startswith("tpg_gcls_gram2_kernel"):
             traffic["pca_gram_classes"] = der["hbm_read_bytes_per_launch"] + der["hbm_write_bytes_per_launch"]
 json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc_one_step.json"), "w"), indent=1)
+import datetime
+import subprocess
+
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip() or "unknown"
+except OSError:
+    commit = "unknown"
 json.dump({"workload": "5000 x 1000000 per GPU, 51 populations, k = 20", "source": f"profiles/{tag}_pmc_one_step.json",
+           "date": datetime.date.today().isoformat(), "commit": commit + " (the tree the summary was made in; the passes ran on its build)",
            "hbm_bytes_per_launch": traffic}, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 for k, o in out.items():
     if any(s in k for s in ("pairwise_kernel", "gram_kernel", "gram2_kernel", "gcls", "t4_expand", "pack_fast", "fst_kernel", "wc84", "grouped_counts")):
