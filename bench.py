@@ -1047,8 +1047,10 @@ def main():
             mfma_roof("pairwise_mfma", "tpg_pairwise_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 operands)", 5.0 * n * n * m,
                       "fused IBS+KING+AS/GRM: 3 symmetric + 1 general product = 2.5 N^2 M MACs on exact FP4 planes "
                       "(0.5 / 1 / +-2 with block scales, integer sums in FP32 below 2^24); peak = dense FP4 at 2.4 GHz; the MFMA pipe is "
-                      "89 % busy at the 1.87 - 2.05 GHz the chip holds under this kernel (profiles/r04_pmc_one_step.json), the bare "
-                      "instruction loop reaches 7.7 POP/s (tools/ubench_mfma_fp4.hip)",
+                      "89 % busy at the 1.87 - 2.05 GHz the chip holds under this kernel (profiles/r05_pmc_one_step.json); that clock is a "
+                      "POWER limit that depends on the operand data: the same kernel on constant genotypes runs at 0.76 - 0.78 of the peak, "
+                      "the rate of the bare instruction loop on constant registers (7.7 POP/s, tools/ubench_mfma_fp4.hip), and a bare MFMA "
+                      "loop on the panel's random planes is SLOWER than the kernel (profiles/r05_pairwise_experiments.txt, DESIGN.md 3.1)",
                       peak=10000.0),
             mfma_roof("pca_gram_mfma", "tpg_pca_gram_kernel (v_mfma_i32_32x32x32_i8)", 4.0 * n * n * m_pca,
                       "PCA Gram: 4 weight digits x symmetric int8 product = 4 * N^2 M / 2 MACs"),
@@ -1060,7 +1062,7 @@ def main():
                       "end is 8 v_pk_fma_f32 per 32 x 32 tile (small weight differences of a group of neighbouring classes, "
                       "summation by parts), a group end the FP64 fold; 64 x 64 wave tiles, two waves per SIMD; each wave waits "
                       "for its own instruction stream and its dependencies (MFMA pipe 42 % busy, 8.4 VALU-class instructions per MFMA, "
-                      "s_waitcnt 27 %: profiles/r04_pmc_one_step.json)",
+                      "s_waitcnt 27 %: profiles/r05_pmc_one_step.json)",
                       peak=10000.0),
         ]
         roofs = [r for r in roofs if r]

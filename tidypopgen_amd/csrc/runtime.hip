@@ -542,7 +542,7 @@ static void xfer_parallel(size_t bytes, F f) {
   for (auto& t : th) t.join();
 }
 
-static uint8_t* nib_stage_acquire();
+static uint8_t* nib_stage_acquire(bool may_pin = true);
 static void nib_stage_release(uint8_t* p);
 static constexpr size_t XFER_PIECE = 64u << 20;  // a quarter of the process's pinned staging buffer (NIB_CHUNK)
 
@@ -556,7 +556,8 @@ static constexpr size_t XFER_PIECE = 64u << 20;  // a quarter of the process's p
 static hipError_t tpg_download_pinned(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes, bool* done) {
   *done = false;
   static const bool off = getenv("TPG_DOWNLOAD_PINNED") && atoi(getenv("TPG_DOWNLOAD_PINNED")) == 0;
-  uint8_t* const pinned = off ? nullptr : nib_stage_acquire();
+  // (a copy below 64 MiB takes the staging buffer only if the process already has one: pinning 256 MiB costs 35 - 40 ms)
+  uint8_t* const pinned = off ? nullptr : nib_stage_acquire(bytes >= XFER_BIG);
   if (!pinned) return hipSuccess;
   struct Back { uint8_t* p; ~Back() { nib_stage_release(p); } } back{pinned};
   const size_t H = XFER_PIECE, np = (bytes + H - 1) / H;
@@ -657,11 +658,12 @@ static constexpr size_t NIB_CHUNK = 256u << 20;  // input bytes per chunk: 128 M
 // every time.  A buffer is taken for the length of one upload and handed back; concurrent uploads get one each.
 static std::mutex g_nib_mu;
 static std::vector<uint8_t*> g_nib_free;
-static uint8_t* nib_stage_acquire() {
+static uint8_t* nib_stage_acquire(bool may_pin) {
   {
     std::lock_guard<std::mutex> lk(g_nib_mu);
     if (!g_nib_free.empty()) { uint8_t* p = g_nib_free.back(); g_nib_free.pop_back(); return p; }
   }
+  if (!may_pin) return nullptr;
   uint8_t* p = nullptr;
   if (hipHostMalloc((void**)&p, NIB_CHUNK, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   return p;
