@@ -8,7 +8,7 @@ v = tpg.View(X, code256=None)
 pw = tpg.Pairwise(ctx, n)
 ref = None
 import numpy as np
-for var in (0, 2, 0, 2):
+for var in [int(x) for x in sys.argv[1:]] or (0, 2, 0, 2):
     os.environ["TPG_PW_VARIANT"] = str(var)
     best = 1e9
     for rep in range(3):
