@@ -1743,7 +1743,12 @@ __global__ __launch_bounds__(256) void tpg_uq_colsum_kernel(const double* __rest
 // tile per wave and a fragment per MFMA straight from L2 the kernel moved 20 GB per launch at C5 through the L1s
 // and was bound by that (1.6 ms).  The A side is the code bytes themselves (no missing values here, see the Gram
 // kernel).
+#ifndef LD_NLT
 #define LD_NLT 2
+#endif
+#ifndef LD_WGS
+#define LD_WGS 2  // workgroups per CU the register budget is cut for
+#endif
 __device__ __forceinline__ int64_t tpg_uniform64_pca(int64_t x) {  // a wave-uniform value the compiler keeps in SGPRs
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
   return (int64_t)(((uint64_t)hi << 32) | lo);
@@ -1758,7 +1763,7 @@ __device__ __forceinline__ void tpg_pca_static_for(F&& f) {
 }
 
 template <int CTP>
-__global__ __launch_bounds__(256, 2) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
+__global__ __launch_bounds__(256, LD_WGS) void tpg_loadings_mfma_kernel(const uint4* __restrict__ L,
                                                                    const uint4* __restrict__ UD, int64_t n_lt,
                                                                    int64_t Q, int ct0, int CT,
                                                                    int32_t* __restrict__ out, int Cpad) {
