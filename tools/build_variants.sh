@@ -1,6 +1,7 @@
 #!/bin/bash
-# builds libtpg_hip.so variants that differ by compile-time macros into abvar/ (A/B timing inside one GPU job; the directory
-# travels to the GPU box, delete it afterwards):  tools/build_variants.sh name1 "-DX=1" name2 "-DX=2" ...
+# builds libtpg_hip.so variants that differ by compile-time macros into abvar/ (A/B timing inside one GPU job with
+# tools/lib_ab.py / tools/enc_ab.py; abvar/ is listed in .gpurunignore so that stale variants do not ship: take the line out
+# for the job that needs them):  tools/build_variants.sh name1 "-DX=1" name2 "-DX=2" ...
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p abvar
