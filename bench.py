@@ -1067,8 +1067,8 @@ def main():
                       "(0.5 / 1 / +-2 with block scales, integer sums in FP32 below 2^24); peak = dense FP4 at 2.4 GHz; the MFMA pipe is "
                       "89 % busy at the 1.87 - 2.05 GHz the chip holds under this kernel (profiles/r05_pmc_one_step.json); that clock is a "
                       "POWER limit that depends on the operand data: the same kernel on constant genotypes runs at 0.76 - 0.78 of the peak, "
-                      "the rate of the bare instruction loop on constant registers (7.7 POP/s, tools/ubench_mfma_fp4.hip), and a bare MFMA "
-                      "loop on the panel's random planes is SLOWER than the kernel (profiles/r05_pairwise_experiments.txt, DESIGN.md 3.1)",
+                      "the rate of the bare instruction loop on constant registers (7.7 POP/s, tools/ubench_mfma_fp4.hip), at a measured "
+                      "2.1 - 2.2 GHz instead of 1.83 - 1.89 (profiles/r05_pairwise_experiments.txt, DESIGN.md 3.1)",
                       peak=10000.0),
             mfma_roof("pca_gram_mfma", "tpg_pca_gram_kernel (v_mfma_i32_32x32x32_i8)", 4.0 * n * n * m_pca,
                       "PCA Gram: 4 weight digits x symmetric int8 product = 4 * N^2 M / 2 MACs"),

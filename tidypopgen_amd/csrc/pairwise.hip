@@ -479,7 +479,9 @@ __device__ __forceinline__ void tpg_static_for(F&& f) {
 constexpr int tpg_waitcnt_vm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | (((n >> 4) & 3) << 14); }
 #define SGB_DS_READ 0x100
 
-template <int RA, int RB, int MASK, int NST>
+// DBGW (timing experiments only, wrong sums; TPG_PW_VARIANT=24 / 25 / 26): 1 = no barrier inside the steps, 2 = neither the barrier
+// nor the LDS-DMA of the steps (the ring keeps what the prologue fetched), 3 = the barrier kept, the LDS-DMA of the steps removed
+template <int RA, int RB, int MASK, int NST, int DBGW = 0>
 __global__ __launch_bounds__(256, 1) void tpg_pairwise_wg_kernel(const uint4* __restrict__ T4, int64_t KG, int64_t kb_begin,
                                                                     int64_t kb_end, int nst, int nct, const int2* __restrict__ order,
                                                                     int64_t nun, int S, const int64_t* __restrict__ rowpad,
@@ -582,9 +584,9 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_wg_kernel(const uint4* __
         constexpr int s = decltype(Sc)::value, cur = decltype(Cc)::value, nx = cur ^ 1, s2 = (s + 2) % NST;
         // my pieces of block kb + 2 have landed (younger DMAs: blocks kb + 3 .. kb + NST - 1); behind the barrier everybody's
         // have, and everybody has read block kb (two steps ago): its stage takes block kb + NST
-        __builtin_amdgcn_s_waitcnt(tpg_waitcnt_vm(NLD * (NST - 3)));
-        __builtin_amdgcn_s_barrier();
-        DMA(Sc, kb + NST < kb1 ? kb + NST : kl);
+        if constexpr (DBGW == 0 || DBGW == 1) __builtin_amdgcn_s_waitcnt(tpg_waitcnt_vm(NLD * (NST - 3)));
+        if constexpr (DBGW == 0 || DBGW == 3) __builtin_amdgcn_s_barrier();
+        if constexpr (DBGW == 0 || DBGW == 1) DMA(Sc, kb + NST < kb1 ? kb + NST : kl);
         const bool live1 = kb + 1 < kb1;  // past the K range: zero A planes, the tail of the last unrolled body adds nothing
 #pragma unroll
         for (int t = 0; t < NT; t++) {
@@ -900,7 +902,7 @@ static int pw_launch_set(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int6
 }
 
 // the workgroup form: units are (64 RA) x (64 RB) blocks of pairs, one per workgroup; TPG_PW_KSPLIT=<S> overrides the K split
-template <int RA, int RB, int MASK, int NST>
+template <int RA, int RB, int MASK, int NST, int DBGW = 0>
 static int pw_launch_wg(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t kg0, int64_t kg1, const char* name) {
   const int2* d_order = nullptr;
   int64_t nun = 0;
@@ -915,7 +917,7 @@ static int pw_launch_wg(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64
     int S = pw_ksplit(nun, 2 * kgs, 16, ceil_div(kgs, max_groups), nblk, 0.0183 * NM, 0.8 * NM);
     if (const char* e = getenv("TPG_PW_KSPLIT")) S = std::max<int>((int)ceil_div(kgs, max_groups), atoi(e));
     if (getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] %s: workgroups of %d x %d tiles, %lld units, S = %d\n", name, 2 * RA, 2 * RB, (long long)nun, S);
-    TPG_LAUNCH(ctx, name, (tpg_pairwise_wg_kernel<RA, RB, MASK, NST>), dim3((unsigned)nblk), dim3(256), 0,
+    TPG_LAUNCH(ctx, name, (tpg_pairwise_wg_kernel<RA, RB, MASK, NST, DBGW>), dim3((unsigned)nblk), dim3(256), 0,
                (const uint4*)v->T4, v->KG, 2 * c0, 2 * c1, (int)pw->nst, (int)ceil_div(pw->n, 32), d_order, nun, S,
                (const int64_t*)pw->rowpad, pw->acc);
   }
@@ -999,18 +1001,21 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
   // {V, D, A} 64 x 64 with 5 / 4 / 3 / 6 slots 16.2 / 16.5 / 23.5 / 16.4, 128 x 32 17.9, 96 x 32 17.8; all five through
   // this template (96 x 32, 4 ... 7 slots) 20.2 - 21.8 against 19.5 for the kernel above with its two-block groups
 #define PW_WG(RA, RB, MASK, NST, name) TPG_TRY((pw_launch_wg<RA, RB, MASK, NST>(ctx, pw, v, kg0, kg1, name)))
-  if (set == TPG_PW_FOR_AS && var >= 10) {        // operands shared through LDS (round 5): 14 / 15 / 16 = 4 / 5 / 6 stages
+  if (set == TPG_PW_FOR_AS && var >= 10 && var < 20) {  // operands shared through LDS (round 5): 14 / 15 / 16 = 4 / 5 / 6 stages
     if (var == 15) PW_WG(4, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
     else if (var == 16) PW_WG(4, 2, TPG_PW_FOR_AS, 6, "pairwise_mfma_as");
     else PW_WG(4, 2, TPG_PW_FOR_AS, 4, "pairwise_mfma_as");
-  } else if (set == TPG_PW_FOR_IBS && var >= 10) {
+  } else if (set == TPG_PW_FOR_IBS && var >= 10 && var < 20) {
     if (var == 16) PW_WG(2, 2, TPG_PW_FOR_IBS, 6, "pairwise_mfma_ibs");
     else PW_WG(2, 2, TPG_PW_FOR_IBS, 4, "pairwise_mfma_ibs");
-  } else if (set == TPG_PW_FOR_KING && var >= 10) {
+  } else if (set == TPG_PW_FOR_KING && var >= 10 && var < 20) {
     if (var == 16) PW_WG(2, 2, TPG_PW_FOR_KING, 6, "pairwise_mfma_king");
     else PW_WG(2, 2, TPG_PW_FOR_KING, 4, "pairwise_mfma_king");
   } else if (set == TPG_PW_FOR_AS) {
-    if (var == 21) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 5, 1>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));       // timing only
+    if (var == 24) TPG_TRY((pw_launch_wg<4, 2, TPG_PW_FOR_AS, 4, 1>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));             // timing only
+    else if (var == 25) TPG_TRY((pw_launch_wg<4, 2, TPG_PW_FOR_AS, 4, 2>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));        // timing only
+    else if (var == 26) TPG_TRY((pw_launch_wg<4, 2, TPG_PW_FOR_AS, 4, 3>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));        // timing only
+    else if (var == 21) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 5, 1>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));  // timing only
     else if (var == 22) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 5, 2>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));  // timing only
     else if (var == 1) PW_SET(4, 2, TPG_PW_FOR_AS, 4, "pairwise_mfma_as");
     else if (var == 2) PW_SET(3, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");

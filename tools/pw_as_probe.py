@@ -30,7 +30,11 @@ def run(var, ksplit=None, products=tpg.PW_FOR_AS, key="pairwise_mfma_as"):
     return best
 
 
-for label, var in (("as it is", 0), ("loads of the loop removed", 21), ("loads and plane masks removed", 22), ("operands through LDS, 4 stages", 14)):
-    print(f"{label:34s} {run(var):7.3f} ms", flush=True)
+for label, var in (("as it is", 0), ("loads of the loop removed", 21), ("loads and plane masks removed", 22), ("operands through LDS, 4 stages", 14),
+                   ("LDS form without its barrier", 24), ("LDS form without barrier and LDS-DMA", 25), ("LDS form without its LDS-DMA", 26),
+                   ("as it is", 0)):
+    print(f"{label:38s} {run(var):7.3f} ms", flush=True)
+if len(sys.argv) > 3:
+    sys.exit(0)
 for S in (8, 12, 16, 20, 24, 32, 48):
     print(f"variant 0, K split {S:3d}: {run(0, S):7.3f} ms    LDS form: {run(14, S):7.3f} ms", flush=True)
