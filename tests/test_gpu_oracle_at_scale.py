@@ -39,31 +39,101 @@ def _sample_rows(n):
     return np.array(sorted(rows + extra), dtype=np.int64)
 
 
-def _check_pairwise_sample(tpg, orc, X, seed, n, m):
-    rows = _sample_rows(n)
-    assert len(set(rows.tolist())) == 64
+def _oracle_pair_counts(orc, seed, rows, m):
+    """the six count matrices of increment_{ibs,king,as}_counts on the sampled rows x ALL loci (the oracle's restatement)"""
     sub = orc.synth_rows(seed, rows, m, npop=G, miss=0.02, imputed_bytes=True)  # 64 x m FBM bytes of those rows
-    v = tpg.View(X, code256=None)
-    pw = tpg.Pairwise(X.ctx, n)
-    pw.accumulate(v)
-    ix = np.ix_(rows, rows)
     o = {k: np.zeros((64, 64), order="F") for k in ("ibs", "ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den")}
     orc.increment_ibs_counts(o["ibs"], o["ibs_valid"], sub, None, None)        # src/snp_ibs.cpp:45-72
     orc.increment_king_numerator(o["king_num"], o["n_Aa_i"], sub, None, None)  # src/snp_king.cpp:45-72
     orc.increment_as_counts(o["as_num"], o["as_den"], sub, None, None)         # src/snp_as.cpp:44-65
-    for names in (("ibs", "ibs_valid", "king_num"), ("n_Aa_i", "as_num", "as_den")):
+    return o
+
+
+# what each product set's accumulators can give (include/tpg.h: IBS = V + D + H, IBS_valid = 2 V, KING = D - V + A + A',
+# N_Aa_i = A, AS = D / V): the count matrices and the epilogues that need nothing else
+_SET_OUTPUTS = {
+    "all": (("ibs", "ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den"), ("ibs", "king", "allele_sharing", "grm")),
+    "as": (("ibs_valid", "as_num", "as_den"), ("allele_sharing", "grm")),
+    "ibs": (("ibs", "ibs_valid", "as_num", "as_den"), ("ibs", "allele_sharing", "grm")),
+    "king": (("ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den"), ("king", "allele_sharing", "grm")),
+}
+
+
+def _check_counts_and_epilogues(tpg, orc, pw, o, rows, m, which):
+    ix = np.ix_(rows, rows)
+    counts, eps = _SET_OUTPUTS[which]
+    for names in (counts[:3], counts[3:]):
+        if not names:
+            continue
         c = pw.counts(names)
         for k in names:
-            assert np.array_equal(c[k][ix], o[k]), k
+            assert np.array_equal(c[k][ix], o[k]), (which, k)
         del c
-    ep = pw.epilogues(("ibs", "king", "allele_sharing", "grm"), m=m)
+    ep = pw.epilogues(eps, m=m)
     with np.errstate(invalid="ignore", divide="ignore"):
-        assert np.array_equal(ep["ibs"][ix], o["ibs"] / o["ibs_valid"], equal_nan=True)       # R/snp_ibs.R:88-95
-    assert np.array_equal(ep["king"][ix], orc.king_epilogue(o["king_num"], o["n_Aa_i"]), equal_nan=True)
+        if "ibs" in eps:
+            assert np.array_equal(ep["ibs"][ix], o["ibs"] / o["ibs_valid"], equal_nan=True)   # R/snp_ibs.R:88-95
+    if "king" in eps:
+        assert np.array_equal(ep["king"][ix], orc.king_epilogue(o["king_num"], o["n_Aa_i"]), equal_nan=True)
     assert np.array_equal(ep["allele_sharing"][ix], orc.as_epilogue(o["as_num"], o["as_den"]), equal_nan=True)
     # GRM = the reference's formula on the (sample-verified) allele-sharing matrix: the mean is over all N (N - 1) pairs
     assert np.allclose(ep["grm"], orc.pairwise_grm(ep["allele_sharing"]), rtol=1e-12, atol=1e-14)
-    return v
+    return ep
+
+
+def _check_pairwise_sample(tpg, orc, X, seed, n, m, monkeypatch=None):
+    """The five-product kernel of the fused pass AND the three product-set kernels a stand-alone snp_ibs / snp_king /
+    pairwise_grm (and every block of an R driver loop) runs on -- tpg_pairwise_set_kernel<RA, RB, MASK, NS>: K split > 1,
+    multi-round unit tables, the 128 x 64 / 64 x 64 wave tiles' diagonal handling and partial last tiles at this N -- each
+    against the same oracle sample; then the {V, D} workgroup form (LDS-DMA ring, TPG_PW_VARIANT=14) once."""
+    rows = _sample_rows(n)
+    assert len(set(rows.tolist())) == 64
+    o = _oracle_pair_counts(orc, seed, rows, m)
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, n)
+    sets = {"all": None, "as": tpg.PW_FOR_AS, "ibs": tpg.PW_FOR_IBS, "king": tpg.PW_FOR_KING}
+    for which, products in sets.items():
+        pw.zero()
+        pw.accumulate(v, products=products)
+        assert pw.products() == (tpg.PW_ALL if products is None else products)
+        ep = _check_counts_and_epilogues(tpg, orc, pw, o, rows, m, which)
+        if which == "king":
+            # BASELINE config 2's literal workload -- pairwise_king + pairwise_grm -- is this kernel + these two epilogues
+            kg = pw.epilogues(which=("king", "grm"))
+            assert np.array_equal(kg["king"], ep["king"], equal_nan=True) and np.array_equal(kg["grm"], ep["grm"])
+            del kg
+        del ep
+    if monkeypatch is not None:
+        monkeypatch.setenv("TPG_PW_VARIANT", "14")
+        pw.zero()
+        pw.accumulate(v, products=tpg.PW_FOR_AS)
+        monkeypatch.delenv("TPG_PW_VARIANT")
+        _check_counts_and_epilogues(tpg, orc, pw, o, rows, m, "as")
+    pw.free()
+    return v, o
+
+
+def _check_increment_block_loop(tpg, orc, X, o, n, m):
+    """The reference's own block loop over the literal mirrors (R/snp_ibs.R:59-82, R/snp_king.R:51-77,
+    R/snp_allele_sharing.R:49-69): blocks of bigstatsr::block_size(n) loci cut by CutBySize, one increment_* call per
+    block on the host FBM, the caller's N x N double matrices incremented in place -- against the same oracle sample."""
+    rows = _sample_rows(n)
+    ix = np.ix_(rows, rows)
+    fbm = X.to_numpy()
+    lo, up = tpg.cut_by_size(m, tpg.block_size(n))  # CutBySize, R/local_reimplementations.R:13-15
+    nb = len(lo)
+    rowInd = np.arange(1, n + 1, dtype=np.int32)
+    for fn, names in ((tpg.increment_ibs_counts, ("ibs", "ibs_valid")), (tpg.increment_king_numerator, ("king_num", "n_Aa_i")),
+                      (tpg.increment_as_counts, ("as_num", "as_den"))):
+        K, K2 = np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
+        for b in range(nb):
+            fn(K, K2, fbm, rowInd, np.arange(lo[b], up[b] + 1, dtype=np.int32), ctx=X.ctx)
+        assert np.array_equal(K[ix], o[names[0]]), names[0]
+        assert np.array_equal(K2[ix], o[names[1]]), names[1]
+        assert np.array_equal(K, K.T) and (names[1] == "n_Aa_i" or np.array_equal(K2, K2.T))
+        del K, K2
+    tpg.resident_drop(X.ctx)
+    return nb
 
 
 def _check_loci_sample(tpg, orc, X, v012, seed, n, m, nblocks=30, width=1000):
@@ -225,28 +295,30 @@ def _check_pca_sample(tpg, orc, X, seed, n, m, k):
     return r
 
 
-def test_config2_hgdp_shape_against_oracle():
+def test_config2_hgdp_shape_against_oracle(monkeypatch):
     """BASELINE config 2: 1 000 x 650 000, pairwise_king + pairwise_grm (+ the per-locus sweeps and PCA)"""
     import tidypopgen_amd as tpg
     from oracle import oracle as orc
 
     n, m, seed = 1000, 650_000, 2
     X = tpg.FBM.synth(seed, n, m, npop=G, miss=0.02, imputed_bytes=True)
-    _check_pairwise_sample(tpg, orc, X, seed, n, m)
+    _, o = _check_pairwise_sample(tpg, orc, X, seed, n, m, monkeypatch)
+    assert _check_increment_block_loop(tpg, orc, X, o, n, m) == 5  # block_size(1000) = 134 217 loci
     v012 = tpg.View(X)
     _check_loci_sample(tpg, orc, X, v012, seed, n, m, nblocks=12)
     _check_fst_sample(tpg, orc, X, seed, n, m)
     _check_pca_sample(tpg, orc, X, seed, n, m, k=10)
 
 
-def test_config3_to_5_bench_panel_against_oracle():
+def test_config3_to_5_bench_panel_against_oracle(monkeypatch):
     """BASELINE configs 3-5: 5 000 x 1 000 000, 51 populations, k = 20 -- the bench.py panel (seed 3)"""
     import tidypopgen_amd as tpg
     from oracle import oracle as orc
 
     n, m, seed = 5000, 1_000_000, 3
     X = tpg.FBM.synth(seed, n, m, npop=G, miss=0.02, imputed_bytes=True)
-    _check_pairwise_sample(tpg, orc, X, seed, n, m)
+    _, o = _check_pairwise_sample(tpg, orc, X, seed, n, m, monkeypatch)
+    assert _check_increment_block_loop(tpg, orc, X, o, n, m) == 38  # the 38 blocks of 26 315 / 26 316 loci of the R drivers
     v012 = tpg.View(X)
     _check_loci_sample(tpg, orc, X, v012, seed, n, m, nblocks=30)
     del v012

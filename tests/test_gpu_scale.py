@@ -284,3 +284,15 @@ def test_pair_counts_stay_exact_past_2_pow_24_loci():
     assert np.array_equal(c["ibs"], m * (V + D + H))
     assert np.array_equal(c["ibs_valid"], 2 * m * V)
     assert np.array_equal(c["king_num"], m * (D - V + A + A.T))
+    del c
+    # the three product-set kernels (tpg_pairwise_set_kernel: what a stand-alone snp_ibs / snp_king / pairwise_grm runs on)
+    # cap and flush their wave-units' K ranges themselves
+    for products, names in ((tpg.PW_FOR_AS, ("as_num", "as_den", "ibs_valid")), (tpg.PW_FOR_IBS, ("ibs", "ibs_valid", "as_num")),
+                            (tpg.PW_FOR_KING, ("king_num", "n_Aa_i", "as_den"))):
+        pw.zero()
+        pw.accumulate(v, products=products)
+        c = pw.counts(names)
+        want = dict(as_num=m * D, as_den=m * V, ibs_valid=2 * m * V, ibs=m * (V + D + H), king_num=m * (D - V + A + A.T),
+                    n_Aa_i=m * A)
+        for k in names:
+            assert np.array_equal(c[k], want[k]), (products, k)
