@@ -383,6 +383,95 @@ int tpg_multi_pca_partial_svd(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t n
                               int64_t n, const int32_t* colInd1, int64_t m, const double* code256, int k, double* d,
                               double* u, double* vload, double* center, double* scale, double* square_frobenius);
 
+/* ---- streamed whole analyses: the reference's block loop inside the library ---------------------------------------
+ * What defines the reference on this path is that the genotype store is a FILE and is swept in blocks of loci
+ * (R/snp_ibs.R:59-82, R/loci_alt_freq.R:351-359, R/gen_tibble_fbm.R:185-194; big_SVD behind
+ * R/gt_pca_partialSVD.R:82-89 sweeps it twice).  A tpg_stream is such a store that STAYS ON THE HOST: tpg_stream_run
+ * sweeps colInd in blocks of loci, an uploader thread (its own stream) filling one of two block buffers while the kernels
+ * of the block before run, and keeps resident only those two blocks of FBM bytes, the packed views of the block at hand
+ * and the additive state (pairwise slabs, Gram matrix, Fst sums); per-locus outputs leave block by block (a downloader
+ * thread, its own stream) into the caller's arrays.  The PCA's second sweep (the loadings v = Z'u / d) reads the imputed
+ * views again if the budget let them stay (n m / 4 bytes), and streams the store a second time otherwise.
+ * budget_bytes bounds the HBM taken by FBM bytes + packed views + per-block scratch (0 = no bound: a few large blocks,
+ * views kept -- the fastest end-to-end route for a panel that fits); the additive state is not part of it.
+ * Results are those of the resident entry points: integer counts bit for bit, FP64 sums in block order. */
+typedef struct tpg_stream tpg_stream;
+/* the host FBM bytes (e.g. the mmap of bigstatsr's .bk; must stay valid until tpg_stream_close) */
+int tpg_stream_open_host(tpg_ctx* ctx, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, size_t budget_bytes,
+                         tpg_stream** out);
+/* <backingfile>.bk, mapped by the library */
+int tpg_stream_open_bk(tpg_ctx* ctx, const char* path, int64_t nrow, int64_t ncol, size_t budget_bytes, tpg_stream** out);
+/* a PLINK .bed: path (magic checked), or the payload behind its 3-byte magic */
+int tpg_stream_open_bed(tpg_ctx* ctx, const char* path, int64_t n, int64_t m, size_t budget_bytes, tpg_stream** out);
+int tpg_stream_open_bed_host(tpg_ctx* ctx, const uint8_t* payload, int64_t n, int64_t m, size_t budget_bytes,
+                             tpg_stream** out);
+/* the synthetic panel of tpg_fbm_synth generated block by block on the device (panels larger than host memory) */
+int tpg_stream_open_synth(tpg_ctx* ctx, uint64_t seed, int64_t nrow, int64_t ncol, int npop, uint32_t miss_thresh,
+                          int imputed_bytes, size_t budget_bytes, tpg_stream** out);
+void tpg_stream_close(tpg_stream* s);
+
+/* What one sweep computes: every output pointer is optional (NULL = not asked for), host or device memory, laid out as
+ * the resident entry point of the same name lays it out.  One (rowInd, colInd) selection serves all of them. */
+#define TPG_STREAM_MAX_FST 3
+typedef struct tpg_stream_job {
+  size_t struct_size;     /* sizeof(tpg_stream_job) of the caller's header */
+  const int32_t* rowInd1; /* NULL = all rows */
+  int64_t n;
+  const int32_t* colInd1; /* NULL = all columns */
+  int64_t m;
+  /* snp_ibs / snp_king / snp_allele_sharing / pairwise_grm (raw-byte semantics, src/snp_ibs.cpp:47-54): n x n.  Only
+   * the cross-products the requested matrices are made of are accumulated (tpg_pairwise_accumulate_products) */
+  int ibs_type;
+  double *ibs, *king, *allele_sharing, *grm;
+  /* per-locus sweeps through code256 (NULL = raw bytes) */
+  const double* code256;
+  const double* ploidy;      /* NULL = all diploid */
+  const int32_t* groupIds0;  /* needed by the grouped outputs and by Fst */
+  int ngroups;
+  int as_counts;
+  double* alt_freq;            /* m x 2   (tpg_alt_freq_dip_pseudo) */
+  double* grouped_alt_freq;    /* m x 2G  (tpg_grouped_alt_freq_dip_pseudo) */
+  double* grouped_missingness; /* m x G   (tpg_grouped_missingness) */
+  int32_t* loci_counts;        /* m x 4 row-major (tpg_loci_counts) */
+  /* pairwise_pop_fst: up to three estimators from one sweep; fst_tot[i] (P) = ratio of the sums over all loci;
+   * fst_by_locus[i] (m x P, may be NULL) = the by_locus ratios */
+  int nfst;
+  int fst_method[TPG_STREAM_MAX_FST];
+  const int32_t* pairs1; /* 2 x P, 1-based */
+  int P;
+  double* fst_tot[TPG_STREAM_MAX_FST];
+  double* fst_by_locus[TPG_STREAM_MAX_FST];
+  /* gt_pca_partialSVD through code256_pca (e.g. CODE_IMPUTE_PRED); k = 0: no PCA.  pca_tol = 0: the partial SVD's
+   * 1e-12, else tpg_pca_random_svd's tolerance */
+  const double* code256_pca;
+  int k;
+  double pca_tol;
+  double *d, *u, *v, *center, *scale, *square_frobenius;
+} tpg_stream_job;
+
+typedef struct tpg_stream_report {
+  int64_t blocks;          /* blocks of the first sweep */
+  int64_t block_loci;      /* loci per block (the last one may be narrower) */
+  int sweeps;              /* 1, or 2 when the loadings streamed the store again */
+  int views_kept;          /* the imputed views stayed in HBM for the loadings */
+  size_t bytes_up;         /* host -> device, all sweeps */
+  size_t bytes_down;       /* device -> host */
+  size_t budget_bytes;     /* as given */
+  size_t planned_bytes;    /* what the block plan expects to hold: FBM blocks + views + scratch (<= budget when one was given) */
+  size_t state_bytes;      /* additive state (pairwise slabs, Gram matrices, N x N outputs): not part of the budget */
+  size_t peak_device_bytes; /* largest growth of the device's used memory over the run (hipMemGetInfo, sampled per block) */
+  double seconds;
+  double seconds_first_sweep;
+} tpg_stream_report;
+
+/* one streamed pass over the store for everything the job asks for; report may be NULL */
+int tpg_stream_run(tpg_ctx* ctx, tpg_stream* s, const tpg_stream_job* job, tpg_stream_report* report);
+/* The same with the loci sharded over the devices of `mg` ("then stream sub-blocks per GPU"): every device
+ * streams its contiguous share of colInd in blocks under the same budget (per device), then one reduce-scatter of the
+ * pairwise slabs, all-reduces of the Fst sums and of the Gram matrix, replicated eigen step, each device the loadings of its
+ * share.  Outputs must be host memory (device threads write disjoint pieces).  `s` supplies the store and the budget. */
+int tpg_multi_stream_run(tpg_multi* mg, tpg_stream* s, const tpg_stream_job* job, tpg_stream_report* report);
+
 /* ---- PCA (gt_pca_partialSVD) ---------------------------------------------- */
 /* center / scale of bigsnpr::snp_scaleBinom; TPG_ENUMERIC on a missing value or zero scale */
 int tpg_pca_center_scale(tpg_ctx* ctx, const tpg_view* v, double* center, double* scale);

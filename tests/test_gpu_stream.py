@@ -1,0 +1,287 @@
+"""The chunk driver inside the library (tpg_stream_run, include/tpg.h "streamed whole analyses"): a genotype store that
+stays on the host is swept in blocks of loci -- the reference's own block loop (R/snp_ibs.R:59-82,
+R/loci_alt_freq.R:351-359, big_SVD's two sweeps behind R/gt_pca_partialSVD.R:82-89) -- under a budget on the HBM its bytes
+and views may take, and must give what the resident entry points give on the whole panel: integer counts bit for bit
+(so IBS / KING / allele sharing identical), per-locus outputs identical, Fst sums to 1e-12 (block order), the PCA to
+1e-10 (d) / 1e-8 (u, v).  The resident entry points themselves are checked against the oracle elsewhere
+(tests/test_gpu_parity.py, tests/test_gpu_oracle_at_scale.py); the small cases here are checked against the oracle too."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+G = 7
+
+
+@pytest.fixture(scope="module")
+def tpg():
+    import tidypopgen_amd as t
+
+    t.default_context()
+    return t
+
+
+def _aligned(a, b):
+    """columns of b with the signs of a"""
+    return b * np.sign((a * b).sum(axis=0))
+
+
+def _resident(tpg, X, rows, cols, gid, k, fst=("Hudson", "WC84"), by_locus=False):
+    out = {}
+    v = tpg.View(X, rows, cols, code256=None)
+    pw = tpg.Pairwise(X.ctx, v.n)
+    pw.accumulate(v)
+    out.update(pw.epilogues(("ibs", "king", "allele_sharing", "grm"), m=v.m))
+    v012 = tpg.View(X, rows, cols, code256=tpg.CODE_012)
+    out["alt_freq"] = tpg.alt_freq_dip_pseudo_cpp(v012, None, False)
+    out["grouped_alt_freq"] = tpg.grouped_alt_freq_dip_pseudo_cpp(v012, gid, G, None, False)
+    out["grouped_missingness"] = tpg.grouped_missingness_cpp(v012, gid, G)
+    out["loci_counts"] = tpg.loci_counts(v012)
+    out["fst_tot"], out["fst_locus"] = {}, {}
+    for method in fst:
+        r = tpg.pairwise_pop_fst(X, rows, cols, gid, G, method=method, by_locus=by_locus)
+        out["fst_tot"][method] = r["fst_tot"]
+        if by_locus:
+            out["fst_locus"][method] = r["fst_locus"]
+    if k:
+        out["pca"] = tpg.gt_pca_partialSVD(X, rows, cols, k=k)
+    return out
+
+
+def _compare(s, r, k, by_locus=False, pca_tol_u=1e-8):
+    for name in ("ibs", "king", "allele_sharing"):
+        assert np.array_equal(s[name], r[name], equal_nan=True), name
+    assert np.allclose(s["grm"], r["grm"], rtol=1e-13, atol=1e-14, equal_nan=True)
+    for name in ("alt_freq", "grouped_alt_freq", "grouped_missingness", "loci_counts"):
+        assert np.array_equal(s[name], r[name], equal_nan=True), name
+    for method, tot in r["fst_tot"].items():
+        assert np.allclose(s["fst_tot"][method], tot, rtol=1e-12, atol=0, equal_nan=True), method
+        if by_locus:
+            assert np.array_equal(s["fst_locus"][method], r["fst_locus"][method], equal_nan=True), method
+    if k:
+        p = r["pca"]
+        assert np.array_equal(s["center"], p["center"]) and np.array_equal(s["scale"], p["scale"])
+        assert s["square_frobenius"] == pytest.approx(p["square_frobenius"], rel=1e-12)
+        # Panels this short take the digit-split Gram kernel on both routes (the class path does not pay): the resident call
+        # with per-locus weights within 2^-23 (its documented 1e-7), the streamed blocks with eight bits more.  So the
+        # streamed result is held to the FP64 oracle (numpy eigh of the FP64 Gram matrix) at 1e-10 / 1e-8 and to the
+        # resident one at the resident one's own bound.
+        assert np.allclose(s["d"], p["d"], rtol=1e-7, atol=0)
+        assert np.abs(_aligned(p["u"], s["u"]) - p["u"]).max() <= 1e-6
+        o = r.get("pca_oracle")
+        if o is not None:
+            assert np.allclose(s["d"], o["d"], rtol=1e-10, atol=0), s["d"] / o["d"] - 1
+            assert np.abs(_aligned(o["u"], s["u"]) - o["u"]).max() <= pca_tol_u
+            assert np.abs(_aligned(o["v"], s["v"]) - o["v"]).max() <= pca_tol_u
+
+
+@pytest.mark.parametrize("budget", [0, 2 << 20, 600 << 10])
+@pytest.mark.parametrize("n,m", [(200, 3000), (333, 5001)])
+def test_stream_equals_resident_and_oracle(tpg, n, m, budget):
+    """host byte store, three budgets (no bound: 8 blocks, views kept; 2 MiB; 600 KiB: blocks of 128 loci and, for the larger
+    panel, a second sweep for the loadings), everything the job can ask for at once"""
+    fbm = orc.synth_fbm(41, n, m, npop=G, miss=0.03, imputed_bytes=True)
+    gid = (np.arange(n) % G).astype(np.int32)
+    k = 5
+    X = tpg.FBM.from_numpy(fbm)
+    r = _resident(tpg, X, None, None, gid, k, by_locus=True)
+    r["pca_oracle"] = orc.gt_pca_partialSVD(fbm, None, None, k=k)
+    st = tpg.Stream.from_numpy(fbm, budget_bytes=budget)
+    s = st.run(pairwise=("ibs", "king", "allele_sharing", "grm"), groupIds=gid, ngroups=G, alt_freq=True, grouped_alt_freq=True,
+               grouped_missingness=True, loci_counts=True, fst=("Hudson", "WC84"), fst_by_locus=True, k=k)
+    _compare(s, r, k, by_locus=True)
+    rep = s["report"]
+    assert rep["blocks"] == -(-m // rep["block_loci"]) and rep["bytes_up"] == n * m * rep["sweeps"]
+    if budget:
+        assert rep["planned_bytes"] <= budget and rep["blocks"] > 1
+    assert rep["sweeps"] == (1 if rep["views_kept"] else 2)
+    if budget == 600 << 10:
+        assert rep["block_loci"] == 128 and (rep["sweeps"] == 2 or n == 200)
+    else:
+        assert rep["views_kept"]
+    # ... and against the oracle (the reference's statements): counts-based outputs identical
+    assert np.array_equal(s["ibs"], orc.snp_ibs(fbm), equal_nan=True)
+    assert np.array_equal(s["king"], orc.snp_king(fbm), equal_nan=True)
+    assert np.array_equal(s["alt_freq"], orc.alt_freq_dip_pseudo_cpp(fbm, None, None, np.full(n, 2.0)), equal_nan=True)
+    assert np.array_equal(s["grouped_alt_freq"], orc.grouped_alt_freq_dip_pseudo_cpp(fbm, None, None, gid, G, np.full(n, 2.0)),
+                          equal_nan=True)
+    for method in ("Hudson", "WC84"):
+        o = orc.pairwise_pop_fst(fbm, None, None, gid, G, method=method)["fst_tot"]
+        assert np.allclose(s["fst_tot"][method], o, rtol=1e-10, atol=0)
+    st.close()
+
+
+def test_stream_subsets_scattered_columns_and_single_requests(tpg):
+    """rowInd / colInd: a row subset in reverse order, columns scattered (gathered on the host block by block), ascending with
+    gaps, and a contiguous run; jobs that ask for one thing only"""
+    n, m = 260, 4000
+    fbm = orc.synth_fbm(43, n, m, npop=G, miss=0.05, imputed_bytes=True)
+    X = tpg.FBM.from_numpy(fbm)
+    rng = np.random.default_rng(1)
+    rows = np.arange(n, 0, -2).astype(np.int32)
+    gid = (np.arange(len(rows)) % G).astype(np.int32)
+    for cols in ((rng.permutation(m)[:1500] + 1).astype(np.int32), np.arange(1, m + 1, 3).astype(np.int32),
+                 np.arange(701, 2750).astype(np.int32)):
+        r = _resident(tpg, X, rows, cols, gid, 4)
+        r["pca_oracle"] = orc.gt_pca_partialSVD(fbm, rows, cols, k=4)
+        st = tpg.Stream.from_numpy(fbm, budget_bytes=1 << 20)
+        s = st.run(rows, cols, pairwise=("ibs", "king", "allele_sharing", "grm"), groupIds=gid, ngroups=G, alt_freq=True,
+                   grouped_alt_freq=True, grouped_missingness=True, loci_counts=True, fst=("Hudson", "WC84"), k=4)
+        _compare(s, r, 4)
+        assert s["report"]["blocks"] > 2
+        # one analysis at a time: only its products / views / outputs
+        one = st.run(rows, cols, pairwise=("king",))
+        assert set(one) == {"king", "report"} and np.array_equal(one["king"], r["king"], equal_nan=True)
+        one = st.run(rows, cols, pairwise=("grm",))
+        assert np.allclose(one["grm"], r["grm"], rtol=1e-13, atol=1e-14)
+        one = st.run(rows, cols, alt_freq=True)
+        assert np.array_equal(one["alt_freq"], r["alt_freq"], equal_nan=True)
+        one = st.run(rows, cols, groupIds=gid, ngroups=G, fst=("Nei87",))
+        assert np.allclose(one["fst_tot"]["Nei87"], tpg.pairwise_pop_fst(X, rows, cols, gid, G, method="Nei87")["fst_tot"], rtol=1e-12)
+        one = st.run(rows, cols, k=4, total_var=False)
+        assert np.allclose(one["d"], r["pca_oracle"]["d"], rtol=1e-10) and "square_frobenius" not in one
+        st.close()
+
+
+def test_stream_bed_and_synth_sources(tpg, tmp_path):
+    """a PLINK .bed as the store (file and payload; contiguous blocks of SNPs and gathered ones) and the synthetic store
+    generated block by block on the device"""
+    from tests.test_gpu_parity import _bed_file
+
+    n, m = 131, 3001  # n not a multiple of 4: padding bits in every SNP's last byte
+    fbm = orc.synth_fbm(47, n, m, npop=G, miss=0.04)
+    path = str(tmp_path / "s.bed")
+    _bed_file(fbm, path)
+    gid = (np.arange(n) % G).astype(np.int32)
+    X = tpg.FBM.from_numpy(fbm)
+    code_imp = np.array([0, 1, 2, 0] + [np.nan] * 252)  # "missing imputed as 0" (the PCA may not see a missing value)
+    for cols in (None, (np.random.default_rng(2).permutation(m)[:1000] + 1).astype(np.int32)):
+        r = _resident(tpg, X, None, cols, gid, 0)
+        rp = tpg.gt_pca_partialSVD(X, None, cols, k=3, code256=code_imp)
+        for st in (tpg.Stream.open_bed(path, n, m, budget_bytes=512 << 10),
+                   tpg.Stream.from_bed_payload(np.fromfile(path, dtype=np.uint8)[3:], n, m, budget_bytes=0)):
+            s = st.run(None, cols, pairwise=("ibs", "king", "allele_sharing", "grm"), groupIds=gid, ngroups=G, alt_freq=True,
+                       grouped_alt_freq=True, grouped_missingness=True, loci_counts=True, fst=("Hudson", "WC84"), k=3,
+                       code256_pca=code_imp)
+            r["pca"] = rp
+            r["pca_oracle"] = orc.gt_pca_partialSVD(fbm, None, cols, k=3, code256=code_imp)
+            _compare(s, r, 3)
+            st.close()
+    with pytest.raises(tpg._lib.TpgError):
+        tpg.Stream.open_bed(path, n, m + 1)
+    # the synthetic store: equal to the resident synthetic FBM
+    n, m = 300, 6000
+    Xs = tpg.FBM.synth(5, n, m, npop=G, miss=0.02, imputed_bytes=True)
+    gid = (np.arange(n) % G).astype(np.int32)
+    r = _resident(tpg, Xs, None, None, gid, 4)
+    st = tpg.Stream.synth(5, n, m, npop=G, miss=0.02, imputed_bytes=True, budget_bytes=512 << 10)
+    s = st.run(pairwise=("ibs", "king", "allele_sharing", "grm"), groupIds=gid, ngroups=G, alt_freq=True, grouped_alt_freq=True,
+               grouped_missingness=True, loci_counts=True, fst=("Hudson", "WC84"), k=4)
+    _compare(s, r, 4)
+    assert s["report"]["bytes_up"] == 0  # nothing crossed PCIe upwards
+    cols = np.arange(1001, 4001, dtype=np.int32)
+    s = st.run(None, cols, pairwise=("ibs",))
+    assert np.array_equal(s["ibs"], tpg.snp_ibs(Xs, None, cols), equal_nan=True)
+    with pytest.raises(tpg._lib.TpgError) as e:
+        st.run(None, cols[::2], pairwise=("ibs",))
+    assert e.value.code == 3
+    st.close()
+
+
+def test_stream_errors(tpg):
+    n, m = 50, 600
+    fbm = orc.synth_fbm(3, n, m, npop=3, miss=0.1)
+    st = tpg.Stream.from_numpy(fbm, budget_bytes=256 << 10)
+    with pytest.raises(tpg._lib.TpgError) as e:
+        st.run()  # nothing asked for
+    assert e.value.code == 1
+    with pytest.raises(tpg._lib.TpgError) as e:
+        st.run(k=3)  # missing values in the PCA's view: big_SVD's error, from whichever block meets it first
+    assert e.value.code == 4 and "missing values" in str(e.value)
+    with pytest.raises(tpg._lib.TpgError) as e:
+        st.run(None, np.array([1, m + 1], dtype=np.int32), alt_freq=True)
+    assert e.value.code == 1
+    with pytest.raises(tpg._lib.TpgError) as e:
+        st.run(grouped_alt_freq=True)  # no groups
+    assert e.value.code == 1
+    bad = np.array([0, 1, 2, 7] + [np.nan] * 252)
+    with pytest.raises(tpg._lib.TpgError) as e:
+        st.run(code256=bad, alt_freq=True)  # an occurring byte maps outside {0, 1, 2, NA}
+    assert e.value.code == 3
+    st.close()
+    tiny = tpg.Stream.from_numpy(fbm, budget_bytes=1000)
+    with pytest.raises(tpg._lib.TpgError) as e:
+        tiny.run(alt_freq=True)
+    assert e.value.code == 1 and "budget" in str(e.value)
+    # the stream is usable after a failed run
+    ok = tpg.Stream.from_numpy(fbm, budget_bytes=256 << 10)
+    with pytest.raises(tpg._lib.TpgError):
+        ok.run(k=3)
+    a = ok.run(alt_freq=True)["alt_freq"]
+    assert np.array_equal(a, orc.alt_freq_dip_pseudo_cpp(fbm, None, None, np.full(n, 2.0)), equal_nan=True)
+
+
+def test_stream_config2_under_an_eighth_of_the_panel(tpg):
+    """BASELINE config 2's shape, 1 000 x 650 000, with the HBM budget forced to 1 / 8 of the panel's bytes: counts bit-exact,
+    Fst 1e-12, PCA d 1e-10 / u 1e-8 against the resident path; the loadings need a second sweep; the device's memory grows
+    by no more than budget + additive state"""
+    n, m, k = 1000, 650_000, 10
+    G51 = 51
+    X = tpg.FBM.synth(2, n, m, npop=G51, miss=0.02, imputed_bytes=True)
+    fbm = X.to_numpy()
+    gid = (np.arange(n) % G51).astype(np.int32)
+    budget = n * m // 8
+    st = tpg.Stream.from_numpy(fbm, budget_bytes=budget)
+    s = st.run(pairwise=("ibs", "king", "allele_sharing", "grm"), groupIds=gid, ngroups=G51, alt_freq=True, grouped_alt_freq=True,
+               fst=("Hudson", "WC84"), k=k)
+    rep = s["report"]
+    assert rep["planned_bytes"] <= budget and rep["blocks"] >= 8 and rep["sweeps"] == 2 and not rep["views_kept"]
+    assert rep["peak_device_bytes"] <= budget + rep["state_bytes"] + (64 << 20), rep
+    v = tpg.View(X, code256=None)
+    pw = tpg.Pairwise(X.ctx, n)
+    pw.accumulate(v)
+    ep = pw.epilogues(("ibs", "king", "allele_sharing", "grm"), m=m)
+    for name in ("ibs", "king", "allele_sharing"):
+        assert np.array_equal(s[name], ep[name], equal_nan=True), name
+    assert np.allclose(s["grm"], ep["grm"], rtol=1e-13, atol=1e-14)
+    v012 = tpg.View(X, code256=tpg.CODE_012)
+    assert np.array_equal(s["alt_freq"], tpg.alt_freq_dip_pseudo_cpp(v012, None, False), equal_nan=True)
+    assert np.array_equal(s["grouped_alt_freq"], tpg.grouped_alt_freq_dip_pseudo_cpp(v012, gid, G51, None, False), equal_nan=True)
+    for method in ("Hudson", "WC84"):
+        tot = tpg.pairwise_pop_fst(X, None, None, gid, G51, method=method)["fst_tot"]
+        assert np.allclose(s["fst_tot"][method], tot, rtol=1e-12, atol=0), method
+    p = tpg.gt_pca_partialSVD(X, None, None, k=k)
+    assert np.array_equal(s["center"], p["center"]) and np.array_equal(s["scale"], p["scale"])
+    assert np.allclose(s["d"], p["d"], rtol=1e-10, atol=0)
+    assert np.abs(_aligned(p["u"], s["u"]) - p["u"]).max() <= 1e-8
+    assert np.abs(_aligned(p["v"], s["v"]) - p["v"]).max() <= 1e-8
+    assert s["square_frobenius"] == pytest.approx(p["square_frobenius"], rel=1e-12)
+
+
+def test_stream_twenty_gigabytes_in_under_six(tpg):
+    """5 000 x 4 000 000 (20 GB of genotype bytes, generated block by block on the device) under a 2-GB budget: the device's
+    memory grows by less than 6 GB over the whole run -- pairwise slabs, two Gram matrices and N x N outputs included.
+    Checked against the resident results of the same synthetic panel (20 GB in HBM, afterwards) where those exist at this
+    size: IBS / KING identical, alt_freq identical, Fst and singular values to block-order rounding."""
+    n, m, k, G51 = 5000, 4_000_000, 10, 51
+    gid = (np.arange(n) % G51).astype(np.int32)
+    ctx = tpg.Context(0)  # a context of its own: an empty pool, so that growth is what the run really takes
+    st = tpg.Stream.synth(3, n, m, npop=G51, miss=0.02, imputed_bytes=True, budget_bytes=2 << 30, ctx=ctx)
+    s = st.run(pairwise=("ibs", "king"), groupIds=gid, ngroups=G51, alt_freq=True, fst=("Hudson",), k=k)
+    rep = s["report"]
+    assert rep["peak_device_bytes"] < 6 << 30, rep
+    assert rep["planned_bytes"] <= 2 << 30 and rep["blocks"] > 10 and rep["bytes_up"] == 0
+    st.close()
+    ctx.close()
+    X = tpg.FBM.synth(3, n, m, npop=G51, miss=0.02, imputed_bytes=True)
+    assert np.array_equal(s["ibs"], tpg.snp_ibs(X), equal_nan=True)
+    assert np.array_equal(s["king"], tpg.snp_king(X), equal_nan=True)
+    assert np.array_equal(s["alt_freq"][:, 0], tpg.loci_alt_freq(X), equal_nan=True)
+    tot = tpg.pairwise_pop_fst(X, None, None, gid, G51, method="Hudson")["fst_tot"]
+    assert np.allclose(s["fst_tot"]["Hudson"], tot, rtol=1e-12, atol=0)
+    p = tpg.gt_pca_partialSVD(X, None, None, k=k)
+    assert np.allclose(s["d"], p["d"], rtol=1e-10, atol=0)
+    assert np.abs(_aligned(p["u"], s["u"]) - p["u"]).max() <= 1e-8
+    assert np.array_equal(s["center"], p["center"])

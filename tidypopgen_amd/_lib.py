@@ -97,7 +97,39 @@ SYMBOLS = [
     "tpg_pca_partial_svd_sharded", "tpg_multi_create", "tpg_multi_destroy", "tpg_multi_ndev", "tpg_multi_ctx", "tpg_multi_comm", "tpg_multi_pairwise",
     "tpg_multi_grouped_alt_freq", "tpg_multi_pop_fst", "tpg_multi_pca_partial_svd",
     "tpg_pairwise_accumulate_products", "tpg_pairwise_products",
+    "tpg_stream_open_host", "tpg_stream_open_bk", "tpg_stream_open_bed", "tpg_stream_open_bed_host", "tpg_stream_open_synth",
+    "tpg_stream_close", "tpg_stream_run", "tpg_multi_stream_run",
 ]
+
+
+class StreamJob(C.Structure):
+    """tpg_stream_job of include/tpg.h, field for field"""
+    _fields_ = [
+        ("struct_size", C.c_size_t), ("rowInd1", vp), ("n", C.c_int64), ("colInd1", vp), ("m", C.c_int64),
+        ("ibs_type", C.c_int), ("ibs", vp), ("king", vp), ("allele_sharing", vp), ("grm", vp),
+        ("code256", vp), ("ploidy", vp), ("groupIds0", vp), ("ngroups", C.c_int), ("as_counts", C.c_int),
+        ("alt_freq", vp), ("grouped_alt_freq", vp), ("grouped_missingness", vp), ("loci_counts", vp),
+        ("nfst", C.c_int), ("fst_method", C.c_int * 3), ("pairs1", vp), ("P", C.c_int),
+        ("fst_tot", vp * 3), ("fst_by_locus", vp * 3),
+        ("code256_pca", vp), ("k", C.c_int), ("pca_tol", C.c_double),
+        ("d", vp), ("u", vp), ("v", vp), ("center", vp), ("scale", vp), ("square_frobenius", vp),
+    ]
+
+
+class StreamReport(C.Structure):
+    """tpg_stream_report of include/tpg.h"""
+    _fields_ = [
+        ("blocks", C.c_int64), ("block_loci", C.c_int64), ("sweeps", C.c_int), ("views_kept", C.c_int),
+        ("bytes_up", C.c_size_t), ("bytes_down", C.c_size_t), ("budget_bytes", C.c_size_t), ("planned_bytes", C.c_size_t),
+        ("state_bytes", C.c_size_t), ("peak_device_bytes", C.c_size_t), ("seconds", C.c_double),
+        ("seconds_first_sweep", C.c_double),
+    ]
+
+
+lib.tpg_stream_close.restype = None
+lib.tpg_stream_close.argtypes = [vp]
+lib.tpg_stream_run.argtypes = [vp, vp, C.POINTER(StreamJob), C.POINTER(StreamReport)]
+lib.tpg_multi_stream_run.argtypes = [vp, vp, C.POINTER(StreamJob), C.POINTER(StreamReport)]
 
 
 def check(rc: int) -> None:

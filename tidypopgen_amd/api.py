@@ -569,6 +569,156 @@ class Multi:
             pass
 
 
+class Stream:
+    """A genotype store that stays on the HOST and is swept in blocks of loci (tpg_stream, include/tpg.h): the
+    reference's own block loop (R/snp_ibs.R:59-82, R/loci_alt_freq.R:351-359, big_SVD's two sweeps behind
+    R/gt_pca_partialSVD.R:82-89) inside the library.  budget_bytes bounds the HBM taken by store bytes + packed views +
+    per-block scratch (0 = no bound)."""
+
+    def __init__(self, ctx: Context, handle, nrow: int, ncol: int, keep=None):
+        self.ctx, self.h, self.nrow, self.ncol, self._keep = ctx, handle, nrow, ncol, keep
+        self.report = None
+
+    @classmethod
+    def from_numpy(cls, bytes_2d, budget_bytes: int = 0, ctx: Optional[Context] = None) -> "Stream":
+        """host FBM bytes (uint8, Fortran order: a numpy memmap of the .bk works) -- not copied, kept referenced"""
+        ctx = ctx or default_context()
+        a = np.asarray(bytes_2d) if not isinstance(bytes_2d, np.memmap) else bytes_2d
+        if a.dtype != np.uint8 or a.ndim != 2 or not a.flags.f_contiguous:
+            raise TypeError("FBM bytes must be a 2-D uint8 array in Fortran order (individuals x loci)")
+        h = C.c_void_p()
+        check(lib.tpg_stream_open_host(ctx.h, _ptr(a), C.c_int64(a.shape[0]), C.c_int64(a.shape[1]),
+                                       C.c_size_t(int(budget_bytes)), C.byref(h)))
+        return cls(ctx, h, a.shape[0], a.shape[1], keep=a)
+
+    @classmethod
+    def open_bk(cls, path: str, nrow: int, ncol: int, budget_bytes: int = 0, ctx: Optional[Context] = None) -> "Stream":
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib.tpg_stream_open_bk(ctx.h, path.encode(), C.c_int64(nrow), C.c_int64(ncol), C.c_size_t(int(budget_bytes)),
+                                     C.byref(h)))
+        return cls(ctx, h, nrow, ncol)
+
+    @classmethod
+    def open_bed(cls, path: str, n: int, m: int, budget_bytes: int = 0, ctx: Optional[Context] = None) -> "Stream":
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib.tpg_stream_open_bed(ctx.h, path.encode(), C.c_int64(n), C.c_int64(m), C.c_size_t(int(budget_bytes)),
+                                      C.byref(h)))
+        return cls(ctx, h, n, m)
+
+    @classmethod
+    def from_bed_payload(cls, payload, n: int, m: int, budget_bytes: int = 0, ctx: Optional[Context] = None) -> "Stream":
+        """the bytes of a PLINK .bed behind its 3-byte magic (uint8, m * ceil(n / 4)) -- not copied, kept referenced"""
+        ctx = ctx or default_context()
+        a = np.ascontiguousarray(payload, dtype=np.uint8)
+        assert a.size == m * ((n + 3) // 4)
+        h = C.c_void_p()
+        check(lib.tpg_stream_open_bed_host(ctx.h, _ptr(a), C.c_int64(n), C.c_int64(m), C.c_size_t(int(budget_bytes)),
+                                           C.byref(h)))
+        return cls(ctx, h, n, m, keep=a)
+
+    @classmethod
+    def synth(cls, seed: int, nrow: int, ncol: int, npop: int = 51, miss: float = 0.02, imputed_bytes: bool = False,
+              budget_bytes: int = 0, ctx: Optional[Context] = None) -> "Stream":
+        """the synthetic panel of FBM.synth generated block by block on the device (panels larger than host memory)"""
+        ctx = ctx or default_context()
+        thr = min(int(round(miss * 2 ** 32)), 2 ** 32 - 1)
+        h = C.c_void_p()
+        check(lib.tpg_stream_open_synth(ctx.h, C.c_uint64(seed), C.c_int64(nrow), C.c_int64(ncol), C.c_int(npop),
+                                        C.c_uint32(thr), C.c_int(int(imputed_bytes)), C.c_size_t(int(budget_bytes)), C.byref(h)))
+        return cls(ctx, h, nrow, ncol)
+
+    def run(self, ind_row=None, ind_col=None, pairwise=(), ibs_type: str = "proportion", code256=CODE_012, ploidy=None,
+            groupIds=None, ngroups: int = 0, as_counts: bool = False, alt_freq: bool = False, grouped_alt_freq: bool = False,
+            grouped_missingness: bool = False, loci_counts: bool = False, fst=(), fst_by_locus: bool = False,
+            pairwise_combn=None, k: int = 0, pca_tol: float = 0.0, code256_pca=CODE_IMPUTE_PRED, total_var: bool = True,
+            multi: Optional["Multi"] = None) -> dict:
+        """One streamed pass for everything asked for (tpg_stream_run; with `multi`, tpg_multi_stream_run: the loci
+        sharded over its devices).  pairwise: any of "ibs", "king", "allele_sharing", "grm"; fst: up to three of
+        "Hudson", "Nei87", "WC84"; k > 0: gt_pca_partialSVD (pca_tol > 0: gt_pca_randomSVD's tolerance).  Returns the
+        results under the names of the resident functions, plus "report" (blocks, bytes moved, peak HBM)."""
+        r, c = _i32(ind_row), _i32(ind_col)
+        n = self.nrow if r is None else len(r)
+        m = self.ncol if c is None else len(c)
+        job = _lib.StreamJob()
+        job.struct_size = C.sizeof(_lib.StreamJob)
+        keep = [r, c]
+        job.rowInd1, job.n, job.colInd1, job.m = _ptr(r), n, _ptr(c), m
+        out = {}
+        job.ibs_type = 0 if ibs_type == "proportion" else 1
+        for name in pairwise:
+            if name not in ("ibs", "king", "allele_sharing", "grm"):
+                raise ValueError(f"unknown pairwise output {name!r}")
+            out[name] = np.full((n, n), np.nan, order="F")
+            setattr(job, name, _ptr(out[name]))
+        code = _f64(code256)
+        pl = None if ploidy is None else _f64(ploidy)
+        gid = _i32(groupIds)
+        keep += [code, pl, gid]
+        job.code256, job.ploidy, job.groupIds0, job.ngroups, job.as_counts = _ptr(code), _ptr(pl), _ptr(gid), int(ngroups), int(as_counts)
+        if alt_freq:
+            out["alt_freq"] = np.zeros((m, 2), order="F")
+            job.alt_freq = _ptr(out["alt_freq"])
+        if grouped_alt_freq:
+            out["grouped_alt_freq"] = np.zeros((m, 2 * ngroups), order="F")
+            job.grouped_alt_freq = _ptr(out["grouped_alt_freq"])
+        if grouped_missingness:
+            out["grouped_missingness"] = np.zeros((m, ngroups), order="F")
+            job.grouped_missingness = _ptr(out["grouped_missingness"])
+        if loci_counts:
+            out["loci_counts"] = np.zeros((m, 4), dtype=np.int32)
+            job.loci_counts = _ptr(out["loci_counts"])
+        if fst:
+            pairs = combn2(ngroups) if pairwise_combn is None else np.asarray(pairwise_combn, dtype=np.int32)
+            pairs_c = np.ascontiguousarray(pairs.T)
+            keep.append(pairs_c)
+            P = pairs_c.shape[0]
+            job.nfst, job.pairs1, job.P = len(fst), _ptr(pairs_c), P
+            out["fst_tot"], out["fst_locus"] = {}, {}
+            for i, method in enumerate(fst):
+                job.fst_method[i] = FST_METHODS[method]
+                out["fst_tot"][method] = np.zeros(P)
+                job.fst_tot[i] = out["fst_tot"][method].ctypes.data
+                if fst_by_locus:
+                    out["fst_locus"][method] = np.zeros((m, P), order="F")
+                    job.fst_by_locus[i] = out["fst_locus"][method].ctypes.data
+            if not fst_by_locus:
+                del out["fst_locus"]
+        fro = C.c_double()
+        if k > 0:
+            cp = _f64(code256_pca)
+            keep.append(cp)
+            out.update(d=np.zeros(k), u=np.zeros((n, k), order="F"), v=np.zeros((m, k), order="F"), center=np.zeros(m),
+                       scale=np.zeros(m), method="partialSVD" if pca_tol == 0 else "randomSVD")
+            job.code256_pca, job.k, job.pca_tol = _ptr(cp), int(k), float(pca_tol)
+            for name in ("d", "u", "v", "center", "scale"):
+                setattr(job, name, _ptr(out[name]))
+            if total_var:
+                job.square_frobenius = C.cast(C.pointer(fro), C.c_void_p)
+        rep = _lib.StreamReport()
+        if multi is not None:
+            check(lib.tpg_multi_stream_run(multi.h, self.h, C.byref(job), C.byref(rep)))
+        else:
+            check(lib.tpg_stream_run(self.ctx.h, self.h, C.byref(job), C.byref(rep)))
+        if k > 0 and total_var:
+            out["square_frobenius"] = fro.value
+        self.report = {f: getattr(rep, f) for f, _ in _lib.StreamReport._fields_}
+        out["report"] = self.report
+        return out
+
+    def close(self):
+        if self.h:
+            lib.tpg_stream_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------
 # R-level functions
 

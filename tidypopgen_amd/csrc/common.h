@@ -55,6 +55,9 @@ struct tpg_ctx {
   int num_cu = 256;
   int pool_id = 0;  // this context's device-memory pool (runtime.hip): blocks are reused in the order of ITS stream
   void* resident = nullptr;  // pairwise.hip: accumulators kept across increment_* calls
+  // pca.hip, digit-split Gram kernel: fractional bits the per-locus weights keep (22: within 2^-23 of the weight, what a
+  // whole-panel Gram matrix averages down to 1e-10; a streamed run (stream.hip) adds up many short blocks and asks for 30)
+  int pca_digit_fbits = 22;
   // small host -> device copies without a stream synchronisation: a ring of pinned slots (runtime.hip: tpg_h2d_async)
   static constexpr int H2D_SLOTS = 8;
   static constexpr size_t H2D_SLOT_BYTES = 256u << 10;
@@ -232,6 +235,11 @@ hipError_t tpg_copy_dev(tpg_ctx* ctx, void* d_dst, const void* d_src, size_t byt
 // bulk transfers (waited for): large ones are chunked through pinned slots with a team of copying threads
 hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);
 hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);
+// `height` contiguous device pieces of `width` bytes -> host pieces `dpitch` bytes apart (rows of a column-major host matrix)
+hipError_t tpg_download_rows(tpg_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t width, size_t height);
+// pinned staging buffers (256 MiB each) the process keeps between transfers: at least `buffers` from now on (freeing one
+// synchronises the device, so a caller that runs several transfers at once -- tpg_multi's device threads -- raises it first)
+void tpg_stage_keep(int buffers);
 
 // device allocation helpers
 template <typename T>
@@ -277,6 +285,9 @@ struct tpg_comm {
   int a2a_state = 0;            // tpg_comm_alltoall_usable: 0 not tried yet, 1 works, -1 does not (on every rank alike)
 };
 #define TPG_COMM_STATUS_INTS 8
+// pca.hip: the k largest eigenpairs of the symmetric K (device memory) at relative residual tol; lambda on the host, U (n x k) in device memory
+int tpg_sym_eig_topk_tol(tpg_ctx* ctx, const double* d_K, int64_t n, int k, double tol, double* lambda_host, double* d_U);
+int tpg_pca_gram_allreduce(tpg_ctx* ctx, tpg_comm* comm, double* d_K, int64_t n);  // pca.hip: K <- sum over the ranks (its triangle travels)
 int tpg_comm_agree(tpg_comm* comm, int rc);  // all ranks get the same status (the worst any of them passed in)
 int tpg_comm_reduce_scatter_i32(tpg_comm* comm, int32_t* d_buf, int64_t chunk_count);  // in place, chunk r -> rank r
 int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype);          // in place, device memory

@@ -747,9 +747,9 @@ static int pca_gram_device(tpg_ctx* ctx, const tpg_view* v, const double* d_cent
   double smin;
   memcpy(&smin, &rng[0], sizeof(double));
   const double wmax = 1.0 / (smin * smin);
-  const int F_TARGET = 22;
   const int wbits = (int)ceil(log2(wmax + 1.0));
-  int T = (wbits + F_TARGET + 1 + 6) / 7;
+  int T = (wbits + ctx->pca_digit_fbits + 1 + 6) / 7;
+  if (T > 8 && ctx->pca_digit_fbits > 22) T = std::max(8, (wbits + 22 + 1 + 6) / 7);  // (extra bits are a wish, 22 the requirement)
   if (T < 4) T = 4;
   TPG_REQUIRE(T <= 8, TPG_ENUMERIC, "per-locus weight range too wide (max 1/scale^2 = %g)", wmax);
   const int F = 7 * T - 1 - wbits;
@@ -1595,6 +1595,28 @@ __global__ void tpg_tri_unpack_kernel(const double* __restrict__ tri, int n, dou
   }
 }
 
+// K (n x n in device memory, bitwise symmetric) <- its sum over the ranks; only the upper triangle travels.  For callers that
+// accumulate the Gram matrix themselves (stream.hip: block by block); the allocation is agreed on before the collective.
+int tpg_pca_gram_allreduce(tpg_ctx* ctx, tpg_comm* comm, double* d_K, int64_t n) {
+  if (!comm || !(comm->nranks > 1 || comm->nccl)) return TPG_OK;
+  const int64_t ntri = n * (n + 1) / 2;
+  double* d_tri = nullptr;
+  hipError_t e = tpg_pmalloc((void**)&d_tri, sizeof(double) * (size_t)ntri);
+  int lrc = TPG_OK;
+  if (e != hipSuccess) { tpg_set_error("gram all-reduce: %s", hipGetErrorString(e)); (void)hipGetLastError(); lrc = TPG_EHIP; }
+  lrc = tpg_comm_agree(comm, lrc);
+  if (lrc != TPG_OK) { tpg_pfree(d_tri); return lrc; }
+  TPG_LAUNCH(ctx, "pca_gram_tri", tpg_tri_pack_kernel, dim3(2048), dim3(256), 0, (const double*)d_K, (int)n, d_tri);
+  int rc;
+  {
+    ProfScope ps(ctx, "pca_gram_allreduce");
+    rc = tpg_comm_allreduce(comm, d_tri, ntri, 1);
+  }
+  if (rc == TPG_OK) TPG_LAUNCH(ctx, "pca_gram_tri", tpg_tri_unpack_kernel, dim3(2048), dim3(256), 0, (const double*)d_tri, (int)n, d_K);
+  tpg_pfree(d_tri);
+  return rc;
+}
+
 static int pca_svd_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_view* v, int k, double tol, double* d, double* u,
                         double* vload, double* center, double* scale, double* square_frobenius) {
   TPG_REQUIRE(ctx && v && d && u && vload && center && scale, TPG_EINVAL, "null argument");
@@ -1949,6 +1971,12 @@ static int pca_loadings_device(tpg_ctx* ctx, const tpg_view* v, const double* d_
   tpg_pfree(d_UD); tpg_pfree(d_acc); tpg_pfree(d_usum);
   if (e != hipSuccess) { tpg_set_error("loadings: %s", hipGetErrorString(e)); return TPG_EHIP; }
   return TPG_OK;
+}
+
+int tpg_sym_eig_topk_tol(tpg_ctx* ctx, const double* d_K, int64_t n, int k, double tol, double* lambda_host, double* d_U) {
+  TPG_REQUIRE(ctx && d_K && lambda_host && d_U, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(n > 0 && k >= 1 && k <= n, TPG_EINVAL, "bad n = %lld / k = %d", (long long)n, k);
+  return eig_topk_any(ctx, d_K, (int)n, k, lambda_host, d_U, tol);
 }
 
 extern "C" int tpg_sym_eig_topk(tpg_ctx* ctx, const double* K, int64_t n, int k, double* lambda, double* U) {

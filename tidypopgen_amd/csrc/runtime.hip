@@ -534,6 +534,7 @@ template <typename F>  // f(thread, lo, hi) over [0, bytes) cut into page-aligne
 static void xfer_parallel(size_t bytes, F f) {
   const size_t pages = (bytes + 4095) / 4096;
   const int nth = (int)std::min<size_t>(XFER_THREADS, std::max<size_t>(1, pages / 256));
+  if (nth == 1) { f(0, 0, bytes); return; }  // below 2 MiB: on the calling thread
   std::vector<std::thread> th;
   for (int t = 0; t < nth; t++) {
     const size_t lo = std::min(bytes, pages * (size_t)t / (size_t)nth * 4096), hi = std::min(bytes, pages * ((size_t)t + 1) / (size_t)nth * 4096);
@@ -553,8 +554,12 @@ static constexpr size_t XFER_PIECE = 64u << 20;  // a quarter of the process's p
 // runtime with something to undo: the NEXT device -> host copy of the process, or the exit of the thread, stood still for
 // 45 - 48 ms after 1.4 GB had gone down that way (seen with the end-to-end routes' downloads beside the step; bench.py
 // TPG_E2E_TRACE=1).  TPG_DOWNLOAD_PINNED=0: the old path (A/B).
-static hipError_t tpg_download_pinned(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes, bool* done) {
+// (width / dpitch: the destination as `bytes / width` pieces of `width` bytes, `dpitch` bytes apart -- a block of rows of a
+// column-major host matrix, tpg_download_rows; width == bytes: one contiguous piece)
+static hipError_t tpg_download_pinned(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes, bool* done,
+                                      size_t width = 0, size_t dpitch = 0) {
   *done = false;
+  if (width == 0 || width >= bytes) { width = bytes; dpitch = bytes; }
   static const bool off = getenv("TPG_DOWNLOAD_PINNED") && atoi(getenv("TPG_DOWNLOAD_PINNED")) == 0;
   // (a copy below 64 MiB takes the staging buffer only if the process already has one: pinning 256 MiB costs 35 - 40 ms)
   uint8_t* const pinned = off ? nullptr : nib_stage_acquire(bytes >= XFER_BIG);
@@ -575,7 +580,17 @@ static hipError_t tpg_download_pinned(tpg_ctx* ctx, uint8_t* dst, const uint8_t*
     if (e != hipSuccess) break;
     const size_t a = i * H, len = std::min(bytes - a, H);
     const uint8_t* pin = pinned + (i & 3) * H;
-    xfer_parallel(len, [=](int, size_t lo, size_t hi) { memcpy(dst + a + lo, pin + lo, hi - lo); });
+    if (width == bytes) {
+      xfer_parallel(len, [=](int, size_t lo, size_t hi) { memcpy(dst + a + lo, pin + lo, hi - lo); });
+    } else {
+      xfer_parallel(len, [=](int, size_t lo, size_t hi) {
+        for (size_t o = lo; o < hi;) {  // source offset a + o = piece (a + o) / width, byte (a + o) % width of it
+          const size_t col = (a + o) / width, within = (a + o) % width, run = std::min(hi - o, width - within);
+          memcpy(dst + col * dpitch + within, pin + o, run);
+          o += run;
+        }
+      });
+    }
     if (i + 4 < np) e = issue(i + 4);
   }
   if (e != hipSuccess) (void)hipStreamSynchronize(ctx->stream);
@@ -598,6 +613,21 @@ hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) 
     xfer_parallel(bytes, [=](int, size_t lo, size_t hi) { for (size_t o = lo; o < hi; o += 4096) d[o] = 0; });
   }
   hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+}
+
+// device memory (height contiguous pieces of `width` bytes) -> the same pieces `dpitch` bytes apart in host memory the caller
+// owns: rows [j0, j0 + ml) of an m-row column-major matrix that is filled block of loci by block of loci (stream.hip,
+// comm.hip).  Through the pinned staging like any large download; hipMemcpy2D otherwise.
+hipError_t tpg_download_rows(tpg_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t width, size_t height) {
+  if (width == 0 || height == 0) return hipSuccess;
+  if (height == 1 || dpitch == width) return tpg_download(ctx, dst, src, width * height);
+  if (width * height >= (256u << 10)) {
+    bool done = false;
+    const hipError_t e = tpg_download_pinned(ctx, (uint8_t*)dst, (const uint8_t*)src, width * height, &done, width, dpitch);
+    if (e != hipSuccess || done) return e;
+  }
+  hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, width, width, height, hipMemcpyDeviceToHost, ctx->stream);
   return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
 }
 
@@ -671,12 +701,18 @@ static uint8_t* nib_stage_acquire(bool may_pin) {
 // at most two buffers stay pinned between uploads (the main context's and a pipeline's uploader thread's); a burst of
 // concurrent uploads hands the others back to the system (the two are the process's, like the HIP runtime's own pools: freeing
 // them from a static destructor would race the runtime's teardown)
+static size_t g_nib_keep = 3;  // (a streamed run has an uploader, a downloader and its main thread; tpg_multi one per device: tpg_stage_keep)
+void tpg_stage_keep(int buffers) {
+  std::lock_guard<std::mutex> lk(g_nib_mu);
+  if ((size_t)buffers > g_nib_keep) g_nib_keep = std::min<size_t>((size_t)buffers, 16);
+}
 static void nib_stage_release(uint8_t* p) {
   {
     std::lock_guard<std::mutex> lk(g_nib_mu);
-    if (g_nib_free.size() < 2) { g_nib_free.push_back(p); return; }
+    static const size_t env_keep = getenv("TPG_PINNED_KEEP") ? (size_t)atoi(getenv("TPG_PINNED_KEEP")) : 0;
+    if (g_nib_free.size() < std::max(g_nib_keep, env_keep)) { g_nib_free.push_back(p); return; }
   }
-  (void)hipHostFree(p);
+  (void)hipHostFree(p);  // (device-synchronising: only a burst beyond what the process keeps gets here)
 }
 
 static hipError_t tpg_upload_packed(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes) {
