@@ -432,164 +432,53 @@ def _e2e_serial(st, path):
         st.X = resident
 
 
-def _e2e_overlapped(st, path, nblocks=8, source="bk"):
-    """The reference's own block loop (R/snp_ibs.R:59-82) as a pipeline: a second host thread, with a context (stream)
-    of its own, uploads block b + 1 of the loci (tpg_fbm_upload_cols; source = "bed": tpg_fbm_upload_bed_snps, the 2-bit
-    payload of a PLINK .bed) while the main context packs block b (raw and imputed view from one read), takes its per-locus
-    statistics and Fst sums and adds its pairwise cross-products and its Gram matrix to the running totals (all additive over
-    loci); a third thread (its own stream) takes the per-locus results of block b down to the host as soon as the block is
-    done.  After the last block: epilogues, then the N x N results go down while eigen step and loadings run."""
-    import queue
-    import threading
-
-    tpg, api, lib, ctx, a = st.tpg, st.api, st.lib, st.ctx, st.args
-    chk = tpg._lib.check
-    n, m, G, k, P = a.n, st.m, a.pops, a.k, st.P
-    groups = -(-m // 128)
-    edges = sorted({min(m, 128 * (groups * b // nblocks)) for b in range(nblocks + 1)})
-    blocks = [(c0, c1) for c0, c1 in zip(edges, edges[1:]) if c1 > c0]
-    mbs = [c1 - c0 for c0, c1 in blocks]
-    bpl = (n + 3) // 4
-    if source == "bed":
-        mm = np.memmap(path, dtype=np.uint8, mode="r", offset=3, shape=(m, bpl), order="C")
-    else:
-        mm = np.memmap(path, dtype=np.uint8, mode="r", shape=(n, m), order="F")
-    up_ctx = tpg.Context(ctx.device)
-    down_ctx = tpg.Context(ctx.device)
-    # device buffers of the results (allocation is not what is being measured)
-    d_freq = [ctx.dev_alloc(16 * mb) for mb in mbs]
-    d_gfreq = [ctx.dev_alloc(16 * G * mb) for mb in mbs]
-    d_K = ctx.dev_alloc(8 * n * n)
-    d_u = ctx.dev_alloc(8 * n * k)
-    pca = []  # per block: (imputed view, d_center, d_scale, d_v, m_pca_block)
-    sums = np.zeros((4, P))
-    part = np.zeros((4, P))
-    host = {}
-    errors = []
+def _e2e_streamed(st, path, source="bk", budget_bytes=0):
+    """The reference's own block loop (R/snp_ibs.R:59-82) as the LIBRARY runs it (tpg_stream_run, csrc/stream.hip): the store
+    stays on the host; an uploader thread (its own stream) fills one of two block buffers -- blocks of loci of the .bk, or of
+    SNPs of the .bed payload -- while the caller's context packs the block before it (raw and imputed view from one read),
+    takes its per-locus statistics and Fst sums and adds its pairwise cross-products and its Gram matrix to the running
+    totals; a downloader thread (a third stream) writes the per-locus results of every block into the caller's arrays; after
+    the last block the N x N results go down beside the eigen step and the loadings.  Until round 5 this pipeline was Python
+    in this file (three threads, three contexts, a queue); now the route is one library call.  budget_bytes = 0: no bound on
+    the HBM the store's bytes and views may take (a few large blocks, views kept: the fastest route for a panel that fits)."""
+    tpg, a = st.tpg, st.args
+    n, m, G, k = a.n, st.m, a.pops, a.k
     t0 = time.perf_counter()
-    X = (tpg.FBM.alloc_bed if source == "bed" else tpg.FBM.alloc)(n, m, ctx=ctx, code256=tpg.CODE_012)
-    ready, done = queue.Queue(), queue.Queue()
-    down = [0]
-
-    def uploader():
-        try:
-            for b, (c0, c1) in enumerate(blocks):
-                if source == "bed":
-                    X.upload_bed_snps(mm[c0:c1], c0, c1 - c0, ctx=up_ctx)
-                else:
-                    X.upload_cols(mm[:, c0:c1], c0, ctx=up_ctx)
-                ready.put(b)
-        except Exception as e:  # noqa: BLE001
-            errors.append(e)
-            ready.put(None)
-
-    def block_downloader():  # alt_freq and grouped_alt_freq of a block, as soon as the main thread says its kernels are done
-        try:
-            host["freq"], host["gfreq"] = [None] * len(blocks), [None] * len(blocks)
-            while True:
-                b = done.get()
-                if b is None:
-                    return
-                for key, dptr, cols in (("freq", d_freq[b], 2), ("gfreq", d_gfreq[b], 2 * G)):
-                    arr = np.empty((mbs[b], cols), order="F")
-                    chk(lib.tpg_dev_to_host(down_ctx.h, api._ptr(arr), dptr, C.c_size_t(arr.nbytes)))
-                    host[key][b] = arr
-                    down[0] += arr.nbytes
-        except Exception as e:  # noqa: BLE001
-            errors.append(e)
-
-    th = threading.Thread(target=uploader)
-    th.start()
-    thd = threading.Thread(target=block_downloader)
-    thd.start()
-    st.pw.zero()
-    fro = 0.0
-    for _ in blocks:
-        b = ready.get()
-        if b is None:
-            raise errors[0]
-        c0, c1 = blocks[b]
-        cols = np.arange(c0 + 1, c1 + 1, dtype=np.int32)
-        pc = cols if st.pca_cols is None else st.pca_cols[(st.pca_cols > c0) & (st.pca_cols <= c1)]
-        if st.pca_cols is None:
-            v, vi = api.View.pair(X, None, cols, st.code_012, st.code_imp)
-        else:
-            v, vi = api.View(X, None, cols, code256=st.code_012), api.View(X, None, pc, code256=st.code_imp)
-        chk(lib.tpg_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(st.ploidy), C.c_int(0), d_freq[b]))
-        chk(lib.tpg_grouped_alt_freq_dip_pseudo(ctx.h, v.h, api._ptr(st.gid), C.c_int(G), api._ptr(st.ploidy), C.c_int(0),
-                                                d_gfreq[b]))
-        for row, code in ((0, 0), (2, 2)):
-            chk(lib.tpg_pairwise_pop_fst_sums(ctx.h, v.h, api._ptr(st.gid), C.c_int(G), api._ptr(st.ploidy), C.c_int(code),
-                                              api._ptr(st.pairs), C.c_int(P), api._ptr(part[row]), api._ptr(part[row + 1])))
-        sums += part
-        done.put(b)  # the Fst sums came back to the host: every kernel of the block enqueued before them has finished
-        st.pw.accumulate(v)
-        v.free()
-        dc, ds, dv = ctx.dev_alloc(8 * len(pc)), ctx.dev_alloc(8 * len(pc)), ctx.dev_alloc(8 * len(pc) * k)
-        chk(lib.tpg_pca_center_scale(ctx.h, vi.h, dc, ds))
-        chk((lib.tpg_pca_gram if not pca else lib.tpg_pca_gram_add)(ctx.h, vi.h, dc, ds, d_K))
-        f = C.c_double()
-        chk(lib.tpg_square_frobenius(ctx.h, vi.h, dc, ds, C.byref(f)))
-        fro += f.value
-        pca.append((vi, dc, ds, dv, len(pc)))
-    th.join()
-    t_up = time.perf_counter()
-    st.pw.reduce()
-    chk(lib.tpg_pairwise_epilogues_sharded(ctx.h, st.comm.h, st.pw.h, C.c_int(0), C.c_int64(m), st.d_nn[0], st.d_nn[1],
-                                           C.c_void_p(None), st.d_nn[2]))
-    ctx.sync()  # the results below are read by another stream
-    done.put(None)
-
-    def downloader():
-        try:
-            down[0] += _e2e_download(st, up_ctx, st.d_nn, [], [], [], host)
-        except Exception as e:  # noqa: BLE001
-            errors.append(e)
-
-    th = threading.Thread(target=downloader)
-    th.start()
-    lam = np.zeros(k)
-    chk(lib.tpg_sym_eig_topk(ctx.h, d_K, C.c_int64(n), C.c_int(k), api._ptr(lam), d_u))
-    d = np.sqrt(np.maximum(lam, 0))
-    for vi, dc, ds, dv, mp in pca:
-        chk(lib.tpg_pca_loadings(ctx.h, vi.h, dc, ds, d_u, api._ptr(d), C.c_int(k), dv))
-    u = np.empty((n, k), order="F")
-    chk(lib.tpg_dev_to_host(ctx.h, api._ptr(u), d_u, C.c_size_t(u.nbytes)))
-    vls = []
-    for vi, dc, ds, dv, mp in pca:
-        vl = np.empty((mp, k), order="F")
-        chk(lib.tpg_dev_to_host(ctx.h, api._ptr(vl), dv, C.c_size_t(vl.nbytes)))
-        vls.append(vl)
-    th.join()
-    thd.join()
-    t1 = time.perf_counter()
-    if errors:
-        raise errors[0]
-    with np.errstate(invalid="ignore", divide="ignore"):
-        fst_h = sums[0] / sums[1]
+    if source == "bed":
+        S = tpg.Stream.open_bed(path, n, m, budget_bytes=budget_bytes, ctx=st.ctx)
+    else:
+        S = tpg.Stream.open_bk(path, n, m, budget_bytes=budget_bytes, ctx=st.ctx)
+    try:
+        pca_here = st.has_pca and st.pca_cols is None
+        r = S.run(pairwise=("ibs", "king", "grm"), code256=st.code_012, ploidy=st.ploidy, groupIds=st.gid, ngroups=G,
+                  alt_freq=True, grouped_alt_freq=True, fst=("Hudson", "WC84"), pairwise_combn=st.pairs.T,
+                  k=k if pca_here else 0, code256_pca=st.code_imp)
+        rep = dict(r["report"])
+        if st.has_pca and not pca_here:  # (monomorphic loci were dropped for the PCA: its own selection, its own sweep)
+            r2 = S.run(None, st.pca_cols, k=k, code256_pca=st.code_imp)
+            r.update({key: r2[key] for key in ("d", "u", "v", "center", "scale", "square_frobenius")})
+            for key in ("bytes_up", "bytes_down"):
+                rep[key] += r2["report"][key]
+        t1 = time.perf_counter()
+    finally:
+        S.close()
     # the pipeline must give what the resident step gives
-    check = {"fst_hudson_max_rel_diff": float(np.nanmax(np.abs(fst_h / st.fst["Hudson"] - 1))),
-             "pca_d_max_rel_diff": float(np.max(np.abs(d / st.pca_d - 1))) if st.has_pca else None,
-             "frobenius_rel_diff": abs(fro / st.pca_fro.value - 1) if st.has_pca else None}
-    for vi, dc, ds, dv, mp in pca:
-        vi.free()
-        for p_ in (dc, ds, dv):
-            ctx.dev_free(p_)
-    for p_ in d_freq + d_gfreq + [d_K, d_u]:
-        ctx.dev_free(p_)
-    X.free()
-    up_ctx.close()
-    down_ctx.close()
-    bytes_down = down[0] + u.nbytes + sum(x.nbytes for x in vls)
-    return {"value": n * m / (t1 - t0), "seconds": t1 - t0, "last_block_in_HBM_s": t_up - t0, "tail_s": t1 - t_up,
-            "blocks": len(blocks), "bytes_up": (bpl * m + 3) if source == "bed" else n * m, "bytes_down": bytes_down,
-            "agreement_with_resident_step": check}
+    check = {"fst_hudson_max_rel_diff": float(np.nanmax(np.abs(r["fst_tot"]["Hudson"] / st.fst["Hudson"] - 1))),
+             "fst_wc84_max_rel_diff": float(np.nanmax(np.abs(r["fst_tot"]["WC84"] / st.fst["WC84"] - 1))),
+             "pca_d_max_rel_diff": float(np.max(np.abs(r["d"] / st.pca_d - 1))) if st.has_pca else None,
+             "frobenius_rel_diff": abs(r["square_frobenius"] / st.pca_fro.value - 1) if st.has_pca else None}
+    return {"value": n * m / (t1 - t0), "seconds": t1 - t0, "last_block_in_HBM_s": rep["seconds_first_sweep"],
+            "tail_s": (t1 - t0) - rep["seconds_first_sweep"], "blocks": rep["blocks"], "block_loci": rep["block_loci"],
+            "bytes_up": rep["bytes_up"], "bytes_down": rep["bytes_down"], "views_kept": bool(rep["views_kept"]),
+            "sweeps": rep["sweeps"], "budget_bytes": budget_bytes, "planned_bytes": rep["planned_bytes"],
+            "state_bytes": rep["state_bytes"], "peak_device_bytes_growth": rep["peak_device_bytes"],
+            "entry_point": "tpg_stream_run (csrc/stream.hip)", "agreement_with_resident_step": check}
 
 
 def end_to_end(st):
     """Host backing file -> HBM -> every result of the step back in host memory, on rank 0's panel at N = 1: what an R
     caller holding a bigstatsr .bk file pays, PCIe included (never `value`).  Two ways: serial (upload, step,
-    download) and the block pipeline of _e2e_overlapped."""
+    download) and the library's block pipeline (_e2e_streamed = tpg_stream_run)."""
     fst_results(st)  # of the resident step: what the pipelines are compared with
     path = _e2e_file(st)
     if path is None:
@@ -618,15 +507,23 @@ def end_to_end(st):
     try:
         ser = median_of(_e2e_serial, st, path)
         d_bk = st.pca_d.copy()
-        ovl = median_of(_e2e_overlapped, st, path)
+        ovl = median_of(_e2e_streamed, st, path)
         routes = {"serial": ("bigstatsr .bk (1 byte per genotype, warm page cache) -> HBM in one upload -> the step, its "
                              "results going down to host memory beside it", ser),
-                  "overlapped": ("bigstatsr .bk (1 byte per genotype, warm page cache) -> HBM in 8 locus blocks uploaded by a "
-                                 "second thread / stream beside pack + accumulate -> all results in host memory", ovl)}
+                  "overlapped": ("bigstatsr .bk (1 byte per genotype, warm page cache) -> tpg_stream_run: HBM in 8 locus blocks uploaded by "
+                                 "the library's uploader thread / stream beside pack + accumulate, per-locus results down block by "
+                                 "block on a third -> all results in host memory", ovl)}
         best = min(routes, key=lambda k_: routes[k_][1]["seconds"])
         out = {"value": routes[best][1]["value"], "unit": "SNP-genotypes/s", "seconds": routes[best][1]["seconds"],
                "route": routes[best][0], "best_bk_route": best, "statistic": "median of 3 runs per route; value = the faster .bk route",
                "overlapped": ovl, "serial": ser}
+        try:  # the same call when the panel may NOT stay: 1 / 8 of its bytes as the budget (a second sweep for the loadings)
+            tight = _e2e_streamed(st, path, budget_bytes=st.args.n * st.m // 8)
+            tight["route"] = ("the same .bk through tpg_stream_run with budget_bytes = 1 / 8 of the panel: the store's bytes and views "
+                              "never take more HBM than that; the loadings stream the file a second time")
+            out["out_of_core"] = tight
+        except Exception as e:  # noqa: BLE001
+            out["out_of_core"] = {"failed": f"{type(e).__name__}: {e}"}
         if not st.args.no_dropin:
             try:
                 out["dropin"] = dropin(st, path)
@@ -643,11 +540,11 @@ def end_to_end(st):
                             "staging -> pack from the .bed bytes -> the step, its results going down to host memory beside it")
             # the same file through the block pipeline (what the pipeline is compared with: the .bed's own resident step)
             fst_results(st)
-            nb_bed = int(os.environ.get("TPG_E2E_BED_BLOCKS", "2"))  # measured: 2 blocks 75.5 ms, 3: 80.7, 4: 80.0, 8: 98 (per-block fixed costs)
-            bed_ovl = median_of(lambda st_, p_: _e2e_overlapped(st_, p_, nblocks=nb_bed, source="bed"), st, bed_path)
-            bed_ovl["route"] = (f"PLINK .bed of the imputed panel -> HBM in {nb_bed} blocks of SNPs uploaded through pinned staging by a second "
-                                "thread / stream beside pack + accumulate, per-locus results down block by block on a third -> all "
-                                "results in host memory")
+            # (blocks: TPG_STREAM_BLOCKS; measured in round 5: 2 blocks 75.5 ms, 3: 80.7, 4: 80.0, 8: 98 -- per-block fixed costs)
+            bed_ovl = median_of(lambda st_, p_: _e2e_streamed(st_, p_, source="bed"), st, bed_path)
+            bed_ovl["route"] = (f"PLINK .bed of the imputed panel -> tpg_stream_run: HBM in {bed_ovl['blocks']} blocks of SNPs uploaded through "
+                                "pinned staging by the library's uploader thread / stream beside pack + accumulate, per-locus results down "
+                                "block by block on a third -> all results in host memory")
             out["bed"] = dict(bed_ovl if bed_ovl["seconds"] < bed["seconds"] else bed)
             out["bed"]["serial"], out["bed"]["overlapped"] = bed, bed_ovl
         except (OSError, MemoryError) as e:

@@ -64,6 +64,35 @@ def multi_against_oracle(ndev, devices=None, setenv=None):
         assert np.allclose(t["d"], o["d"], rtol=1e-6, atol=0)
         so = o["u"] * o["d"]
         assert np.max(np.abs(align_sign(t["u"] * t["d"], so) - so)) <= 1e-6 * np.max(np.abs(so))
+    # the streamed form (tpg_multi_stream_run): the store stays on the host, every device sweeps ITS share of colInd in blocks
+    # under a budget (two block buffers, an uploader and a downloader thread per device), then the same exchanges -- one
+    # reduce-scatter of the pairwise slabs, all-reduces of the Fst sums, of the Gram matrix and of its Frobenius norm
+    for budget in (0, 1 << 20):
+        S = tpg.Stream.from_numpy(fbm, budget_bytes=budget)
+        s = S.run(None, pc, pairwise=("ibs", "king", "allele_sharing", "grm"), groupIds=gid, ngroups=G, alt_freq=True,
+                  grouped_alt_freq=True, loci_counts=True, fst=("Hudson", "WC84"), fst_by_locus=True, k=k, multi=mg)
+        sub = np.asfortranarray(fbm[:, pc - 1])
+        assert np.array_equal(s["ibs"], orc.snp_ibs(sub), equal_nan=True)
+        assert np.array_equal(s["king"], orc.snp_king(sub), equal_nan=True)
+        as_s = orc.snp_allele_sharing(sub)
+        assert np.array_equal(s["allele_sharing"], as_s, equal_nan=True)
+        assert np.allclose(s["grm"], orc.pairwise_grm(as_s), rtol=1e-12, atol=1e-14)
+        assert np.array_equal(s["alt_freq"], orc.alt_freq_dip_pseudo_cpp(sub, None, None, np.full(n, 2.0)), equal_nan=True)
+        assert np.array_equal(s["grouped_alt_freq"], orc.grouped_alt_freq_dip_pseudo_cpp(sub, None, None, gid, G, np.full(n, 2.0)))
+        assert np.array_equal(s["loci_counts"][:, 3], (sub > 2).sum(axis=0))
+        for method in ("Hudson", "WC84"):
+            of = orc.pairwise_pop_fst(sub, None, None, gid, G, method=method, by_locus=True)
+            assert np.array_equal(s["fst_locus"][method], of["fst_locus"], equal_nan=True), method
+            assert np.allclose(s["fst_tot"][method], of["fst_tot"], rtol=1e-12, atol=0), method
+        assert np.array_equal(s["center"], o["center"]) and np.array_equal(s["scale"], o["scale"])
+        assert np.allclose(s["d"], o["d"], rtol=1e-8, atol=0)
+        so = o["u"] * o["d"]
+        assert np.max(np.abs(align_sign(s["u"] * s["d"], so) - so)) <= 1e-6 * np.max(np.abs(so))
+        assert np.max(np.abs(align_sign(s["v"], o["v"]) - o["v"])) <= 1e-6 * np.max(np.abs(o["v"]))
+        assert abs(s["square_frobenius"] / o["square_frobenius"] - 1) < 1e-12
+        if budget:
+            assert s["report"]["blocks"] > 1
+        S.close()
     transport = mg.transport()
     mg.close()
     return transport

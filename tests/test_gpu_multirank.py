@@ -364,6 +364,18 @@ def test_rccl_ranks_on_distinct_gpus_equal_one_gpu(tmp_path, ngpu, exchange):
     _digests_match(json.load(open(d1)), json.load(open(dn)), exchange)
 
 
+@pytest.mark.parametrize("ndev", [1, 2, 3])
+def test_multi_and_multi_stream_device_threads_against_oracle(ndev, monkeypatch):
+    """tests/multi_cases.py::multi_against_oracle -- tpg_multi_* and the streamed form, tpg_multi_stream_run (every device
+    sweeps its share of colInd in blocks under a budget, then the exchanges) -- with device 0 listed ndev times: the device
+    threads exchange through the in-process transport.  The same body runs over the mock RCCL (below) and, on a box that has
+    them, on distinct GPUs (next test)."""
+    from tests import multi_cases
+
+    tr = multi_cases.multi_against_oracle(ndev, devices=[0] * ndev, setenv=monkeypatch.setenv)
+    assert tr == ("none" if ndev == 1 else "host callback"), tr
+
+
 @pytest.mark.parametrize("ndev", [pytest.param(2, marks=_need_gpus(2)), pytest.param(8, marks=_need_gpus(8))])
 def test_multi_on_distinct_gpus_against_oracle(ndev, monkeypatch):
     """tpg.Multi(ndev) on devices 0 .. ndev-1 (ncclCommInitAll, one host thread per device, RCCL between them) against the

@@ -650,7 +650,7 @@ class Stream:
         for name in pairwise:
             if name not in ("ibs", "king", "allele_sharing", "grm"):
                 raise ValueError(f"unknown pairwise output {name!r}")
-            out[name] = np.full((n, n), np.nan, order="F")
+            out[name] = np.empty((n, n), order="F")  # (every element is written: rows and their mirror images)
             setattr(job, name, _ptr(out[name]))
         code = _f64(code256)
         pl = None if ploidy is None else _f64(ploidy)
@@ -658,16 +658,16 @@ class Stream:
         keep += [code, pl, gid]
         job.code256, job.ploidy, job.groupIds0, job.ngroups, job.as_counts = _ptr(code), _ptr(pl), _ptr(gid), int(ngroups), int(as_counts)
         if alt_freq:
-            out["alt_freq"] = np.zeros((m, 2), order="F")
+            out["alt_freq"] = np.empty((m, 2), order="F")
             job.alt_freq = _ptr(out["alt_freq"])
         if grouped_alt_freq:
-            out["grouped_alt_freq"] = np.zeros((m, 2 * ngroups), order="F")
+            out["grouped_alt_freq"] = np.empty((m, 2 * ngroups), order="F")
             job.grouped_alt_freq = _ptr(out["grouped_alt_freq"])
         if grouped_missingness:
-            out["grouped_missingness"] = np.zeros((m, ngroups), order="F")
+            out["grouped_missingness"] = np.empty((m, ngroups), order="F")
             job.grouped_missingness = _ptr(out["grouped_missingness"])
         if loci_counts:
-            out["loci_counts"] = np.zeros((m, 4), dtype=np.int32)
+            out["loci_counts"] = np.empty((m, 4), dtype=np.int32)
             job.loci_counts = _ptr(out["loci_counts"])
         if fst:
             pairs = combn2(ngroups) if pairwise_combn is None else np.asarray(pairwise_combn, dtype=np.int32)
@@ -681,7 +681,7 @@ class Stream:
                 out["fst_tot"][method] = np.zeros(P)
                 job.fst_tot[i] = out["fst_tot"][method].ctypes.data
                 if fst_by_locus:
-                    out["fst_locus"][method] = np.zeros((m, P), order="F")
+                    out["fst_locus"][method] = np.empty((m, P), order="F")
                     job.fst_by_locus[i] = out["fst_locus"][method].ctypes.data
             if not fst_by_locus:
                 del out["fst_locus"]
@@ -689,8 +689,8 @@ class Stream:
         if k > 0:
             cp = _f64(code256_pca)
             keep.append(cp)
-            out.update(d=np.zeros(k), u=np.zeros((n, k), order="F"), v=np.zeros((m, k), order="F"), center=np.zeros(m),
-                       scale=np.zeros(m), method="partialSVD" if pca_tol == 0 else "randomSVD")
+            out.update(d=np.zeros(k), u=np.empty((n, k), order="F"), v=np.empty((m, k), order="F"), center=np.empty(m),
+                       scale=np.empty(m), method="partialSVD" if pca_tol == 0 else "randomSVD")
             job.code256_pca, job.k, job.pca_tol = _ptr(cp), int(k), float(pca_tol)
             for name in ("d", "u", "v", "center", "scale"):
                 setattr(job, name, _ptr(out[name]))

@@ -1118,7 +1118,9 @@ static int gram_classes_core(tpg_ctx* ctx, int64_t n, int64_t Q, int64_t m, cons
   const double cost_cls = gcls_cost_classes(nun, nruns, nblocks, nwaves, &S) + 350.0 + 1.25e-3 * (double)m * ((double)n / 5000.0);
   // the digit kernel: 32 x 128 wave tiles, 64 int8 MFMAs (~1.0 us) per 128 loci, 4 row tiles x super-tiles of 4
   const int64_t nun_dig = (int64_t)nrtv * ceil_div((int64_t)nrtv, 4) / 2 + nrtv;
-  const double cost_dig = (double)ceil_div(nun_dig, (int64_t)(4 * ncu8)) * ((double)ceil_div(m, 128) * 1.0) + 65.0;
+  // (1.0 us is its four digits of a weight kept to 22 fractional bits; a caller that asks for more bits, pca.hip, pays per digit)
+  const int t_dig = std::max(4, ((int)ceil(log2(2.0 * (double)n + 1.0)) + ctx->pca_digit_fbits + 7) / 7);
+  const double cost_dig = (double)ceil_div(nun_dig, (int64_t)(4 * ncu8)) * ((double)ceil_div(m, 128) * 0.25 * t_dig) + 65.0;
   if (getenv("TPG_GRAM_S")) S = std::max(2, atoi(getenv("TPG_GRAM_S")) & ~1);  // (experiments)
   while ((nblocks / 2 + S) / S + 2 >= (1 << 21)) S += 2;  // a K range stays below 2^21 block pairs (32-bit lane offsets)
   if (getenv("TPG_DEBUG"))

@@ -20,6 +20,7 @@
 // Everything here is orchestration over the library's own entry points: no kernel of the hot path lives in this file.
 #include <fcntl.h>
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -180,6 +181,11 @@ struct StreamRun {
   int saved_fbits = 0;
 
   static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  // TPG_STREAM_TRACE=1: a timeline of the run on stderr (milliseconds since its start; who waited for whom)
+  bool trace = getenv("TPG_STREAM_TRACE") != nullptr;  // (read per run)
+  void stamp(const char* what, long long b = -1) const {
+    if (trace) fprintf(stderr, "[stream] %8.2f ms  %s %lld\n", 1e3 * (now() - t_start), what, b);
+  }
 
   ~StreamRun() { cleanup(); }
 
@@ -337,8 +343,10 @@ struct StreamRun {
         sh.cv.wait(lk, [&] { return sh.failed || released[slot] >= b - 2; });
         if (sh.failed) return;
       }
+      stamp("  upload starts", b);
       const int rc = fill(slot, b, stage);
       if (rc != TPG_OK) { sh.fail(rc, tpg_last_error()); return; }
+      stamp("  upload done", b);
       {
         std::lock_guard<std::mutex> lk(sh.mu);
         ready_q.push_back(b);
@@ -386,7 +394,9 @@ struct StreamRun {
       }
       hipError_t e = hipSuccess;
       if (t.ready) e = hipStreamWaitEvent(down_ctx->stream, t.ready, 0);
+      stamp("    download starts, MB:", (long long)(t.width * t.height >> 20));
       if (e == hipSuccess) e = tpg_download_rows(down_ctx, t.dst, t.dpitch, t.src, t.width, t.height);
+      stamp("    download done");
       if (e != hipSuccess) {
         char buf[160];
         snprintf(buf, sizeof(buf), "download of a block's results failed: %s", hipGetErrorString(e));
@@ -512,10 +522,12 @@ struct StreamRun {
       TPG_TRY(d_K.alloc(sizeof(double) * (size_t)n * (size_t)n));
       have_K = false;
       fro = 0.0;
-      // short blocks take the digit-split Gram kernel (pca.hip), whose weights are fixed point: the sum over many blocks
-      // keeps eight more bits than a whole-panel call needs (restored in cleanup())
+      // short blocks take the digit-split Gram kernel (pca.hip), whose weights are fixed point (22 fractional bits: 1e-10 on
+      // the singular values of a whole panel).  Under a budget -- many short blocks, and a second sweep over PCIe that the
+      // extra digits hide behind -- the weights keep eight more bits (restored in cleanup()); without one the pipeline is
+      // paced by its kernels, and a block's Gram matrix costs what the resident path's costs.
       saved_fbits = ctx->pca_digit_fbits;
-      ctx->pca_digit_fbits = 30;
+      if (budget) ctx->pca_digit_fbits = 30;
     }
     for (int s = 0; s < 2 && s < nblocks; s++) {
       OutSlot& o = out[s];
@@ -538,7 +550,9 @@ struct StreamRun {
       block_range(b, &q0, &q1);
       const int64_t mb = q1 - q0;
       const int slot = (int)(b & 1);
+      stamp("wait for block", b);
       TPG_TRY(wait_block(b));
+      stamp("got block", b);
       tpg_fbm f{ctx, d_blk[slot], src->nrow, mb};
       f.bed_bpl = src->kind == SRC_BED ? src->bpl : 0;
       tpg_view* v[3];
@@ -549,8 +563,10 @@ struct StreamRun {
       TPG_TRY(make_views(&f, v));
       // (a view creation ends with a host round trip behind its pack kernel: the block buffer has been read)
       release_block(b);
+      stamp("packed", b);
       OutSlot& o = out[slot];
       TPG_TRY(wait_slot(slot));
+      stamp("output slot free", b);
       if (want_loc || want_fst) {
         const tpg_view* vl = v[view_of_loc];
         if (j->alt_freq) TPG_TRY(tpg_alt_freq_dip_pseudo(ctx, vl, j->ploidy, j->as_counts, o.af.as<double>()));
@@ -578,6 +594,7 @@ struct StreamRun {
         if (j->loci_counts) TPG_TRY(rows_out(j->loci_counts, 16, 1, q0, o.lc.p, mb, 1, o.ev, slot));
         for (int i = 0; i < j->nfst; i++) TPG_TRY(rows_out(j->fst_by_locus[i], 8, m, q0, o.fl[i].p, mb, P, o.ev, slot));
       }
+      stamp("per-locus enqueued", b);
       if (want_pw) TPG_TRY(tpg_pairwise_accumulate_products(ctx, pw, v[view_of_pw], 0, -1, products));
       if (want_pca) {
         tpg_view* vp = v[view_of_pca];
@@ -623,6 +640,7 @@ struct StreamRun {
     up_th.join();
     if (sh.failed) { tpg_set_error("%s", sh.msg.c_str()); return sh.code; }
     t_sweep1 = now() - t_start;
+    stamp("first sweep enqueued");
     return TPG_OK;
   }
 
@@ -648,6 +666,7 @@ struct StreamRun {
         }
         TPG_TRY(tpg_pairwise_epilogues(ctx, pw, j->ibs_type, m, dev[0], dev[1], dev[2], dev[3]));
         TPG_HIP(hipEventRecord(ev_fin[0], ctx->stream));
+        stamp("epilogues enqueued");
         // the N x N results go down beside the eigen step
         for (int q = 0; q < 4; q++)
           if (outs[q] && dev[q] != outs[q]) TPG_TRY(rows_out(outs[q], 8, n * n, 0, dev[q], n * n, 1, ev_fin[0], -1));
@@ -681,6 +700,7 @@ struct StreamRun {
     std::vector<double> lam((size_t)k);
     TPG_TRY(tpg_sym_eig_topk_tol(ctx, d_K.as<double>(), n, k, j->pca_tol > 0 ? std::max(j->pca_tol, 1e-12) : 1e-12, lam.data(), d_u.as<double>()));
     d_K.free();
+    stamp("eigen step done");
     dh.resize((size_t)k);
     for (int q = 0; q < k; q++) dh[(size_t)q] = sqrt(lam[(size_t)q] > 0 ? lam[(size_t)q] : 0.0);
     if (!comm || comm->rank == 0) {
@@ -748,7 +768,9 @@ struct StreamRun {
 
   int end() {  // everything enqueued has run, every download has landed
     TpgEnter _enter(ctx);
+    stamp("everything enqueued");
     int rc = join_downloader();
+    stamp("downloads landed");
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (rc == TPG_OK && e != hipSuccess) { tpg_set_error("stream: %s", hipGetErrorString(e)); rc = TPG_EHIP; }
     sample();
