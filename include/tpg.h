@@ -433,14 +433,17 @@ typedef struct tpg_stream_job {
   double* grouped_alt_freq;    /* m x 2G  (tpg_grouped_alt_freq_dip_pseudo) */
   double* grouped_missingness; /* m x G   (tpg_grouped_missingness) */
   int32_t* loci_counts;        /* m x 4 row-major (tpg_loci_counts) */
-  /* pairwise_pop_fst: up to three estimators from one sweep; fst_tot[i] (P) = ratio of the sums over all loci;
-   * fst_by_locus[i] (m x P, may be NULL) = the by_locus ratios */
+  /* pairwise_pop_fst: up to three estimators from one sweep; fst_tot[i] (P, may be NULL) = ratio of the sums over all
+   * loci; fst_by_locus[i] (m x P, may be NULL) = the by_locus ratios -- or, with fst_return_num_dem, the numerators, and
+   * fst_by_locus_den[i] (m x P) the denominators (R/pairwise_pop_fst.R:103-106) */
   int nfst;
   int fst_method[TPG_STREAM_MAX_FST];
   const int32_t* pairs1; /* 2 x P, 1-based */
   int P;
+  int fst_return_num_dem;
   double* fst_tot[TPG_STREAM_MAX_FST];
   double* fst_by_locus[TPG_STREAM_MAX_FST];
+  double* fst_by_locus_den[TPG_STREAM_MAX_FST];
   /* gt_pca_partialSVD through code256_pca (e.g. CODE_IMPUTE_PRED); k = 0: no PCA.  pca_tol = 0: the partial SVD's
    * 1e-12, else tpg_pca_random_svd's tolerance */
   const double* code256_pca;

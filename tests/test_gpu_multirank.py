@@ -199,15 +199,20 @@ def _align_sign(a, b):
     return a * s
 
 
+@pytest.mark.parametrize("stream_budget", [None, 1 << 20])
 @pytest.mark.parametrize("ndev", [1, 2, 3])
-def test_multi_fst_freq_pca_against_oracle(ndev):
+def test_multi_fst_freq_pca_against_oracle(ndev, stream_budget, monkeypatch):
     """tpg_multi_pop_fst / tpg_multi_grouped_alt_freq / tpg_multi_pca_partial_svd: what ONE R process calls for
     BASELINE configs 4 and 5.  ndev = 1 is the plain single-device path; ndev = 2, 3 list device 0 several times, so the
     device threads exchange through the in-process host transport (RCCL refuses one GPU twice): thread teams, phases,
-    status agreement and the row-range writes into the caller's matrices are the code an 8-GPU run executes."""
+    status agreement and the row-range writes into the caller's matrices are the code an 8-GPU run executes.
+    stream_budget: TPG_STREAM_BUDGET makes a device's share "too large to hold", so that the same entry points take the
+    streamed form (csrc/stream.hip: the share swept in blocks, two block buffers per device) -- same results asked."""
     import tidypopgen_amd as tpg
     from oracle import oracle as orc
 
+    if stream_budget:
+        monkeypatch.setenv("TPG_STREAM_BUDGET", str(stream_budget))
     n, m, G, k = 180, 2900, 5, 6
     fbm = orc.synth_fbm(29, n, m, npop=G, miss=0.04, imputed_bytes=True)
     gid = (np.arange(n) % G).astype(np.int32)
@@ -364,14 +369,17 @@ def test_rccl_ranks_on_distinct_gpus_equal_one_gpu(tmp_path, ngpu, exchange):
     _digests_match(json.load(open(d1)), json.load(open(dn)), exchange)
 
 
+@pytest.mark.parametrize("stream_budget", [None, 1 << 20])
 @pytest.mark.parametrize("ndev", [1, 2, 3])
-def test_multi_and_multi_stream_device_threads_against_oracle(ndev, monkeypatch):
+def test_multi_and_multi_stream_device_threads_against_oracle(ndev, stream_budget, monkeypatch):
     """tests/multi_cases.py::multi_against_oracle -- tpg_multi_* and the streamed form, tpg_multi_stream_run (every device
     sweeps its share of colInd in blocks under a budget, then the exchanges) -- with device 0 listed ndev times: the device
     threads exchange through the in-process transport.  The same body runs over the mock RCCL (below) and, on a box that has
     them, on distinct GPUs (next test)."""
     from tests import multi_cases
 
+    if stream_budget:  # tpg_multi_pairwise / _grouped_alt_freq / _pop_fst / _pca_partial_svd themselves take the streamed form
+        monkeypatch.setenv("TPG_STREAM_BUDGET", str(stream_budget))
     tr = multi_cases.multi_against_oracle(ndev, devices=[0] * ndev, setenv=monkeypatch.setenv)
     assert tr == ("none" if ndev == 1 else "host callback"), tr
 

@@ -109,8 +109,8 @@ class StreamJob(C.Structure):
         ("ibs_type", C.c_int), ("ibs", vp), ("king", vp), ("allele_sharing", vp), ("grm", vp),
         ("code256", vp), ("ploidy", vp), ("groupIds0", vp), ("ngroups", C.c_int), ("as_counts", C.c_int),
         ("alt_freq", vp), ("grouped_alt_freq", vp), ("grouped_missingness", vp), ("loci_counts", vp),
-        ("nfst", C.c_int), ("fst_method", C.c_int * 3), ("pairs1", vp), ("P", C.c_int),
-        ("fst_tot", vp * 3), ("fst_by_locus", vp * 3),
+        ("nfst", C.c_int), ("fst_method", C.c_int * 3), ("pairs1", vp), ("P", C.c_int), ("fst_return_num_dem", C.c_int),
+        ("fst_tot", vp * 3), ("fst_by_locus", vp * 3), ("fst_by_locus_den", vp * 3),
         ("code256_pca", vp), ("k", C.c_int), ("pca_tol", C.c_double),
         ("d", vp), ("u", vp), ("v", vp), ("center", vp), ("scale", vp), ("square_frobenius", vp),
     ]

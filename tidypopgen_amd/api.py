@@ -632,7 +632,7 @@ class Stream:
     def run(self, ind_row=None, ind_col=None, pairwise=(), ibs_type: str = "proportion", code256=CODE_012, ploidy=None,
             groupIds=None, ngroups: int = 0, as_counts: bool = False, alt_freq: bool = False, grouped_alt_freq: bool = False,
             grouped_missingness: bool = False, loci_counts: bool = False, fst=(), fst_by_locus: bool = False,
-            pairwise_combn=None, k: int = 0, pca_tol: float = 0.0, code256_pca=CODE_IMPUTE_PRED, total_var: bool = True,
+            fst_return_num_dem: bool = False, pairwise_combn=None, k: int = 0, pca_tol: float = 0.0, code256_pca=CODE_IMPUTE_PRED, total_var: bool = True,
             multi: Optional["Multi"] = None) -> dict:
         """One streamed pass for everything asked for (tpg_stream_run; with `multi`, tpg_multi_stream_run: the loci
         sharded over its devices).  pairwise: any of "ibs", "king", "allele_sharing", "grm"; fst: up to three of
@@ -675,16 +675,24 @@ class Stream:
             keep.append(pairs_c)
             P = pairs_c.shape[0]
             job.nfst, job.pairs1, job.P = len(fst), _ptr(pairs_c), P
-            out["fst_tot"], out["fst_locus"] = {}, {}
+            if fst_return_num_dem:
+                fst_by_locus = True  # R/pairwise_pop_fst.R:103-106
+            job.fst_return_num_dem = int(fst_return_num_dem)
+            out["fst_tot"], out["fst_locus"], out["fst_locus_den"] = {}, {}, {}
             for i, method in enumerate(fst):
                 job.fst_method[i] = FST_METHODS[method]
                 out["fst_tot"][method] = np.zeros(P)
                 job.fst_tot[i] = out["fst_tot"][method].ctypes.data
                 if fst_by_locus:
-                    out["fst_locus"][method] = np.empty((m, P), order="F")
+                    out["fst_locus"][method] = np.empty((m, P), order="F")  # (the numerators under fst_return_num_dem)
                     job.fst_by_locus[i] = out["fst_locus"][method].ctypes.data
+                if fst_return_num_dem:
+                    out["fst_locus_den"][method] = np.empty((m, P), order="F")
+                    job.fst_by_locus_den[i] = out["fst_locus_den"][method].ctypes.data
             if not fst_by_locus:
                 del out["fst_locus"]
+            if not fst_return_num_dem:
+                del out["fst_locus_den"]
         fro = C.c_double()
         if k > 0:
             cp = _f64(code256_pca)

@@ -611,6 +611,33 @@ struct PoolBuf {  // device scratch of one device thread, back to its pool on sc
   template <typename T> T* as() { return (T*)p; }
 };
 
+// A device holds its share of the panel whole (one upload, one pack) unless the share's bytes exceed the streaming budget:
+// then the call is the streamed form (stream.hip: every device sweeps its share in blocks, two block buffers, the same
+// exchanges afterwards) -- a 5 000 x 80 000 000 panel (400 GB) goes through the same entry points as a 5-GB one.
+// TPG_STREAM_BUDGET=<bytes> sets the budget (default: a quarter of the device's memory).
+static bool multi_stream_budget(tpg_multi* mg, int64_t nrow, int64_t m, size_t* budget) {
+  size_t b = 0;
+  if (const char* e = getenv("TPG_STREAM_BUDGET")) {
+    b = (size_t)strtoull(e, nullptr, 10);
+  } else {
+    TpgEnter _enter(mg->ctx[0]);
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
+    b = tot / 4;
+  }
+  if (b == 0) return false;
+  *budget = b;
+  return (size_t)nrow * (size_t)ceil_div(m, mg->ndev) > b;
+}
+static void stream_job_init(tpg_stream_job* job, const int32_t* rowInd1, int64_t n, const int32_t* colInd1, int64_t m) {
+  memset(job, 0, sizeof(*job));
+  job->struct_size = sizeof(*job);
+  job->rowInd1 = rowInd1;
+  job->n = n;
+  job->colInd1 = colInd1;
+  job->m = m;
+}
+
 // snp_ibs / snp_king / snp_allele_sharing / pairwise_grm of one host FBM on all the devices of `mg`
 // (R/snp_ibs.R:42-104, R/snp_king.R:32-103, R/snp_allele_sharing.R:33-82, R/pairwise_grm.R:30-51 -- their block loops
 // become: every device takes a contiguous share of colInd, uploads just those columns, packs, accumulates; one
@@ -619,6 +646,17 @@ extern "C" int tpg_multi_pairwise(tpg_multi* mg, const uint8_t* fbm_bytes, int64
                                   const int32_t* rowInd1, int64_t n, const int32_t* colInd1, int64_t m, int ibs_type,
                                   double* ibs, double* king, double* allele_sharing, double* grm) {
   TPG_TRY(multi_check_args(mg, fbm_bytes, nrow, ncol, rowInd1, &n, colInd1, &m));
+  size_t budget = 0;
+  if (multi_stream_budget(mg, nrow, m, &budget)) {
+    tpg_stream_job job;
+    stream_job_init(&job, rowInd1, n, colInd1, m);
+    job.ibs_type = ibs_type;
+    job.ibs = ibs;
+    job.king = king;
+    job.allele_sharing = allele_sharing;
+    job.grm = grm;
+    return tpg_multi_stream_host(mg, fbm_bytes, nrow, ncol, budget, &job);
+  }
   std::vector<MultiShard> st((size_t)mg->ndev);
   std::vector<tpg_pairwise*> pw((size_t)mg->ndev, nullptr);
   // only the cross-products the requested matrices are made of (2 of 5 for allele sharing / GRM alone, 3 for IBS, 4 for KING)
@@ -665,6 +703,19 @@ extern "C" int tpg_multi_grouped_alt_freq(tpg_multi* mg, const uint8_t* fbm_byte
   TPG_REQUIRE(out, TPG_EINVAL, "null output");
   TPG_REQUIRE(!groupIds0 || ngroups > 0, TPG_EINVAL, "ngroups must be positive");
   const int64_t ncols = groupIds0 ? 2 * (int64_t)ngroups : 2;
+  size_t budget = 0;
+  if (multi_stream_budget(mg, nrow, m, &budget)) {
+    tpg_stream_job job;
+    stream_job_init(&job, rowInd1, n, colInd1, m);
+    job.code256 = code256;
+    job.ploidy = ploidy;
+    job.groupIds0 = groupIds0;
+    job.ngroups = ngroups;
+    job.as_counts = as_counts;
+    if (groupIds0) job.grouped_alt_freq = out;
+    else job.alt_freq = out;
+    return tpg_multi_stream_host(mg, fbm_bytes, nrow, ncol, budget, &job);
+  }
   std::vector<MultiShard> st((size_t)mg->ndev);
   int rc = multi_run(mg, [&](int r) -> int {
     tpg_ctx* ctx = mg->ctx[(size_t)r];
@@ -701,6 +752,24 @@ extern "C" int tpg_multi_pop_fst(tpg_multi* mg, const uint8_t* fbm_bytes, int64_
   TPG_REQUIRE(!by_locus || out_a, TPG_EINVAL, "by_locus output requested but out_a is NULL");
   TPG_REQUIRE(!return_num_dem || out_b, TPG_EINVAL, "return_num_dem requested but out_b is NULL");
   TPG_REQUIRE(return_num_dem || fst_tot, TPG_EINVAL, "fst_tot is NULL");
+  size_t budget = 0;
+  if (multi_stream_budget(mg, nrow, m, &budget)) {
+    tpg_stream_job job;
+    stream_job_init(&job, rowInd1, n, colInd1, m);
+    job.code256 = code256;
+    job.ploidy = ploidy;
+    job.groupIds0 = groupIds0;
+    job.ngroups = ngroups;
+    job.nfst = 1;
+    job.fst_method[0] = method;
+    job.pairs1 = pairs1;
+    job.P = P;
+    job.fst_return_num_dem = return_num_dem;
+    job.fst_tot[0] = return_num_dem ? nullptr : fst_tot;
+    job.fst_by_locus[0] = by_locus ? out_a : nullptr;
+    job.fst_by_locus_den[0] = return_num_dem ? out_b : nullptr;
+    return tpg_multi_stream_host(mg, fbm_bytes, nrow, ncol, budget, &job);
+  }
   std::vector<MultiShard> st((size_t)mg->ndev);
   std::vector<std::vector<double>> sums((size_t)mg->ndev, std::vector<double>(2 * (size_t)P, 0.0));
   int rc = multi_run(mg, [&](int r) -> int {
@@ -757,6 +826,20 @@ extern "C" int tpg_multi_pca_partial_svd(tpg_multi* mg, const uint8_t* fbm_bytes
   TPG_TRY(multi_check_args(mg, fbm_bytes, nrow, ncol, rowInd1, &n, colInd1, &m));
   TPG_REQUIRE(d && u && vload && center && scale, TPG_EINVAL, "null output");
   TPG_REQUIRE(k >= 1 && k <= n && k <= m, TPG_EINVAL, "k = %d out of range", k);
+  size_t budget = 0;
+  if (multi_stream_budget(mg, nrow, m, &budget)) {
+    tpg_stream_job job;
+    stream_job_init(&job, rowInd1, n, colInd1, m);
+    job.code256_pca = code256;
+    job.k = k;
+    job.d = d;
+    job.u = u;
+    job.v = vload;
+    job.center = center;
+    job.scale = scale;
+    job.square_frobenius = square_frobenius;
+    return tpg_multi_stream_host(mg, fbm_bytes, nrow, ncol, budget, &job);
+  }
   bool spread = mg->ndev > 1;
   for (int r = 0; r < mg->ndev && spread; r++) {
     int64_t j0, j1;

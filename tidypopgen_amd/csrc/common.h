@@ -288,6 +288,8 @@ struct tpg_comm {
 // pca.hip: the k largest eigenpairs of the symmetric K (device memory) at relative residual tol; lambda on the host, U (n x k) in device memory
 int tpg_sym_eig_topk_tol(tpg_ctx* ctx, const double* d_K, int64_t n, int k, double tol, double* lambda_host, double* d_U);
 int tpg_pca_gram_allreduce(tpg_ctx* ctx, tpg_comm* comm, double* d_K, int64_t n);  // pca.hip: K <- sum over the ranks (its triangle travels)
+// stream.hip: a tpg_multi_* analysis of a host FBM with every device streaming its share in blocks under `budget` bytes
+int tpg_multi_stream_host(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, size_t budget, const tpg_stream_job* job);
 int tpg_comm_agree(tpg_comm* comm, int rc);  // all ranks get the same status (the worst any of them passed in)
 int tpg_comm_reduce_scatter_i32(tpg_comm* comm, int32_t* d_buf, int64_t chunk_count);  // in place, chunk r -> rank r
 int tpg_comm_allreduce(tpg_comm* comm, void* d_buf, int64_t count, int dtype);          // in place, device memory

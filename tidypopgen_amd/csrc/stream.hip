@@ -155,7 +155,7 @@ struct StreamRun {
   int64_t released[2] = {-1, -1};  // slot k may be overwritten for block b when released[k] >= b - 2
   // per-block outputs (two slots) and the downloader
   struct OutSlot {
-    DevBuf af, gaf, gm, lc, fl[TPG_STREAM_MAX_FST], dc, ds, dv;
+    DevBuf af, gaf, gm, lc, fl[TPG_STREAM_MAX_FST], fd[TPG_STREAM_MAX_FST], dc, ds, dv;
     hipEvent_t ev = nullptr, ev2 = nullptr;  // behind the per-locus kernels / behind the PCA's center and scale of the block
     int pending = 0;  // download tasks of this slot not finished yet
   } out[2];
@@ -203,6 +203,8 @@ struct StreamRun {
       for (int i = 0; i < j->nfst; i++) {
         TPG_REQUIRE(j->fst_method[i] >= 0 && j->fst_method[i] <= 2, TPG_EINVAL, "bad Fst method %d", j->fst_method[i]);
         TPG_REQUIRE(j->fst_tot[i] || j->fst_by_locus[i], TPG_EINVAL, "Fst method %d has no output", i);
+        TPG_REQUIRE(!j->fst_return_num_dem || !j->fst_by_locus[i] || j->fst_by_locus_den[i], TPG_EINVAL,
+                    "return_num_dem needs fst_by_locus_den for method %d", i);
       }
     }
     if (j->grouped_alt_freq || j->grouped_missingness || want_fst)
@@ -252,7 +254,7 @@ struct StreamRun {
     if (j->grouped_missingness) outp += 8 * (size_t)G;
     if (j->loci_counts) outp += 16;
     for (int i = 0; i < j->nfst; i++)
-      if (j->fst_by_locus[i]) outp += 8 * (size_t)j->P;
+      if (j->fst_by_locus[i]) outp += 8 * (size_t)j->P * (j->fst_return_num_dem ? 2 : 1);
     if (want_pca) outp += 16 + 8 * (size_t)j->k;
     per += 2 * outp;
     if (want_pca) per += 16 + 24 + npad / 4 + (npad / 4) * 5 / 4;  // counts, weights, the class path's locus-major copy + sorted operands
@@ -536,7 +538,10 @@ struct StreamRun {
       if (j->grouped_missingness) TPG_TRY(o.gm.alloc(8 * (size_t)G * (size_t)bmax));
       if (j->loci_counts) TPG_TRY(o.lc.alloc(16 * (size_t)bmax));
       for (int i = 0; i < j->nfst; i++)
-        if (j->fst_by_locus[i]) TPG_TRY(o.fl[i].alloc(8 * (size_t)P * (size_t)bmax));
+        if (j->fst_by_locus[i]) {
+          TPG_TRY(o.fl[i].alloc(8 * (size_t)P * (size_t)bmax));
+          if (j->fst_return_num_dem) TPG_TRY(o.fd[i].alloc(8 * (size_t)P * (size_t)bmax));
+        }
       if (want_pca) {
         TPG_TRY(o.dc.alloc(8 * (size_t)bmax));
         TPG_TRY(o.ds.alloc(8 * (size_t)bmax));
@@ -583,8 +588,8 @@ struct StreamRun {
             TPG_CHECK_LAUNCH();
           }
           if (j->fst_by_locus[i])
-            TPG_TRY(tpg_pairwise_pop_fst(ctx, vl, j->groupIds0, G, j->ploidy, j->fst_method[i], j->pairs1, P, 1, 0, tot_scratch.data(),
-                                         o.fl[i].as<double>(), nullptr));
+            TPG_TRY(tpg_pairwise_pop_fst(ctx, vl, j->groupIds0, G, j->ploidy, j->fst_method[i], j->pairs1, P, 1, j->fst_return_num_dem ? 1 : 0,
+                                         tot_scratch.data(), o.fl[i].as<double>(), j->fst_return_num_dem ? o.fd[i].as<double>() : nullptr));
         }
         TPG_HIP(hipEventRecord(o.ev, ctx->stream));
         TPG_TRY(rows_out(j->alt_freq, 8, m, q0, o.af.p, mb, 2, o.ev, slot));
@@ -592,7 +597,10 @@ struct StreamRun {
         TPG_TRY(rows_out(j->grouped_missingness, 8, m, q0, o.gm.p, mb, G, o.ev, slot));
         // m x 4 int32 ROW-major: the block's rows are one contiguous piece
         if (j->loci_counts) TPG_TRY(rows_out(j->loci_counts, 16, 1, q0, o.lc.p, mb, 1, o.ev, slot));
-        for (int i = 0; i < j->nfst; i++) TPG_TRY(rows_out(j->fst_by_locus[i], 8, m, q0, o.fl[i].p, mb, P, o.ev, slot));
+        for (int i = 0; i < j->nfst; i++) {
+          TPG_TRY(rows_out(j->fst_by_locus[i], 8, m, q0, o.fl[i].p, mb, P, o.ev, slot));
+          if (j->fst_return_num_dem && j->fst_by_locus[i]) TPG_TRY(rows_out(j->fst_by_locus_den[i], 8, m, q0, o.fd[i].p, mb, P, o.ev, slot));
+        }
       }
       stamp("per-locus enqueued", b);
       if (want_pw) TPG_TRY(tpg_pairwise_accumulate_products(ctx, pw, v[view_of_pw], 0, -1, products));
@@ -795,7 +803,7 @@ struct StreamRun {
         if (d_blk[k]) { tpg_pfree(d_blk[k]); d_blk[k] = nullptr; }
         OutSlot& o = out[k];
         o.af.free(); o.gaf.free(); o.gm.free(); o.lc.free(); o.dc.free(); o.ds.free(); o.dv.free();
-        for (int i = 0; i < TPG_STREAM_MAX_FST; i++) o.fl[i].free();
+        for (int i = 0; i < TPG_STREAM_MAX_FST; i++) { o.fl[i].free(); o.fd[i].free(); }
         if (o.ev) { (void)hipEventDestroy(o.ev); o.ev = nullptr; }
         if (o.ev2) { (void)hipEventDestroy(o.ev2); o.ev2 = nullptr; }
       }
@@ -982,6 +990,18 @@ extern "C" int tpg_stream_run(tpg_ctx* ctx, tpg_stream* s, const tpg_stream_job*
   run.cleanup();
   if (rc != TPG_OK) tpg_set_error("%s", err.c_str());
   return rc;
+}
+
+// for the tpg_multi_* entry points of comm.hip when a device's share of the panel is not to be held whole (multi_stream_budget)
+int tpg_multi_stream_host(tpg_multi* mg, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, size_t budget, const tpg_stream_job* job) {
+  tpg_stream s;
+  s.ctx = tpg_multi_ctx(mg, 0);
+  s.src.kind = SRC_BYTES;
+  s.src.bytes = fbm_bytes;
+  s.src.nrow = nrow;
+  s.src.ncol = ncol;
+  s.budget = budget;
+  return tpg_multi_stream_run(mg, &s, job, nullptr);
 }
 
 // Several devices (one process): every device streams its contiguous share of colInd (tpg_shard_loci), then the exchanges.
