@@ -152,6 +152,11 @@ static mapped_file* map_file(const char* path, size_t bytes, int writable, int64
   for (int k = 0; k < g_nfiles; k++)
     if (strcmp(g_files[k]->path, path) == 0 && g_files[k]->bytes == bytes && g_files[k]->writable == writable) {
       if (have_st && g_files[k]->dev_id == (uint64_t)st.st_dev && g_files[k]->ino == (uint64_t)st.st_ino) return g_files[k];
+      /* Under TPG_RSHIM_DEFERRED=1 the library may still hold this mapping's address for sums it has not written yet: they
+         belong to the OLD file (the one the block loop was filling), so they are written there before the mapping goes --
+         never into unmapped memory, never into the new file. */
+      if (writable && deferred() && g_ctx && tpg_increment_flush(g_ctx) != TPG_OK)
+        Rf_error("tidypopgen (GPU): %s", tpg_last_error());
       forget_file(k);
       break;
     }

@@ -156,8 +156,13 @@ def test_backing_file_rewritten_in_place_is_reuploaded(shim, tmp_path, monkeypat
                           orc.alt_freq_dip_pseudo_cpp(imputed2, rows, sub, ploidy, True, orc.CODE_IMPUTE_PRED))
 
 
-def test_whole_analysis_entry_points(shim, tmp_path, monkeypatch):
+@pytest.mark.parametrize("stream_budget", [None, 512 << 10])
+def test_whole_analysis_entry_points(shim, tmp_path, monkeypatch, stream_budget):
+    """stream_budget: the backing file is "larger than the GPU may hold" (TPG_STREAM_BUDGET), so the same .Call entry points
+    sweep it in blocks from the file mapping (csrc/stream.hip) -- what an R session with a 400-GB .bk gets"""
     monkeypatch.setenv("TPG_DEVICES", "1")
+    if stream_budget:
+        monkeypatch.setenv("TPG_STREAM_BUDGET", str(stream_budget))
     n, m, G, k = 160, 3000, 4, 5
     fbm = orc.synth_fbm(53, n, m, npop=G, miss=0.0)
     fbm[:, :2] = np.array([0, 1] * (n // 2), dtype=np.uint8)[:, None]  # no monomorphic loci by accident

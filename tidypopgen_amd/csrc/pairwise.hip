@@ -892,7 +892,7 @@ static int pw_launch_set(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int6
     const int64_t kgs = c1 - c0;
     // per 64-locus block: NM MFMAs at ~18 ns; flush: 16 atomic wave-instructions per accumulator tile (12 us for 15)
     int S = pw_ksplit(nun, 2 * kgs, 16, ceil_div(kgs, max_groups), nwaves, 0.0183 * NM, 0.8 * NM);
-    if (const char* e = getenv("TPG_PW_KSPLIT")) S = std::max<int>((int)ceil_div(kgs, max_groups), atoi(e));
+    if (const char* e = getenv("TPG_PW_KSPLIT")) S = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(kgs, max_groups), atoi(e)), std::max<int64_t>(1, 2 * kgs));  // (experiments; any S in range gives the same sums)
     if (getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] %s: %d x %d tiles, %lld units, S = %d\n", name, RA, RB, (long long)nun, S);
     TPG_LAUNCH(ctx, name, (tpg_pairwise_set_kernel<RA, RB, MASK, NS, DBG>), dim3((unsigned)nblk), dim3(256), 0,
                (const uint4*)v->T4, v->KG, 2 * c0, 2 * c1, (int)pw->nst, (int)ceil_div(pw->n, 32), d_order, nun, S,
@@ -915,7 +915,7 @@ static int pw_launch_wg(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64
     const int64_t c1 = std::min(kg1, c0 + 8 * max_groups);
     const int64_t kgs = c1 - c0;
     int S = pw_ksplit(nun, 2 * kgs, 16, ceil_div(kgs, max_groups), nblk, 0.0183 * NM, 0.8 * NM);
-    if (const char* e = getenv("TPG_PW_KSPLIT")) S = std::max<int>((int)ceil_div(kgs, max_groups), atoi(e));
+    if (const char* e = getenv("TPG_PW_KSPLIT")) S = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(kgs, max_groups), atoi(e)), std::max<int64_t>(1, 2 * kgs));
     if (getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] %s: workgroups of %d x %d tiles, %lld units, S = %d\n", name, 2 * RA, 2 * RB, (long long)nun, S);
     TPG_LAUNCH(ctx, name, (tpg_pairwise_wg_kernel<RA, RB, MASK, NST, DBGW>), dim3((unsigned)nblk), dim3(256), 0,
                (const uint4*)v->T4, v->KG, 2 * c0, 2 * c1, (int)pw->nst, (int)ceil_div(pw->n, 32), d_order, nun, S,
@@ -1012,11 +1012,20 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
     if (var == 16) PW_WG(2, 2, TPG_PW_FOR_KING, 6, "pairwise_mfma_king");
     else PW_WG(2, 2, TPG_PW_FOR_KING, 4, "pairwise_mfma_king");
   } else if (set == TPG_PW_FOR_AS) {
-    if (var == 24) TPG_TRY((pw_launch_wg<4, 2, TPG_PW_FOR_AS, 4, 1>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));             // timing only
-    else if (var == 25) TPG_TRY((pw_launch_wg<4, 2, TPG_PW_FOR_AS, 4, 2>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));        // timing only
-    else if (var == 26) TPG_TRY((pw_launch_wg<4, 2, TPG_PW_FOR_AS, 4, 3>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));        // timing only
-    else if (var == 21) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 5, 1>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));  // timing only
-    else if (var == 22) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 5, 2>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));  // timing only
+    // 21 ... 26: timing-only instantiations that give WRONG sums (loads / barriers / LDS-DMA removed: DESIGN.md 3.1 "Round 5").
+    // They exist only in a library built with -DTPG_PW_EXPERIMENTS (tools/build_variants.sh); the shipped one refuses them.
+    if (var >= 21 && var <= 26) {
+#ifdef TPG_PW_EXPERIMENTS
+      if (var == 24) TPG_TRY((pw_launch_wg<4, 2, TPG_PW_FOR_AS, 4, 1>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+      else if (var == 25) TPG_TRY((pw_launch_wg<4, 2, TPG_PW_FOR_AS, 4, 2>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+      else if (var == 26) TPG_TRY((pw_launch_wg<4, 2, TPG_PW_FOR_AS, 4, 3>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+      else if (var == 21) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 5, 1>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+      else if (var == 22) TPG_TRY((pw_launch_set<4, 2, TPG_PW_FOR_AS, 5, 2>(ctx, pw, v, kg0, kg1, "pairwise_mfma_as")));
+      else TPG_REQUIRE(false, TPG_EUNSUPPORTED, "TPG_PW_VARIANT=%d does not exist", var);
+#else
+      TPG_REQUIRE(false, TPG_EUNSUPPORTED, "TPG_PW_VARIANT=%d is a timing experiment with wrong sums: build with -DTPG_PW_EXPERIMENTS", var);
+#endif
+    }
     else if (var == 1) PW_SET(4, 2, TPG_PW_FOR_AS, 4, "pairwise_mfma_as");
     else if (var == 2) PW_SET(3, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
     else PW_SET(4, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
