@@ -604,9 +604,12 @@ def standalone(st):
         lambda pw, d, m_: chk(lib.tpg_pairwise_grm(ctx.h, pw.h, d[0])), "V, D (2 of 5): src/snp_as.cpp:64-65")
     one("snp_king", st.X, n, m, api.PW_FOR_KING, 4.0, "pairwise_mfma_king",
         lambda pw, d, m_: chk(lib.tpg_pairwise_king(ctx.h, pw.h, d[0])), "V, D, A, A' (4 of 5): src/snp_king.cpp:70-72")
-    one("snp_ibs", st.X, n, m, api.PW_FOR_IBS, 3.0, "pairwise_mfma_ibs",
+    one("snp_ibs", st.X, n, m, api.PW_FOR_IBS_ALONE, 3.0, "pairwise_mfma_ibs1",
         lambda pw, d, m_: chk(lib.tpg_pairwise_ibs(ctx.h, pw.h, C.c_int(0), C.c_int64(m_), d[0])),
-        "V, D, H (3 of 5): src/snp_ibs.cpp:67-72")
+        "V and D + H (three of the five rank-1 products, the last two into one sum: TPG_PW_DH): src/snp_ibs.cpp:67-72")
+    one("snp_ibs_with_allele_sharing", st.X, n, m, api.PW_FOR_IBS, 3.0, "pairwise_mfma_ibs",
+        lambda pw, d, m_: chk(lib.tpg_pairwise_ibs(ctx.h, pw.h, C.c_int(0), C.c_int64(m_), d[0])),
+        "V, D, H apart (3 of 5), for callers that want allele sharing / GRM from the same pass")
     # BASELINE config 2, literally: pairwise_king + pairwise_grm of an HGDP-like 1 000 x 650 000 panel on one MI355X
     n2, m2 = 1000, 650000
     X2 = tpg.FBM.synth(2, n2, m2, npop=a.pops, miss=0.02, imputed_bytes=True, ctx=ctx, code256=tpg.CODE_012)

@@ -230,8 +230,14 @@ int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, i
 #define TPG_PW_D 2
 #define TPG_PW_H 4
 #define TPG_PW_A 8
+/* D and H added up in ONE sum (IBS = V + (D + H), IBS_valid = 2 V: snp_ibs needs nothing else, src/snp_ibs.cpp:67-72).  Two
+ * sums per pair instead of three leave registers for a 128 x 64 wave tile: 24 MFMAs per 6 operand fragments where the
+ * {V, D, H} kernel has 12 per 4.  Goes with TPG_PW_V only; afterwards D and H are unknown on their own -- the allele-sharing
+ * and KING outputs are refused -- and tpg_pairwise_products reports TPG_PW_V | TPG_PW_DH. */
+#define TPG_PW_DH 16
 #define TPG_PW_FOR_AS (TPG_PW_V | TPG_PW_D)               /* snp_allele_sharing, pairwise_grm */
-#define TPG_PW_FOR_IBS (TPG_PW_V | TPG_PW_D | TPG_PW_H)   /* snp_ibs */
+#define TPG_PW_FOR_IBS (TPG_PW_V | TPG_PW_D | TPG_PW_H)   /* snp_ibs together with allele sharing / GRM */
+#define TPG_PW_FOR_IBS_ALONE (TPG_PW_V | TPG_PW_DH)       /* snp_ibs on its own */
 #define TPG_PW_FOR_KING (TPG_PW_V | TPG_PW_D | TPG_PW_A)  /* snp_king */
 #define TPG_PW_ALL (TPG_PW_V | TPG_PW_D | TPG_PW_H | TPG_PW_A)
 int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int64_t col_begin,

@@ -55,6 +55,7 @@ _SET_OUTPUTS = {
     "all": (("ibs", "ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den"), ("ibs", "king", "allele_sharing", "grm")),
     "as": (("ibs_valid", "as_num", "as_den"), ("allele_sharing", "grm")),
     "ibs": (("ibs", "ibs_valid", "as_num", "as_den"), ("ibs", "allele_sharing", "grm")),
+    "ibs1": (("ibs", "ibs_valid", "as_den"), ("ibs",)),  # V and D + H in one sum (TPG_PW_DH): what snp_ibs alone runs on
     "king": (("ibs_valid", "king_num", "n_Aa_i", "as_num", "as_den"), ("king", "allele_sharing", "grm")),
 }
 
@@ -75,9 +76,10 @@ def _check_counts_and_epilogues(tpg, orc, pw, o, rows, m, which):
             assert np.array_equal(ep["ibs"][ix], o["ibs"] / o["ibs_valid"], equal_nan=True)   # R/snp_ibs.R:88-95
     if "king" in eps:
         assert np.array_equal(ep["king"][ix], orc.king_epilogue(o["king_num"], o["n_Aa_i"]), equal_nan=True)
-    assert np.array_equal(ep["allele_sharing"][ix], orc.as_epilogue(o["as_num"], o["as_den"]), equal_nan=True)
-    # GRM = the reference's formula on the (sample-verified) allele-sharing matrix: the mean is over all N (N - 1) pairs
-    assert np.allclose(ep["grm"], orc.pairwise_grm(ep["allele_sharing"]), rtol=1e-12, atol=1e-14)
+    if "allele_sharing" in eps:
+        assert np.array_equal(ep["allele_sharing"][ix], orc.as_epilogue(o["as_num"], o["as_den"]), equal_nan=True)
+        # GRM = the reference's formula on the (sample-verified) allele-sharing matrix: the mean is over all N (N - 1) pairs
+        assert np.allclose(ep["grm"], orc.pairwise_grm(ep["allele_sharing"]), rtol=1e-12, atol=1e-14)
     return ep
 
 
@@ -91,7 +93,7 @@ def _check_pairwise_sample(tpg, orc, X, seed, n, m, monkeypatch=None):
     o = _oracle_pair_counts(orc, seed, rows, m)
     v = tpg.View(X, code256=None)
     pw = tpg.Pairwise(X.ctx, n)
-    sets = {"all": None, "as": tpg.PW_FOR_AS, "ibs": tpg.PW_FOR_IBS, "king": tpg.PW_FOR_KING}
+    sets = {"all": None, "as": tpg.PW_FOR_AS, "ibs": tpg.PW_FOR_IBS, "ibs1": tpg.PW_FOR_IBS_ALONE, "king": tpg.PW_FOR_KING}
     for which, products in sets.items():
         pw.zero()
         pw.accumulate(v, products=products)

@@ -402,7 +402,7 @@ def test_pairwise_counts_bit_exact_and_epilogues(tpg, monkeypatch, n, m, miss, v
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 13, 14, 16])  # 13 ... 16: operands shared through LDS (3 ... 6 stages)
-@pytest.mark.parametrize("which", ["as", "ibs", "king"])
+@pytest.mark.parametrize("which", ["as", "ibs", "ibs1", "king"])
 @pytest.mark.parametrize("n,m,miss", [(1, 1, 0.0), (65, 129, 0.05), (130, 700, 0.3), (333, 5001, 0.1), (500, 8000, 0.02)])
 def test_pairwise_product_sets_bit_exact(tpg, monkeypatch, n, m, miss, which, variant):
     """tpg_pairwise_accumulate_products: the kernels specialised for {V, D} / {V, D, H} / {V, D, A} (every wave-tile
@@ -415,7 +415,9 @@ def test_pairwise_product_sets_bit_exact(tpg, monkeypatch, n, m, miss, which, va
     v = tpg.View(X, code256=None)
     pw = tpg.Pairwise(X.ctx, n)
     assert pw.products() == tpg.PW_ALL
-    sets = {"as": tpg.PW_FOR_AS, "ibs": tpg.PW_FOR_IBS, "king": tpg.PW_FOR_KING}
+    if which == "ibs1" and variant > 4:
+        pytest.skip("the D + H kernel has no workgroup form")
+    sets = {"as": tpg.PW_FOR_AS, "ibs": tpg.PW_FOR_IBS, "ibs1": tpg.PW_FOR_IBS_ALONE, "king": tpg.PW_FOR_KING}
     # in two aligned pieces when the panel is long enough: a second launch adds to the same slabs
     cut = (m // 2) // 128 * 128
     if cut:
@@ -440,6 +442,16 @@ def test_pairwise_product_sets_bit_exact(tpg, monkeypatch, n, m, miss, which, va
         assert np.array_equal(pw.ibs("proportion"), orc.snp_ibs(fbm), equal_nan=True)
         assert np.array_equal(pw.allele_sharing(), orc.snp_allele_sharing(fbm), equal_nan=True)  # V, D are in the set
         refused = (lambda: pw.king(), lambda: pw.counts(("king_num",)), lambda: pw.epilogues(which=("ibs", "king")))
+    elif which == "ibs1":
+        # snp_ibs on its own: D and H in ONE sum (TPG_PW_DH) -- IBS and IBS_valid are all it gives (src/snp_ibs.cpp:67-72)
+        c = pw.counts(("ibs", "ibs_valid", "as_den"))
+        orc.increment_ibs_counts(K, K2, fbm, None, None)
+        assert np.array_equal(c["ibs"], K) and np.array_equal(c["ibs_valid"], K2) and np.array_equal(2 * c["as_den"], K2)
+        assert np.array_equal(pw.ibs("proportion"), orc.snp_ibs(fbm), equal_nan=True)
+        assert np.array_equal(pw.epilogues(which=("ibs",), ibs_type="adjusted_counts", m=m)["ibs"],
+                              orc.snp_ibs(fbm, type="adjusted_counts"), equal_nan=True)
+        refused = (lambda: pw.king(), lambda: pw.allele_sharing(), lambda: pw.grm(), lambda: pw.counts(("as_num",)),
+                   lambda: pw.counts(("king_num",)), lambda: pw.epilogues(which=("ibs", "grm")))
     else:
         c = pw.counts(("king_num", "n_Aa_i", "as_num", "as_den"))
         orc.increment_king_numerator(K, K2, fbm, None, None)
@@ -455,6 +467,11 @@ def test_pairwise_product_sets_bit_exact(tpg, monkeypatch, n, m, miss, which, va
     # a later pass with all five products does not make the earlier loci's missing products appear
     pw.accumulate(v)
     assert pw.products() == sets[which]
+    if which == "ibs1":  # ... but D + H stays a sum whatever kernel adds to it: IBS of both passes = twice the counts
+        c2 = pw.counts(("ibs", "ibs_valid"))
+        assert np.array_equal(c2["ibs"], 2 * K) and np.array_equal(c2["ibs_valid"], 2 * K2)
+        with pytest.raises(tpg._lib.TpgError):
+            pw.accumulate(v, products=tpg.PW_DH | tpg.PW_D)  # D + H goes with V only
     pw.zero()
     assert pw.products() == tpg.PW_ALL
     # the R-level entry points take the minimal set themselves

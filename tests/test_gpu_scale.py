@@ -288,6 +288,7 @@ def test_pair_counts_stay_exact_past_2_pow_24_loci():
     # the three product-set kernels (tpg_pairwise_set_kernel: what a stand-alone snp_ibs / snp_king / pairwise_grm runs on)
     # cap and flush their wave-units' K ranges themselves
     for products, names in ((tpg.PW_FOR_AS, ("as_num", "as_den", "ibs_valid")), (tpg.PW_FOR_IBS, ("ibs", "ibs_valid", "as_num")),
+                            (tpg.PW_FOR_IBS_ALONE, ("ibs", "ibs_valid", "as_den")),
                             (tpg.PW_FOR_KING, ("king_num", "n_Aa_i", "as_den"))):
         pw.zero()
         pw.accumulate(v, products=products)

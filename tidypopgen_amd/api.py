@@ -37,6 +37,8 @@ FST_METHODS = {"Hudson": 0, "Nei87": 1, "WC84": 2}
 # cross-products of the pairwise accumulators (include/tpg.h: TPG_PW_*)
 PW_V, PW_D, PW_H, PW_A = 1, 2, 4, 8
 PW_FOR_AS, PW_FOR_IBS, PW_FOR_KING, PW_ALL = PW_V | PW_D, PW_V | PW_D | PW_H, PW_V | PW_D | PW_A, 15
+PW_DH = 16  # D and H added up in one sum: all snp_ibs needs beside V (include/tpg.h)
+PW_FOR_IBS_ALONE = PW_V | PW_DH
 
 
 def _ptr(x):
@@ -747,7 +749,7 @@ def snp_ibs(X: FBM, ind_row=None, ind_col=None, type: str = "proportion", block_
     range is swept in one device pass (results do not depend on it)."""
     if type not in ("proportion", "adjusted_counts", "raw_counts"):
         raise ValueError("'arg' should be one of 'proportion', 'adjusted_counts', 'raw_counts'")
-    v, pw = _pairwise_pass(X, ind_row, ind_col, PW_FOR_IBS)  # V, D, H: 3 of the 5 cross-products
+    v, pw = _pairwise_pass(X, ind_row, ind_col, PW_FOR_IBS_ALONE)  # V and D + H: three MFMAs into two sums per tile pair
     if type == "raw_counts":
         c = pw.counts(("ibs", "ibs_valid"))
         return dict(ibs=c["ibs"], valid_n=c["ibs_valid"])

@@ -660,7 +660,7 @@ extern "C" int tpg_multi_pairwise(tpg_multi* mg, const uint8_t* fbm_bytes, int64
   std::vector<MultiShard> st((size_t)mg->ndev);
   std::vector<tpg_pairwise*> pw((size_t)mg->ndev, nullptr);
   // only the cross-products the requested matrices are made of (2 of 5 for allele sharing / GRM alone, 3 for IBS, 4 for KING)
-  const int products = (ibs ? TPG_PW_FOR_IBS : 0) | (king ? TPG_PW_FOR_KING : 0) | (allele_sharing || grm ? TPG_PW_FOR_AS : 0);
+  const int products = tpg_pw_products_for(ibs != nullptr, king != nullptr, allele_sharing || grm);
   TPG_REQUIRE(products, TPG_EINVAL, "no output requested");
   // phase 1, no exchange: upload, pack and accumulate this device's loci.  The phases are separate thread teams so
   // that a failure on one device (out of memory, a bad index) is known to all before anyone enters a collective --

@@ -196,11 +196,17 @@ struct tpg_pairwise {
   int64_t* rowpad = nullptr;   // device int64[nst]
   bool reduced = false;        // after tpg_pairwise_reduce: only this rank's band holds (complete) sums
   // products (TPG_PW_V | D | H | A) every accumulate since the last zero has added: what the epilogues may read
-  int have = 15;
+  int have = 31;  // TPG_PW_HAVE_ALL
   // unit tables of the product-subset kernels (pairwise.hip), one per wave-tile shape: key 16 RA + RB -> (device int2[], count)
   std::map<int, std::pair<void*, int64_t>> orders;
 };
 #define TPG_PW_MAX_LOCI 2147483647ll
+#define TPG_PW_HAVE_ALL (TPG_PW_ALL | TPG_PW_DH)  // tpg_pairwise.have after a zero: every product, and with D and H their sum
+// the smallest product set that serves the outputs asked for (pairwise.hip kernels: {V, D+H}, {V, D}, {V, D, H}, {V, D, A}, all five)
+static inline int tpg_pw_products_for(bool ibs, bool king, bool as_or_grm) {
+  if (ibs && !king && !as_or_grm) return TPG_PW_FOR_IBS_ALONE;
+  return (ibs ? TPG_PW_FOR_IBS : 0) | (king ? TPG_PW_FOR_KING : 0) | (as_or_grm ? TPG_PW_FOR_AS : 0);
+}
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -309,10 +309,13 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_kernel(const uint4* __res
 // into the slot block b - 1 left (prefetch distance NS - 1 steps).
 template <int MASK>
 struct PwSet {
+  // pS: D and H into ONE accumulator (TPG_PW_DH: IBS = V + (D + H) needs nothing else) -- K-concatenation: the d x d and the
+  // h x h MFMA of a tile pair add to the same sums, each with its own block scales, so the pair costs two accumulator tiles
+  // instead of three and the wave tile can be the {V, D} kernel's 128 x 64
   static constexpr bool pV = (MASK & TPG_PW_V) != 0, pD = (MASK & TPG_PW_D) != 0, pH = (MASK & TPG_PW_H) != 0,
-                        pA = (MASK & TPG_PW_A) != 0;
-  static constexpr int NP = (pV ? 1 : 0) + (pD ? 1 : 0) + (pH ? 1 : 0) + (pA ? 2 : 0);
-  static constexpr bool wv = pV || pA, wd = pD, wh = pH || pA;  // operand planes wanted
+                        pA = (MASK & TPG_PW_A) != 0, pS = (MASK & TPG_PW_DH) != 0;
+  static constexpr int NP = (pV ? 1 : 0) + (pD ? 1 : 0) + (pH ? 1 : 0) + (pA ? 2 : 0) + (pS ? 2 : 0);  // MFMAs per tile pair
+  static constexpr bool wv = pV || pA, wd = pD || pS, wh = pH || pA || pS;  // operand planes wanted
   static constexpr int NPL = (wv ? 1 : 0) + (wd ? 1 : 0) + (wh ? 1 : 0);
 };
 
@@ -416,11 +419,18 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
 #pragma unroll
           for (int b = 0; b < RB; b++) {
             if constexpr (PS::pV) cV[a][b] = MFMA_F4(P[cur][a].v, P[cur][RA + b].v, cV[a][b], sc1, sc1);
-            if constexpr (PS::pD) cD[a][b] = MFMA_F4(P[cur][a].d, P[cur][RA + b].d, cD[a][b], sch, sch);
+            if constexpr (PS::pD || PS::pS) cD[a][b] = MFMA_F4(P[cur][a].d, P[cur][RA + b].d, cD[a][b], sch, sch);
             if constexpr (PS::pH) cH[a][b] = MFMA_F4(P[cur][a].h, P[cur][RA + b].h, cH[a][b], sc2, sc2);
             if constexpr (PS::pA) cHV[a][b] = MFMA_F4(P[cur][a].h, P[cur][RA + b].v, cHV[a][b], sc2, sc1);
             if constexpr (PS::pA) cVH[a][b] = MFMA_F4(P[cur][a].v, P[cur][RA + b].h, cVH[a][b], sc1, sc2);
           }
+        // (the second MFMA into the D + H sums: a pass of its own, 2 RA RB MFMAs behind the first into the same registers)
+        if constexpr (PS::pS) {
+#pragma unroll
+          for (int a = 0; a < RA; a++)
+#pragma unroll
+            for (int b = 0; b < RB; b++) cD[a][b] = MFMA_F4(P[cur][a].h, P[cur][RA + b].h, cD[a][b], sc2, sc2);
+        }
         // NV plane masks (+ address arithmetic) and NT loads spread over the NM MFMAs of the step
 #pragma unroll
         for (int q = 0; q < NM; q++) {
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void tpg_pairwise_set_kernel(const uint4* _
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             if constexpr (PS::pV) atomicAdd(slab + 0 * TPG_PW_PLANE_INTS + r * 64, (int)cV[a][b][r]);
-            if constexpr (PS::pD) atomicAdd(slab + 1 * TPG_PW_PLANE_INTS + r * 64, (int)cD[a][b][r]);
+            if constexpr (PS::pD || PS::pS) atomicAdd(slab + 1 * TPG_PW_PLANE_INTS + r * 64, (int)cD[a][b][r]);  // (pS: D + H)
             if constexpr (PS::pH) atomicAdd(slab + 2 * TPG_PW_PLANE_INTS + r * 64, (int)cH[a][b][r]);
             if constexpr (PS::pA) atomicAdd(slab + 3 * TPG_PW_PLANE_INTS + r * 64, (int)cHV[a][b][r]);
             if constexpr (PS::pA) atomicAdd(slab + 4 * TPG_PW_PLANE_INTS + r * 64, (int)cVH[a][b][r]);
@@ -742,10 +752,10 @@ extern "C" int tpg_pairwise_reduce(tpg_ctx* ctx, tpg_comm* comm, tpg_pairwise* p
   // With it travels, per product, the number of ranks that did NOT accumulate it since their last zero: the sums of a product
   // are complete only if every rank added it (`have` is rank-local; a rank that ran all five products must not pass pw_need
   // for IBS / KING when another contributed {V, D} alone).
-  const int bits[4] = {TPG_PW_V, TPG_PW_D, TPG_PW_H, TPG_PW_A};
-  double word[5] = {(double)pw->loci, 0, 0, 0, 0};
-  for (int b = 0; b < 4; b++) word[1 + b] = (pw->have & bits[b]) ? 0.0 : 1.0;
-  if (comm->nranks > 1 || comm->nccl) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, word, 5));
+  const int bits[5] = {TPG_PW_V, TPG_PW_D, TPG_PW_H, TPG_PW_A, TPG_PW_DH};
+  double word[6] = {(double)pw->loci, 0, 0, 0, 0, 0};
+  for (int b = 0; b < 5; b++) word[1 + b] = (pw->have & bits[b]) ? 0.0 : 1.0;
+  if (comm->nranks > 1 || comm->nccl) TPG_TRY(tpg_comm_allreduce_f64(ctx, comm, word, 6));
   const double loci = word[0];
   TPG_REQUIRE(loci <= (double)TPG_PW_MAX_LOCI, TPG_EUNSUPPORTED, "%.0f loci over all ranks overflow the int32 pair counts", loci);
   {
@@ -753,7 +763,7 @@ extern "C" int tpg_pairwise_reduce(tpg_ctx* ctx, tpg_comm* comm, tpg_pairwise* p
     TPG_TRY(tpg_comm_reduce_scatter_i32(comm, pw->acc, pw->chunk_units * TPG_PW_TILE_INTS));
   }
   pw->loci = (int64_t)loci;
-  for (int b = 0; b < 4; b++)
+  for (int b = 0; b < 5; b++)
     if (word[1 + b] > 0) pw->have &= ~bits[b];
   pw->reduced = true;
   return TPG_OK;
@@ -795,7 +805,7 @@ extern "C" int tpg_pairwise_zero(tpg_ctx* ctx, tpg_pairwise* pw) {
   TPG_HIP(hipMemsetAsync(pw->acc, 0, pw_buffer_bytes(pw->n, pw->nranks), ctx->stream));
   pw->loci = 0;
   pw->reduced = false;
-  pw->have = TPG_PW_ALL;
+  pw->have = TPG_PW_HAVE_ALL;
   return TPG_OK;
 }
 
@@ -965,7 +975,9 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
   TPG_REQUIRE(ctx && pw && v, TPG_EINVAL, "null argument");
   TPG_REQUIRE(pw->n == v->n, TPG_EINVAL, "pairwise n = %lld but view n = %lld", (long long)pw->n, (long long)v->n);
   TPG_REQUIRE(!pw->reduced, TPG_EINVAL, "the accumulators were reduced over the ranks: zero them before accumulating again");
-  TPG_REQUIRE(products > 0 && (products & ~TPG_PW_ALL) == 0, TPG_EINVAL, "bad product set 0x%x", products);
+  TPG_REQUIRE(products > 0 && (products & ~(TPG_PW_ALL | TPG_PW_DH)) == 0, TPG_EINVAL, "bad product set 0x%x", products);
+  TPG_REQUIRE(!(products & TPG_PW_DH) || (products & ~(TPG_PW_V | TPG_PW_DH)) == 0, TPG_EINVAL,
+              "TPG_PW_DH (D + H in one sum) goes with TPG_PW_V only, not with 0x%x", products & ~(TPG_PW_V | TPG_PW_DH));
   if (col_end < 0) col_end = v->m;
   TPG_REQUIRE(col_begin >= 0 && col_begin <= col_end && col_end <= v->m, TPG_EINVAL, "bad locus range [%lld,%lld)",
               (long long)col_begin, (long long)col_end);
@@ -981,6 +993,7 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
   // the kernels that exist: {V, D}, {V, D, H}, {V, D, A}, all five; anything else takes the smallest one that covers it
   int set = products | TPG_PW_V | TPG_PW_D;
   if ((set & TPG_PW_H) && (set & TPG_PW_A)) set = TPG_PW_ALL;
+  if (products & TPG_PW_DH) set = TPG_PW_FOR_IBS_ALONE;
   // (pw->loci and pw->have are committed at the end, once every launch has been accepted: a failed accumulate must not leave
   // them claiming work that never ran)
   // the FP4 operand form of the view: written by the pack kernel (tpg_view_create_pair) or made here on first use
@@ -1026,9 +1039,22 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
       TPG_REQUIRE(false, TPG_EUNSUPPORTED, "TPG_PW_VARIANT=%d is a timing experiment with wrong sums: build with -DTPG_PW_EXPERIMENTS", var);
 #endif
     }
-    else if (var == 1) PW_SET(4, 2, TPG_PW_FOR_AS, 4, "pairwise_mfma_as");
+    else if (var == 1) PW_SET(4, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
     else if (var == 2) PW_SET(3, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
-    else PW_SET(4, 2, TPG_PW_FOR_AS, 5, "pairwise_mfma_as");
+    // (96 x 96 = 18 accumulator tiles, 32 of their registers VGPRs: 15.0 ms with three slots, 21.7 with four -- 54 spills --
+    // against 8.1; instantiations removed again)
+    else PW_SET(4, 2, TPG_PW_FOR_AS, 4, "pairwise_mfma_as");  // (round 6: 8.1 ms with four slots, 8.5 with five; round 4 had it the other way, before the lean scalar stream)
+  } else if (set == TPG_PW_FOR_IBS_ALONE) {
+    // measured at 5 000 x 1 000 000 (tools/pw_only.py, one GPU job): 128 x 64 with 4 / 5 / 3 slots 10.7 / 10.8 / 13.3 ms, 96 x 64
+    // with 4 / 5 slots 11.2 / 11.2, 64 x 64 11.9; the {V, D, H} kernel (three sums per pair, 64 x 64) 12.2
+    if (var == 1) PW_SET(4, 2, TPG_PW_FOR_IBS_ALONE, 4, "pairwise_mfma_ibs1");
+    else if (var == 2) PW_SET(3, 2, TPG_PW_FOR_IBS_ALONE, 4, "pairwise_mfma_ibs1");
+    else if (var == 3) PW_SET(3, 2, TPG_PW_FOR_IBS_ALONE, 5, "pairwise_mfma_ibs1");
+    else if (var == 4) PW_SET(2, 2, TPG_PW_FOR_IBS_ALONE, 5, "pairwise_mfma_ibs1");
+    else if (var == 5) PW_SET(4, 2, TPG_PW_FOR_IBS_ALONE, 5, "pairwise_mfma_ibs1");
+    else if (var == 6) PW_SET(4, 2, TPG_PW_FOR_IBS_ALONE, 3, "pairwise_mfma_ibs1");
+    // (96 x 96, 27 MFMAs per 6 fragments: 17.9 ms with three slots, 21.2 with four -- 86 spills; removed again)
+    else PW_SET(4, 2, TPG_PW_FOR_IBS_ALONE, 4, "pairwise_mfma_ibs1");
   } else if (set == TPG_PW_FOR_IBS) {
     if (var == 1) PW_SET(2, 2, TPG_PW_FOR_IBS, 4, "pairwise_mfma_ibs");
     else if (var == 2) PW_SET(3, 1, TPG_PW_FOR_IBS, 6, "pairwise_mfma_ibs");
@@ -1045,7 +1071,8 @@ extern "C" int tpg_pairwise_accumulate_products(tpg_ctx* ctx, tpg_pairwise* pw, 
 #undef PW_WG
   TPG_CHECK_LAUNCH();
   pw->loci += col_end - col_begin;
-  pw->have &= set;
+  // what stays complete: the products of this set; the D + H sum (plane D + plane H) after anything that added D and H, apart or together
+  pw->have &= set | (((set & TPG_PW_D) && (set & TPG_PW_H)) ? TPG_PW_DH : 0);
   return TPG_OK;
 }
 
@@ -1054,7 +1081,12 @@ extern "C" int tpg_pairwise_accumulate(tpg_ctx* ctx, tpg_pairwise* pw, const tpg
   return tpg_pairwise_accumulate_products(ctx, pw, v, col_begin, col_end, TPG_PW_ALL);
 }
 
-extern "C" int tpg_pairwise_products(const tpg_pairwise* pw) { return pw ? pw->have : 0; }
+// (TPG_PW_DH is reported only where it is all there is of D and H: a caller that never uses it sees the four bits it always saw)
+extern "C" int tpg_pairwise_products(const tpg_pairwise* pw) {
+  if (!pw) return 0;
+  const bool apart = (pw->have & TPG_PW_D) && (pw->have & TPG_PW_H);
+  return (pw->have & TPG_PW_ALL) | ((pw->have & TPG_PW_DH) && !apart ? TPG_PW_DH : 0);
+}
 
 // ---------------------------------------------------------------------------
 // epilogues.  FP64 arithmetic follows the R drivers' operation order (file compiled with
@@ -1191,7 +1223,7 @@ static int pw_commit(tpg_ctx* ctx, OutBuf& o, int64_t n, const PwBand& b) {
 // an output may only be formed from products every accumulate since the last zero has added (tpg_pairwise_accumulate_products)
 static int pw_need(const tpg_pairwise* pw, int products, const char* what) {
   TPG_REQUIRE((pw->have & products) == products, TPG_EINVAL,
-              "%s needs the products 0x%x but only 0x%x were accumulated (TPG_PW_V = 1, D = 2, H = 4, A = 8): pass them to "
+              "%s needs the products 0x%x but only 0x%x were accumulated (TPG_PW_V = 1, D = 2, H = 4, A = 8, D + H as one sum = 16): pass them to "
               "tpg_pairwise_accumulate_products", what, products, pw->have);
   return TPG_OK;
 }
@@ -1219,7 +1251,7 @@ extern "C" int tpg_pairwise_counts(tpg_ctx* ctx, const tpg_pairwise* pw, double*
                                    double* king_num, double* n_Aa_i, double* as_num, double* as_den) {
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
-  if (ibs) TPG_TRY(pw_need(pw, TPG_PW_FOR_IBS, "ibs"));
+  if (ibs) TPG_TRY(pw_need(pw, TPG_PW_FOR_IBS_ALONE, "ibs"));
   if (ibs_valid) TPG_TRY(pw_need(pw, TPG_PW_V, "ibs_valid"));
   if (king_num) TPG_TRY(pw_need(pw, TPG_PW_FOR_KING, "king_num"));
   if (n_Aa_i) TPG_TRY(pw_need(pw, TPG_PW_A, "n_Aa_i"));
@@ -1233,7 +1265,7 @@ extern "C" int tpg_pairwise_ibs(tpg_ctx* ctx, const tpg_pairwise* pw, int type, 
   TpgEnter _enter(ctx);
   TPG_REQUIRE(ctx && pw && out, TPG_EINVAL, "null argument");
   TPG_REQUIRE(type == TPG_IBS_PROPORTION || type == TPG_IBS_ADJUSTED_COUNTS, TPG_EINVAL, "bad IBS type %d", type);
-  TPG_TRY(pw_need(pw, TPG_PW_FOR_IBS, "IBS"));
+  TPG_TRY(pw_need(pw, TPG_PW_FOR_IBS_ALONE, "IBS"));
   double* outs[6] = {out, nullptr, nullptr, nullptr, nullptr, nullptr};
   return run_epilogue(ctx, pw, 1, type == TPG_IBS_PROPORTION ? 1.0 : (double)m, outs);
 }
@@ -1262,7 +1294,7 @@ static int epilogues_impl(tpg_ctx* ctx, tpg_comm* comm, const tpg_pairwise* pw, 
   TPG_REQUIRE(ctx && pw, TPG_EINVAL, "null argument");
   TPG_REQUIRE(ibs_type == TPG_IBS_PROPORTION || ibs_type == TPG_IBS_ADJUSTED_COUNTS, TPG_EINVAL, "bad IBS type");
   // every rank has accumulated the same product set (the sharded entry points pass the same mask everywhere)
-  if (ibs) TPG_TRY(pw_need(pw, TPG_PW_FOR_IBS, "IBS"));
+  if (ibs) TPG_TRY(pw_need(pw, TPG_PW_FOR_IBS_ALONE, "IBS"));
   if (king) TPG_TRY(pw_need(pw, TPG_PW_FOR_KING, "KING"));
   if (allele_sharing || grm) TPG_TRY(pw_need(pw, TPG_PW_FOR_AS, "allele sharing / GRM"));
   const int n = (int)pw->n;
@@ -1663,7 +1695,7 @@ static int add_counts_to_caller(tpg_ctx* ctx, int which, const tpg_pairwise* pw,
     });
     return TPG_OK;
   }
-  TPG_TRY(pw_need(pw, which == 0 ? TPG_PW_FOR_IBS : which == 1 ? TPG_PW_FOR_KING : TPG_PW_FOR_AS, "increment"));
+  TPG_TRY(pw_need(pw, which == 0 ? TPG_PW_FOR_IBS_ALONE : which == 1 ? TPG_PW_FOR_KING : TPG_PW_FOR_AS, "increment"));
   // widths on the wire: 16 bits where the block's bounds allow it (see the kernel); TPG_INCREMENT_I32=1: always int32 (A/B)
   static const bool wide = getenv("TPG_INCREMENT_I32") && atoi(getenv("TPG_INCREMENT_I32")) != 0;
   const int64_t bound = 2 * pw->loci + pw->as_pad_quirk;  // of |IBS|, |valid|, |KING numerator|; N_Aa, |D|, V <= loci + quirk
@@ -1795,7 +1827,7 @@ static int increment_common(tpg_ctx* ctx, int which, double* A, double* B, const
   int rc = upload_block_columns(ctx, fbm_bytes, nrow, ncol, colInd1, m, &f, cols);
   if (rc == TPG_OK) rc = tpg_view_create(ctx, f, rowInd1, n, cols.data(), m, nullptr /* raw bytes, src/snp_ibs.cpp:47-54 */, &v);
   // the products this entry point's two matrices are made of (src/snp_ibs.cpp:67-72, src/snp_king.cpp:70-72, src/snp_as.cpp:64-65)
-  const int products = which == 0 ? TPG_PW_FOR_IBS : which == 1 ? TPG_PW_FOR_KING : TPG_PW_FOR_AS;
+  const int products = which == 0 ? TPG_PW_FOR_IBS_ALONE : which == 1 ? TPG_PW_FOR_KING : TPG_PW_FOR_AS;
   if (rc == TPG_OK) rc = tpg_pairwise_accumulate_products(ctx, pw, v, 0, -1, products);
   if (rc == TPG_OK && pw == r->spare) rc = add_counts_to_caller(ctx, which, pw, A, B);  // immediate: as the reference
   tpg_view_free(v);  // stream-ordered: the blocks return to this context's pool

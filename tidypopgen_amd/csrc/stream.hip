@@ -197,7 +197,7 @@ struct StreamRun {
     want_fst = j->nfst > 0;
     want_pca = j->k > 0;
     TPG_REQUIRE(want_pw || want_loc || want_fst || want_pca, TPG_EINVAL, "the job asks for nothing");
-    products = (j->ibs ? TPG_PW_FOR_IBS : 0) | (j->king ? TPG_PW_FOR_KING : 0) | (j->allele_sharing || j->grm ? TPG_PW_FOR_AS : 0);
+    products = tpg_pw_products_for(j->ibs != nullptr, j->king != nullptr, j->allele_sharing || j->grm);
     if (want_fst) {
       TPG_REQUIRE(j->nfst <= TPG_STREAM_MAX_FST && j->pairs1 && j->P > 0, TPG_EINVAL, "bad Fst request");
       for (int i = 0; i < j->nfst; i++) {

@@ -15,7 +15,10 @@ X = tpg.FBM.synth(3, n, m, npop=51, imputed_bytes=True)
 v = tpg.View(X, code256=None)
 pw = tpg.Pairwise(ctx, n)
 sets = (("all", None, 5.0, "pairwise_mfma"), ("as", tpg.PW_FOR_AS, 2.0, "pairwise_mfma_as"),
-        ("ibs", tpg.PW_FOR_IBS, 3.0, "pairwise_mfma_ibs"), ("king", tpg.PW_FOR_KING, 4.0, "pairwise_mfma_king"))
+        ("ibs", tpg.PW_FOR_IBS, 3.0, "pairwise_mfma_ibs"), ("ibs1", tpg.PW_FOR_IBS_ALONE, 3.0, "pairwise_mfma_ibs1"),
+        ("king", tpg.PW_FOR_KING, 4.0, "pairwise_mfma_king"))
+if os.environ.get("PW_ONLY_SETS"):
+    sets = tuple(s for s in sets if s[0] in os.environ["PW_ONLY_SETS"].split(","))
 for name, products, ops, key in sets:
     for var in variants:
         os.environ["TPG_PW_VARIANT"] = str(var)
