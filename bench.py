@@ -109,6 +109,14 @@ class Step:
                 self.transport = comm.transport().replace("rccl: ", "rccl (") + ")"  # names the library that was loaded
                 if share == "rccl":
                     self.transport += ", all ranks on ONE GPU (rehearsal of the nccl call sites)"
+        # TPG_OVERLAP_REDUCE=1 (opt-in, several ranks over RCCL): the reduce-scatter of the pair counts goes to a SECOND
+        # communicator on a second context / stream (tpg_pairwise_reduce_begin / _end) and runs beside the PCA instead of in
+        # front of it; the epilogues then follow the PCA.  Rehearsed over the stream-ordered mock RCCL, never on two GPUs.
+        self.side_ctx = self.side_comm = None
+        if os.environ.get("TPG_OVERLAP_REDUCE") == "1" and world > 1 and not share_gpu and self.transport.startswith("rccl"):
+            self.side_ctx = tpg.Context(device)
+            self.side_comm = api.Comm.from_torch_distributed(self.side_ctx)
+            self.transport += "; pair-count reduce-scatter on a second communicator beside the PCA"
         n, G = args.n, args.pops
         if args.scaling == "strong":
             self.m_total = args.m
@@ -187,13 +195,22 @@ class Step:
         self.pw.zero()
         self.pw.accumulate(v)
         # data-path exchanges (identities on one rank): integer N x N partials, one reduce-scatter; 4 P doubles
-        self.pw.reduce()
+        overlap = self.side_comm is not None
+
+        def epilogues():
+            chk(lib.tpg_pairwise_epilogues_sharded(ctx.h, self.comm.h, self.pw.h, C.c_int(0), C.c_int64(self.m_total),
+                                                   self.d_nn[0], self.d_nn[1], C.c_void_p(None), self.d_nn[2]))
+            if after_nn:
+                after_nn()
+
+        if overlap:
+            self.pw.reduce_begin(self.side_comm)  # enqueued on the side stream behind the pairwise kernel; returns at once
+        else:
+            self.pw.reduce()
         self.comm.allreduce_f64(self.d_fst.value, 4 * P)
-        chk(lib.tpg_pairwise_epilogues_sharded(ctx.h, self.comm.h, self.pw.h, C.c_int(0), C.c_int64(self.m_total),
-                                               self.d_nn[0], self.d_nn[1], C.c_void_p(None), self.d_nn[2]))
+        if not overlap:
+            epilogues()
         v.free()
-        if after_nn:
-            after_nn()
         # ---- imputed view + PCA ----
         if self.has_pca:
             try:
@@ -208,6 +225,9 @@ class Step:
                 self.has_pca = False
         elif v_pca is not None:
             v_pca.free()
+        if overlap:
+            self.pw.reduce_end(self.side_comm)
+            epilogues()
         ctx.sync()
 
 

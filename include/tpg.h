@@ -346,6 +346,15 @@ int tpg_comm_allreduce_f64(tpg_ctx* ctx, tpg_comm* comm, double* buf, int64_t co
 size_t tpg_pairwise_buffer_bytes_sharded(int64_t n, int nranks);
 int tpg_pairwise_create_sharded(tpg_ctx* ctx, const tpg_comm* comm, int64_t n, tpg_pairwise** out);
 int tpg_pairwise_reduce(tpg_ctx* ctx, tpg_comm* comm, tpg_pairwise* pw);
+/* The same reduction on a SECOND communicator -- one made on another context (= another stream) of the same device, same
+ * ranks -- so that the reduce-scatter runs beside what pw's own context enqueues next (in the fused analysis: the PCA's Gram
+ * kernels) instead of in front of it.  _begin orders the reduce-scatter behind the accumulate kernels already enqueued on
+ * pw's context and returns at once; _end orders pw's context behind the reduce-scatter (nothing may read the accumulators in
+ * between).  RCCL orders the operations of ONE communicator, hence the second one; every rank must issue _begin and the
+ * collectives of its first communicator in the same order.  Rehearsed over the stream-ordered mock RCCL only:
+ * opt-in, nothing in the library calls it by itself. */
+int tpg_pairwise_reduce_begin(tpg_ctx* ctx, tpg_comm* side_comm, tpg_pairwise* pw);
+int tpg_pairwise_reduce_end(tpg_ctx* ctx, tpg_comm* side_comm, tpg_pairwise* pw);
 int tpg_pairwise_band(const tpg_pairwise* pw, int64_t* row0, int64_t* row1);
 /* the band rank `rank` of `nranks` gets for n individuals (host arithmetic; no GPU needed) */
 int tpg_pairwise_band_of(int64_t n, int nranks, int rank, int64_t* row0, int64_t* row1);

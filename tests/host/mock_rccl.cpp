@@ -10,13 +10,15 @@
 //     or silent corruption).
 // The ranks may be threads of one process (ncclCommInitAll with a device listed several times: tpg_multi) or processes
 // (ncclCommInitRank with a broadcast id: bench.py's ranks); either way they meet in POSIX shared memory: one control file per
-// communicator (arrival counter, barrier, per-rank operation records) and one payload file per rank.  Every operation is
-// synchronous -- wait for the caller's stream, copy the send buffer to the rank's payload file, barrier, check that all
-// ranks posted the SAME operation with the same count and type, combine on the host in rank order, copy the result to the
-// receive buffer, barrier -- so what this proves is the call sites' arguments (units, offsets, in-place use, buffer
-// extents, the order of collectives on every rank); what it does not prove is stream ordering against later kernels,
-// RCCL's own kernels, or anything about xGMI.  Every wait has a timeout: a rank that never arrives is an error
-// (ncclSystemError), not a hang.  Every buffer is checked to be device memory and the accessed range to lie inside its
+// communicator (arrival counter, barrier, per-rank operation records) and one payload file per rank.  By default every
+// operation is synchronous -- wait for the caller's stream, copy the send buffer to the rank's payload file, barrier, check
+// that all ranks posted the SAME operation with the same count and type, combine on the host in rank order, copy the result
+// to the receive buffer, barrier -- which proves the call sites' arguments (units, offsets, in-place use, buffer extents, the
+// order of collectives on every rank).  MOCK_RCCL_ASYNC=1 makes it stream-ordered and adversarial instead (see "One
+// collective = a plan" below): the call only enqueues, the receive buffer holds poison until a delayed combine has run, so a
+// consumer that is not ordered behind the collective on the stream fails its parity test.  What neither mode proves: RCCL's
+// own kernels and protocols, peer mappings, xGMI.  Every wait has a timeout: a rank that never arrives is an error
+// (ncclSystemError), not a hang; the wait kernel of the stream-ordered mode is bounded by the wall clock.  Every buffer is checked to be device memory and the accessed range to lie inside its
 // allocation (hipMemGetAddressRange), which is how a count passed in bytes shows up even when the sums happen to agree.
 // Selected by TPG_RCCL_LIBRARY=<path to this .so> (comm.hip: rccl_load).
 #include <errno.h>
@@ -31,10 +33,14 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 
 extern "C" {
 typedef struct mockComm* ncclComm_t;
@@ -67,6 +73,9 @@ struct Control {
   std::atomic<int32_t> bar_count;
   std::atomic<int32_t> bar_gen;
   std::atomic<int32_t> failed;    // some rank saw an error inside a collective: everybody returns it
+  std::atomic<int32_t> bar_failed[2];  // `failed` as the rank that completed barrier generation g saw it, at [g & 1]: every rank
+                                       // leaves a barrier with the SAME verdict (a rank that read `failed` later could see the
+                                       // flag a faster peer raised after the barrier and skip the next one: its peer waits for ever)
   int32_t nranks;
   uint64_t ops;                   // collectives completed (statistics for the tests: mock_rccl_stats)
   RankRecord rec[MAX_RANKS];
@@ -103,6 +112,7 @@ struct mockComm {
   Mapping mine;                 // this rank's payload file (grows)
   std::vector<Mapping> peer;    // read-only views of the others', remapped when they grow
   uint64_t n_allreduce = 0, n_reducescatter = 0, n_alltoallv = 0, bytes_moved = 0;
+  void* async = nullptr;  // AsyncState of the stream-ordered mode (made by the first collective)
   Control* C() { return (Control*)ctl.p; }
 };
 
@@ -152,16 +162,18 @@ static bool barrier(mockComm* c) {
   Control* C = c->C();
   const int gen = C->bar_gen.load(std::memory_order_acquire);
   if (C->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == c->nranks) {
+    const int32_t verdict = C->failed.load();
+    C->bar_failed[gen & 1].store(verdict, std::memory_order_relaxed);
     C->bar_count.store(0, std::memory_order_relaxed);
     C->bar_gen.store(gen + 1, std::memory_order_release);
-    return C->failed.load() == 0;
+    return verdict == 0;
   }
   const double t0 = now_s();
   while (C->bar_gen.load(std::memory_order_acquire) == gen) {
     if (now_s() - t0 > TIMEOUT_S) { C->failed.store(1); return false; }
     nap();
   }
-  return C->failed.load() == 0;
+  return C->bar_failed[gen & 1].load(std::memory_order_relaxed) == 0;
 }
 
 // device buffer [p, p + bytes) must be device memory and lie inside ONE allocation
@@ -237,33 +249,288 @@ static bool sum_typed(void* acc, const void* src, size_t n, ncclDataType_t t) {
   }
 }
 
-// common frame of a collective: post the record + payload, barrier, run `combine` (reads the peers), barrier
-template <typename Post, typename Combine>
-static ncclResult_t collective(mockComm* c, hipStream_t stream, Op op, ncclDataType_t dtype, uint64_t count, size_t payload, Post post,
-                               Combine combine) {
-  if (!c) return fail(ncclInvalidArgument, "null communicator");
+// ---------------------------------------------------------------------------------------------------------------------
+// One collective = a plan: which device pieces go into this rank's payload file, how the result is made on the host from
+// the ranks' payloads, which device pieces receive it.  Two ways to run a plan:
+//
+//   synchronous (default): wait for the caller's stream, copy out, rendezvous, combine, copy in, return.  Arguments,
+//     units, offsets and "every rank in the same collective" are checked and reported by the return code
+//     (tests/test_gpu_multirank.py::test_mock_rccl_semantics_and_misuse_detection).
+//
+//   stream-ordered and adversarial (MOCK_RCCL_ASYNC=1): like RCCL, the call only ENQUEUES and returns.  On the caller's stream,
+//     in order: the send pieces are copied to pinned memory; the receive pieces are filled with a poison pattern (0xA5);
+//     a one-thread kernel waits -- bounded: MOCK_RCCL_KERNEL_TIMEOUT_S, default 30 -- for a word in pinned memory; the result
+//     is copied from pinned memory into the receive pieces.  A helper thread per communicator does the rendezvous: it waits
+//     for the event behind the staging copy, posts the payload, meets the other ranks, sleeps MOCK_RCCL_DELAY_MS (default 3),
+//     combines on the host and only then raises the word.  So between the call and the stream reaching the end of the
+//     collective the receive buffer holds poison: a consumer that is not ordered behind the collective ON THE STREAM (a read
+//     from another stream or from the host without the event / the synchronisation it needs, a pool block handed to
+//     somebody else while the collective still owns it) computes on poison and the parity tests fail.  Argument checks still
+//     happen at the call; what only the rendezvous can see (a rank in another collective, mismatched all-to-all counts) makes
+//     the communicator sticky-failed: the word is raised so that no kernel is left waiting, every later call returns the
+//     error, and mock_rccl_async_errors() counts it for the tests.
+//   What neither mode is: RCCL's kernels, its protocols, peer mappings, xGMI.
+struct Piece {
+  void* dev;
+  size_t bytes;
+  size_t off;  // offset in the staged payload / in the host result
+};
+
+struct Plan {
+  Op op = OP_NONE;
+  ncclDataType_t dtype = ncclInt8;
+  uint64_t count = 0;
+  size_t payload = 0, result = 0;
+  std::vector<Piece> send, recv;
+  uint64_t a2a_off[MAX_RANKS] = {}, a2a_cnt[MAX_RANKS] = {};
+  std::vector<size_t> a2a_recvcounts;  // all-to-all: what this rank expects from each peer
+  size_t es = 0;
+};
+
+// the host side of a plan, identical in both modes: post, barrier, same-operation check, combine into `result`, barrier
+static ncclResult_t rendezvous(mockComm* c, const Plan& pl, const uint8_t* staged, uint8_t* result, int delay_ms) {
   Control* C = c->C();
   ncclResult_t rc = ncclSuccess;
-  if (hipStreamSynchronize(stream) != hipSuccess) rc = fail(ncclUnhandledCudaError, "hipStreamSynchronize failed before the collective");
-  if (rc == ncclSuccess && !grow_mine(c, payload)) rc = fail(ncclSystemError, "cannot grow the payload file of rank %s%lld", "", c->rank);
+  if (!grow_mine(c, pl.payload)) rc = fail(ncclSystemError, "cannot grow the payload file of rank %s%lld", "", c->rank);
+  if (rc == ncclSuccess && pl.payload) memcpy(c->mine.p, staged, pl.payload);
   RankRecord& me = C->rec[c->rank];
-  me.op = op; me.dtype = (int32_t)dtype; me.count = count; me.bytes = payload;
-  if (rc == ncclSuccess) rc = post(me);
+  me.op = pl.op; me.dtype = (int32_t)pl.dtype; me.count = pl.count; me.bytes = pl.payload;
+  memcpy(me.a2a_off, pl.a2a_off, sizeof me.a2a_off);
+  memcpy(me.a2a_cnt, pl.a2a_cnt, sizeof me.a2a_cnt);
   if (rc != ncclSuccess) C->failed.store(1);
-  if (!barrier(c)) return rc != ncclSuccess ? rc : fail(ncclSystemError, "a rank failed or did not arrive (operation %s%lld)", "", op);
+  if (!barrier(c)) return rc != ncclSuccess ? rc : fail(ncclSystemError, "a rank failed or did not arrive (operation %s%lld)", "", pl.op);
   // every rank must have posted the same operation (a rank in another collective is the classic multi-GPU hang)
   for (int r = 0; r < c->nranks && rc == ncclSuccess; r++) {
     const RankRecord& o = C->rec[r];
-    if (o.op != op || o.dtype != (int32_t)dtype || (op != OP_ALLTOALLV && o.count != count))
+    if (o.op != pl.op || o.dtype != (int32_t)pl.dtype || (pl.op != OP_ALLTOALLV && o.count != pl.count))
       rc = fail(ncclInvalidUsage, "rank %s%lld posted another operation / count / type than this rank", "", r);
   }
-  if (rc == ncclSuccess) rc = combine();
+  if (rc == ncclSuccess && delay_ms > 0) {
+    timespec ts{delay_ms / 1000, (long)(delay_ms % 1000) * 1000000L};
+    nanosleep(&ts, nullptr);
+  }
+  if (rc == ncclSuccess) {
+    const int R = c->nranks;
+    if (pl.op == OP_ALLREDUCE || pl.op == OP_REDUCESCATTER) {
+      const size_t chunk = pl.result, skip = pl.op == OP_REDUCESCATTER ? (size_t)c->rank * chunk : 0;
+      memset(result, 0, chunk ? chunk : 1);
+      for (int r = 0; r < R && rc == ncclSuccess; r++) {  // rank order: the same bits on every rank
+        const uint8_t* p = (const uint8_t*)peer_payload(c, r, pl.payload);
+        if (!p) rc = fail(ncclSystemError, "cannot map the payload of rank %s%lld", "", r);
+        else if (!sum_typed(result, p + skip, chunk / pl.es, pl.dtype)) rc = fail(ncclInvalidArgument, "datatype cannot be summed");
+      }
+      if (rc == ncclSuccess) { (pl.op == OP_ALLREDUCE ? c->n_allreduce : c->n_reducescatter)++; c->bytes_moved += pl.payload; }
+    } else {
+      size_t o_res = 0;
+      for (int s = 0; s < R && rc == ncclSuccess; s++) {
+        const RankRecord& o = C->rec[s];
+        if (o.a2a_cnt[c->rank] != pl.a2a_recvcounts[(size_t)s]) {
+          rc = fail(ncclInvalidUsage, "ncclAllToAllv: rank %s%lld sends %lld elements here, another count is expected", "", s,
+                    (long long)o.a2a_cnt[c->rank]);
+          break;
+        }
+        const size_t bts = pl.a2a_recvcounts[(size_t)s] * pl.es;
+        if (bts) {
+          const uint8_t* p = (const uint8_t*)peer_payload(c, s, o.bytes);
+          if (!p) { rc = fail(ncclSystemError, "cannot map the payload of rank %s%lld", "", s); break; }
+          memcpy(result + o_res, p + o.a2a_off[c->rank], bts);
+          c->bytes_moved += bts;
+        }
+        o_res += bts;
+      }
+      if (rc == ncclSuccess) c->n_alltoallv++;
+    }
+  }
   if (rc != ncclSuccess) C->failed.store(1);
-  if (!barrier(c)) return rc != ncclSuccess ? rc : fail(ncclSystemError, "a rank failed inside operation %s%lld", "", op);
+  if (!barrier(c)) return rc != ncclSuccess ? rc : fail(ncclSystemError, "a rank failed inside operation %s%lld", "", pl.op);
   if (c->rank == 0) C->ops++;
   g_total_ops++;
-  g_counts[op]++;
+  g_counts[pl.op]++;
   return rc;
+}
+
+static ncclResult_t run_sync(mockComm* c, hipStream_t stream, const Plan& pl) {
+  if (hipStreamSynchronize(stream) != hipSuccess) return fail(ncclUnhandledCudaError, "hipStreamSynchronize failed before the collective");
+  std::vector<uint8_t> staged(pl.payload ? pl.payload : 1), result(pl.result ? pl.result : 1);
+  for (const Piece& p : pl.send)
+    if (p.bytes && hipMemcpy(staged.data() + p.off, p.dev, p.bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      c->C()->failed.store(1);
+      (void)barrier(c);
+      return fail(ncclUnhandledCudaError, "device -> host copy failed");
+    }
+  ncclResult_t rc = rendezvous(c, pl, staged.data(), result.data(), 0);
+  if (rc != ncclSuccess) return rc;
+  for (const Piece& p : pl.recv)
+    if (p.bytes && hipMemcpy(p.dev, result.data() + p.off, p.bytes, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(ncclUnhandledCudaError, "host -> device copy failed");
+  return ncclSuccess;
+}
+
+// ---- the stream-ordered mode ------------------------------------------------------------------------------------------
+static bool async_mode() {
+  static const bool on = getenv("MOCK_RCCL_ASYNC") && atoi(getenv("MOCK_RCCL_ASYNC")) != 0;
+  return on;
+}
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static std::atomic<uint64_t> g_async_errors{0}, g_async_ops{0}, g_kernel_timeouts{0};
+
+__global__ void mock_rccl_wait_kernel(const uint32_t* flag, uint32_t seq, unsigned long long timeout_ticks, uint32_t* timed_out) {
+  // one thread; the 100 MHz wall clock bounds the wait, so the grid drains whatever the host does
+  const unsigned long long t0 = wall_clock64();
+  while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+    if (wall_clock64() - t0 > timeout_ticks) {
+      __hip_atomic_store(timed_out, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(64);
+  }
+}
+
+struct AsyncTask {
+  Plan plan;
+  uint32_t seq = 0;
+  hipEvent_t staged = nullptr, done = nullptr;
+  uint8_t *h_send = nullptr, *h_recv = nullptr;  // pinned
+  size_t cap_send = 0, cap_recv = 0;
+};
+
+struct AsyncState {
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<AsyncTask*> queue, retired;
+  bool stop = false;
+  uint32_t seq = 0;
+  uint32_t* flags = nullptr;  // pinned, coherent: [0] = sequence number of the last completed collective, [1] = a kernel timed out
+  ncclResult_t sticky = ncclSuccess;
+  std::string sticky_msg;
+  int device = 0;
+};
+
+static void async_worker(mockComm* c, AsyncState* st) {
+  (void)hipSetDevice(st->device);
+  const int delay = env_int("MOCK_RCCL_DELAY_MS", 3);
+  for (;;) {
+    AsyncTask* t = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(st->mu);
+      st->cv.wait(lk, [&] { return st->stop || !st->queue.empty(); });
+      if (st->queue.empty()) return;
+      t = st->queue.front();
+      st->queue.pop_front();
+    }
+    ncclResult_t rc = ncclSuccess;
+    if (hipEventSynchronize(t->staged) != hipSuccess) rc = fail(ncclUnhandledCudaError, "the staging copy of a collective failed");
+    if (rc == ncclSuccess) rc = rendezvous(c, t->plan, t->h_send, t->h_recv, delay);
+    else { c->C()->failed.store(1); (void)barrier(c); }
+    if (rc != ncclSuccess) {
+      g_async_errors++;
+      fprintf(stderr, "[mock_rccl] rank %d: collective %u failed behind the call: %s\n", c->rank, t->seq, t_err.c_str());
+      std::lock_guard<std::mutex> lk(st->mu);
+      if (st->sticky == ncclSuccess) { st->sticky = rc; st->sticky_msg = t_err; }
+      // (the poison stays in the pinned result: whoever consumes it sees it)
+      memset(t->h_recv, 0xA5, t->plan.result ? t->plan.result : 1);
+    }
+    g_async_ops++;
+    __atomic_store_n(&st->flags[0], t->seq, __ATOMIC_RELEASE);  // the wait kernel of this collective may go on
+    {
+      std::lock_guard<std::mutex> lk(st->mu);
+      st->retired.push_back(t);
+    }
+  }
+}
+
+static AsyncState* async_of(mockComm* c);
+
+static ncclResult_t run_async(mockComm* c, hipStream_t stream, const Plan& pl) {
+  AsyncState* st = async_of(c);
+  if (!st) return fail(ncclSystemError, "cannot start the helper thread / pinned memory of the stream-ordered mode");
+  {
+    std::lock_guard<std::mutex> lk(st->mu);
+    if (st->sticky != ncclSuccess) { t_err = st->sticky_msg; return st->sticky; }
+  }
+  // a task whose copies have all run is recycled (its pinned buffers with it): hipEventQuery never blocks, and nothing here
+  // frees pinned memory while work is in flight -- a hipHostFree would synchronise the device and hide what this mode is for
+  AsyncTask* t = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(st->mu);
+    for (auto it = st->retired.begin(); it != st->retired.end(); ++it)
+      if (hipEventQuery((*it)->done) == hipSuccess) { t = *it; st->retired.erase(it); break; }
+  }
+  (void)hipGetLastError();
+  if (!t) {
+    t = new AsyncTask();
+    if (hipEventCreateWithFlags(&t->staged, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&t->done, hipEventDisableTiming) != hipSuccess)
+      return fail(ncclUnhandledCudaError, "cannot create events");
+  }
+  auto need = [](uint8_t*& p, size_t& cap, size_t bytes) -> bool {
+    if (bytes <= cap) return true;
+    size_t want = cap ? cap : 4096;
+    while (want < bytes) want *= 2;
+    uint8_t* q = nullptr;
+    if (hipHostMalloc((void**)&q, want, hipHostMallocDefault) != hipSuccess) return false;
+    // (the smaller buffer is leaked on purpose: freeing pinned memory synchronises the device)
+    p = q;
+    cap = want;
+    return true;
+  };
+  if (!need(t->h_send, t->cap_send, pl.payload ? pl.payload : 1) || !need(t->h_recv, t->cap_recv, pl.result ? pl.result : 1))
+    return fail(ncclSystemError, "cannot pin staging memory");
+  t->plan = pl;
+  {
+    std::lock_guard<std::mutex> lk(st->mu);
+    t->seq = ++st->seq;
+  }
+  const unsigned long long ticks = 100000000ull * (unsigned long long)env_int("MOCK_RCCL_KERNEL_TIMEOUT_S", 30);
+  hipError_t e = hipSuccess;
+  for (const Piece& p : pl.send)
+    if (p.bytes && e == hipSuccess) e = hipMemcpyAsync(t->h_send + p.off, p.dev, p.bytes, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipEventRecord(t->staged, stream);
+  for (const Piece& p : pl.recv)
+    if (p.bytes && e == hipSuccess) e = hipMemsetAsync(p.dev, 0xA5, p.bytes, stream);  // poison until the collective completes
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(mock_rccl_wait_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)st->flags, t->seq, ticks, st->flags + 1);
+    e = hipGetLastError();
+  }
+  for (const Piece& p : pl.recv)
+    if (p.bytes && e == hipSuccess) e = hipMemcpyAsync(p.dev, t->h_recv + p.off, p.bytes, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipEventRecord(t->done, stream);
+  if (e != hipSuccess) {
+    // nothing may be left waiting: run the rendezvous as a failure and raise the word
+    c->C()->failed.store(1);
+    std::lock_guard<std::mutex> lk(st->mu);
+    st->sticky = ncclUnhandledCudaError;
+    st->sticky_msg = std::string("mock rccl: enqueueing a collective failed: ") + hipGetErrorString(e);
+    __atomic_store_n(&st->flags[0], t->seq, __ATOMIC_RELEASE);
+    t_err = st->sticky_msg;
+    return ncclUnhandledCudaError;
+  }
+  {
+    std::lock_guard<std::mutex> lk(st->mu);
+    st->queue.push_back(t);
+  }
+  st->cv.notify_all();
+  return ncclSuccess;
+}
+
+static AsyncState* async_of(mockComm* c) {
+  if (c->async) return (AsyncState*)c->async;
+  AsyncState* st = new AsyncState();
+  if (hipGetDevice(&st->device) != hipSuccess) { delete st; return nullptr; }
+  if (hipHostMalloc((void**)&st->flags, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { delete st; return nullptr; }
+  memset(st->flags, 0, 64);
+  st->worker = std::thread(async_worker, c, st);
+  c->async = st;
+  return st;
+}
+
+static ncclResult_t run_plan(mockComm* c, hipStream_t stream, const Plan& pl) {
+  if (!c) return fail(ncclInvalidArgument, "null communicator");
+  return async_mode() ? run_async(c, stream, pl) : run_sync(c, stream, pl);
 }
 
 extern "C" {
@@ -311,6 +578,21 @@ ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
 
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
   if (!c) return ncclSuccess;
+  if (c->async) {  // every collective enqueued on this communicator has been handed to the helper: let it finish them, then stop it
+    AsyncState* st = (AsyncState*)c->async;
+    {
+      std::lock_guard<std::mutex> lk(st->mu);
+      st->stop = true;
+    }
+    st->cv.notify_all();
+    if (st->worker.joinable()) st->worker.join();
+    if (st->flags && st->flags[1]) {
+      g_kernel_timeouts++;
+      fprintf(stderr, "[mock_rccl] rank %d: a wait kernel gave up after its timeout: its collective handed back poison\n", c->rank);
+    }
+    // (tasks, events and pinned buffers are left to the process: their copies may still be in flight on the caller's stream)
+    c->async = nullptr;
+  }
   Control* C = c->C();
   const bool last = C->detached.fetch_add(1) + 1 == c->nranks;
   for (auto& m : c->peer) m.drop();
@@ -327,27 +609,16 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
   const size_t es = dtype_size(dtype), bytes = count * es;
   if (op != ncclSum) return fail(ncclInvalidArgument, "only ncclSum");
   if (!es) return fail(ncclInvalidArgument, "datatype");
-  return collective(
-      c, stream, OP_ALLREDUCE, dtype, count, bytes,
-      [&](RankRecord&) -> ncclResult_t {
-        if (!device_range_ok(sendbuff, bytes, "ncclAllReduce sendbuff") || !device_range_ok(recvbuff, bytes, "ncclAllReduce recvbuff"))
-          return ncclInvalidArgument;
-        if (bytes && hipMemcpy(c->mine.p, sendbuff, bytes, hipMemcpyDeviceToHost) != hipSuccess)
-          return fail(ncclUnhandledCudaError, "device -> host copy failed");
-        return ncclSuccess;
-      },
-      [&]() -> ncclResult_t {
-        std::vector<uint8_t> acc(bytes ? bytes : 1, 0);
-        for (int r = 0; r < c->nranks; r++) {  // rank order: the same bits on every rank
-          const void* p = peer_payload(c, r, bytes);
-          if (!p) return fail(ncclSystemError, "cannot map the payload of rank %s%lld", "", r);
-          if (!sum_typed(acc.data(), p, count, dtype)) return fail(ncclInvalidArgument, "datatype cannot be summed");
-        }
-        if (bytes && hipMemcpy(recvbuff, acc.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
-          return fail(ncclUnhandledCudaError, "host -> device copy failed");
-        c->n_allreduce++; c->bytes_moved += bytes;
-        return ncclSuccess;
-      });
+  if (!c) return fail(ncclInvalidArgument, "null communicator");
+  if (!device_range_ok(sendbuff, bytes, "ncclAllReduce sendbuff") || !device_range_ok(recvbuff, bytes, "ncclAllReduce recvbuff")) {
+    if (!async_mode()) { c->C()->failed.store(1); (void)barrier(c); }
+    return ncclInvalidArgument;
+  }
+  Plan pl;
+  pl.op = OP_ALLREDUCE; pl.dtype = dtype; pl.count = count; pl.payload = bytes; pl.result = bytes; pl.es = es;
+  pl.send.push_back(Piece{(void*)sendbuff, bytes, 0});
+  pl.recv.push_back(Piece{recvbuff, bytes, 0});
+  return run_plan(c, stream, pl);
 }
 
 ncclResult_t ncclReduceScatter(const void* sendbuff, void* recvbuff, size_t recvcount, ncclDataType_t dtype, ncclRedOp_t op,
@@ -356,32 +627,25 @@ ncclResult_t ncclReduceScatter(const void* sendbuff, void* recvbuff, size_t recv
   if (op != ncclSum) return fail(ncclInvalidArgument, "only ncclSum");
   if (!es || !c) return fail(ncclInvalidArgument, "datatype / communicator");
   const size_t chunk = recvcount * es, bytes = chunk * (size_t)c->nranks;
-  return collective(
-      c, stream, OP_REDUCESCATTER, dtype, recvcount, bytes,
-      [&](RankRecord&) -> ncclResult_t {
-        if (!device_range_ok(sendbuff, bytes, "ncclReduceScatter sendbuff") || !device_range_ok(recvbuff, chunk, "ncclReduceScatter recvbuff"))
-          return ncclInvalidArgument;
-        // rccl.h: in place when recvbuff == sendbuff + rank * recvcount; any OTHER overlap of the two is undefined
-        const char *s = (const char*)sendbuff, *d = (const char*)recvbuff;
-        const bool overlap = d < s + bytes && s < d + chunk;
-        if (overlap && d != s + (size_t)c->rank * chunk)
-          return fail(ncclInvalidUsage, "ncclReduceScatter: recvbuff overlaps sendbuff but is not sendbuff + rank * recvcount");
-        if (bytes && hipMemcpy(c->mine.p, sendbuff, bytes, hipMemcpyDeviceToHost) != hipSuccess)
-          return fail(ncclUnhandledCudaError, "device -> host copy failed");
-        return ncclSuccess;
-      },
-      [&]() -> ncclResult_t {
-        std::vector<uint8_t> acc(chunk ? chunk : 1, 0);
-        for (int r = 0; r < c->nranks; r++) {
-          const uint8_t* p = (const uint8_t*)peer_payload(c, r, bytes);
-          if (!p) return fail(ncclSystemError, "cannot map the payload of rank %s%lld", "", r);
-          if (!sum_typed(acc.data(), p + (size_t)c->rank * chunk, recvcount, dtype)) return fail(ncclInvalidArgument, "datatype cannot be summed");
-        }
-        if (chunk && hipMemcpy(recvbuff, acc.data(), chunk, hipMemcpyHostToDevice) != hipSuccess)
-          return fail(ncclUnhandledCudaError, "host -> device copy failed");
-        c->n_reducescatter++; c->bytes_moved += bytes;
-        return ncclSuccess;
-      });
+  ncclResult_t bad = ncclSuccess;
+  if (!device_range_ok(sendbuff, bytes, "ncclReduceScatter sendbuff") || !device_range_ok(recvbuff, chunk, "ncclReduceScatter recvbuff"))
+    bad = ncclInvalidArgument;
+  if (bad == ncclSuccess) {
+    // rccl.h: in place when recvbuff == sendbuff + rank * recvcount; any OTHER overlap of the two is undefined
+    const char *s = (const char*)sendbuff, *d = (const char*)recvbuff;
+    const bool overlap = d < s + bytes && s < d + chunk;
+    if (overlap && d != s + (size_t)c->rank * chunk)
+      bad = fail(ncclInvalidUsage, "ncclReduceScatter: recvbuff overlaps sendbuff but is not sendbuff + rank * recvcount");
+  }
+  if (bad != ncclSuccess) {
+    if (!async_mode()) { c->C()->failed.store(1); (void)barrier(c); }
+    return bad;
+  }
+  Plan pl;
+  pl.op = OP_REDUCESCATTER; pl.dtype = dtype; pl.count = recvcount; pl.payload = bytes; pl.result = chunk; pl.es = es;
+  pl.send.push_back(Piece{(void*)sendbuff, bytes, 0});
+  pl.recv.push_back(Piece{recvbuff, chunk, 0});
+  return run_plan(c, stream, pl);
 }
 
 ncclResult_t ncclAllToAllv(const void* sendbuff, const size_t sendcounts[], const size_t sdispls[], void* recvbuff,
@@ -389,48 +653,34 @@ ncclResult_t ncclAllToAllv(const void* sendbuff, const size_t sendcounts[], cons
   const size_t es = dtype_size(dtype);
   if (!es || !c || !sendcounts || !sdispls || !recvcounts || !rdispls) return fail(ncclInvalidArgument, "null argument / datatype");
   const int R = c->nranks;
-  size_t total = 0;
-  for (int d = 0; d < R; d++) total += sendcounts[d] * es;
-  return collective(
-      c, stream, OP_ALLTOALLV, dtype, 0, total,
-      [&](RankRecord& me) -> ncclResult_t {
-        size_t o = 0;
-        for (int d = 0; d < R; d++) {
-          const size_t b = sendcounts[d] * es;
-          if (!device_range_ok((const char*)sendbuff + sdispls[d] * es, b, "ncclAllToAllv send piece")) return ncclInvalidArgument;
-          if (!device_range_ok((char*)recvbuff + rdispls[d] * es, recvcounts[d] * es, "ncclAllToAllv receive piece")) return ncclInvalidArgument;
-          me.a2a_off[d] = o; me.a2a_cnt[d] = sendcounts[d];
-          if (b && hipMemcpy((char*)c->mine.p + o, (const char*)sendbuff + sdispls[d] * es, b, hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(ncclUnhandledCudaError, "device -> host copy failed");
-          o += b;
-        }
-        // receive pieces must not overlap each other (a displacement in bytes instead of elements makes them collide or
-        // run off the end)
-        for (int a = 0; a < R; a++)
-          for (int b = a + 1; b < R; b++) {
-            const size_t a0 = rdispls[a], a1 = a0 + recvcounts[a], b0 = rdispls[b], b1 = b0 + recvcounts[b];
-            if (recvcounts[a] && recvcounts[b] && a0 < b1 && b0 < a1) return fail(ncclInvalidUsage, "ncclAllToAllv: receive pieces overlap");
-          }
-        return ncclSuccess;
-      },
-      [&]() -> ncclResult_t {
-        Control* C = c->C();
-        for (int s = 0; s < R; s++) {
-          const RankRecord& o = C->rec[s];
-          if (o.a2a_cnt[c->rank] != recvcounts[s])
-            return fail(ncclInvalidUsage, "ncclAllToAllv: rank %s%lld sends %lld elements here, another count is expected", "", s,
-                        (long long)o.a2a_cnt[c->rank]);
-          const size_t b = recvcounts[s] * es;
-          if (!b) continue;
-          const uint8_t* p = (const uint8_t*)peer_payload(c, s, o.bytes);
-          if (!p) return fail(ncclSystemError, "cannot map the payload of rank %s%lld", "", s);
-          if (hipMemcpy((char*)recvbuff + rdispls[s] * es, p + o.a2a_off[c->rank], b, hipMemcpyHostToDevice) != hipSuccess)
-            return fail(ncclUnhandledCudaError, "host -> device copy failed");
-          c->bytes_moved += b;
-        }
-        c->n_alltoallv++;
-        return ncclSuccess;
-      });
+  Plan pl;
+  pl.op = OP_ALLTOALLV; pl.dtype = dtype; pl.count = 0; pl.es = es;
+  ncclResult_t bad = ncclSuccess;
+  size_t o = 0, ores = 0;
+  for (int d = 0; d < R && bad == ncclSuccess; d++) {
+    const size_t b = sendcounts[d] * es, rb = recvcounts[d] * es;
+    if (!device_range_ok((const char*)sendbuff + sdispls[d] * es, b, "ncclAllToAllv send piece")) bad = ncclInvalidArgument;
+    else if (!device_range_ok((char*)recvbuff + rdispls[d] * es, rb, "ncclAllToAllv receive piece")) bad = ncclInvalidArgument;
+    pl.a2a_off[d] = o; pl.a2a_cnt[d] = sendcounts[d];
+    pl.send.push_back(Piece{(void*)((const char*)sendbuff + sdispls[d] * es), b, o});
+    pl.recv.push_back(Piece{(char*)recvbuff + rdispls[d] * es, rb, ores});
+    pl.a2a_recvcounts.push_back(recvcounts[d]);
+    o += b;
+    ores += rb;
+  }
+  // receive pieces must not overlap each other (a displacement in bytes instead of elements makes them collide or run off the end)
+  for (int a = 0; a < R && bad == ncclSuccess; a++)
+    for (int b = a + 1; b < R; b++) {
+      const size_t a0 = rdispls[a], a1 = a0 + recvcounts[a], b0 = rdispls[b], b1 = b0 + recvcounts[b];
+      if (recvcounts[a] && recvcounts[b] && a0 < b1 && b0 < a1) { bad = fail(ncclInvalidUsage, "ncclAllToAllv: receive pieces overlap"); break; }
+    }
+  if (bad != ncclSuccess) {
+    if (!async_mode()) { c->C()->failed.store(1); (void)barrier(c); }
+    return bad;
+  }
+  pl.payload = o;
+  pl.result = ores;
+  return run_plan(c, stream, pl);
 }
 
 // for the tests: collectives this PROCESS has completed over the mock, by kind {all, all-reduce, reduce-scatter, all-to-all}
@@ -439,6 +689,13 @@ void mock_rccl_stats(uint64_t out[4]) {
   out[1] = g_counts[OP_ALLREDUCE].load();
   out[2] = g_counts[OP_REDUCESCATTER].load();
   out[3] = g_counts[OP_ALLTOALLV].load();
+}
+// the stream-ordered mode: {1 if it is on, collectives completed behind their calls, of those failed, wait kernels that timed out}
+void mock_rccl_async_stats(uint64_t out[4]) {
+  out[0] = async_mode() ? 1 : 0;
+  out[1] = g_async_ops.load();
+  out[2] = g_async_errors.load();
+  out[3] = g_kernel_timeouts.load();
 }
 
 }  // extern "C"

@@ -14,11 +14,10 @@ MOCK_SO = os.path.join(ROOT, "tests", "host", "libmock_rccl.so")
 
 
 def build_mock_rccl() -> str:
-    """host-only translation unit (no device code): g++ against the HIP runtime API"""
+    """one translation unit, host code + the one-thread wait kernel of its stream-ordered mode: hipcc for gfx950"""
     if not os.path.exists(MOCK_SO) or os.path.getmtime(MOCK_SO) < os.path.getmtime(MOCK_SRC):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__",
-                               "-I/opt/rocm/include", MOCK_SRC, "-o", MOCK_SO, "-L/opt/rocm/lib", "-lamdhip64",
-                               "-Wl,-rpath,/opt/rocm/lib"])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-x", "hip",
+                               "--offload-arch=gfx950", MOCK_SRC, "-o", MOCK_SO, "-lpthread"])
     return MOCK_SO
 
 
@@ -106,7 +105,67 @@ def mock_stats():
     return dict(zip(("all", "allreduce", "reducescatter", "alltoallv"), [int(x) for x in out]))
 
 
+def async_mock_selftest():
+    """MOCK_RCCL_ASYNC=1, one rank, driven directly: the call returns before the collective has run; a reader that is NOT ordered
+    behind it (a kernel on another stream: the library's mailbox fetch through a second context) sees the poison pattern in the
+    receive buffer; a reader behind it on the stream sees the sum.  This is the property the stream-ordered mode exists for,
+    shown on the mock itself."""
+    import time
+
+    import tidypopgen_amd as tpg
+    from tidypopgen_amd import api
+
+    hip = C.CDLL("libamdhip64.so")
+    lib = C.CDLL(MOCK_SO)
+    tlib = tpg._lib.lib
+
+    def chk(rc, what):
+        assert rc == 0, (what, rc)
+
+    n = 1 << 12  # 16 KiB: what the contexts read back goes through their mailbox kernel, not a copy engine
+    ctx_a, ctx_b = tpg.Context(0), tpg.Context(0)
+    sa, sb = C.c_void_p(), C.c_void_p()
+    chk(hip.hipStreamCreateWithFlags(C.byref(sa), C.c_uint(1)), "stream")  # non-blocking streams: no implicit ordering between them
+    chk(hip.hipStreamCreateWithFlags(C.byref(sb), C.c_uint(1)), "stream")
+    ctx_a.set_stream(sa.value)
+    ctx_b.set_stream(sb.value)
+    d_send, d_recv = ctx_a.dev_alloc(4 * n), ctx_a.dev_alloc(4 * n)
+    src = np.arange(n, dtype=np.int32)
+    zero = np.zeros(n, dtype=np.int32)
+    tpg._lib.check(tlib.tpg_dev_from_host(ctx_a.h, d_send, api._ptr(src), C.c_size_t(4 * n)))
+    tpg._lib.check(tlib.tpg_dev_from_host(ctx_a.h, d_recv, api._ptr(zero), C.c_size_t(4 * n)))
+    warm = np.zeros(n, dtype=np.int32)  # (the contexts' mailboxes are set up by their first use)
+    tpg._lib.check(tlib.tpg_dev_to_host(ctx_b.h, api._ptr(warm), d_recv, C.c_size_t(4 * n)))
+    tpg._lib.check(tlib.tpg_dev_to_host(ctx_a.h, api._ptr(warm), d_recv, C.c_size_t(4 * n)))
+    cs = (C.c_void_p * 1)()
+    chk(lib.ncclCommInitAll(cs, C.c_int(1), (C.c_int * 1)(0)), "init")
+    comm = C.c_void_p(cs[0])
+    t0 = time.perf_counter()
+    chk(lib.ncclAllReduce(d_send, d_recv, C.c_size_t(n), C.c_int(2), C.c_int(0), comm, sa), "allreduce")
+    t_call = time.perf_counter() - t0
+    early, late = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    tpg._lib.check(tlib.tpg_dev_to_host(ctx_b.h, api._ptr(early), d_recv, C.c_size_t(4 * n)))  # the other stream
+    t_early = time.perf_counter() - t0
+    tpg._lib.check(tlib.tpg_dev_to_host(ctx_a.h, api._ptr(late), d_recv, C.c_size_t(4 * n)))   # behind the collective
+    t_late = time.perf_counter() - t0
+    print(f"call {t_call * 1e3:.2f} ms, other-stream read done at {t_early * 1e3:.2f} ms, ordered read at {t_late * 1e3:.2f} ms", flush=True)
+    poison = np.uint32(0xA5A5A5A5).astype(np.int32)
+    delay = int(os.environ.get("MOCK_RCCL_DELAY_MS", "3")) * 1e-3
+    assert t_call < 0.5 * delay, t_call                  # the call did not wait for the (delayed) combine
+    assert t_early < 0.8 * delay and t_late >= delay, (t_early, t_late)
+    assert np.all(early == poison), early[:4]            # not ordered behind the collective: poison
+    assert np.array_equal(late, src), late[:4]           # ordered behind it on its stream: the sum over the one rank
+    chk(lib.ncclCommDestroy(comm), "destroy")
+    a = (C.c_uint64 * 4)()
+    lib.mock_rccl_async_stats(a)
+    assert list(a) == [1, 1, 0, 0], list(a)
+    print("SELFTEST_OK", f"call returned after {t_call * 1e3:.2f} ms")
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "selftest":
+        async_mock_selftest()
+        sys.exit(0)
     ndev = int(sys.argv[1])
     assert os.environ.get("TPG_RCCL_LIBRARY") == MOCK_SO and os.environ.get("TPG_MULTI_FORCE_RCCL") == "1"
     tr = multi_against_oracle(ndev, devices=[0] * ndev)
@@ -115,3 +174,10 @@ if __name__ == "__main__":
     assert "mock_rccl" in tr, tr
     # per rank: two pairwise calls = two reduce-scatters; the forced class exchange = at least one real all-to-all + its self-test
     assert st["reducescatter"] >= 2 * ndev and st["alltoallv"] >= 2 * ndev and st["allreduce"] >= 10 * ndev, st
+    a = (C.c_uint64 * 4)()
+    C.CDLL(MOCK_SO).mock_rccl_async_stats(a)
+    if os.environ.get("MOCK_RCCL_ASYNC") == "1":  # every collective completed BEHIND its call, none failed there, no wait kernel gave up
+        assert a[0] == 1 and a[1] >= st["all"] and a[2] == 0 and a[3] == 0, list(a)
+        print("ASYNC_OK", list(a))
+    else:
+        assert a[0] == 0 and a[1] == 0, list(a)

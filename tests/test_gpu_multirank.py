@@ -532,21 +532,40 @@ def test_mock_rccl_semantics_and_misuse_detection(mock_rccl):
     ctx.close()
 
 
+# stream-ordered, adversarial mock (MOCK_RCCL_ASYNC=1): a collective only ENQUEUES; until a delayed combine has run its receive
+# buffer holds poison, so whatever consumes a collective's output without being ordered behind it on the stream fails parity
+_MOCK_ASYNC = dict(MOCK_RCCL_ASYNC="1", MOCK_RCCL_DELAY_MS="3", MOCK_RCCL_KERNEL_TIMEOUT_S="30")
+
+
+def test_mock_rccl_stream_ordered_mode_shows_an_unordered_reader_poison(mock_rccl):
+    """tests/multi_cases.py::async_mock_selftest in a child process (the mode is fixed per process)"""
+    r = subprocess.run([sys.executable, "-m", "tests.multi_cases", "selftest"], cwd=ROOT, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MOCK_RCCL_ASYNC="1", MOCK_RCCL_DELAY_MS="50"))
+    assert r.returncode == 0 and "SELFTEST_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+# (rank THREADS stay on the synchronous mock: with all ranks on ONE device and in one process, any runtime call that waits for
+# the device -- a hipMalloc of the library's pool, a pinned allocation -- waits for the OTHER rank's wait kernel, which waits
+# for this rank: measured, the first collective sits out its 30 s and hands back poison.  Ranks that are processes have a
+# device context each, and so do threads on distinct GPUs.)
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["sync"])
 @pytest.mark.parametrize("ndev", [2, 8])
-def test_mock_rccl_multi_against_oracle(mock_rccl, ndev):
+def test_mock_rccl_multi_against_oracle(mock_rccl, ndev, mode):
     """tpg.Multi with device 0 listed ndev times and TPG_MULTI_FORCE_RCCL=1: ncclCommInitAll, then ndev rank threads through
     ncclReduceScatter (in place at rank offsets, band-padded slabs), the FP64 / int32 ncclAllReduce calls, and -- with the class
     exchange forced -- ncclAllToAllv with the library's element counts and displacements; results against the oracle.  A child
     process, because the library loads its RCCL once per process."""
-    r = subprocess.run([sys.executable, "-m", "tests.multi_cases", str(ndev)], cwd=ROOT, capture_output=True, text=True, timeout=800,
-                       env=dict(os.environ, TPG_RCCL_LIBRARY=mock_rccl, TPG_MULTI_FORCE_RCCL="1"))
+    env = dict(os.environ, TPG_RCCL_LIBRARY=mock_rccl, TPG_MULTI_FORCE_RCCL="1", **(_MOCK_ASYNC if mode == "async" else {}))
+    r = subprocess.run([sys.executable, "-m", "tests.multi_cases", str(ndev)], cwd=ROOT, capture_output=True, text=True, timeout=800, env=env)
     assert r.returncode == 0 and "MOCK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert ("ASYNC_OK" in r.stdout) == (mode == "async"), r.stdout[-2000:]
 
 
 @pytest.mark.timeout(1200)
+@pytest.mark.parametrize("mode", ["sync", "async", "async+overlap"])
 @pytest.mark.parametrize("nproc,exchange,scaling", [(2, False, "strong"), (2, True, "strong"), (4, True, "strong")])  # (weak scaling: test_two_shards_equal_one)
-def test_mock_rccl_rank_processes_equal_one_gpu(tmp_path, mock_rccl, nproc, exchange, scaling):
+def test_mock_rccl_rank_processes_equal_one_gpu(tmp_path, mock_rccl, nproc, exchange, scaling, mode):
     """`bench.py --gpus N --digest` with one PROCESS per rank, all on device 0, over the mock (TPG_BENCH_SHARE_GPU=rccl):
     tpg_comm_unique_id -> broadcast -> ncclCommInitRank, the reduce-scatter of the pairwise slabs, the Fst / Gram / GRM-mean
     all-reduces, tpg_comm_agree's status words and (exchange) ncclAllToAllv -- the digest must equal the 1-GPU digest with the
@@ -562,11 +581,17 @@ def test_mock_rccl_rank_processes_equal_one_gpu(tmp_path, mock_rccl, nproc, exch
     r = subprocess.run([sys.executable, "bench.py", "--gpus", str(nproc), "--digest", dn, "--snps",
                         str(snps if scaling == "strong" else snps // nproc)] + common, cwd=ROOT, capture_output=True,
                        text=True, timeout=900, env=dict(env, MASTER_ADDR="127.0.0.1", TPG_BENCH_SHARE_GPU="rccl", TPG_RCCL_LIBRARY=mock_rccl,
-                                                        **({"TPG_GRAM_EXCHANGE": "1"} if exchange else {})))
+                                                        **({"TPG_GRAM_EXCHANGE": "1"} if exchange else {}),
+                                                        **(_MOCK_ASYNC if mode.startswith("async") else {}),
+                                                        # the reduce-scatter of the pair counts on a second communicator / stream
+                                                        # beside the PCA (tpg_pairwise_reduce_begin / _end), under the adversarial mock
+                                                        **({"TPG_OVERLAP_REDUCE": "1"} if mode.endswith("overlap") else {})))
     assert r.returncode == 0, r.stderr[-3000:]
+    assert "[mock_rccl]" not in r.stderr, r.stderr[-3000:]  # (a collective that failed behind its call says so there)
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == nproc
     assert "libmock_rccl.so" in line["config"]["collectives"] and "ONE GPU" in line["config"]["collectives"], line["config"]["collectives"]
     if exchange:
         assert "all-to-all" in line["config"]["pca_gram_path"], line["config"]["pca_gram_path"]
+    assert ("second communicator" in line["config"]["collectives"]) == mode.endswith("overlap"), line["config"]["collectives"]
     _digests_match(_MOCK_DIGEST_CACHE["one"], json.load(open(dn)), exchange)

@@ -96,7 +96,7 @@ SYMBOLS = [
     "tpg_pairwise_create_sharded", "tpg_pairwise_reduce", "tpg_pairwise_band", "tpg_pairwise_band_of", "tpg_pairwise_epilogues_sharded",
     "tpg_pca_partial_svd_sharded", "tpg_multi_create", "tpg_multi_destroy", "tpg_multi_ndev", "tpg_multi_ctx", "tpg_multi_comm", "tpg_multi_pairwise",
     "tpg_multi_grouped_alt_freq", "tpg_multi_pop_fst", "tpg_multi_pca_partial_svd",
-    "tpg_pairwise_accumulate_products", "tpg_pairwise_products",
+    "tpg_pairwise_accumulate_products", "tpg_pairwise_products", "tpg_pairwise_reduce_begin", "tpg_pairwise_reduce_end",
     "tpg_stream_open_host", "tpg_stream_open_bk", "tpg_stream_open_bed", "tpg_stream_open_bed_host", "tpg_stream_open_synth",
     "tpg_stream_close", "tpg_stream_run", "tpg_multi_stream_run",
 ]

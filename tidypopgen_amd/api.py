@@ -462,6 +462,14 @@ class ShardedPairwise(Pairwise):
     def reduce(self):
         check(lib.tpg_pairwise_reduce(self.ctx.h, self.comm.h, self.h))
 
+    def reduce_begin(self, side_comm: "Comm"):
+        """the reduce-scatter on a second communicator (one made on another context of the same device): runs beside what this
+        context enqueues next; nothing may read the accumulators until reduce_end (include/tpg.h; opt-in)"""
+        check(lib.tpg_pairwise_reduce_begin(self.ctx.h, side_comm.h, self.h))
+
+    def reduce_end(self, side_comm: "Comm"):
+        check(lib.tpg_pairwise_reduce_end(self.ctx.h, side_comm.h, self.h))
+
     def band(self):
         a, b = C.c_int64(), C.c_int64()
         check(lib.tpg_pairwise_band(self.h, C.byref(a), C.byref(b)))

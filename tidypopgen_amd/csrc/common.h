@@ -195,6 +195,11 @@ struct tpg_pairwise {
   std::vector<int32_t> band;   // nranks + 1 super-tile boundaries: band r = rows [band[r], band[r + 1])
   int64_t* rowpad = nullptr;   // device int64[nst]
   bool reduced = false;        // after tpg_pairwise_reduce: only this rank's band holds (complete) sums
+  // tpg_pairwise_reduce_begin / _end (the reduce-scatter on a second communicator's stream)
+  bool reducing = false;
+  hipEvent_t ev_acc = nullptr, ev_red = nullptr;
+  int64_t pending_loci = 0;
+  int pending_lack = 0;
   // products (TPG_PW_V | D | H | A) every accumulate since the last zero has added: what the epilogues may read
   int have = 31;  // TPG_PW_HAVE_ALL
   // unit tables of the product-subset kernels (pairwise.hip), one per wave-tile shape: key 16 RA + RB -> (device int2[], count)

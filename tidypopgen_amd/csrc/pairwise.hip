@@ -769,6 +769,58 @@ extern "C" int tpg_pairwise_reduce(tpg_ctx* ctx, tpg_comm* comm, tpg_pairwise* p
   return TPG_OK;
 }
 
+// tpg_pairwise_reduce with the reduce-scatter on the stream of ANOTHER communicator's context (include/tpg.h).  The small
+// all-reduce that carries the locus count and the per-product "some rank lacks it" words is host data: it goes first, on the
+// side stream, before that stream is made to wait for the accumulate kernels -- otherwise the host would stand still for the
+// length of the pairwise kernel and enqueue nothing beside it.
+extern "C" int tpg_pairwise_reduce_begin(tpg_ctx* ctx, tpg_comm* side, tpg_pairwise* pw) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && side && pw && side->ctx, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(pw->ctx == ctx, TPG_EINVAL, "the accumulators belong to another context");
+  TPG_REQUIRE(side->ctx != ctx && side->ctx->device == ctx->device, TPG_EINVAL,
+              "the side communicator must sit on another context of the same device");
+  TPG_REQUIRE(pw->nranks == side->nranks && pw->rank == side->rank, TPG_EINVAL,
+              "accumulators were created for rank %d of %d, the side communicator is rank %d of %d", pw->rank, pw->nranks, side->rank,
+              side->nranks);
+  TPG_REQUIRE(!pw->reduced && !pw->reducing, TPG_EINVAL, "already reduced, or a reduction is in flight");
+  const int bits[5] = {TPG_PW_V, TPG_PW_D, TPG_PW_H, TPG_PW_A, TPG_PW_DH};
+  double word[6] = {(double)pw->loci, 0, 0, 0, 0, 0};
+  for (int b = 0; b < 5; b++) word[1 + b] = (pw->have & bits[b]) ? 0.0 : 1.0;
+  tpg_ctx* sc = side->ctx;
+  if (side->nranks > 1 || side->nccl) {
+    TpgEnter _side(sc);
+    TPG_TRY(tpg_comm_allreduce_f64(sc, side, word, 6));
+  }
+  TPG_REQUIRE(word[0] <= (double)TPG_PW_MAX_LOCI, TPG_EUNSUPPORTED, "%.0f loci over all ranks overflow the int32 pair counts", word[0]);
+  if (!pw->ev_acc) TPG_HIP(hipEventCreateWithFlags(&pw->ev_acc, hipEventDisableTiming));
+  if (!pw->ev_red) TPG_HIP(hipEventCreateWithFlags(&pw->ev_red, hipEventDisableTiming));
+  TPG_HIP(hipEventRecord(pw->ev_acc, ctx->stream));          // behind the accumulate kernels of pw's context
+  TPG_HIP(hipStreamWaitEvent(sc->stream, pw->ev_acc, 0));
+  {
+    TpgEnter _side(sc);
+    TPG_TRY(tpg_comm_reduce_scatter_i32(side, pw->acc, pw->chunk_units * TPG_PW_TILE_INTS));
+  }
+  TPG_HIP(hipEventRecord(pw->ev_red, sc->stream));
+  pw->reducing = true;
+  pw->pending_loci = (int64_t)word[0];
+  pw->pending_lack = 0;
+  for (int b = 0; b < 5; b++)
+    if (word[1 + b] > 0) pw->pending_lack |= bits[b];
+  return TPG_OK;
+}
+
+extern "C" int tpg_pairwise_reduce_end(tpg_ctx* ctx, tpg_comm* side, tpg_pairwise* pw) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && side && pw, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(pw->ctx == ctx && pw->reducing, TPG_EINVAL, "no reduction in flight on these accumulators");
+  TPG_HIP(hipStreamWaitEvent(ctx->stream, pw->ev_red, 0));  // what follows on pw's context sees the reduced sums
+  pw->loci = pw->pending_loci;
+  pw->have &= ~pw->pending_lack;
+  pw->reduced = true;
+  pw->reducing = false;
+  return TPG_OK;
+}
+
 // the band of rank `rank` when n individuals are shared among nranks ranks (host arithmetic only: no GPU needed)
 extern "C" int tpg_pairwise_band_of(int64_t n, int nranks, int rank, int64_t* row0, int64_t* row1) {
   TPG_REQUIRE(row0 && row1 && n > 0 && nranks >= 1 && rank >= 0 && rank < nranks, TPG_EINVAL, "bad argument");
@@ -791,6 +843,8 @@ extern "C" int tpg_pairwise_band(const tpg_pairwise* pw, int64_t* row0, int64_t*
 
 extern "C" void tpg_pairwise_free(tpg_pairwise* pw) {
   if (!pw) return;
+  if (pw->ev_acc) (void)hipEventDestroy(pw->ev_acc);
+  if (pw->ev_red) (void)hipEventDestroy(pw->ev_red);
   if (pw->owns && pw->acc) tpg_pfree(pw->acc);
   tpg_pfree(pw->order);
   tpg_pfree(pw->rowpad);
@@ -804,6 +858,7 @@ extern "C" int tpg_pairwise_zero(tpg_ctx* ctx, tpg_pairwise* pw) {
   ProfScope ps(ctx, "pairwise_zero");
   TPG_HIP(hipMemsetAsync(pw->acc, 0, pw_buffer_bytes(pw->n, pw->nranks), ctx->stream));
   pw->loci = 0;
+  TPG_REQUIRE(!pw->reducing, TPG_EINVAL, "a reduction is in flight: tpg_pairwise_reduce_end first");
   pw->reduced = false;
   pw->have = TPG_PW_HAVE_ALL;
   return TPG_OK;
