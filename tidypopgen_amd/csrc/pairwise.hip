@@ -1010,7 +1010,9 @@ static int pw_launch_all(tpg_ctx* ctx, tpg_pairwise* pw, const tpg_view* v, int6
   for (int64_t c0 = kg0; c0 < kg1; c0 += 8 * max_groups) {
     const int64_t c1 = std::min(kg1, c0 + 8 * max_groups);
     const int64_t kgs = c1 - c0;
-    const int bestS = pw_ksplit(pw->nun, kgs, 8, ceil_div(kgs, max_groups), nwaves, 0.55, 12.0);
+    int bestS = pw_ksplit(pw->nun, kgs, 8, ceil_div(kgs, max_groups), nwaves, 0.55, 12.0);
+    // (experiments, tools/pw_ksplit_probe.py: any S in range gives the same sums)
+    if (const char* e = getenv("TPG_PW_KSPLIT")) bestS = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(kgs, max_groups), atoi(e)), std::max<int64_t>(1, kgs));
     if (getenv("TPG_DEBUG")) fprintf(stderr, "[tpg] pairwise: %lld units, S = %d\n", (long long)pw->nun, bestS);
     if (pw_variant() == 2)  // A/B: three groups of prefetch
       TPG_LAUNCH(ctx, "pairwise_mfma", tpg_pairwise_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (const uint4*)v->T4, v->KG,
