@@ -55,7 +55,14 @@ __device__ __forceinline__ int tpg_lut(uint32_t lut, uint32_t codes) {
 #define TPG_T4_MD 1u
 #endif
 // 2-bit code -> nibble: dosage 0 -> v | d | sign, 1 -> v | h, 2 -> v | d, missing -> 0  (0x0006030E for TPG_T4_ENC = 0)
+#ifndef TPG_T4_VMISS
 #define TPG_NIB_LUT ((TPG_T4_MV | TPG_T4_MD | 8u) | ((TPG_T4_MV | TPG_T4_MH) << 8) | ((TPG_T4_MV | TPG_T4_MD) << 16))
+#else
+// TIMING EXPERIMENT (round 6, wrong sums): the "v" bit marks the MISSING genotypes instead of the typed ones, i.e. the plane
+// that three of the five products multiply is 2 % ones instead of 98 % -- what the complement form V = L - m_i - m_j + MM,
+// HV = H_ii - HM would feed the matrix cores -- to see what the power-limited clock does with it (DESIGN.md 3.1 "Round 6")
+#define TPG_NIB_LUT ((TPG_T4_MD | 8u) | ((TPG_T4_MH) << 8) | ((TPG_T4_MD) << 16) | ((TPG_T4_MV) << 24))
+#endif
 // E8M0 block scale (all four bytes equal) that turns a plane of magnitude bit M into 0 / +-1: 0.5 x 2, 1 x 1, 2 x 0.5
 #define TPG_T4_SC(M) ((M) == 1u ? (int)0x80808080 : (M) == 2u ? 0x7f7f7f7f : 0x7e7e7e7e)
 // one T dword (16 codes) -> two T4 dwords (16 nibbles)
