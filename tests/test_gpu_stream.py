@@ -285,3 +285,57 @@ def test_stream_twenty_gigabytes_in_under_six(tpg):
     assert np.allclose(s["d"], p["d"], rtol=1e-10, atol=0)
     assert np.abs(_aligned(p["u"], s["u"]) - p["u"]).max() <= 1e-8
     assert np.array_equal(s["center"], p["center"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_stream_fuzz(tpg, seed):
+    """random shapes around the tile / block edges (m below one block, one locus past a block, n = 1 ... 300), random budgets,
+    random subsets, random choice of what is asked for: streamed == resident"""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 31, 33, 64, 127, 129, 200, 300]))
+    m = int(rng.choice([1, 5, 127, 128, 129, 255, 257, 1000, 1025, 2048, 3333]))
+    Gf = int(min(n, rng.integers(1, 6)))
+    fbm = orc.synth_fbm(500 + seed, n, m, npop=Gf, miss=float(rng.choice([0.0, 0.05, 0.4])), imputed_bytes=True)
+    X = tpg.FBM.from_numpy(fbm)
+    rows = None if rng.random() < 0.5 or n < 3 else (rng.permutation(n)[: max(2, n // 2)] + 1).astype(np.int32)
+    kind = rng.integers(0, 3)
+    cols = None if kind == 0 or m < 4 else ((rng.permutation(m)[: max(2, m // 2)] + 1).astype(np.int32) if kind == 1 else
+                                            np.arange(m // 4 + 1, m - m // 5 + 1, dtype=np.int32))
+    nn = n if rows is None else len(rows)
+    mm = m if cols is None else len(cols)
+    gid = (np.arange(nn) % Gf).astype(np.int32)
+    # a budget between "one 128-locus block" and "everything": per-locus bytes are a few nn + a few hundred
+    per = 8 * max(nn, 128) + 4000
+    budget = int(rng.choice([0, 140 * per, 400 * per, 4000 * per]))
+    st = tpg.Stream.from_numpy(fbm, budget_bytes=budget)
+    want_pw = [w for w in ("ibs", "king", "allele_sharing", "grm") if rng.random() < 0.6]
+    want_fst = Gf >= 2 and rng.random() < 0.7
+    s = st.run(rows, cols, pairwise=tuple(want_pw), groupIds=gid, ngroups=Gf, alt_freq=True, grouped_alt_freq=bool(rng.random() < 0.7),
+               grouped_missingness=bool(rng.random() < 0.5), loci_counts=True, fst=("Hudson", "WC84") if want_fst else (),
+               fst_by_locus=bool(rng.random() < 0.5))
+    v = tpg.View(X, rows, cols, code256=None)
+    if want_pw:
+        pw = tpg.Pairwise(X.ctx, v.n)
+        pw.accumulate(v)
+        ep = pw.epilogues(tuple(want_pw), m=mm)
+        for name in want_pw:
+            if name == "grm":
+                assert np.allclose(s[name], ep[name], rtol=1e-13, atol=1e-14, equal_nan=True)
+            else:
+                assert np.array_equal(s[name], ep[name], equal_nan=True), name
+    v012 = tpg.View(X, rows, cols, code256=tpg.CODE_012)
+    assert np.array_equal(s["alt_freq"], tpg.alt_freq_dip_pseudo_cpp(v012, None, False), equal_nan=True)
+    assert np.array_equal(s["loci_counts"], tpg.loci_counts(v012))
+    if "grouped_alt_freq" in s:
+        assert np.array_equal(s["grouped_alt_freq"], tpg.grouped_alt_freq_dip_pseudo_cpp(v012, gid, Gf, None, False), equal_nan=True)
+    if "grouped_missingness" in s:
+        assert np.array_equal(s["grouped_missingness"], tpg.grouped_missingness_cpp(v012, gid, Gf))
+    if want_fst:
+        for method in ("Hudson", "WC84"):
+            r = tpg.pairwise_pop_fst(X, rows, cols, gid, Gf, method=method, by_locus="fst_locus" in s)
+            assert np.allclose(s["fst_tot"][method], r["fst_tot"], rtol=1e-12, atol=0, equal_nan=True), method
+            if "fst_locus" in s:
+                assert np.array_equal(s["fst_locus"][method], r["fst_locus"], equal_nan=True), method
+    rep = s["report"]
+    assert rep["blocks"] == -(-mm // rep["block_loci"]) and (not budget or rep["planned_bytes"] <= budget)
+    st.close()
