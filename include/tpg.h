@@ -115,6 +115,12 @@ int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, in
 int tpg_view_create_pair(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, int64_t n, const int32_t* colInd1,
                          int64_t m, const double* code256_a, const double* code256_b, tpg_view** out_a,
                          tpg_view** out_b);
+/* The view of HOST FBM bytes (e.g. the columns a block of an R driver loop covers) without a store that outlives the call:
+ * upload, pack, release.  One code table is known, so the bytes cross PCIe as 2 bits per genotype where table and bytes
+ * allow it (every table entry below 16 a code, no byte >= 16: both true for CODE_012 / CODE_IMPUTE_PRED stores), as nibbles
+ * or bytes otherwise; the result is the view tpg_fbm_from_host + tpg_view_create give. */
+int tpg_view_create_from_host(tpg_ctx* ctx, const uint8_t* fbm_bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
+                              const int32_t* colInd1, int64_t m, const double* code256, tpg_view** out);
 void tpg_view_free(tpg_view* v);
 int64_t tpg_view_n(const tpg_view* v);
 int64_t tpg_view_m(const tpg_view* v);

@@ -277,10 +277,11 @@ static tpg_view* view_of(SEXP BM, SEXP rowInd, SEXP colInd, int raw_bytes) {
   }
   const int64_t span = (int64_t)hi - lo + 1;
   int* cols = (int*)R_alloc((size_t)m, sizeof(int)); /* R's transient storage: freed when .Call returns or errors */
-  tpg_fbm* dev = NULL;
+  /* tpg_view_create_from_host: upload for this ONE code table (2 bits per genotype over PCIe where table and bytes allow it),
+     pack, release the uploaded columns -- nothing of the FBM outlives the call */
   if (span <= 2 * m + 64) {
     for (int64_t j = 0; j < m; j++) cols[j] = ci[j] - (lo - 1);
-    TPG_R(tpg_fbm_from_host(ctx(), bytes + (size_t)(lo - 1) * (size_t)nrow, nrow, span, &dev));
+    TPG_R(tpg_view_create_from_host(ctx(), bytes + (size_t)(lo - 1) * (size_t)nrow, nrow, span, INTEGER(rowInd), n, cols, m, code, &v));
   } else {
     uint8_t* stage = (uint8_t*)malloc((size_t)nrow * (size_t)m);
     if (!stage) Rf_error("tidypopgen (GPU): out of memory gathering %lld columns", (long long)m);
@@ -288,13 +289,10 @@ static tpg_view* view_of(SEXP BM, SEXP rowInd, SEXP colInd, int raw_bytes) {
       memcpy(stage + (size_t)j * (size_t)nrow, bytes + (size_t)(ci[j] - 1) * (size_t)nrow, (size_t)nrow);
       cols[j] = (int)(j + 1);
     }
-    const int rc = tpg_fbm_from_host(ctx(), stage, nrow, m, &dev); /* waited for: the staging buffer may go */
+    const int rc = tpg_view_create_from_host(ctx(), stage, nrow, m, INTEGER(rowInd), n, cols, m, code, &v); /* waited for: the staging buffer may go */
     free(stage);
     TPG_R(rc);
   }
-  const int rc = tpg_view_create(ctx(), dev, INTEGER(rowInd), n, cols, m, code, &v);
-  tpg_fbm_free(dev); /* stream-ordered: the pack kernel has been enqueued, the block returns to the pool behind it */
-  TPG_R(rc);
   return v;
 }
 

@@ -1,7 +1,7 @@
 // tests/host/host_pieces.cpp -- self-checking driver for the host-only pieces of libtpg_hip.so (tidypopgen_amd/csrc/host/*.h),
 // built WITHOUT HIP by tests/test_host_sanitizers.py with -fsanitize=address,undefined and (the transport) -fsanitize=thread:
 // the CPU-side equivalent of the reference's valgrind job (.github/workflows/R-CMD-check-valgrind.yaml:50-51).
-//   host_pieces eig | bands | relfilter | nibpack | fsttiles | bits2 | inproc [threads] | inproc_mismatch
+//   host_pieces eig | bands | relfilter | nibpack | bedpack | fsttiles | bits2 | inproc [threads] | inproc_mismatch
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,6 +16,7 @@
 #include "host/host_eig.h"
 #include "host/host_fsttiles.h"
 #include "host/host_inproc.h"
+#include "host/host_bedpack.h"
 #include "host/host_nibpack.h"
 #include "host/host_relfilter.h"
 #include "host/host_bits2.h"
@@ -294,6 +295,35 @@ static int test_nibpack() {
   return 0;
 }
 
+// 2-bit pack into the .bed layout (a streamed run with one code table): lengths and alignments around the 128-byte vector step,
+// the last byte's unused bit pairs, the OR of the input bytes, every byte through the table
+static int test_bedpack() {
+  uint8_t lut[16];
+  for (int k = 0; k < 16; k++) lut[k] = (uint8_t)((k * 7 + 3) & 3);
+  for (size_t n : {0, 1, 3, 4, 5, 127, 128, 129, 131, 255, 256, 260, 4096, 4099, 100001}) {
+    for (int shift = 0; shift < 3; shift++) {
+      std::vector<uint8_t> in(n + 8), out((n + 3) / 4 + 8, 0xAA);
+      for (size_t i = 0; i < n; i++) in[shift + i] = (uint8_t)(urand() * 16);
+      const uint8_t seen = tpg_bedpack(in.data() + shift, out.data() + shift, n, lut);
+      uint8_t want_seen = 0;
+      for (size_t i = 0; i < n; i++) want_seen |= in[shift + i];
+      CHECK(seen == want_seen && seen < 16, "OR of the input bytes: %u, want %u (n = %zu)", seen, want_seen, n);
+      for (size_t i = 0; i < (n + 3) / 4; i++) {
+        uint8_t want = 0;
+        for (size_t r = 0; r < 4 && 4 * i + r < n; r++) want |= (uint8_t)(lut[in[shift + 4 * i + r]] << (2 * r));
+        CHECK(out[shift + i] == want, "byte %zu of %zu: %02x, want %02x (n = %zu)", i, (n + 3) / 4, out[shift + i], want, n);
+      }
+      CHECK(out[shift + (n + 3) / 4] == 0xAA, "wrote past the end (n = %zu)", n);
+      if (n >= 1) {  // one byte that no 16-entry table holds, anywhere: reported
+        const size_t at = (size_t)(urand() * n);
+        in[shift + at] = (uint8_t)(16 + urand() * 239);
+        CHECK(tpg_bedpack(in.data() + shift, out.data() + shift, n, lut) >= 16, "a byte >= 16 at %zu of %zu went unnoticed", at, n);
+      }
+    }
+  }
+  return 0;
+}
+
 // the pair list of pairwise_pop_fst cut into tiles of populations: every listed pair in exactly one slot of the right tile,
 // whatever the order, the orientation and the repeats of the list
 static int test_fsttiles() {
@@ -360,9 +390,10 @@ int main(int argc, char** argv) {
   else if (what == "inproc") rc = test_inproc(argc > 2 ? atoi(argv[2]) : 4);
   else if (what == "inproc_mismatch") rc = test_inproc_mismatch();
   else if (what == "nibpack") rc = test_nibpack();
+  else if (what == "bedpack") rc = test_bedpack();
   else if (what == "fsttiles") rc = test_fsttiles();
   else if (what == "bits2") rc = test_bits2();
-  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | nibpack | fsttiles | bits2 | inproc [threads] | inproc_mismatch\n");
+  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | nibpack | bedpack | fsttiles | bits2 | inproc [threads] | inproc_mismatch\n");
   if (rc == 0) printf("ok %s\n", what.c_str());
   return rc;
 }

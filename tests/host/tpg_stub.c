@@ -82,6 +82,14 @@ int tpg_view_create(tpg_ctx* ctx, const tpg_fbm* fbm, const int32_t* rowInd1, in
   *out = v;
   return TPG_OK;
 }
+int tpg_view_create_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
+                              const int32_t* colInd1, int64_t m, const double* code256, tpg_view** out) {
+  tpg_fbm* f = NULL;
+  if (tpg_fbm_from_host(ctx, bytes, nrow, ncol, &f) != TPG_OK) return TPG_EINVAL;
+  const int rc = tpg_view_create(ctx, f, rowInd1, n, colInd1, m, code256, out);
+  tpg_fbm_free(f);
+  return rc;
+}
 void tpg_view_free(tpg_view* v) {
   if (!v) return;
   free(v->codes);

@@ -93,7 +93,10 @@ def test_stream_equals_resident_and_oracle(tpg, n, m, budget):
                grouped_missingness=True, loci_counts=True, fst=("Hudson", "WC84"), fst_by_locus=True, k=k)
     _compare(s, r, k, by_locus=True, pca_tol_d=1e-10 if budget else 1e-8, pca_tol_u=1e-8 if budget else 1e-6)
     rep = s["report"]
-    assert rep["blocks"] == -(-m // rep["block_loci"]) and rep["bytes_up"] == n * m * rep["sweeps"]
+    # what crossed PCIe upwards: the store's bytes once (two code tables are wanted: raw + imputed); a second sweep for the
+    # loadings wants ONE table and takes the store as 2 bits per genotype, packed on the host (csrc/host/host_bedpack.h)
+    assert rep["blocks"] == -(-m // rep["block_loci"])
+    assert rep["bytes_up"] == n * m + (rep["sweeps"] - 1) * m * ((n + 3) // 4)
     if budget:
         assert rep["planned_bytes"] <= budget and rep["blocks"] > 1
     assert rep["sweeps"] == (1 if rep["views_kept"] else 2)
@@ -134,6 +137,10 @@ def test_stream_subsets_scattered_columns_and_single_requests(tpg):
         # one analysis at a time: only its products / views / outputs
         one = st.run(rows, cols, pairwise=("king",))
         assert set(one) == {"king", "report"} and np.array_equal(one["king"], r["king"], equal_nan=True)
+        # one code table: a contiguous colInd goes up as 2 bits per genotype (all n rows of the store: rowInd is applied on the
+        # device), a scattered one is gathered on the host and goes up as bytes
+        contiguous = bool(np.all(np.diff(cols) == 1))
+        assert one["report"]["bytes_up"] == (len(cols) * ((n + 3) // 4) if contiguous else len(cols) * n)
         one = st.run(rows, cols, pairwise=("grm",))
         assert np.allclose(one["grm"], r["grm"], rtol=1e-13, atol=1e-14)
         one = st.run(rows, cols, alt_freq=True)
@@ -239,6 +246,7 @@ def test_stream_config2_under_an_eighth_of_the_panel(tpg):
     rep = s["report"]
     assert rep["planned_bytes"] <= budget and rep["blocks"] >= 8 and rep["sweeps"] == 2 and not rep["views_kept"]
     assert rep["peak_device_bytes"] <= budget + rep["state_bytes"] + (64 << 20), rep
+    assert rep["bytes_up"] == n * m + m * (n // 4)  # the second sweep: 2 bits per genotype
     v = tpg.View(X, code256=None)
     pw = tpg.Pairwise(X.ctx, n)
     pw.accumulate(v)
@@ -339,3 +347,45 @@ def test_stream_fuzz(tpg, seed):
     rep = s["report"]
     assert rep["blocks"] == -(-mm // rep["block_loci"]) and (not budget or rep["planned_bytes"] <= budget)
     st.close()
+
+
+@pytest.mark.parametrize("bedpack", ["1", "0"])
+def test_stream_one_table_goes_up_as_two_bits(tpg, monkeypatch, bedpack):
+    """A streamed run that needs ONE code table packs the store's bytes to 2 bits per genotype on the host (the layout of a
+    .bed payload) and the device packs its views with the .bed front end: n not a multiple of 4 (per-column packing, padding bits),
+    n a multiple of 4 (a block is one contiguous piece), bytes 4 .. 6 of an imputed store through both tables, a byte >= 16 in
+    ONE block (that block goes as bytes), and TPG_STREAM_BEDPACK=0 as the A/B -- same results, different bytes_up."""
+    monkeypatch.setenv("TPG_STREAM_BEDPACK", bedpack)
+    for n, m in ((131, 3001), (256, 4096)):
+        fbm = orc.synth_fbm(61, n, m, npop=G, miss=0.05, imputed_bytes=True)
+        gid = (np.arange(n) % G).astype(np.int32)
+        X = tpg.FBM.from_numpy(fbm)
+        st = tpg.Stream.from_numpy(fbm, budget_bytes=1 << 20)
+        packed = m * ((n + 3) // 4)
+        s = st.run(pairwise=("ibs", "king", "allele_sharing", "grm"))  # raw table
+        assert s["report"]["bytes_up"] == (packed if bedpack == "1" else n * m) and s["report"]["blocks"] > 1
+        assert np.array_equal(s["ibs"], orc.snp_ibs(fbm), equal_nan=True) and np.array_equal(s["king"], orc.snp_king(fbm), equal_nan=True)
+        assert np.array_equal(s["allele_sharing"], orc.snp_allele_sharing(fbm), equal_nan=True)
+        s = st.run(code256=tpg.CODE_IMPUTE_PRED, groupIds=gid, ngroups=G, alt_freq=True, grouped_alt_freq=True, loci_counts=True,
+                   fst=("Hudson",))  # the imputed table: bytes 4 .. 6 are dosages
+        assert s["report"]["bytes_up"] == (packed if bedpack == "1" else n * m)
+        vi = tpg.View(X, code256=tpg.CODE_IMPUTE_PRED)
+        assert np.array_equal(s["alt_freq"], tpg.alt_freq_dip_pseudo_cpp(vi, None, False), equal_nan=True)
+        assert np.array_equal(s["grouped_alt_freq"], tpg.grouped_alt_freq_dip_pseudo_cpp(vi, gid, G, None, False), equal_nan=True)
+        assert np.array_equal(s["loci_counts"], tpg.loci_counts(vi)) and s["loci_counts"][:, 3].sum() == 0
+        s = st.run(k=4)  # the PCA's table
+        o = orc.gt_pca_partialSVD(fbm, None, None, k=4)
+        assert np.allclose(s["d"], o["d"], rtol=1e-10) and np.array_equal(s["center"], o["center"])
+        assert np.abs(_aligned(o["v"], s["v"]) - o["v"]).max() <= 1e-8
+        st.close()
+        # a byte no 16-entry table holds, in one block only: that block goes as bytes, the others packed; raw semantics: missing
+        odd = fbm.copy(order="F")
+        odd[5, 1000] = 200
+        st = tpg.Stream.from_numpy(odd, budget_bytes=1 << 20)
+        s = st.run(pairwise=("ibs",))
+        assert np.array_equal(s["ibs"], orc.snp_ibs(odd), equal_nan=True)
+        if bedpack == "1":
+            B = s["report"]["block_loci"]
+            mb = min(m, (1000 // B + 1) * B) - 1000 // B * B
+            assert s["report"]["bytes_up"] == (m - mb) * ((n + 3) // 4) + mb * n
+        st.close()

@@ -569,8 +569,10 @@ static int multi_shard_view(tpg_multi* mg, int r, const uint8_t* fbm_bytes, int6
     cols.resize((size_t)(j1 - j0));
     for (int64_t j = j0; j < j1; j++) cols[(size_t)(j - j0)] = colInd1[j] - (int32_t)c0;
   }
-  TPG_TRY(tpg_fbm_from_host(ctx, fbm_bytes + (size_t)c0 * (size_t)nrow, nrow, c1 - c0, &me->f));
-  return tpg_view_create(ctx, me->f, rowInd1, n, colInd1 ? cols.data() : nullptr, j1 - j0, code256, &me->v);
+  // (one code table per call: the share goes up as 2 bits per genotype where table and bytes allow it)
+  const double* table = code256;
+  TPG_TRY(tpg_fbm_from_host_for_table(ctx, fbm_bytes + (size_t)c0 * (size_t)nrow, nrow, c1 - c0, code256, &me->f, &table));
+  return tpg_view_create(ctx, me->f, rowInd1, n, colInd1 ? cols.data() : nullptr, j1 - j0, table, &me->v);
 }
 
 static void multi_shard_free(tpg_multi* mg, std::vector<MultiShard>& st) {
@@ -851,8 +853,9 @@ extern "C" int tpg_multi_pca_partial_svd(tpg_multi* mg, const uint8_t* fbm_bytes
     TpgEnter _enter(ctx);
     tpg_fbm* f = nullptr;
     tpg_view* v = nullptr;
-    int rc = tpg_fbm_from_host(ctx, fbm_bytes, nrow, ncol, &f);
-    if (rc == TPG_OK) rc = tpg_view_create(ctx, f, rowInd1, n, colInd1, m, code256, &v);
+    const double* table = code256;
+    int rc = tpg_fbm_from_host_for_table(ctx, fbm_bytes, nrow, ncol, code256, &f, &table);
+    if (rc == TPG_OK) rc = tpg_view_create(ctx, f, rowInd1, n, colInd1, m, table, &v);
     if (rc == TPG_OK) rc = tpg_pca_partial_svd(ctx, v, k, d, u, vload, center, scale, square_frobenius);
     std::string err = rc == TPG_OK ? "" : tpg_last_error();
     tpg_view_free(v);

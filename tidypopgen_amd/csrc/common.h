@@ -246,6 +246,11 @@ hipError_t tpg_copy_dev(tpg_ctx* ctx, void* d_dst, const void* d_src, size_t byt
 // bulk transfers (waited for): large ones are chunked through pinned slots with a team of copying threads
 hipError_t tpg_upload(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);
 hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes);
+// host FBM bytes that will be read through ONE code table: as 2 bits per genotype where table and bytes allow it (runtime.hip)
+int tpg_fbm_from_host_for_table(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, const double* code256, tpg_fbm** out,
+                                const double** view_table);
+// FBM bytes -> a .bed payload in HBM, packed to 2 bits per genotype on the host through lut16 (runtime.hip); *ok = false: send bytes instead
+hipError_t tpg_upload_bedpacked(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, int64_t nrow, int64_t ncols, const uint8_t* lut16, bool* ok);
 // `height` contiguous device pieces of `width` bytes -> host pieces `dpitch` bytes apart (rows of a column-major host matrix)
 hipError_t tpg_download_rows(tpg_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t width, size_t height);
 // pinned staging buffers (256 MiB each) the process keeps between transfers: at least `buffers` from now on (freeing one

@@ -1845,14 +1845,17 @@ static int upload_block_columns(tpg_ctx* ctx, const uint8_t* fbm_bytes, int64_t 
   cols.resize((size_t)m);
   if (span <= 2 * m + 64) {
     for (int64_t j = 0; j < m; j++) cols[(size_t)j] = colInd1[j] - (lo - 1);
-    return tpg_fbm_from_host(ctx, fbm_bytes + (size_t)(lo - 1) * (size_t)nrow, nrow, span, f);
+    // (the increment_* functions compare raw bytes: one table, so the block goes up as 2 bits per genotype where its bytes allow it)
+    const double* raw = nullptr;
+    return tpg_fbm_from_host_for_table(ctx, fbm_bytes + (size_t)(lo - 1) * (size_t)nrow, nrow, span, nullptr, f, &raw);
   }
   std::vector<uint8_t> stage((size_t)nrow * (size_t)m);
   for (int64_t j = 0; j < m; j++) {
     memcpy(stage.data() + (size_t)j * (size_t)nrow, fbm_bytes + (size_t)(colInd1[j] - 1) * (size_t)nrow, (size_t)nrow);
     cols[(size_t)j] = (int32_t)(j + 1);
   }
-  return tpg_fbm_from_host(ctx, stage.data(), nrow, m, f);  // waited for: the staging buffer may go
+  const double* raw = nullptr;
+  return tpg_fbm_from_host_for_table(ctx, stage.data(), nrow, m, nullptr, f, &raw);  // waited for: the staging buffer may go
 }
 
 static int increment_common(tpg_ctx* ctx, int which, double* A, double* B, const uint8_t* fbm_bytes, int64_t nrow,

@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include "common.h"
+#include "host/host_bedpack.h"
 #include "host/host_nibpack.h"
 
 #include <mutex>
@@ -773,6 +774,79 @@ static hipError_t tpg_upload_packed(tpg_ctx* ctx, uint8_t* dst, const uint8_t* s
   return e;
 }
 
+// FBM bytes (nrow x ncols, column-major) -> a .bed payload in HBM (ceil(nrow / 4) bytes per column), packed to 2 bits per
+// genotype on the host by the upload team (host_bedpack.h) through lut16 (byte < 16 -> .bed code): for a streamed run that
+// needs ONE code table (stream.hip) a quarter of the store's bytes cross PCIe.  Same pipeline as tpg_upload_packed: the team
+// packs chunk c + 1 into one half of the pinned buffer while chunk c leaves the other.  *ok = false (nothing usable in dst)
+// when there is no pinned staging to be had or a byte >= 16 turned up: the caller sends the block as bytes.
+hipError_t tpg_upload_bedpacked(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, int64_t nrow, int64_t ncols, const uint8_t* lut16, bool* ok) {
+  *ok = false;
+  const size_t bpl = (size_t)((nrow + 3) / 4), half = NIB_CHUNK / 2;
+  if ((size_t)nrow * (size_t)ncols < XFER_BIG) {
+    // a small block (a tight budget, a short panel): packed into ordinary memory, one copy -- pinning the 256-MiB staging
+    // buffer for it would cost more than the whole transfer
+    std::vector<uint8_t> tmp(bpl * (size_t)ncols + 32);
+    uint8_t seen = 0;
+    if (nrow % 4 == 0) seen = tpg_bedpack(src, tmp.data(), (size_t)nrow * (size_t)ncols, lut16);
+    else for (int64_t c = 0; c < ncols; c++) seen |= tpg_bedpack(src + (size_t)c * (size_t)nrow, tmp.data() + (size_t)c * bpl, (size_t)nrow, lut16);
+    if (seen >= 16) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(dst, tmp.data(), bpl * (size_t)ncols, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    *ok = e == hipSuccess;
+    return e;
+  }
+  uint8_t* const pinned = nib_stage_acquire();
+  if (!pinned) return hipSuccess;
+  struct Back { uint8_t* p; ~Back() { nib_stage_release(p); } } back{pinned};
+  if (bpl > half) return hipSuccess;
+  const int64_t cpc = std::max<int64_t>(1, (int64_t)(half / bpl));  // columns per chunk
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+  bool used[2] = {false, false};
+  bool clean = true;
+  int k = 0;
+  for (int64_t c0 = 0; c0 < ncols && e == hipSuccess && clean; c0 += cpc, k ^= 1) {
+    const int64_t c1 = std::min(ncols, c0 + cpc), nc = c1 - c0;
+    uint8_t* pin = pinned + (size_t)k * half;
+    if (used[k]) e = hipEventSynchronize(ev[k]);  // the copy that last read this half of the pinned buffer is done
+    if (e != hipSuccess) break;
+    const uint8_t* in = src + (size_t)c0 * (size_t)nrow;
+    const size_t nbytes = (size_t)nc * (size_t)nrow;
+    const int nth = (int)std::min<size_t>(XFER_THREADS, std::max<size_t>(1, nbytes >> 20));
+    std::vector<uint8_t> seen((size_t)nth, 0);
+    auto work = [&](int t) {
+      if (nrow % 4 == 0) {  // the run of columns is contiguous in both layouts: stripes on 128-byte boundaries
+        const size_t units = nbytes / 128, lo = units * (size_t)t / (size_t)nth * 128, hi = t + 1 == nth ? nbytes : units * ((size_t)t + 1) / (size_t)nth * 128;
+        seen[(size_t)t] = tpg_bedpack(in + lo, pin + lo / 4, hi - lo, lut16);
+      } else {
+        uint8_t s = 0;
+        for (int64_t c = nc * t / nth; c < nc * (t + 1) / nth; c++) s |= tpg_bedpack(in + (size_t)c * (size_t)nrow, pin + (size_t)c * bpl, (size_t)nrow, lut16);
+        seen[(size_t)t] = s;
+      }
+    };
+    if (nth == 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nth; t++) th.emplace_back(work, t);
+      for (auto& t : th) t.join();
+    }
+    for (uint8_t x : seen)
+      if (x >= 16) clean = false;
+    if (!clean) break;
+    e = hipMemcpyAsync(dst + (size_t)c0 * bpl, pin, (size_t)nc * bpl, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev[k], ctx->stream);
+    used[k] = true;
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  else (void)hipStreamSynchronize(ctx->stream);
+  for (int q = 0; q < 2; q++)
+    if (ev[q]) (void)hipEventDestroy(ev[q]);
+  *ok = e == hipSuccess && clean;
+  return e;
+}
+
 // The same pipeline WITHOUT the packing, for bytes that are already dense (a PLINK .bed payload: 2 bits per genotype): the
 // team copies chunk c + 1 of the source (a file mapping: 39 - 46 GB/s when the DMA reads it directly, page faults included)
 // into one half of the pinned buffer while chunk c leaves the other half at the rate of pinned memory (55 - 57 GB/s).
@@ -831,6 +905,65 @@ extern "C" int tpg_fbm_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nro
   if (e != hipSuccess) { tpg_fbm_free(f); tpg_set_error("FBM upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
   *out = f;
   return TPG_OK;
+}
+
+// Host FBM bytes that will be read through ONE code table (code256; NULL = raw bytes): when every entry of the table below 16
+// is a code and no byte >= 16 turns up, they go up as 2 bits per genotype (host_bedpack.h: a quarter of the bytes over PCIe,
+// half of the nibble pack's) into a store in the layout of a .bed payload, and *view_table is the table to make the views
+// through (raw where the caller's was raw -- a lone pairwise view then gets its FP4 layout from the pack --, else 0 / 1 / 2 /
+// NA); otherwise the byte store of tpg_fbm_from_host and *view_table = code256.  TPG_UPLOAD_BEDPACK=0: always bytes (A/B).
+static void make_lut(const double* code256, uint8_t* lut);
+int tpg_fbm_from_host_for_table(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, const double* code256, tpg_fbm** out,
+                                const double** view_table) {
+  *view_table = code256;
+  const char* sw = getenv("TPG_UPLOAD_BEDPACK");
+  uint8_t lut[256], l16[16];
+  make_lut(code256, lut);
+  static const uint8_t bedcode[4] = {3, 2, 0, 1};  // code 0, 1, 2, missing -> .bed 11, 10, 00, 01 = bigsnpr's bytes 0, 1, 2, 3
+  bool can = !(sw && atoi(sw) == 0) && nrow > 0 && ncol > 0 && (size_t)nrow * (size_t)ncol >= (64u << 10);
+  for (int b = 0; b < 16 && can; b++) {
+    if (lut[b] > 3) can = false;
+    else l16[b] = bedcode[lut[b]];
+  }
+  if (can) {
+    TPG_HIP(hipSetDevice(ctx->device));
+    tpg_fbm* f = new tpg_fbm{ctx, nullptr, nrow, ncol};
+    f->bed_bpl = (nrow + 3) / 4;
+    const size_t sz = (size_t)f->bed_bpl * (size_t)ncol;
+    f->pooled = true;
+    hipError_t e = tpg_pmalloc((void**)&f->d_bytes, sz);
+    if (e != hipSuccess) { (void)hipGetLastError(); delete f; return tpg_fbm_from_host(ctx, bytes, nrow, ncol, out); }
+    bool ok = false;
+    {
+      ProfScope ps(ctx, "upload_bedpacked");
+      e = tpg_upload_bedpacked(ctx, f->d_bytes, bytes, nrow, ncol, l16, &ok);
+    }
+    if (e != hipSuccess) { tpg_fbm_free(f); tpg_set_error("FBM upload failed: %s", hipGetErrorString(e)); return TPG_EHIP; }
+    if (ok) {
+      static double code012[256];
+      static const bool init = [] { for (int b = 0; b < 256; b++) code012[b] = b < 3 ? (double)b : __builtin_nan(""); return true; }();
+      (void)init;
+      *view_table = code256 ? code012 : nullptr;
+      *out = f;
+      return TPG_OK;
+    }
+    tpg_fbm_free(f);  // a byte >= 16 somewhere: as bytes
+  }
+  return tpg_fbm_from_host(ctx, bytes, nrow, ncol, out);
+}
+
+// a view straight from host bytes: upload (for this one table: tpg_fbm_from_host_for_table), pack, release the store
+extern "C" int tpg_view_create_from_host(tpg_ctx* ctx, const uint8_t* bytes, int64_t nrow, int64_t ncol, const int32_t* rowInd1, int64_t n,
+                                         const int32_t* colInd1, int64_t m, const double* code256, tpg_view** out) {
+  TpgEnter _enter(ctx);
+  TPG_REQUIRE(ctx && bytes && out, TPG_EINVAL, "null argument");
+  TPG_REQUIRE(nrow > 0 && ncol > 0, TPG_EINVAL, "empty FBM (%lld x %lld)", (long long)nrow, (long long)ncol);
+  tpg_fbm* f = nullptr;
+  const double* table = code256;
+  TPG_TRY(tpg_fbm_from_host_for_table(ctx, bytes, nrow, ncol, code256, &f, &table));
+  const int rc = tpg_view_create(ctx, f, rowInd1, n, colInd1, m, table, out);
+  tpg_fbm_free(f);  // stream-ordered: the pack kernel has run (a view creation ends with a host round trip)
+  return rc;
 }
 
 // An FBM whose bytes arrive block of columns by block of columns (the reference's own block loop, R/snp_ibs.R:59-82):

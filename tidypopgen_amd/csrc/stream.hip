@@ -150,6 +150,13 @@ struct StreamRun {
 
   // block buffers of the store
   uint8_t* d_blk[2] = {nullptr, nullptr};
+  // A byte store whose blocks are wanted through ONE code table goes up as 2 bits per genotype, packed on the host into the
+  // layout of a .bed payload (host_bedpack.h: a quarter of the bytes over PCIe, half of the nibble pack's), and the device
+  // packs its views with the .bed front end.  bedpack_lut: byte < 16 -> .bed code (valid = false: not this table); a block in
+  // which a byte >= 16 turns up goes as bytes (blk_bed[slot] tells the main thread which it got).
+  uint8_t bedpack_lut[16] = {};
+  bool bedpack = false;
+  bool blk_bed[2] = {false, false};
   // uploader <-> main
   std::deque<int64_t> ready_q;     // blocks uploaded, in order
   int64_t released[2] = {-1, -1};  // slot k may be overwritten for block b when released[k] >= b - 2
@@ -296,6 +303,37 @@ struct StreamRun {
     return TPG_OK;
   }
 
+  // the 2-bit host pack serves a byte store and ONE table whose every entry below 16 is a code (TPG_STREAM_BEDPACK=0: off)
+  void set_bedpack(const double* table) {
+    bedpack = false;
+    const char* e = getenv("TPG_STREAM_BEDPACK");  // (read per run: the tests switch it)
+    if ((e && atoi(e) == 0) || src->kind != SRC_BYTES) return;
+    uint8_t l[256];
+    lut_of(table, l);
+    static const uint8_t bedcode[4] = {3, 2, 0, 1};  // code 0, 1, 2, missing -> .bed 11, 10, 00, 01 (the bytes 0, 1, 2, 3 of bigsnpr's reading)
+    for (int b = 0; b < 16; b++) {
+      if (l[b] > 3) return;
+      bedpack_lut[b] = bedcode[l[b]];
+    }
+    bedpack = true;
+  }
+  // the table a view of a block is made through: the job's for a block that arrived as bytes; for one that arrived packed the
+  // codes are already those of the job's table, read back as bytes 0, 1, 2, 3 = NA (raw semantics where the job's were raw, so
+  // that a lone pairwise view is packed with its FP4 layout)
+  const double* block_table(int slot, const double* job_table) const {
+    static const double* code012 = [] {
+      static double t[256];
+      for (int b = 0; b < 256; b++) t[b] = b < 3 ? (double)b : __builtin_nan("");
+      return (const double*)t;
+    }();
+    return blk_bed[slot] ? (job_table ? code012 : nullptr) : job_table;
+  }
+  tpg_fbm block_fbm(int slot, int64_t mb) const {
+    tpg_fbm f{ctx, d_blk[slot], src->nrow, mb};
+    f.bed_bpl = src->kind == SRC_BED ? src->bpl : blk_bed[slot] ? (src->nrow + 3) / 4 : 0;
+    return f;
+  }
+
   void block_range(int64_t b, int64_t* q0, int64_t* q1) const {
     *q0 = P0 + b * B;
     *q1 = std::min(P1, *q0 + B);
@@ -315,7 +353,17 @@ struct StreamRun {
       TPG_HIP(hipStreamSynchronize(up_ctx->stream));
       return TPG_OK;
     }
+    blk_bed[slot] = false;
     const uint8_t* host = nullptr;
+    if (bedpack && contiguous[(size_t)b]) {
+      bool ok = false;
+      TPG_HIP(tpg_upload_bedpacked(up_ctx, d_blk[slot], src->bytes + (size_t)first_col(q0) * unit, src->nrow, nb, bedpack_lut, &ok));
+      if (ok) {
+        blk_bed[slot] = true;
+        bytes_up += (size_t)nb * (size_t)((src->nrow + 3) / 4);
+        return TPG_OK;
+      }
+    }
     if (contiguous[(size_t)b]) {
       host = src->bytes + (size_t)first_col(q0) * unit;
     } else {  // scattered columns: gathered on the host first (a column / a SNP is one contiguous piece of the store)
@@ -474,10 +522,10 @@ struct StreamRun {
   }
 
   // ------------------------------------------------------------------ the views of a block
-  int make_views(const tpg_fbm* f, tpg_view** v /* [3] */) {
+  int make_views(const tpg_fbm* f, int slot, tpg_view** v /* [3] */) {
     const tpg_stream_job* j = job;
     v[0] = v[1] = v[2] = nullptr;
-    if (ntab == 1) return tpg_view_create(ctx, f, j->rowInd1, n, nullptr, 0, tab[0], &v[0]);
+    if (ntab == 1) return tpg_view_create(ctx, f, j->rowInd1, n, nullptr, 0, block_table(slot, tab[0]), &v[0]);
     // (two tables: one read of the block's bytes; three: the odd one out on its own)
     const int a = 0, b = ntab == 2 ? 1 : (view_of_pca >= 0 ? view_of_pca : 2);
     TPG_TRY(tpg_view_create_pair(ctx, f, j->rowInd1, n, nullptr, 0, tab[a], tab[b], &v[a], &v[b]));
@@ -548,6 +596,7 @@ struct StreamRun {
       }
     }
     if (nblocks == 0) return TPG_OK;
+    if (ntab == 1) set_bedpack(tab[0]);
     TPG_TRY(start_uploader());
     std::vector<double> tot_scratch((size_t)(P > 0 ? P : 1));
     for (int64_t b = 0; b < nblocks; b++) {
@@ -558,14 +607,13 @@ struct StreamRun {
       stamp("wait for block", b);
       TPG_TRY(wait_block(b));
       stamp("got block", b);
-      tpg_fbm f{ctx, d_blk[slot], src->nrow, mb};
-      f.bed_bpl = src->kind == SRC_BED ? src->bpl : 0;
+      const tpg_fbm f = block_fbm(slot, mb);
       tpg_view* v[3];
       struct Views {
         tpg_view** v;
         ~Views() { for (int t = 0; t < 3; t++) tpg_view_free(v[t]); }
       } views{v};
-      TPG_TRY(make_views(&f, v));
+      TPG_TRY(make_views(&f, slot, v));
       // (a view creation ends with a host round trip behind its pack kernel: the block buffer has been read)
       release_block(b);
       stamp("packed", b);
@@ -744,6 +792,7 @@ struct StreamRun {
       return TPG_OK;
     }
     sweeps = 2;
+    set_bedpack(code_pca);  // one table now, whatever the first sweep needed
     TPG_TRY(start_uploader());
     for (int64_t b = 0; b < nblocks; b++) {
       int64_t q0, q1;
@@ -751,10 +800,9 @@ struct StreamRun {
       const int64_t mb = q1 - q0;
       const int slot = (int)(b & 1);
       TPG_TRY(wait_block(b));
-      tpg_fbm f{ctx, d_blk[slot], src->nrow, mb};
-      f.bed_bpl = src->kind == SRC_BED ? src->bpl : 0;
+      const tpg_fbm f = block_fbm(slot, mb);
       tpg_view* vp = nullptr;
-      TPG_TRY(tpg_view_create(ctx, &f, j->rowInd1, n, nullptr, 0, code_pca, &vp));
+      TPG_TRY(tpg_view_create(ctx, &f, j->rowInd1, n, nullptr, 0, block_table(slot, code_pca), &vp));
       release_block(b);
       OutSlot& o = out[slot];
       int rc = wait_slot(slot);
