@@ -43,6 +43,8 @@ def multi_against_oracle(ndev, devices=None, setenv=None):
     as_ = orc.snp_allele_sharing(fbm)
     assert np.array_equal(out["allele_sharing"], as_, equal_nan=True)
     assert np.allclose(out["grm"], orc.pairwise_grm(as_), rtol=1e-12, atol=1e-14)
+    ibs_alone = mg.pairwise(fbm, which=("ibs",))  # V and D + H in one sum (TPG_PW_DH) on every device: the "lacks a product" words of the reduction carry it
+    assert np.array_equal(ibs_alone["ibs"], out["ibs"], equal_nan=True)
     only = mg.pairwise(fbm, which=("king", "grm"))  # the {V, D, A} kernel on every device, one reduce-scatter
     assert np.array_equal(only["king"], out["king"], equal_nan=True) and np.array_equal(only["grm"], out["grm"], equal_nan=True)
     assert np.array_equal(mg.loci_alt_freq(fbm, None, None, gid, G),
