@@ -389,3 +389,35 @@ def test_stream_one_table_goes_up_as_two_bits(tpg, monkeypatch, bedpack):
             mb = min(m, (1000 // B + 1) * B) - 1000 // B * B
             assert s["report"]["bytes_up"] == (m - mb) * ((n + 3) // 4) + mb * n
         st.close()
+
+
+def test_stream_api_from_c(tpg, tmp_path):
+    """include/tpg.h's streamed entry points from plain C (tests/host/stream_example.c: gcc, the header, libtpg_hip.so -- no Python
+    in the call path): the struct layouts and the calling sequence of INTEGRATION.md 3a, results equal to the Python mirror's"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "stream_example")
+    libdir = os.path.join(root, "tidypopgen_amd")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "host", "stream_example.c"), "-o", exe, "-L", libdir, "-ltpg_hip",
+                           f"-Wl,-rpath,{libdir}"])
+    n, m, Gc, k = 150, 2600, 4, 3
+    fbm = orc.synth_fbm(71, n, m, npop=Gc, miss=0.03, imputed_bytes=True)
+    bk = tmp_path / "c.bk"
+    fbm.T.tofile(bk)
+    budget = 400 << 10
+    r = subprocess.run([exe, str(bk), str(n), str(m), str(budget), str(Gc), str(k)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "C_OK" in r.stdout, (r.stdout, r.stderr)
+    got = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln and ln != "C_OK"}
+    gid = (np.arange(n) % Gc).astype(np.int32)
+    s = tpg.Stream.open_bk(str(bk), n, m, budget_bytes=budget).run(pairwise=("ibs",), code256=None, groupIds=gid, ngroups=Gc,
+                                                                    grouped_alt_freq=True, fst=("Hudson",), k=k)
+    assert int(got["blocks"][0]) == s["report"]["blocks"] > 1 and int(got["blocks"][2]) == s["report"]["sweeps"]
+    assert float(got["ibs_sum"][0]) == pytest.approx(np.nansum(s["ibs"]), rel=1e-14)
+    assert float(got["gaf_sum"][0]) == pytest.approx(np.nansum(s["grouped_alt_freq"]), rel=1e-14)
+    assert float(got["fst_sum"][0]) == pytest.approx(np.nansum(s["fst_tot"]["Hudson"]), rel=1e-12)
+    assert np.allclose([float(x) for x in got["d"]], s["d"], rtol=1e-12)
+    assert float(got["fro"][0]) == pytest.approx(s["square_frobenius"], rel=1e-14)
+    assert float(got["center_sum"][0]) == pytest.approx(s["center"].sum(), rel=1e-14)
