@@ -295,6 +295,49 @@ def test_stream_twenty_gigabytes_in_under_six(tpg):
     assert np.array_equal(s["center"], p["center"])
 
 
+def test_stream_many_individuals(tpg):
+    """20 000 individuals x 4 096 loci under a 48-MiB budget: every N x N output is 3.2 GB (past 2^31 bytes: the sizes
+    and offsets of the slab reads, the epilogues and the downloads), the PCA takes the Gram route at N = 20 000.
+    Against the resident entry points on the same panel, one output at a time (each is 3.2 GB on the host)."""
+    n, m, k, G51 = 20_000, 4096, 4, 51
+    X = tpg.FBM.synth(5, n, m, npop=G51, miss=0.03, imputed_bytes=True)
+    fbm = X.to_numpy()
+    gid = (np.arange(n) % G51).astype(np.int32)
+    st = tpg.Stream.from_numpy(fbm, budget_bytes=48 << 20)
+    s = st.run(pairwise=("ibs", "king", "grm"), groupIds=gid, ngroups=G51, grouped_alt_freq=True, fst=("Hudson",), k=k)
+    rep = s["report"]
+    assert rep["blocks"] >= 3 and rep["planned_bytes"] <= 48 << 20, rep
+    st.close()
+    for name, fn in (("ibs", tpg.snp_ibs), ("king", tpg.snp_king)):
+        r = fn(X)
+        assert np.array_equal(s[name], r, equal_nan=True), name
+        del r
+        s.pop(name)
+    pw = tpg.Pairwise(X.ctx, n)
+    pw.accumulate(tpg.View(X, code256=None), products=tpg.PW_FOR_AS)  # GRM wants V and D
+    r = pw.epilogues(("grm",), m=m)["grm"]
+    assert np.allclose(s["grm"], r, rtol=1e-13, atol=1e-14)
+    del r, pw
+    s.pop("grm")
+    v012 = tpg.View(X, code256=tpg.CODE_012)
+    assert np.array_equal(s["grouped_alt_freq"], tpg.grouped_alt_freq_dip_pseudo_cpp(v012, gid, G51, None, False), equal_nan=True)
+    tot = tpg.pairwise_pop_fst(X, None, None, gid, G51, method="Hudson")["fst_tot"]
+    assert np.allclose(s["fst_tot"]["Hudson"], tot, rtol=1e-12, atol=0)
+    # a panel this short takes the digit-split Gram kernel on both routes: the resident call at its documented 1e-7, the
+    # budgeted blocks with eight bits more -- held to FP64 through the SMALL side (eigenvalues of Z'Z, 4 096 x 4 096)
+    p = tpg.gt_pca_partialSVD(X, None, None, k=k)
+    assert np.array_equal(s["center"], p["center"]) and np.array_equal(s["scale"], p["scale"])
+    assert np.allclose(s["d"], p["d"], rtol=1e-7, atol=0)
+    assert np.abs(_aligned(p["u"], s["u"]) - p["u"]).max() <= 1e-6
+    Z = (np.asarray(tpg.CODE_IMPUTE_PRED)[fbm] - s["center"]) / s["scale"]
+    w, W = np.linalg.eigh(Z.T @ Z)
+    d64, v64 = np.sqrt(w[::-1][:k]), W[:, ::-1][:, :k]
+    assert np.allclose(s["d"], d64, rtol=1e-10, atol=0), s["d"] / d64 - 1
+    assert np.abs(_aligned(v64, s["v"]) - v64).max() <= 1e-8
+    u64 = Z @ v64 / d64
+    assert np.abs(_aligned(u64, s["u"]) - u64).max() <= 1e-8
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_stream_fuzz(tpg, seed):
     """random shapes around the tile / block edges (m below one block, one locus past a block, n = 1 ... 300), random budgets,
