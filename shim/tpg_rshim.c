@@ -49,6 +49,10 @@ static int deferred(void) {
 static tpg_ctx* ctx(void) {
   if (!g_ctx) {
     const char* dev = getenv("TPG_DEVICE");
+    /* TPG_RSHIM_NUMA_BIND=1 (opt-in: it changes the CPU affinity of the R session's thread, as starting R under
+       `numactl --cpunodebind` would): stay on the host NUMA node of the GPU -- INTEGRATION.md 3b */
+    const char* nb = getenv("TPG_RSHIM_NUMA_BIND");
+    if (nb && nb[0] == '1') (void)tpg_host_bind_near_device(dev ? atoi(dev) : 0, NULL);
     if (tpg_ctx_create(dev ? atoi(dev) : 0, &g_ctx) != TPG_OK) Rf_error("tidypopgen (GPU): %s", tpg_last_error());
     if (deferred() && tpg_increment_defer(g_ctx, 1) != TPG_OK) Rf_error("tidypopgen (GPU): %s", tpg_last_error());
   }

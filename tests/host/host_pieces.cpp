@@ -1,7 +1,7 @@
 // tests/host/host_pieces.cpp -- self-checking driver for the host-only pieces of libtpg_hip.so (tidypopgen_amd/csrc/host/*.h),
 // built WITHOUT HIP by tests/test_host_sanitizers.py with -fsanitize=address,undefined and (the transport) -fsanitize=thread:
 // the CPU-side equivalent of the reference's valgrind job (.github/workflows/R-CMD-check-valgrind.yaml:50-51).
-//   host_pieces eig | bands | relfilter | nibpack | bedpack | fsttiles | bits2 | inproc [threads] | inproc_mismatch
+//   host_pieces eig | bands | relfilter | nibpack | bedpack | addcounts | fsttiles | bits2 | inproc [threads] | inproc_mismatch
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,6 +16,7 @@
 #include "host/host_eig.h"
 #include "host/host_fsttiles.h"
 #include "host/host_inproc.h"
+#include "host/host_addcounts.h"
 #include "host/host_bedpack.h"
 #include "host/host_nibpack.h"
 #include "host/host_relfilter.h"
@@ -324,6 +325,32 @@ static int test_bedpack() {
   return 0;
 }
 
+// K += counts (the literal increment_* mirrors): lengths and alignments around the vector step, the bias of a signed 16-bit
+// count, large sums (exact: integers below 2^53), nothing written past the end
+static int test_addcounts() {
+  for (size_t n : {0, 1, 7, 8, 15, 16, 17, 31, 33, 4096, 4099, 100001}) {
+    for (int shift = 0; shift < 3; shift++) {
+      for (int bias : {0, 32768}) {
+        std::vector<double> dst(n + 8), want(n + 8);
+        std::vector<uint16_t> q(n + 8);
+        std::vector<int32_t> w(n + 8);
+        for (size_t i = 0; i < n + 8; i++) {
+          dst[i] = want[i] = (double)(int64_t)(urand() * 9.0e15) - 4.5e15;
+          q[i] = (uint16_t)(urand() * 65536);
+          w[i] = (int32_t)((urand() - 0.5) * 4.0e9);
+        }
+        for (size_t i = 0; i < n; i++) want[shift + i] += (double)((int)q[shift + i] - bias);
+        tpg_add_counts_u16(dst.data() + shift, q.data() + shift, n, bias);
+        for (size_t i = 0; i < n + 8; i++) CHECK(dst[i] == want[i], "u16, bias %d: element %zu of %zu (shift %d)", bias, i, n, shift);
+        for (size_t i = 0; i < n; i++) want[shift + i] += (double)w[shift + i];
+        tpg_add_counts_i32(dst.data() + shift, w.data() + shift, n);
+        for (size_t i = 0; i < n + 8; i++) CHECK(dst[i] == want[i], "i32: element %zu of %zu (shift %d)", i, n, shift);
+      }
+    }
+  }
+  return 0;
+}
+
 // the pair list of pairwise_pop_fst cut into tiles of populations: every listed pair in exactly one slot of the right tile,
 // whatever the order, the orientation and the repeats of the list
 static int test_fsttiles() {
@@ -391,9 +418,10 @@ int main(int argc, char** argv) {
   else if (what == "inproc_mismatch") rc = test_inproc_mismatch();
   else if (what == "nibpack") rc = test_nibpack();
   else if (what == "bedpack") rc = test_bedpack();
+  else if (what == "addcounts") rc = test_addcounts();
   else if (what == "fsttiles") rc = test_fsttiles();
   else if (what == "bits2") rc = test_bits2();
-  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | nibpack | bedpack | fsttiles | bits2 | inproc [threads] | inproc_mismatch\n");
+  else fprintf(stderr, "usage: host_pieces eig | bands | relfilter | nibpack | bedpack | addcounts | fsttiles | bits2 | inproc [threads] | inproc_mismatch\n");
   if (rc == 0) printf("ok %s\n", what.c_str());
   return rc;
 }

@@ -23,6 +23,7 @@ int64_t g_stub_bytes_uploaded = 0;
 
 const char* tpg_last_error(void) { return g_err; }
 int tpg_device_count(int* count) { *count = 1; return TPG_OK; }
+int tpg_host_bind_near_device(int device, int* node) { (void)device; if (node) *node = -1; return TPG_OK; }
 int tpg_ctx_create(int device, tpg_ctx** out) { *out = (tpg_ctx*)calloc(1, sizeof(tpg_ctx)); (*out)->device = device; return TPG_OK; }
 void tpg_ctx_destroy(tpg_ctx* ctx) { free(ctx); }
 

@@ -51,7 +51,7 @@ def pieces(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("what", ["eig", "bands", "relfilter", "nibpack", "bedpack", "fsttiles", "bits2", "inproc", "inproc_mismatch"])
+@pytest.mark.parametrize("what", ["eig", "bands", "relfilter", "nibpack", "bedpack", "addcounts", "fsttiles", "bits2", "inproc", "inproc_mismatch"])
 def test_host_pieces_under_address_and_undefined_sanitizers(pieces, what):
     r = _sh([pieces["asan"], what], env=ENV)
     assert r.stdout.strip() == f"ok {what}"

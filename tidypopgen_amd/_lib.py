@@ -77,7 +77,7 @@ for _name in ("tpg_ctx_destroy", "tpg_fbm_free", "tpg_view_free", "tpg_pairwise_
 
 # every symbol include/tpg.h declares (checked by tests/test_abi.py against the header)
 SYMBOLS = [
-    "tpg_last_error", "tpg_version", "tpg_device_count", "tpg_ctx_create", "tpg_ctx_destroy", "tpg_ctx_set_stream", "tpg_ctx_sync",
+    "tpg_last_error", "tpg_version", "tpg_device_count", "tpg_host_bind_near_device", "tpg_ctx_create", "tpg_ctx_destroy", "tpg_ctx_set_stream", "tpg_ctx_sync",
     "tpg_prof_enable", "tpg_prof_reset", "tpg_prof_only", "tpg_prof_get", "tpg_prof_dump", "tpg_dev_alloc", "tpg_dev_free",
     "tpg_dev_to_host", "tpg_dev_from_host", "tpg_sym_eig_topk", "tpg_pca_loadings", "tpg_pairwise_pop_fst_sums", "tpg_fbm_from_host", "tpg_fbm_open_bk",
     "tpg_fbm_synth", "tpg_fbm_alloc", "tpg_fbm_upload_cols", "tpg_pca_gram_add", "tpg_fbm_open_bed", "tpg_fbm_from_bed_host", "tpg_fbm_alloc_bed", "tpg_fbm_upload_bed_snps", "tpg_fbm_to_host", "tpg_fbm_free", "tpg_view_create", "tpg_view_create_pair", "tpg_view_create_from_host", "tpg_view_free", "tpg_view_n",

@@ -130,6 +130,15 @@ def device_count() -> int:
     return c.value
 
 
+def bind_host_near_device(device: int = 0) -> int:
+    """Keep this thread, and the threads started from it afterwards, on the host NUMA node of GPU `device`
+    (tpg_host_bind_near_device: what `numactl --cpunodebind` does for a one-process-per-GPU launcher).  Returns the node,
+    or -1 when nothing was done (one node, node unknown, too few of this process's CPUs on it)."""
+    node = C.c_int(-1)
+    check(lib.tpg_host_bind_near_device(C.c_int(device), C.byref(node)))
+    return node.value
+
+
 def default_context() -> Context:
     global _default_ctx
     if _default_ctx is None:

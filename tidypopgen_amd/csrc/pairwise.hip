@@ -1616,6 +1616,7 @@ extern "C" int tpg_block_means(tpg_ctx* ctx, const double* A, int64_t n, const i
 // grand total are kept up to date in long double, and a comparison whose two means are closer than 1e-12 relative is
 // recomputed literally -- R's two-pass long-double mean() over the same entries in the same order -- so the decisions
 // are R's.
+#include "host/host_addcounts.h"  // tpg_add_counts_u16, tpg_add_counts_i32
 #include "host/host_relfilter.h"  // r_mean_ld, tpg_host_filter_high_relatedness
 
 extern "C" int tpg_filter_high_relatedness(tpg_ctx* ctx, const double* matrix, int64_t n, double kings_threshold,
@@ -1662,6 +1663,7 @@ struct Resident {
   tpg_pairwise* spare = nullptr;  // the accumulators of the last immediate call, reused while n stays the same
   int32_t* stage = nullptr;       // pinned host staging of the two int32 count matrices (add_counts_to_caller)
   size_t stage_ints = 0;
+  const double *last_A = nullptr, *last_B = nullptr;  // the matrices of the previous immediate call (never dereferenced)
 };
 
 static Resident* resident_of(tpg_ctx* ctx) {
@@ -1730,9 +1732,18 @@ __global__ __launch_bounds__(256) void tpg_pairwise_counts2_i32_kernel(const int
 // unmodified R driver pays PER BLOCK (38 times at 5 000 x 1 000 000), so it is built for that: the two matrices leave the
 // device as int32 (2 x 100 MB instead of 2 x 200 MB) into pinned staging buffers the context keeps between calls (no
 // 400 MB of fresh pages per block), and a team of threads adds the first to K while the second is still on its way.
+// TPG_INCREMENT_TRACE=1: one line per call of an increment_* mirror with the milliseconds of its phases (stderr)
+static bool increment_trace() {
+  const char* e = getenv("TPG_INCREMENT_TRACE");
+  return e && atoi(e) != 0;
+}
+static double inc_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e3; }
+
 static int add_counts_to_caller(tpg_ctx* ctx, int which, const tpg_pairwise* pw, double* A, double* B) {
   const size_t nn = (size_t)pw->n * (size_t)pw->n;
   Resident* r = resident_of(ctx);
+  const bool trace = increment_trace();
+  double tr[6] = {inc_now(), 0, 0, 0, 0, 0};
   // every int32 entry is bounded by 2 x loci + quirk
   const bool fits = 2 * pw->loci + pw->as_pad_quirk < (1ll << 31) && pw->nranks == 1;
   const int NT = nn >= (1u << 20) ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
@@ -1770,9 +1781,8 @@ static int add_counts_to_caller(tpg_ctx* ctx, int which, const tpg_pairwise* pw,
   uint8_t* d_out = nullptr;
   TPG_HIP(tpg_pmalloc((void**)&d_out, bytesA + bytesB));
   const unsigned nt = (unsigned)ceil_div(pw->n, 32);
-  hipEvent_t evA = nullptr;
-  hipError_t e = hipEventCreateWithFlags(&evA, hipEventDisableTiming);
-  if (e == hipSuccess) {
+  hipError_t e = hipSuccess;
+  {
     ProfScope ps(ctx, "pairwise_counts_i32");
     const dim3 grid(nt, nt);
 #define CNT2(TA_, TB_)                                                                                                        \
@@ -1787,45 +1797,83 @@ static int add_counts_to_caller(tpg_ctx* ctx, int which, const tpg_pairwise* pw,
     e = hipGetLastError();
   }
   uint8_t* stage = (uint8_t*)r->stage;
-  if (e == hipSuccess) e = hipMemcpyAsync(stage, d_out, bytesA, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipEventRecord(evA, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(stage + bytesA, d_out + bytesA, bytesB, hipMemcpyDeviceToHost, ctx->stream);
+  // Each matrix leaves the device in PIECES (an event behind each), and the team adds a piece as soon as it is in the staging
+  // buffer: the additions run beside the transfer instead of a whole matrix behind it.  Piece p < NP: of the first matrix,
+  // p >= NP: of the second; boundaries on multiples of 16 elements (the vector step of host_addcounts.h).
+  constexpr int NP = 4;
+  const int npieces = nn >= (1u << 20) ? NP : 1;
+  auto piece_lo = [&](int q) { return q >= npieces ? nn : (nn * (size_t)q / (size_t)npieces) & ~(size_t)15; };
+  hipEvent_t ev[2 * NP] = {};
+  for (int q = 0; q < 2 * npieces && e == hipSuccess; q++) e = hipEventCreateWithFlags(&ev[q], hipEventDisableTiming);
+  for (int q = 0; q < 2 * npieces && e == hipSuccess; q++) {
+    const bool second = q >= npieces;
+    const size_t es = (second ? b16 : a16) ? 2 : 4, lo = piece_lo(q % npieces), hi = piece_lo(q % npieces + 1);
+    const size_t off = (second ? bytesA : 0) + lo * es;
+    e = hipMemcpyAsync(stage + off, d_out + off, (hi - lo) * es, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev[q], ctx->stream);
+  }
   tpg_pfree(d_out);  // stream-ordered
-  auto add = [&](int t, double* dst, const uint8_t* src, bool is16, int bias) {
-    const size_t k0 = nn * (size_t)t / (size_t)NT, k1 = nn * (size_t)(t + 1) / (size_t)NT;
-    if (is16) {
-      const uint16_t* q = (const uint16_t*)src;
-      for (size_t k = k0; k < k1; k++) dst[k] += (double)((int)q[k] - bias);
-    } else {
-      const int32_t* q = (const int32_t*)src;
-      for (size_t k = k0; k < k1; k++) dst[k] += (double)q[k];
-    }
+  auto add = [&](int t, int q) {  // thread t's stripe of piece q
+    const bool second = q >= npieces;
+    const size_t lo = piece_lo(q % npieces), hi = piece_lo(q % npieces + 1);
+    const size_t k0 = lo + (hi - lo) * (size_t)t / (size_t)NT, k1 = lo + (hi - lo) * (size_t)(t + 1) / (size_t)NT;
+    double* dst = second ? B : A;
+    const uint8_t* src = stage + (second ? bytesA : 0);
+    if (second ? b16 : a16) tpg_add_counts_u16(dst + k0, (const uint16_t*)src + k0, k1 - k0, second ? 0 : biasA);
+    else tpg_add_counts_i32(dst + k0, (const int32_t*)src + k0, k1 - k0);
   };
-  // ONE team for both matrices (starting sixteen threads is ~0.8 ms, and this runs once per block of the R loop): a thread
-  // adds its stripe of the first matrix when that has arrived, of the second when the stream is drained; thread 0 does the
-  // waiting.  state: 0 nothing yet, 1 the first matrix is in the staging buffer, 2 both, -1 a transfer failed
-  std::atomic<int> state{0};
-  if (e != hipSuccess) state.store(-1);
-  team([&](int t) {
-    if (t == 0 && state.load() == 0) {
-      hipError_t w = hipEventSynchronize(evA);
-      if (w != hipSuccess) { e = w; state.store(-1); }
-      else state.store(1);
-    }
+  // ONE team for both matrices (this runs once per block of the R loop).  arrived = pieces in the staging buffer (-1: a
+  // transfer failed); thread 0 does the waiting, then adds its own stripe of what it waited for.
+  //
+  // The FIRST call on a pair of matrices finds their pages unmapped: the accumulators of the R drivers are MAP_SHARED file
+  // mappings made just before the loop, and a write fault on one costs 2-25 us (the file system's page_mkwrite; 49 000 pages
+  // per matrix at n = 5 000: 75-125 ms per matrix on the pool's overlay file system however many threads share it, but two
+  // FILES in parallel take little more than one -- tools/host_rmw_probe.cpp).  So on a pair not seen in the previous call
+  // half of the team starts with the second matrix: both files are being faulted in at any time.
+  const bool first_touch = r->last_A != A || r->last_B != B;
+  r->last_A = A;
+  r->last_B = B;
+  std::atomic<int> arrived{0};
+  if (e != hipSuccess) arrived.store(-1);
+  auto wait_for = [&](int need) {
     int sv;
-    while ((sv = state.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
-    if (sv < 0) return;
-    add(t, A, stage, a16, biasA);
+    while ((sv = arrived.load(std::memory_order_acquire)) >= 0 && sv < need) std::this_thread::yield();
+    return sv >= 0;
+  };
+  tr[1] = inc_now();
+  team([&](int t) {
     if (t == 0) {
-      hipError_t w = hipStreamSynchronize(ctx->stream);
-      if (w != hipSuccess) { e = w; state.store(-1); }
-      else state.store(2);
+      if (arrived.load() < 0) return;
+      if (first_touch) {  // (nobody waits for this thread's stripes, which are slow this time)
+        hipError_t w = hipStreamSynchronize(ctx->stream);
+        if (w != hipSuccess) { e = w; arrived.store(-1); return; }
+        tr[2] = tr[3] = inc_now();
+        arrived.store(2 * npieces, std::memory_order_release);
+      } else {
+        for (int q = 0; q < 2 * npieces; q++) {
+          hipError_t w = hipEventSynchronize(ev[q]);
+          if (w != hipSuccess) { e = w; arrived.store(-1); return; }
+          if (q == 0) tr[2] = inc_now();
+          arrived.store(q + 1, std::memory_order_release);
+          add(0, q);
+        }
+        tr[3] = inc_now();
+        return;
+      }
     }
-    while ((sv = state.load(std::memory_order_acquire)) == 1) std::this_thread::yield();
-    if (sv < 0) return;
-    add(t, B, stage + bytesA, b16, 0);
+    const int start = first_touch && t >= (NT + 1) / 2 ? npieces : 0;
+    for (int i = 0; i < 2 * npieces; i++) {
+      const int q = (start + i) % (2 * npieces);
+      if (!wait_for(first_touch ? 2 * npieces : q + 1)) return;
+      add(t, q);
+    }
   });
-  if (evA) (void)hipEventDestroy(evA);
+  tr[5] = inc_now();
+  if (trace)
+    fprintf(stderr, "[tpg increment] counts: enqueued %.2f | first piece arrives %.2f | thread 0 done %.2f | team joined %.2f ms (%d threads, "
+                    "%d pieces%s)\n", tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[5] - tr[3], NT, 2 * npieces, first_touch ? ", first touch" : "");
+  for (int q = 0; q < 2 * NP; q++)
+    if (ev[q]) (void)hipEventDestroy(ev[q]);
   if (e != hipSuccess) { tpg_set_error("increment: counts to the caller: %s", hipGetErrorString(e)); return TPG_EHIP; }
   return TPG_OK;
 }
@@ -1867,6 +1915,8 @@ static int increment_common(tpg_ctx* ctx, int which, double* A, double* B, const
   for (auto& e : r->accs)
     if (e.A == A && e.B == B) acc = &e;
   tpg_pairwise* pw = nullptr;
+  const bool trace = increment_trace();
+  const double t_in = trace ? inc_now() : 0;
   if (acc) {
     TPG_REQUIRE(acc->which == which, TPG_EINVAL, "these accumulators are pending for another increment_* function; flush first");
     TPG_REQUIRE((int64_t)acc->rows.size() == n && memcmp(acc->rows.data(), rowInd1, sizeof(int32_t) * (size_t)n) == 0,
@@ -1884,14 +1934,19 @@ static int increment_common(tpg_ctx* ctx, int which, double* A, double* B, const
   tpg_fbm* f = nullptr;
   tpg_view* v = nullptr;
   std::vector<int32_t> cols;
+  const double t0 = trace ? inc_now() : 0;
   int rc = upload_block_columns(ctx, fbm_bytes, nrow, ncol, colInd1, m, &f, cols);
+  const double t1 = trace ? inc_now() : 0;
   if (rc == TPG_OK) rc = tpg_view_create(ctx, f, rowInd1, n, cols.data(), m, nullptr /* raw bytes, src/snp_ibs.cpp:47-54 */, &v);
   // the products this entry point's two matrices are made of (src/snp_ibs.cpp:67-72, src/snp_king.cpp:70-72, src/snp_as.cpp:64-65)
   const int products = which == 0 ? TPG_PW_FOR_IBS_ALONE : which == 1 ? TPG_PW_FOR_KING : TPG_PW_FOR_AS;
   if (rc == TPG_OK) rc = tpg_pairwise_accumulate_products(ctx, pw, v, 0, -1, products);
+  if (trace) fprintf(stderr, "[tpg increment] %lld loci: columns up %.2f | view + products enqueued %.2f ms\n", (long long)m, t1 - t0, inc_now() - t1);
   if (rc == TPG_OK && pw == r->spare) rc = add_counts_to_caller(ctx, which, pw, A, B);  // immediate: as the reference
+  const double t_add = trace ? inc_now() : 0;
   tpg_view_free(v);  // stream-ordered: the blocks return to this context's pool
   tpg_fbm_free(f);
+  if (trace) fprintf(stderr, "[tpg increment] accumulators ready %.2f | frees %.2f | whole call %.2f ms\n", t0 - t_in, inc_now() - t_add, inc_now() - t_in);
   return rc;
 }
 

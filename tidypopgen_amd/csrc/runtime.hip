@@ -1,6 +1,8 @@
 // runtime.hip -- context, error state, HIP-event profiling, FBM residency, view creation.
+#include <ctype.h>
 #include <fcntl.h>
 #include <math.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -238,6 +240,8 @@ extern "C" int tpg_device_count(int* count) {
   return TPG_OK;
 }
 
+static constexpr int XFER_THREADS_MIN_CPUS = 16;  // a node must offer the teams' sixteen threads a CPU each
+
 extern "C" int tpg_ctx_create(int device, tpg_ctx** out) {
   TPG_REQUIRE(out, TPG_EINVAL, "null out");
   int count = 0;
@@ -259,6 +263,61 @@ extern "C" int tpg_ctx_create(int device, tpg_ctx** out) {
   c->own_stream = true;
   c->pool_id = pool_open(device);
   *out = c;
+  return TPG_OK;
+}
+
+// "0-63,128-191" -> the CPUs of the list that are also in `allowed`
+static void parse_cpulist(const char* line, const cpu_set_t* allowed, cpu_set_t* out) {
+  CPU_ZERO(out);
+  for (const char* q = line; *q;) {
+    char* end = nullptr;
+    const long a = strtol(q, &end, 10);
+    if (end == q) break;
+    long b = a;
+    if (*end == '-') { q = end + 1; b = strtol(q, &end, 10); }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+      if (c >= 0 && CPU_ISSET((int)c, allowed)) CPU_SET((int)c, out);
+    if (*end != ',') break;
+    q = end + 1;
+  }
+}
+
+extern "C" int tpg_host_bind_near_device(int device, int* node_out) {
+  if (node_out) *node_out = -1;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    tpg_set_error("no HIP device available (%s)", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return TPG_EHIP;
+  }
+  TPG_REQUIRE(device >= 0 && device < count, TPG_EINVAL, "device %d out of range [0,%d)", device, count);
+  char bus[64] = {0};
+  TPG_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device));  // "0000:c1:00.0"
+  for (char* q = bus; *q; q++) *q = (char)tolower((unsigned char)*q);
+  char path[160], line[4096];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  FILE* f = fopen(path, "r");
+  int node = -1;
+  if (f) {
+    if (fgets(line, sizeof(line), f)) node = atoi(line);
+    fclose(f);
+  }
+  if (node < 0) return TPG_OK;  // unknown (or a one-node host that says -1)
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* g = fopen("/sys/devices/system/node/node1/cpulist", "r");  // a second node at all?
+  if (!g) return TPG_OK;
+  fclose(g);
+  f = fopen(path, "r");
+  if (!f) return TPG_OK;
+  cpu_set_t allowed, mine;
+  CPU_ZERO(&mine);
+  const bool ok = fgets(line, sizeof(line), f) && sched_getaffinity(0, sizeof(allowed), &allowed) == 0;
+  fclose(f);
+  if (!ok) return TPG_OK;
+  parse_cpulist(line, &allowed, &mine);
+  if (CPU_COUNT(&mine) < XFER_THREADS_MIN_CPUS) return TPG_OK;
+  if (sched_setaffinity(0, sizeof(mine), &mine) != 0) return TPG_OK;  // (0: the calling thread; threads started later inherit)
+  if (node_out) *node_out = node;
   return TPG_OK;
 }
 
@@ -799,7 +858,9 @@ hipError_t tpg_upload_bedpacked(tpg_ctx* ctx, uint8_t* dst, const uint8_t* src, 
   if (!pinned) return hipSuccess;
   struct Back { uint8_t* p; ~Back() { nib_stage_release(p); } } back{pinned};
   if (bpl > half) return hipSuccess;
-  const int64_t cpc = std::max<int64_t>(1, (int64_t)(half / bpl));  // columns per chunk
+  // columns per chunk.  (A block that fits ONE chunk -- the 134-MB blocks of an R driver loop -- is NOT cut further so that its
+  // copy could run beside its packing: four chunks measured 2.3 ms against 1.9, a team start and join per chunk.)
+  const int64_t cpc = std::max<int64_t>(1, (int64_t)(half / bpl));
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipError_t e = hipSuccess;
   for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
