@@ -955,15 +955,21 @@ def test_pca_loadings_entry_point_and_small_context_calls(tpg):
     want = ((g.astype(float) - center) / scale).T @ U / d
     got = tpg.pca_loadings(v, center, scale, U, d)
     assert got.shape == want.shape and np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
-    import torch
-    st = torch.cuda.Stream()
+    # a caller's stream, made with the HIP runtime the library itself runs on (dlopen by soname gives the copy already loaded.
+    # Not torch.cuda.Stream(): when torch is imported AFTER the library the process holds two HIP runtimes -- torch's bundled one
+    # and /opt/rocm's -- and the second to initialise sees no device; README.md "with PyTorch in the same process")
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0 and st.value
     ctx = tpg.default_context()
-    ctx.set_stream(st.cuda_stream)
+    ctx.set_stream(st.value)
     try:
         again = tpg.pca_loadings(v, center, scale, U, d)
         ctx.sync()
     finally:
         ctx.set_stream(None)
+        assert hip.hipStreamDestroy(st) == 0
     assert np.array_equal(again, got)
     assert tpg.Pairwise.buffer_bytes(n) >= 5 * 4 * n * (n + 1) // 2  # five int32 planes over the tiles of one triangle
     try:
