@@ -661,8 +661,24 @@ static hipError_t tpg_download_pinned(tpg_ctx* ctx, uint8_t* dst, const uint8_t*
 }
 
 // device memory -> host memory the caller owns (pageable)
+// A large result buffer the caller has just allocated is first touched by the download: with 4-KiB pages a team of sixteen
+// threads fills such a buffer at 16 GB/s on the pool's hosts (one fault per page), with transparent huge pages at 120
+// (tools/thp_probe.cpp; the hosts run THP in `madvise` mode, so somebody has to ask: numpy does for its own arrays, R and malloc
+// do not).  Advisory and harmless where it does not apply (pages already present, file mappings, THP off).
+// TPG_DOWNLOAD_THP=0: do not ask (A/B).
+static void advise_huge_pages(void* dst, size_t extent) {
+#ifdef MADV_HUGEPAGE
+  static const bool off = getenv("TPG_DOWNLOAD_THP") && atoi(getenv("TPG_DOWNLOAD_THP")) == 0;
+  const uintptr_t H = 2u << 20, lo = ((uintptr_t)dst + H - 1) & ~(H - 1), hi = ((uintptr_t)dst + extent) & ~(H - 1);
+  if (!off && extent >= (4u << 20) && hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+#else
+  (void)dst; (void)extent;
+#endif
+}
+
 hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes <= tpg_ctx::MAIL_FETCH_BYTES) return tpg_fetch_small(ctx, dst, src, bytes);  // (falls back to the copy engine by itself)
+  advise_huge_pages(dst, bytes);
   if (bytes >= (256u << 10)) {
     bool done = false;
     const hipError_t e = tpg_download_pinned(ctx, (uint8_t*)dst, (const uint8_t*)src, bytes, &done);
@@ -682,6 +698,7 @@ hipError_t tpg_download(tpg_ctx* ctx, void* dst, const void* src, size_t bytes) 
 hipError_t tpg_download_rows(tpg_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t width, size_t height) {
   if (width == 0 || height == 0) return hipSuccess;
   if (height == 1 || dpitch == width) return tpg_download(ctx, dst, src, width * height);
+  advise_huge_pages(dst, (height - 1) * dpitch + width);
   if (width * height >= (256u << 10)) {
     bool done = false;
     const hipError_t e = tpg_download_pinned(ctx, (uint8_t*)dst, (const uint8_t*)src, width * height, &done, width, dpitch);
