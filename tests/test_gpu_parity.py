@@ -1480,3 +1480,42 @@ def test_code_dosage_table_is_accepted_when_no_dosage_byte_occurs(tpg):
     with pytest.raises(tpg._lib.TpgError) as e:
         tpg.View(tpg.FBM.from_numpy(bad), code256=code_dosage)
     assert e.value.code == 3
+
+
+def test_host_bind_near_device_in_a_child_process():
+    """tpg_host_bind_near_device (include/tpg.h): in a child process (the binding is the calling thread's for good), the node it
+    reports is the one sysfs gives for the GPU, the thread's CPUs afterwards are CPUs of that node, a thread started later
+    inherits them; -1 = nothing changed; a device that does not exist is an error"""
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys, threading
+sys.path.insert(0, os.getcwd())
+import tidypopgen_amd as tpg
+before = os.sched_getaffinity(0)
+node = tpg.bind_host_near_device(0)
+after = os.sched_getaffinity(0)
+seen = []
+t = threading.Thread(target=lambda: seen.append(os.sched_getaffinity(0)))
+t.start(); t.join()
+if node < 0:
+    assert after == before, "affinity changed although nothing was reported"
+else:
+    cpus = set()
+    for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    assert after == before & cpus and len(after) >= 16 and seen[0] == after, (node, len(after))
+try:
+    tpg.bind_host_near_device(99)
+    raise SystemExit("device 99 accepted")
+except tpg._lib.TpgError:
+    pass
+X = tpg.FBM.synth(3, 100, 500, npop=3)
+assert tpg.snp_ibs(X).shape == (100, 100)  # the library works from the bound thread
+print("node", node, "cpus", len(after))
+"""
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.startswith("node ")
