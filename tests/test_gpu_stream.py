@@ -176,6 +176,16 @@ def test_stream_bed_and_synth_sources(tpg, tmp_path):
             r["pca_oracle"] = orc.gt_pca_partialSVD(fbm, None, cols, k=3, code256=code_imp)
             _compare(s, r, 3, pca_tol_d=1e-10 if st.report["budget_bytes"] else 1e-8, pca_tol_u=1e-8 if st.report["budget_bytes"] else 1e-6)
             st.close()
+    # a row subset in reverse order on the .bed store (the generic pack front end), blocks of SNPs under a budget
+    rows = np.arange(n, 0, -2).astype(np.int32)
+    gid_r = (np.arange(len(rows)) % G).astype(np.int32)
+    r = _resident(tpg, X, rows, None, gid_r, 0)
+    st = tpg.Stream.open_bed(path, n, m, budget_bytes=512 << 10)
+    s = st.run(rows, None, pairwise=("ibs", "king", "allele_sharing", "grm"), groupIds=gid_r, ngroups=G, alt_freq=True,
+               grouped_alt_freq=True, grouped_missingness=True, loci_counts=True, fst=("Hudson", "WC84"))
+    _compare(s, r, 0)
+    assert s["report"]["blocks"] > 1
+    st.close()
     with pytest.raises(tpg._lib.TpgError):
         tpg.Stream.open_bed(path, n, m + 1)
     # the synthetic store: equal to the resident synthetic FBM
