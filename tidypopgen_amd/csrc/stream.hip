@@ -177,8 +177,24 @@ struct StreamRun {
   DevBuf d_K, d_fsum, d_fpart;
   bool have_K = false;
   double fro = 0.0;
-  struct Kept { tpg_view* v = nullptr; DevBuf dc, ds; int64_t q0 = 0, mb = 0; };
+  struct Kept { tpg_view* v = nullptr; DevBuf dc, ds; int64_t q0 = 0, mb = 0; bool L_borrowed = false; };
   std::deque<Kept> kept;
+  // The PCA Gram of a run that keeps its imputed views (no budget) is NOT taken block by block: the class path pays for every
+  // weight class a block holds (whole 64-locus MFMA blocks + a fold), and a block of an eighth of the panel still holds nearly
+  // all of them -- 8.1 ms for the panel in one piece, 29.3 in eight (profiles/r06_stream_kernels_vs_blocks.txt).  The kept
+  // views' L layouts are laid end to end in ONE buffer (L is locus-tile major: appending loci appends memory) and the Gram runs
+  // ONCE, after the last block -- for a store whose run is paced by the kernels (.bed payload, synthetic): 70.9 -> 64.4 ms for
+  // the bench panel from a .bed, with 4 - 8 blocks instead of 2.  A byte store is paced by its uploads: its blocks' Gram
+  // matrices hide behind them, and batching (everything but the last two blocks while those are on their way, then each of
+  // them alone) measured 113.7 ms against 108.6 block by block -- so it keeps the Gram per block.
+  bool batch_gram = false;
+  DevBuf bigL, big_c, big_s;
+  int64_t gram_from = 0;  // loci (positions from P0) whose Gram is in K
+  void free_kept(Kept& kp) {
+    if (kp.v && kp.L_borrowed) kp.v->L = nullptr;  // it points into bigL
+    tpg_view_free(kp.v);
+    kp.v = nullptr;
+  }
   DevBuf d_u, d_nn[4];
   hipEvent_t ev_fin[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<double> dh;
@@ -275,8 +291,8 @@ struct StreamRun {
     int64_t target_blocks;
     if (budget == 0) {
       // no bound: the pipeline's own optimum -- a handful of blocks (per-block fixed costs against overlap: 8 blocks of a
-      // byte store, 2 of a .bed payload measured best at 5 000 x 1 000 000), views kept
-      target_blocks = src->kind == SRC_BED ? 2 : 8;
+      // byte store, 4 of a .bed payload measured best at 5 000 x 1 000 000), views kept
+      target_blocks = src->kind == SRC_BED ? 4 : 8;
       if (const char* e = getenv("TPG_STREAM_BLOCKS")) target_blocks = std::max(1, atoi(e));
       B = ceil_div(ceil_div(mloc, target_blocks), 128) * 128;
       keep_views = want_pca;
@@ -578,6 +594,17 @@ struct StreamRun {
       // paced by its kernels, and a block's Gram matrix costs what the resident path's costs.
       saved_fbits = ctx->pca_digit_fbits;
       if (budget) ctx->pca_digit_fbits = 30;
+      // the Gram in batches of blocks (see `batch_gram`): a run without a budget that keeps its views and has more than two
+      // blocks (with one or two the batches ARE the blocks).  TPG_STREAM_GRAM_BATCH=0: block by block (A/B)
+      const char* gb = getenv("TPG_STREAM_GRAM_BATCH");
+      batch_gram = budget == 0 && keep_views && nblocks > 2 && src->kind != SRC_BYTES && !(gb && atoi(gb) == 0);
+      gram_from = 0;
+      if (batch_gram) {
+        const size_t per128 = (size_t)ceil_div(n, 128) * 4096;
+        TPG_TRY(bigL.alloc((size_t)ceil_div(P1 - P0, 128) * per128));
+        TPG_TRY(big_c.alloc(8 * (size_t)(P1 - P0)));
+        TPG_TRY(big_s.alloc(8 * (size_t)(P1 - P0)));
+      }
     }
     for (int s = 0; s < 2 && s < nblocks; s++) {
       OutSlot& o = out[s];
@@ -667,9 +694,11 @@ struct StreamRun {
           ds = kp->ds.as<double>();
         }
         TPG_TRY(tpg_pca_center_scale(ctx, vp, dc, ds));  // TPG_ENUMERIC on a missing value / a zero scale, as big_SVD stops
-        if (!have_K) TPG_TRY(tpg_pca_gram(ctx, vp, dc, ds, d_K.as<double>()));
-        else TPG_TRY(tpg_pca_gram_add(ctx, vp, dc, ds, d_K.as<double>()));
-        have_K = true;
+        if (!batch_gram) {
+          if (!have_K) TPG_TRY(tpg_pca_gram(ctx, vp, dc, ds, d_K.as<double>()));
+          else TPG_TRY(tpg_pca_gram_add(ctx, vp, dc, ds, d_K.as<double>()));
+          have_K = true;
+        }
         if (j->square_frobenius) {
           double fb = 0;
           TPG_TRY(tpg_square_frobenius(ctx, vp, dc, ds, &fb));
@@ -689,6 +718,33 @@ struct StreamRun {
           if (kp->v->lc_part) { tpg_pfree(kp->v->lc_part); kp->v->lc_part = nullptr; kp->v->lc_chunks = 0; }
           if (kp->v->gc_cache.cnt) { tpg_pfree(kp->v->gc_cache.cnt); kp->v->gc_cache.cnt = nullptr; kp->v->gc_cache.nclass = 0; }
           kp->v->gc_cls.clear();
+        }
+        if (batch_gram) {
+          // the block's L joins the others (a block starts on a multiple of 128 loci: whole locus tiles), its own copy goes back
+          const size_t per128 = (size_t)ceil_div(n, 128) * 4096;  // bytes of L per 128 loci
+          uint8_t* at = bigL.as<uint8_t>() + (size_t)((q0 - P0) / 128) * per128;
+          TPG_HIP(tpg_copy_dev(ctx, at, kp->v->L, (size_t)kp->v->KG * per128));
+          TPG_HIP(tpg_copy_dev(ctx, big_c.as<double>() + (q0 - P0), dc, 8 * (size_t)mb));
+          TPG_HIP(tpg_copy_dev(ctx, big_s.as<double>() + (q0 - P0), ds, 8 * (size_t)mb));
+          tpg_pfree(kp->v->L);  // stream-ordered
+          kp->v->L = (uint4*)at;
+          kp->L_borrowed = true;
+          if (b == nblocks - 1) {
+            tpg_view bv{};
+            bv.ctx = ctx;
+            bv.n = n;
+            bv.m = (q1 - P0) - gram_from;
+            bv.Q = ceil_div(n, 128);
+            bv.KG = ceil_div(bv.m, 128);
+            bv.L = (uint4*)(bigL.as<uint8_t>() + (size_t)(gram_from / 128) * per128);
+            bv.bytes_each = (size_t)bv.KG * per128;
+            const double *bc = big_c.as<double>() + gram_from, *bs = big_s.as<double>() + gram_from;
+            if (!have_K) TPG_TRY(tpg_pca_gram(ctx, &bv, bc, bs, d_K.as<double>()));
+            else TPG_TRY(tpg_pca_gram_add(ctx, &bv, bc, bs, d_K.as<double>()));
+            have_K = true;
+            gram_from = q1 - P0;
+            stamp("gram batch enqueued", b);
+          }
         }
       }
       sample();
@@ -784,8 +840,7 @@ struct StreamRun {
         TPG_TRY(tpg_pca_loadings(ctx, kp.v, kp.dc.as<double>(), kp.ds.as<double>(), d_u.as<double>(), dh.data(), k, o.dv.as<double>()));
         TPG_HIP(hipEventRecord(o.ev, ctx->stream));
         TPG_TRY(rows_out(j->v, 8, m, kp.q0, o.dv.p, kp.mb, k, o.ev, slot));
-        tpg_view_free(kp.v);
-        kp.v = nullptr;
+        free_kept(kp);
         b++;
         sample();
       }
@@ -844,8 +899,11 @@ struct StreamRun {
       (void)hipStreamSynchronize(ctx->stream);
       if (down_ctx) (void)hipStreamSynchronize(down_ctx->stream);
       if (up_ctx) (void)hipStreamSynchronize(up_ctx->stream);
-      for (Kept& kp : kept) { tpg_view_free(kp.v); kp.v = nullptr; kp.dc.free(); kp.ds.free(); }
+      for (Kept& kp : kept) { free_kept(kp); kp.dc.free(); kp.ds.free(); }
       kept.clear();
+      bigL.free();
+      big_c.free();
+      big_s.free();
       if (pw) { tpg_pairwise_free(pw); pw = nullptr; }
       for (int k = 0; k < 2; k++) {
         if (d_blk[k]) { tpg_pfree(d_blk[k]); d_blk[k] = nullptr; }

@@ -12,6 +12,7 @@ n, m, G, k = 5000, 1_000_000, 51, 20
 gid = (np.arange(n) % G).astype(np.int32)
 ctx = tpg.default_context()
 tables = {}
+os.environ.setdefault("TPG_STREAM_GRAM_BATCH", "0")  # the per-block cost is what is being measured (a synthetic store would batch its Gram)
 for blocks in [int(x) for x in sys.argv[1:]] or [1, 2, 8]:
     os.environ["TPG_STREAM_BLOCKS"] = str(blocks)
     S = tpg.Stream.synth(3, n, m, npop=G, miss=0.02, imputed_bytes=True)
