@@ -188,7 +188,9 @@ struct StreamRun {
   // matrices hide behind them, and batching (everything but the last two blocks while those are on their way, then each of
   // them alone) measured 113.7 ms against 108.6 block by block -- so it keeps the Gram per block.
   bool batch_gram = false;
-  DevBuf bigL, big_c, big_s;
+  bool big_views = false;  // the kept views' L layouts end to end in bigL (every run without a budget that keeps several views):
+                           // the loadings are then ONE call and ONE download (eight pieces of 19 MB took 7 ms, one of 160 MB 3)
+  DevBuf bigL, big_c, big_s, d_vbig;
   int64_t gram_from = 0;  // loci (positions from P0) whose Gram is in K
   void free_kept(Kept& kp) {
     if (kp.v && kp.L_borrowed) kp.v->L = nullptr;  // it points into bigL
@@ -597,9 +599,10 @@ struct StreamRun {
       // the Gram in batches of blocks (see `batch_gram`): a run without a budget that keeps its views and has more than two
       // blocks (with one or two the batches ARE the blocks).  TPG_STREAM_GRAM_BATCH=0: block by block (A/B)
       const char* gb = getenv("TPG_STREAM_GRAM_BATCH");
-      batch_gram = budget == 0 && keep_views && nblocks > 2 && src->kind != SRC_BYTES && !(gb && atoi(gb) == 0);
+      big_views = budget == 0 && keep_views && nblocks > 1;
+      batch_gram = big_views && nblocks > 2 && src->kind != SRC_BYTES && !(gb && atoi(gb) == 0);
       gram_from = 0;
-      if (batch_gram) {
+      if (big_views) {
         const size_t per128 = (size_t)ceil_div(n, 128) * 4096;
         TPG_TRY(bigL.alloc((size_t)ceil_div(P1 - P0, 128) * per128));
         TPG_TRY(big_c.alloc(8 * (size_t)(P1 - P0)));
@@ -719,7 +722,7 @@ struct StreamRun {
           if (kp->v->gc_cache.cnt) { tpg_pfree(kp->v->gc_cache.cnt); kp->v->gc_cache.cnt = nullptr; kp->v->gc_cache.nclass = 0; }
           kp->v->gc_cls.clear();
         }
-        if (batch_gram) {
+        if (big_views) {
           // the block's L joins the others (a block starts on a multiple of 128 loci: whole locus tiles), its own copy goes back
           const size_t per128 = (size_t)ceil_div(n, 128) * 4096;  // bytes of L per 128 loci
           uint8_t* at = bigL.as<uint8_t>() + (size_t)((q0 - P0) / 128) * per128;
@@ -729,7 +732,7 @@ struct StreamRun {
           tpg_pfree(kp->v->L);  // stream-ordered
           kp->v->L = (uint4*)at;
           kp->L_borrowed = true;
-          if (b == nblocks - 1) {
+          if (batch_gram && b == nblocks - 1) {
             tpg_view bv{};
             bv.ctx = ctx;
             bv.n = n;
@@ -831,6 +834,24 @@ struct StreamRun {
     const int64_t bmax = std::min<int64_t>(B, P1 - P0);
     if (nblocks == 0) return TPG_OK;
     for (int s = 0; s < 2 && s < nblocks; s++) TPG_TRY(out[s].dv.alloc(8 * (size_t)k * (size_t)bmax));
+    if (keep_views && big_views) {
+      const size_t per128 = (size_t)ceil_div(n, 128) * 4096;
+      tpg_view bv{};
+      bv.ctx = ctx;
+      bv.n = n;
+      bv.m = P1 - P0;
+      bv.Q = ceil_div(n, 128);
+      bv.KG = ceil_div(bv.m, 128);
+      bv.L = bigL.as<uint4>();
+      bv.bytes_each = (size_t)bv.KG * per128;
+      TPG_TRY(d_vbig.alloc(8 * (size_t)k * (size_t)bv.m));
+      TPG_TRY(tpg_pca_loadings(ctx, &bv, big_c.as<double>(), big_s.as<double>(), d_u.as<double>(), dh.data(), k, d_vbig.as<double>()));
+      TPG_HIP(hipEventRecord(ev_fin[2], ctx->stream));
+      TPG_TRY(rows_out(j->v, 8, m, P0, d_vbig.p, bv.m, k, ev_fin[2], -1));
+      for (Kept& kp : kept) free_kept(kp);
+      sample();
+      return TPG_OK;
+    }
     if (keep_views) {
       int64_t b = 0;
       for (Kept& kp : kept) {
@@ -904,6 +925,7 @@ struct StreamRun {
       bigL.free();
       big_c.free();
       big_s.free();
+      d_vbig.free();
       if (pw) { tpg_pairwise_free(pw); pw = nullptr; }
       for (int k = 0; k < 2; k++) {
         if (d_blk[k]) { tpg_pfree(d_blk[k]); d_blk[k] = nullptr; }
