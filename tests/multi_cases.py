@@ -94,6 +94,34 @@ def multi_against_oracle(ndev, devices=None, setenv=None):
         if budget:
             assert s["report"]["blocks"] > 1
         S.close()
+    # ... and from a PLINK .bed payload: a store whose run is paced by its kernels takes the Gram ONCE over the kept views
+    # laid end to end (StreamRun::batch_gram) -- here on every device over its own share, then the same all-reduce
+    import shutil
+    import tempfile
+
+    dec = np.where(fbm > 3, fbm - 4, fbm).astype(np.uint8)  # the imputed genotypes as genotypes: nothing missing
+    tmp = tempfile.mkdtemp(prefix="tpg_multi_bed_")
+    try:
+        code = np.array([3, 2, 0, 1], dtype=np.uint8)[dec]  # PLINK: 00 hom A1 (dosage 2), 01 missing, 10 het, 11 hom A2
+        code = np.vstack([code, np.zeros(((-n) % 4, m), dtype=np.uint8)])
+        q = code.T.reshape(m, -1, 4)
+        with open(os.path.join(tmp, "s.bed"), "wb") as f:
+            f.write(bytes([0x6C, 0x1B, 0x01]))
+            f.write((q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8).tobytes())
+        S = tpg.Stream.open_bed(os.path.join(tmp, "s.bed"), n, m, budget_bytes=0)
+        s = S.run(None, pc, pairwise=("ibs", "king"), k=k, multi=mg)
+        sub = np.asfortranarray(dec[:, pc - 1])
+        assert s["report"]["blocks"] > 2 and s["report"]["views_kept"]
+        assert np.array_equal(s["ibs"], orc.snp_ibs(sub), equal_nan=True)
+        assert np.array_equal(s["king"], orc.snp_king(sub), equal_nan=True)
+        assert np.array_equal(s["center"], o["center"]) and np.array_equal(s["scale"], o["scale"])
+        assert np.allclose(s["d"], o["d"], rtol=1e-8, atol=0)
+        so = o["u"] * o["d"]
+        assert np.max(np.abs(align_sign(s["u"] * s["d"], so) - so)) <= 1e-6 * np.max(np.abs(so))
+        assert np.max(np.abs(align_sign(s["v"], o["v"]) - o["v"])) <= 1e-6 * np.max(np.abs(o["v"]))
+        S.close()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     transport = mg.transport()
     mg.close()
     return transport
