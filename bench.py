@@ -915,7 +915,10 @@ def main():
     if not args.no_numa_bind:
         import tidypopgen_amd as _tpg
 
-        numa_node = _tpg.bind_host_near_device(local_rank % max(1, _tpg.device_count()))
+        try:
+            numa_node = _tpg.bind_host_near_device(local_rank % max(1, _tpg.device_count()))
+        except Exception as e:  # (an optimisation of the host-side legs: never a reason to lose the line)
+            sys.stderr.write(f"[bench] rank {rank}: not bound to a NUMA node: {e}\n")
     st = Step(args, rank, world, local_rank)
     st.numa_node = numa_node
     from tidypopgen_amd import sharding
